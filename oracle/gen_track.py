@@ -1,0 +1,43 @@
+#!/usr/bin/env python3
+"""ORACLE / TEST INFRASTRUCTURE.  Writes a synthetic track in the reference's on-disk formats:
+surfaces.bin (58-byte packed BlobSurface header + float[3] verts + uint16 indices,
+Sim/Surface.h:25-45, Sim/Track.cpp:97-150), spline.bin (SlimTrackPoint = float[3] best +
+float[2] sides, Sim/Track.h:12-17), spline.ini (Sim/Track.cpp:158-186).
+
+Tracks:
+  flat    : one 2-triangle TRACK surface spanning +-2 km at y=0, straight spline along +z every
+            10 m with 6 m sides.
+"""
+import os, struct, sys, math
+
+MAGIC = 0xAABBCCDD
+
+def write_surface(f, verts, indices, sector=0, category=1, grip=1.0, valid=1):
+    hdr = struct.pack('<5I9f2B', MAGIC, len(verts), len(indices), sector, category,
+                      grip, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, valid, 0)
+    assert len(hdr) == 58
+    f.write(hdr)
+    for v in verts:
+        f.write(struct.pack('<3f', *v))
+    f.write(struct.pack('<%dH' % len(indices), *indices))
+
+def gen_flat(out, half=2000.0, z0=-1500.0, z1=1500.0, step=10.0, side=6.0):
+    os.makedirs(out, exist_ok=True)
+    with open(os.path.join(out, 'surfaces.bin'), 'wb') as f:
+        # (v1-v0)x(v2-v0) = +y for both triangles (front face seen from above)
+        verts = [(-half, 0.0, -half), (-half, 0.0, half), (half, 0.0, half), (half, 0.0, -half)]
+        write_surface(f, verts, [0, 1, 2, 0, 2, 3])
+    n = int(round((z1 - z0) / step)) + 1
+    with open(os.path.join(out, 'spline.bin'), 'wb') as f:
+        for i in range(n):
+            f.write(struct.pack('<5f', 0.0, 0.0, z0 + step * i, side, side))
+    with open(os.path.join(out, 'spline.ini'), 'w') as f:
+        f.write('[SPLINE]\nCLOSED_LOOP=0\nTRACE_SIDES=0\n')
+    # remove stale fat-point cache so the loader recomputes it
+    c = os.path.join(out, 'spline.cache')
+    if os.path.exists(c):
+        os.remove(c)
+
+if __name__ == '__main__':
+    kind, out = sys.argv[1], sys.argv[2]
+    {'flat': gen_flat}[kind](out)

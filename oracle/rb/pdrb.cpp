@@ -1,0 +1,681 @@
+// ORACLE / TEST INFRASTRUCTURE -- see pdrb.h header comment.  PARITY UNPINNED (ODE library absent).
+#include "pdrb.h"
+#include <cmath>
+#include <cstring>
+#include <algorithm>
+
+namespace pdrb {
+
+// ---------------------------------------------------------------------------------------------
+// small math; evaluation order follows thirdparty/ode/include/ode/odemath.h (dCalcVectorDot3 :213,
+// dMultiplyHelper0_331 :317, dMultiplyHelper1_331 :326)
+// ---------------------------------------------------------------------------------------------
+void mul0_331(float* r, const float* M, const float* v) {
+    const float r0 = M[0] * v[0] + M[1] * v[1] + M[2] * v[2];
+    const float r1 = M[3] * v[0] + M[4] * v[1] + M[5] * v[2];
+    const float r2 = M[6] * v[0] + M[7] * v[1] + M[8] * v[2];
+    r[0] = r0; r[1] = r1; r[2] = r2;
+}
+void mul1_331(float* r, const float* M, const float* v) {
+    const float r0 = M[0] * v[0] + M[3] * v[1] + M[6] * v[2];
+    const float r1 = M[1] * v[0] + M[4] * v[1] + M[7] * v[2];
+    const float r2 = M[2] * v[0] + M[5] * v[1] + M[8] * v[2];
+    r[0] = r0; r[1] = r1; r[2] = r2;
+}
+// res = a * b (3x3)
+static void mul0_333(float* res, const float* a, const float* b) {
+    float t[9];
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j)
+            t[i * 3 + j] = a[i * 3 + 0] * b[0 * 3 + j] + a[i * 3 + 1] * b[1 * 3 + j] + a[i * 3 + 2] * b[2 * 3 + j];
+    memcpy(res, t, sizeof(t));
+}
+// res = a * b^T
+static void mul2_333(float* res, const float* a, const float* b) {
+    float t[9];
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j)
+            t[i * 3 + j] = a[i * 3 + 0] * b[j * 3 + 0] + a[i * 3 + 1] * b[j * 3 + 1] + a[i * 3 + 2] * b[j * 3 + 2];
+    memcpy(res, t, sizeof(t));
+}
+
+void normalize3(float v[3]) {
+    const float l = v[0] * v[0] + v[1] * v[1] + v[2] * v[2];
+    if (l > 0.0f) {
+        const float s = 1.0f / sqrtf(l);
+        v[0] *= s; v[1] *= s; v[2] *= s;
+    } else {
+        v[0] = 1; v[1] = 0; v[2] = 0;
+    }
+}
+void normalize4(float q[4]) {
+    const float l = q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3];
+    if (l > 0.0f) {
+        const float s = 1.0f / sqrtf(l);
+        q[0] *= s; q[1] *= s; q[2] *= s; q[3] *= s;
+    } else {
+        q[0] = 1; q[1] = 0; q[2] = 0; q[3] = 0;
+    }
+}
+
+// ODE rotation.cpp dRfromQ
+void rFromQ(float R[9], const float q[4]) {
+    const float qq1 = 2 * q[1] * q[1];
+    const float qq2 = 2 * q[2] * q[2];
+    const float qq3 = 2 * q[3] * q[3];
+    R[0] = 1 - qq2 - qq3;
+    R[1] = 2 * (q[1] * q[2] - q[0] * q[3]);
+    R[2] = 2 * (q[1] * q[3] + q[0] * q[2]);
+    R[3] = 2 * (q[1] * q[2] + q[0] * q[3]);
+    R[4] = 1 - qq1 - qq3;
+    R[5] = 2 * (q[2] * q[3] - q[0] * q[1]);
+    R[6] = 2 * (q[1] * q[3] - q[0] * q[2]);
+    R[7] = 2 * (q[2] * q[3] + q[0] * q[1]);
+    R[8] = 1 - qq1 - qq2;
+}
+
+// ODE rotation.cpp dQfromR
+void qFromR(float q[4], const float R[9]) {
+#define RR(i, j) R[(i) * 3 + (j)]
+    const float tr = RR(0, 0) + RR(1, 1) + RR(2, 2);
+    float s;
+    if (tr >= 0) {
+        s = sqrtf(tr + 1);
+        q[0] = 0.5f * s;
+        s = 0.5f * (1.0f / s);
+        q[1] = (RR(2, 1) - RR(1, 2)) * s;
+        q[2] = (RR(0, 2) - RR(2, 0)) * s;
+        q[3] = (RR(1, 0) - RR(0, 1)) * s;
+        return;
+    }
+    int c;
+    if (RR(1, 1) > RR(0, 0)) c = (RR(2, 2) > RR(1, 1)) ? 2 : 1;
+    else c = (RR(2, 2) > RR(0, 0)) ? 2 : 0;
+    if (c == 0) {
+        s = sqrtf((RR(0, 0) - (RR(1, 1) + RR(2, 2))) + 1);
+        q[1] = 0.5f * s;
+        s = 0.5f * (1.0f / s);
+        q[2] = (RR(0, 1) + RR(1, 0)) * s;
+        q[3] = (RR(2, 0) + RR(0, 2)) * s;
+        q[0] = (RR(2, 1) - RR(1, 2)) * s;
+    } else if (c == 1) {
+        s = sqrtf((RR(1, 1) - (RR(2, 2) + RR(0, 0))) + 1);
+        q[2] = 0.5f * s;
+        s = 0.5f * (1.0f / s);
+        q[3] = (RR(1, 2) + RR(2, 1)) * s;
+        q[1] = (RR(0, 1) + RR(1, 0)) * s;
+        q[0] = (RR(0, 2) - RR(2, 0)) * s;
+    } else {
+        s = sqrtf((RR(2, 2) - (RR(0, 0) + RR(1, 1))) + 1);
+        q[3] = 0.5f * s;
+        s = 0.5f * (1.0f / s);
+        q[1] = (RR(2, 0) + RR(0, 2)) * s;
+        q[2] = (RR(1, 2) + RR(2, 1)) * s;
+        q[0] = (RR(1, 0) - RR(0, 1)) * s;
+    }
+#undef RR
+}
+
+// qa = qb * qc
+static void qmul0(float* qa, const float* qb, const float* qc) {
+    const float a0 = qb[0] * qc[0] - qb[1] * qc[1] - qb[2] * qc[2] - qb[3] * qc[3];
+    const float a1 = qb[0] * qc[1] + qb[1] * qc[0] + qb[2] * qc[3] - qb[3] * qc[2];
+    const float a2 = qb[0] * qc[2] + qb[2] * qc[0] + qb[3] * qc[1] - qb[1] * qc[3];
+    const float a3 = qb[0] * qc[3] + qb[3] * qc[0] + qb[1] * qc[2] - qb[2] * qc[1];
+    qa[0] = a0; qa[1] = a1; qa[2] = a2; qa[3] = a3;
+}
+// qa = inv(qb) * qc
+static void qmul1(float* qa, const float* qb, const float* qc) {
+    const float a0 = qb[0] * qc[0] + qb[1] * qc[1] + qb[2] * qc[2] + qb[3] * qc[3];
+    const float a1 = qb[0] * qc[1] - qb[1] * qc[0] - qb[2] * qc[3] + qb[3] * qc[2];
+    const float a2 = qb[0] * qc[2] - qb[2] * qc[0] - qb[3] * qc[1] + qb[1] * qc[3];
+    const float a3 = qb[0] * qc[3] - qb[3] * qc[0] - qb[1] * qc[2] + qb[2] * qc[1];
+    qa[0] = a0; qa[1] = a1; qa[2] = a2; qa[3] = a3;
+}
+// qa = qb * inv(qc)
+static void qmul2(float* qa, const float* qb, const float* qc) {
+    const float a0 = qb[0] * qc[0] + qb[1] * qc[1] + qb[2] * qc[2] + qb[3] * qc[3];
+    const float a1 = -qb[0] * qc[1] + qb[1] * qc[0] - qb[2] * qc[3] + qb[3] * qc[2];
+    const float a2 = -qb[0] * qc[2] + qb[2] * qc[0] - qb[3] * qc[1] + qb[1] * qc[3];
+    const float a3 = -qb[0] * qc[3] + qb[3] * qc[0] - qb[1] * qc[2] + qb[2] * qc[1];
+    qa[0] = a0; qa[1] = a1; qa[2] = a2; qa[3] = a3;
+}
+
+// ODE odemath.cpp dPlaneSpace
+void planeSpace(const float n[3], float p[3], float q[3]) {
+    if (fabsf(n[2]) > 0.70710678118654752440f) {
+        const float a = n[1] * n[1] + n[2] * n[2];
+        const float k = 1.0f / sqrtf(a);
+        p[0] = 0; p[1] = -n[2] * k; p[2] = n[1] * k;
+        q[0] = a * k; q[1] = -n[0] * p[2]; q[2] = n[0] * p[1];
+    } else {
+        const float a = n[0] * n[0] + n[1] * n[1];
+        const float k = 1.0f / sqrtf(a);
+        p[0] = -n[1] * k; p[1] = n[0] * k; p[2] = 0;
+        q[0] = -n[2] * p[1]; q[1] = n[2] * p[0]; q[2] = a * k;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Body
+// ---------------------------------------------------------------------------------------------
+void Body::setMassBoxTotal(float m, float lx, float ly, float lz) {
+    // dMassSetBoxTotal = dMassSetBox(density 1) then dMassAdjust (RigidBodyODE.cpp:64-70)
+    const float M = lx * ly * lz * 1.0f;
+    float i0 = M / 12.0f * (ly * ly + lz * lz);
+    float i1 = M / 12.0f * (lx * lx + lz * lz);
+    float i2 = M / 12.0f * (lx * lx + ly * ly);
+    const float scale = m / M;
+    i0 *= scale; i1 *= scale; i2 *= scale;
+    mass = m;
+    invMass = 1.0f / m;
+    for (int k = 0; k < 9; ++k) { I[k] = 0; invI[k] = 0; }
+    I[0] = i0; I[4] = i1; I[8] = i2;
+    invI[0] = 1.0f / i0; invI[4] = 1.0f / i1; invI[8] = 1.0f / i2;
+}
+
+void Body::setRotation(const float Rin[9]) {
+    // dBodySetRotation: copy, dOrthogonalizeR, q = dQfromR(R_in), normalise q
+    float m[9];
+    memcpy(m, Rin, sizeof(m));
+    const float n0 = m[0] * m[0] + m[1] * m[1] + m[2] * m[2];
+    if (n0 != 1.0f) normalize3(m);
+    const float proj = m[0] * m[3] + m[1] * m[4] + m[2] * m[5];
+    if (proj != 0.0f) { m[3] -= proj * m[0]; m[4] -= proj * m[1]; m[5] -= proj * m[2]; }
+    const float n1 = m[3] * m[3] + m[4] * m[4] + m[5] * m[5];
+    if (n1 != 1.0f) normalize3(m + 3);
+    cross3(m + 6, m, m + 3);
+    memcpy(R, m, sizeof(m));
+    qFromR(q, Rin);
+    normalize4(q);
+}
+
+void Body::relPointPos(const float p[3], float out[3]) const {
+    float t[3];
+    mul0_331(t, R, p);
+    out[0] = t[0] + pos[0]; out[1] = t[1] + pos[1]; out[2] = t[2] + pos[2];
+}
+void Body::posRelPoint(const float p[3], float out[3]) const {
+    const float d[3] = {p[0] - pos[0], p[1] - pos[1], p[2] - pos[2]};
+    mul1_331(out, R, d);
+}
+void Body::vectorToWorld(const float v[3], float out[3]) const { mul0_331(out, R, v); }
+void Body::vectorFromWorld(const float v[3], float out[3]) const { mul1_331(out, R, v); }
+void Body::relPointVel(const float p[3], float out[3]) const {
+    float w[3], c[3];
+    mul0_331(w, R, p);
+    cross3(c, avel, w);
+    out[0] = lvel[0] + c[0]; out[1] = lvel[1] + c[1]; out[2] = lvel[2] + c[2];
+}
+void Body::pointVel(const float p[3], float out[3]) const {
+    const float d[3] = {p[0] - pos[0], p[1] - pos[1], p[2] - pos[2]};
+    float c[3];
+    cross3(c, avel, d);
+    out[0] = lvel[0] + c[0]; out[1] = lvel[1] + c[1]; out[2] = lvel[2] + c[2];
+}
+void Body::addForceAtPos(const float f[3], const float p[3]) {
+    facc[0] += f[0]; facc[1] += f[1]; facc[2] += f[2];
+    const float d[3] = {p[0] - pos[0], p[1] - pos[1], p[2] - pos[2]};
+    float c[3];
+    cross3(c, d, f);
+    tacc[0] += c[0]; tacc[1] += c[1]; tacc[2] += c[2];
+}
+void Body::addForceAtRelPos(const float f[3], const float p[3]) {
+    float w[3], c[3];
+    mul0_331(w, R, p);
+    facc[0] += f[0]; facc[1] += f[1]; facc[2] += f[2];
+    cross3(c, w, f);
+    tacc[0] += c[0]; tacc[1] += c[1]; tacc[2] += c[2];
+}
+void Body::addRelForceAtRelPos(const float fl[3], const float p[3]) {
+    float f[3], w[3], c[3];
+    mul0_331(f, R, fl);
+    mul0_331(w, R, p);
+    facc[0] += f[0]; facc[1] += f[1]; facc[2] += f[2];
+    cross3(c, w, f);
+    tacc[0] += c[0]; tacc[1] += c[1]; tacc[2] += c[2];
+}
+void Body::addRelForceAtPos(const float fl[3], const float p[3]) {
+    float f[3];
+    mul0_331(f, R, fl);
+    addForceAtPos(f, p);
+}
+void Body::addTorque(const float t[3]) { tacc[0] += t[0]; tacc[1] += t[1]; tacc[2] += t[2]; }
+void Body::addRelTorque(const float tl[3]) {
+    float t[3];
+    mul0_331(t, R, tl);
+    tacc[0] += t[0]; tacc[1] += t[1]; tacc[2] += t[2];
+}
+void Body::stop() {
+    for (int k = 0; k < 3; ++k) { lvel[k] = 0; avel[k] = 0; facc[k] = 0; tacc[k] = 0; }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Joint creation (ODE setters take WORLD coordinates; JointODE.cpp:21-89)
+// ---------------------------------------------------------------------------------------------
+int World::createFixed(int b0, int b1) {
+    Joint j;
+    j.type = JT_FIXED; j.b0 = b0; j.b1 = b1; j.erp = erp; j.cfm = cfm;
+    const Body& A = bodies[b0];
+    const Body& B = bodies[b1];
+    // dJointSetFixed: offset = R0^T (p0 - p1); qrel = inv(q0) q1
+    const float ofs[3] = {A.pos[0] - B.pos[0], A.pos[1] - B.pos[1], A.pos[2] - B.pos[2]};
+    mul1_331(j.offset, A.R, ofs);
+    qmul1(j.qrel, A.q, B.q);
+    joints.push_back(j);
+    orderDirty = true;
+    return (int)joints.size() - 1;
+}
+int World::createBall(int b0, int b1, const float aw[3]) {
+    Joint j;
+    j.type = JT_BALL; j.b0 = b0; j.b1 = b1; j.erp = erp; j.cfm = cfm;
+    bodies[b0].posRelPoint(aw, j.anchor1);
+    bodies[b1].posRelPoint(aw, j.anchor2);
+    joints.push_back(j);
+    orderDirty = true;
+    return (int)joints.size() - 1;
+}
+int World::createSlider(int b0, int b1, const float axisWorld[3]) {
+    Joint j;
+    j.type = JT_SLIDER; j.b0 = b0; j.b1 = b1; j.erp = erp; j.cfm = cfm;
+    const Body& A = bodies[b0];
+    const Body& B = bodies[b1];
+    float a[3] = {axisWorld[0], axisWorld[1], axisWorld[2]};
+    normalize3(a);
+    mul1_331(j.axis1, A.R, a);
+    // computeOffset: offset = R1^T (p0 - p1); computeInitialRelativeRotation: qrel = inv(q0) q1
+    const float c[3] = {A.pos[0] - B.pos[0], A.pos[1] - B.pos[1], A.pos[2] - B.pos[2]};
+    mul1_331(j.offset, B.R, c);
+    qmul1(j.qrel, A.q, B.q);
+    joints.push_back(j);
+    orderDirty = true;
+    return (int)joints.size() - 1;
+}
+int World::createDBall(int b0, int b1, const float a1w[3], const float a2w[3]) {
+    Joint j;
+    j.type = JT_DBALL; j.b0 = b0; j.b1 = b1; j.erp = erp; j.cfm = cfm;
+    joints.push_back(j);
+    const int id = (int)joints.size() - 1;
+    dballSetAnchor1(id, a1w);
+    dballSetAnchor2(id, a2w);
+    orderDirty = true;
+    return id;
+}
+void World::dballUpdateTargetDistance(int id) {
+    Joint& j = joints[id];
+    float g1[3], g2[3];
+    bodies[j.b0].relPointPos(j.anchor1, g1);
+    bodies[j.b1].relPointPos(j.anchor2, g2);
+    const float d[3] = {g1[0] - g2[0], g1[1] - g2[1], g1[2] - g2[2]};
+    j.targetDistance = sqrtf(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);
+}
+void World::dballSetAnchor1(int id, const float w[3]) {
+    bodies[joints[id].b0].posRelPoint(w, joints[id].anchor1);
+    dballUpdateTargetDistance(id);
+}
+void World::dballSetAnchor2(int id, const float w[3]) {
+    bodies[joints[id].b1].posRelPoint(w, joints[id].anchor2);
+    dballUpdateTargetDistance(id);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Island traversal order (ODE util.cpp dxProcessIslands): bodies are visited from the head of the
+// world's body list (most recently created first); each body's joint list has the most recently
+// attached joint first; depth-first with an explicit stack.  All joints used here are fully
+// unbounded (nub == m), so the stepper's unbounded/mixed/LCP regrouping leaves this order intact.
+// ---------------------------------------------------------------------------------------------
+void World::buildOrder() {
+    const int nb = (int)bodies.size();
+    const int nj = (int)joints.size();
+    std::vector<std::vector<int>> bj(nb);
+    for (int j = 0; j < nj; ++j) {  // attach order == creation order here
+        bj[joints[j].b0].insert(bj[joints[j].b0].begin(), j);
+        if (joints[j].b1 >= 0) bj[joints[j].b1].insert(bj[joints[j].b1].begin(), j);
+    }
+    std::vector<char> btag(nb, 0), jtag(nj, 0);
+    jointOrder.clear();
+    std::vector<int> stack;
+    for (int bb = nb - 1; bb >= 0; --bb) {
+        if (btag[bb]) continue;
+        btag[bb] = 1;
+        int b = bb;
+        stack.clear();
+        while (true) {
+            for (int j : bj[b]) {
+                if (jtag[j]) continue;
+                jtag[j] = 1;
+                jointOrder.push_back(j);
+                const int other = (joints[j].b0 == b) ? joints[j].b1 : joints[j].b0;
+                if (other >= 0 && !btag[other]) { btag[other] = 1; stack.push_back(other); }
+            }
+            if (stack.empty()) break;
+            b = stack.back();
+            stack.pop_back();
+        }
+    }
+    orderDirty = false;
+}
+
+// ---------------------------------------------------------------------------------------------
+// joint rows.  Row layout: J[12] = {J1l(3), J1a(3), J2l(3), J2a(3)}, c, cfm.
+// ---------------------------------------------------------------------------------------------
+struct Row { float J[12]; float c; float cfm; };
+
+static void setFixedOrientation(const Body& A, const Body& B, const Joint& j, float k, Row* rows) {
+    // ODE joints/joint.cpp setFixedOrientation: J1a = I, J2a = -I, c = 2 k R0 * vec(qerr)
+    for (int r = 0; r < 3; ++r) {
+        for (int t = 0; t < 12; ++t) rows[r].J[t] = 0;
+        rows[r].J[3 + r] = 1.0f;
+        rows[r].J[9 + r] = -1.0f;
+    }
+    float qq[4], qerr[4], e[3];
+    qmul1(qq, A.q, B.q);
+    qmul2(qerr, qq, j.qrel);
+    if (qerr[0] < 0) { qerr[1] = -qerr[1]; qerr[2] = -qerr[2]; qerr[3] = -qerr[3]; }
+    mul0_331(e, A.R, qerr + 1);
+    rows[0].c = 2 * k * e[0];
+    rows[1].c = 2 * k * e[1];
+    rows[2].c = 2 * k * e[2];
+}
+
+static int jointRows(const World& w, const Joint& j, float fps, Row* rows) {
+    const Body& A = w.bodies[j.b0];
+    const Body& B = w.bodies[j.b1];
+    const int m = j.rows();
+    for (int r = 0; r < m; ++r) {
+        for (int t = 0; t < 12; ++t) rows[r].J[t] = 0;
+        rows[r].c = 0;
+        rows[r].cfm = w.cfm;
+    }
+    switch (j.type) {
+    case JT_BALL: {
+        // ODE joints/ball.cpp + setBall: J1l = I, J1a = -[a1]x, J2l = -I, J2a = +[a2]x
+        float a1[3], a2[3];
+        mul0_331(a1, A.R, j.anchor1);
+        mul0_331(a2, B.R, j.anchor2);
+        for (int r = 0; r < 3; ++r) { rows[r].J[r] = 1.0f; rows[r].J[6 + r] = -1.0f; rows[r].cfm = j.cfm; }
+        // dSetCrossMatrixMinus(J1a, a1) (odemath.h:288)
+        rows[0].J[3 + 1] = +a1[2]; rows[0].J[3 + 2] = -a1[1];
+        rows[1].J[3 + 0] = -a1[2]; rows[1].J[3 + 2] = +a1[0];
+        rows[2].J[3 + 0] = +a1[1]; rows[2].J[3 + 1] = -a1[0];
+        // dSetCrossMatrixPlus(J2a, a2) (odemath.h:277)
+        rows[0].J[9 + 1] = -a2[2]; rows[0].J[9 + 2] = +a2[1];
+        rows[1].J[9 + 0] = +a2[2]; rows[1].J[9 + 2] = -a2[0];
+        rows[2].J[9 + 0] = -a2[1]; rows[2].J[9 + 1] = +a2[0];
+        const float k = fps * j.erp;
+        for (int r = 0; r < 3; ++r) rows[r].c = k * (a2[r] + B.pos[r] - a1[r] - A.pos[r]);
+        break;
+    }
+    case JT_FIXED: {
+        // ODE joints/fixed.cpp: rows 0-2 position, rows 3-5 orientation
+        float ofs[3];
+        mul0_331(ofs, A.R, j.offset);
+        for (int r = 0; r < 3; ++r) { rows[r].J[r] = 1.0f; rows[r].J[6 + r] = -1.0f; rows[r].cfm = j.cfm; }
+        // dSetCrossMatrixPlus(J1a, ofs)
+        rows[0].J[3 + 1] = -ofs[2]; rows[0].J[3 + 2] = +ofs[1];
+        rows[1].J[3 + 0] = +ofs[2]; rows[1].J[3 + 2] = -ofs[0];
+        rows[2].J[3 + 0] = -ofs[1]; rows[2].J[3 + 1] = +ofs[0];
+        const float k = fps * j.erp;
+        for (int r = 0; r < 3; ++r) rows[r].c = k * (B.pos[r] - A.pos[r] + ofs[r]);
+        setFixedOrientation(A, B, j, fps * w.erp, rows + 3);
+        for (int r = 3; r < 6; ++r) rows[r].cfm = w.cfm;
+        break;
+    }
+    case JT_SLIDER: {
+        // ODE joints/slider.cpp getInfo2 (no limit / motor row: no stops, fmax = 0)
+        float c[3] = {B.pos[0] - A.pos[0], B.pos[1] - A.pos[1], B.pos[2] - A.pos[2]};
+        const float k = fps * w.erp;
+        setFixedOrientation(A, B, j, k, rows);
+        float ax1[3], p[3], q[3], tmp[3];
+        mul0_331(ax1, A.R, j.axis1);
+        planeSpace(ax1, p, q);
+        cross3(tmp, c, p);
+        for (int t = 0; t < 3; ++t) { tmp[t] *= 0.5f; rows[3].J[3 + t] = tmp[t]; rows[3].J[9 + t] = tmp[t]; }
+        cross3(tmp, c, q);
+        for (int t = 0; t < 3; ++t) { tmp[t] *= 0.5f; rows[4].J[3 + t] = tmp[t]; rows[4].J[9 + t] = tmp[t]; }
+        for (int t = 0; t < 3; ++t) {
+            rows[3].J[6 + t] = -p[t]; rows[4].J[6 + t] = -q[t];
+            rows[3].J[t] = p[t];      rows[4].J[t] = q[t];
+        }
+        float ofs[3];
+        mul0_331(ofs, B.R, j.offset);
+        for (int t = 0; t < 3; ++t) c[t] += ofs[t];
+        rows[3].c = k * dot3(p, c);
+        rows[4].c = k * dot3(q, c);
+        break;
+    }
+    case JT_DBALL: {
+        // ODE joints/dball.cpp getInfo2
+        float g1[3], g2[3], q[3];
+        A.relPointPos(j.anchor1, g1);
+        B.relPointPos(j.anchor2, g2);
+        q[0] = g1[0] - g2[0]; q[1] = g1[1] - g2[1]; q[2] = g1[2] - g2[2];
+        const float dist = sqrtf(q[0] * q[0] + q[1] * q[1] + q[2] * q[2]);
+        if (dist < 1e-7f) {
+            // too small: direction from anchor velocity difference, else arbitrary
+            float v1[3], v2[3];
+            A.relPointVel(j.anchor1, v1);
+            B.relPointVel(j.anchor2, v2);
+            q[0] = v1[0] - v2[0]; q[1] = v1[1] - v2[1]; q[2] = v1[2] - v2[2];
+            if (sqrtf(q[0] * q[0] + q[1] * q[1] + q[2] * q[2]) < 1e-7f) { q[0] = 1; q[1] = 0; q[2] = 0; }
+        }
+        normalize3(q);
+        float r1[3], r2[3], t[3];
+        mul0_331(r1, A.R, j.anchor1);
+        mul0_331(r2, B.R, j.anchor2);
+        for (int k2 = 0; k2 < 3; ++k2) { rows[0].J[k2] = q[k2]; rows[0].J[6 + k2] = -q[k2]; }
+        cross3(t, r1, q);  // (-[r1]x)^T q = r1 x q
+        rows[0].J[3] = t[0]; rows[0].J[4] = t[1]; rows[0].J[5] = t[2];
+        cross3(t, q, r2);  // ([r2]x)^T q = -(r2 x q) = q x r2
+        rows[0].J[9] = t[0]; rows[0].J[10] = t[1]; rows[0].J[11] = t[2];
+        rows[0].cfm = j.cfm;
+        rows[0].c = (fps * j.erp) * (j.targetDistance - dist);
+        break;
+    }
+    }
+    return m;
+}
+
+// ---------------------------------------------------------------------------------------------
+// dWorldStep (ODE step.cpp dxStepIsland), all rows unbounded => one SPD factor-solve.
+// Canonical factorisation (project choice): right-looking LDL^T with fmaf, column-oriented
+// substitutions -- each element sees its updates in k order, independent of any parallel split.
+// ---------------------------------------------------------------------------------------------
+static inline float sinc_ode(float x) {
+    if (fabsf(x) < 1.0e-4f) return 1.0f - x * x * 0.166666666666666666667f;
+    return sinf(x) / x;
+}
+
+void World::step(float h) {
+    if (orderDirty) buildOrder();
+    const int nb = (int)bodies.size();
+    const float fps = 1.0f / h;
+
+    std::vector<float> invIw(nb * 9);
+    for (int bi = 0; bi < nb; ++bi) {
+        Body& b = bodies[bi];
+        float tmp[9];
+        float* iw = &invIw[bi * 9];
+        mul2_333(tmp, b.invI, b.R);
+        mul0_333(iw, b.R, tmp);
+        // gyroscopic torque, implicit form (ODE >= 0.13 step.cpp, "Stabilizing Gyroscopic Forces")
+        {
+            float I[9], L[3];
+            mul2_333(tmp, b.I, b.R);
+            mul0_333(I, b.R, tmp);
+            mul0_331(L, I, b.avel);
+            float It[9] = {0, +L[2], -L[1], -L[2], 0, +L[0], +L[1], -L[0], 0};  // dSetCrossMatrixMinus
+            for (int k = 0; k < 9; ++k) It[k] = It[k] * h + I[k];
+            L[0] *= fps; L[1] *= fps; L[2] *= fps;
+            // dInvertMatrix3 (odemath.h:463-503)
+            const float det = It[0] * (It[4] * It[8] - It[7] * It[5]) - It[1] * (It[3] * It[8] - It[6] * It[5]) +
+                              It[2] * (It[3] * It[7] - It[6] * It[4]);
+            if (det != 0.0f) {
+                const float dr = 1.0f / det;
+                float inv[9];
+                inv[0] = (It[4] * It[8] - It[5] * It[7]) * dr;
+                inv[1] = (It[7] * It[2] - It[1] * It[8]) * dr;
+                inv[2] = (It[1] * It[5] - It[4] * It[2]) * dr;
+                inv[3] = (It[5] * It[6] - It[3] * It[8]) * dr;
+                inv[4] = (It[0] * It[8] - It[6] * It[2]) * dr;
+                inv[5] = (It[3] * It[2] - It[0] * It[5]) * dr;
+                inv[6] = (It[3] * It[7] - It[6] * It[4]) * dr;
+                inv[7] = (It[6] * It[1] - It[0] * It[7]) * dr;
+                inv[8] = (It[0] * It[4] - It[1] * It[3]) * dr;
+                float M[9], tau[3];
+                mul0_333(M, I, inv);
+                M[0] -= 1; M[4] -= 1; M[8] -= 1;
+                mul0_331(tau, M, L);
+                b.tacc[0] += tau[0]; b.tacc[1] += tau[1]; b.tacc[2] += tau[2];
+            }
+        }
+        b.facc[0] += b.mass * gravity[0];
+        b.facc[1] += b.mass * gravity[1];
+        b.facc[2] += b.mass * gravity[2];
+    }
+
+    // rows
+    int m = 0;
+    for (int j : jointOrder) m += joints[j].rows();
+    lastM = m;
+    std::vector<Row> rows(m > 0 ? m : 1);
+    std::vector<int> rb0(m), rb1(m), jofs(jointOrder.size() + 1);
+    {
+        int o = 0;
+        for (size_t t = 0; t < jointOrder.size(); ++t) {
+            const Joint& j = joints[jointOrder[t]];
+            jofs[t] = o;
+            const int mm = jointRows(*this, j, fps, &rows[o]);
+            for (int r = 0; r < mm; ++r) { rb0[o + r] = j.b0; rb1[o + r] = j.b1; }
+            o += mm;
+        }
+        jofs[jointOrder.size()] = o;
+    }
+
+    std::vector<float> lambda(m, 0.0f);
+    if (m > 0) {
+        // JinvM
+        std::vector<float> JinvM(m * 12);
+        for (int i = 0; i < m; ++i) {
+            const float* J = rows[i].J;
+            float* o = &JinvM[i * 12];
+            const Body& A = bodies[rb0[i]];
+            const Body& B = bodies[rb1[i]];
+            const float* ia = &invIw[rb0[i] * 9];
+            const float* ib = &invIw[rb1[i] * 9];
+            for (int k = 0; k < 3; ++k) { o[k] = J[k] * A.invMass; o[6 + k] = J[6 + k] * B.invMass; }
+            // row-vector times matrix (dMultiply0_133)
+            for (int c2 = 0; c2 < 3; ++c2) {
+                o[3 + c2] = J[3] * ia[0 * 3 + c2] + J[4] * ia[1 * 3 + c2] + J[5] * ia[2 * 3 + c2];
+                o[9 + c2] = J[9] * ib[0 * 3 + c2] + J[10] * ib[1 * 3 + c2] + J[11] * ib[2 * 3 + c2];
+            }
+        }
+        // A = JinvM J^T (lower triangle), + cfm*fps on the diagonal
+        std::vector<float> Am(m * m, 0.0f);
+        auto dot6 = [](const float* a, const float* b) {
+            return a[0] * b[0] + a[1] * b[1] + a[2] * b[2] + a[3] * b[3] + a[4] * b[4] + a[5] * b[5];
+        };
+        for (int i = 0; i < m; ++i) {
+            for (int jx = 0; jx <= i; ++jx) {
+                float s = 0.0f;
+                bool any = false;
+                const int ib[2] = {rb0[i], rb1[i]};
+                const int jb[2] = {rb0[jx], rb1[jx]};
+                for (int si = 0; si < 2; ++si)
+                    for (int sj = 0; sj < 2; ++sj)
+                        if (ib[si] == jb[sj]) {
+                            const float d = dot6(&JinvM[i * 12 + si * 6], &rows[jx].J[sj * 6]);
+                            s = any ? (s + d) : d;
+                            any = true;
+                        }
+                Am[i * m + jx] = s;
+            }
+            Am[i * m + i] += rows[i].cfm * fps;
+        }
+        // rhs = c*fps - J (v*fps + invM fe)
+        std::vector<float> tmp1(nb * 6);
+        for (int bi = 0; bi < nb; ++bi) {
+            const Body& b = bodies[bi];
+            float* t = &tmp1[bi * 6];
+            for (int k = 0; k < 3; ++k) t[k] = b.facc[k] * b.invMass + b.lvel[k] * fps;
+            mul0_331(t + 3, &invIw[bi * 9], b.tacc);
+            for (int k = 0; k < 3; ++k) t[3 + k] += b.avel[k] * fps;
+        }
+        std::vector<float> rhs(m);
+        for (int i = 0; i < m; ++i) {
+            float r = rows[i].c * fps;
+            r -= dot6(&rows[i].J[0], &tmp1[rb0[i] * 6]);
+            r -= dot6(&rows[i].J[6], &tmp1[rb1[i] * 6]);
+            rhs[i] = r;
+        }
+        lastA = Am;
+        lastRhs = rhs;
+        // right-looking LDL^T, lower triangle, explicit fmaf
+        std::vector<float> dinv(m);
+        for (int k = 0; k < m; ++k) {
+            const float d = Am[k * m + k];
+            const float id = 1.0f / d;
+            dinv[k] = id;
+            for (int i = k + 1; i < m; ++i) {
+                const float lik = Am[i * m + k] * id;
+                for (int jx = k + 1; jx <= i; ++jx)
+                    Am[i * m + jx] = fmaf(-lik, Am[jx * m + k], Am[i * m + jx]);
+            }
+            for (int i = k + 1; i < m; ++i) Am[i * m + k] *= id;  // store L
+        }
+        // forward (column oriented), diagonal, backward (column oriented)
+        for (int k = 0; k < m; ++k)
+            for (int i = k + 1; i < m; ++i) rhs[i] = fmaf(-Am[i * m + k], rhs[k], rhs[i]);
+        for (int k = 0; k < m; ++k) rhs[k] *= dinv[k];
+        for (int k = m - 1; k >= 0; --k)
+            for (int i = 0; i < k; ++i) rhs[i] = fmaf(-Am[k * m + i], rhs[k], rhs[i]);
+        lambda = rhs;
+    }
+    lastLambda = lambda;
+
+    // cforce = J^T lambda (per joint, per component: sum over the joint's rows, then accumulate)
+    std::vector<float> cf(nb * 6, 0.0f);
+    for (size_t t = 0; t < jointOrder.size(); ++t) {
+        const Joint& j = joints[jointOrder[t]];
+        const int o = jofs[t], mm = jofs[t + 1] - jofs[t];
+        for (int k = 0; k < 6; ++k) {
+            float s0 = 0.0f, s1 = 0.0f;
+            for (int r = 0; r < mm; ++r) {
+                s0 += rows[o + r].J[k] * lambda[o + r];
+                s1 += rows[o + r].J[6 + k] * lambda[o + r];
+            }
+            cf[j.b0 * 6 + k] += s0;
+            cf[j.b1 * 6 + k] += s1;
+        }
+    }
+    // velocity update, position update (dxStepBody, finite rotation mode 1, no finite-rotation axis:
+    // RigidBodyODE.cpp:15-16), zero accumulators
+    for (int bi = 0; bi < nb; ++bi) {
+        Body& b = bodies[bi];
+        const float* c = &cf[bi * 6];
+        const float ims = h * b.invMass;
+        for (int k = 0; k < 3; ++k) b.lvel[k] += (c[k] + b.facc[k]) * ims;
+        float tt[3], dw[3];
+        for (int k = 0; k < 3; ++k) tt[k] = (c[3 + k] + b.tacc[k]) * h;
+        mul0_331(dw, &invIw[bi * 9], tt);
+        for (int k = 0; k < 3; ++k) b.avel[k] += dw[k];
+
+        for (int k = 0; k < 3; ++k) b.pos[k] += h * b.lvel[k];
+        {
+            const float wlen = sqrtf(b.avel[0] * b.avel[0] + b.avel[1] * b.avel[1] + b.avel[2] * b.avel[2]);
+            const float hh = h * 0.5f;
+            const float theta = wlen * hh;
+            float qr[4], q2[4];
+            qr[0] = cosf(theta);
+            const float s = sinc_ode(theta) * hh;
+            qr[1] = b.avel[0] * s; qr[2] = b.avel[1] * s; qr[3] = b.avel[2] * s;
+            qmul0(q2, qr, b.q);
+            b.q[0] = q2[0]; b.q[1] = q2[1]; b.q[2] = q2[2]; b.q[3] = q2[3];
+        }
+        normalize4(b.q);
+        rFromQ(b.R, b.q);
+        for (int k = 0; k < 3; ++k) { b.facc[k] = 0; b.tacc[k] = 0; }
+    }
+}
+
+}  // namespace pdrb

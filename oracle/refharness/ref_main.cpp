@@ -1,0 +1,223 @@
+// ORACLE / TEST INFRASTRUCTURE (fixture generator; runs only in the build container, where
+// /root/reference is mounted).  Drives the reference's own Simulator / Track / Car translation
+// units (compiled in place from /root/reference/src/ProjectD, never copied) through the exact call
+// sequence of pyprojectd/projectd_env.py:118-227 and records a probe vector per tick.  The
+// rigid-body engine behind IPhysicsEngine is this project's pdrb (see ref_physics.cpp): everything
+// above that seam -- suspension, tyre, drivetrain, engine, aero, assists, scoring, track queries --
+// is the reference's code; the solver is not (ODE absent => that part is unpinned).
+#include "Sim/Simulator.h"
+#include "Sim/Track.h"
+#include "Car/CarImpl.h"
+#include "ref_physics.h"
+#include "../probe.h"
+#include "../scenarios.h"
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <map>
+
+using namespace D;
+using pdoracle::Probe;
+
+static void fillProbe(Probe& P, Simulator* sim, Car* car) {
+    pdrb::World* w = ref_get_world(sim->physics.get());
+    P.p("time", sim->physicsTime);
+    auto* s0 = (SuspensionStrut*)car->suspensions[0];
+    auto* s1 = (SuspensionStrut*)car->suspensions[1];
+    IRigidBody* bodies[7] = {car->body.get(), car->fuelTankBody.get(), car->rigidAxle.get(), s0->hub.get(),
+                             s0->strutBody.get(), s1->hub.get(), s1->strutBody.get()};
+    const char* bn[7] = {"chassis", "tank", "axle", "hub0", "strut0", "hub1", "strut1"};
+    char nm[96];
+    for (int i = 0; i < 7; ++i) {
+        const pdrb::Body& b = w->bodies[ref_body_id(bodies[i])];
+        snprintf(nm, sizeof(nm), "%s.pos", bn[i]); P.p3(nm, b.pos);
+        snprintf(nm, sizeof(nm), "%s.q", bn[i]); P.pn(nm, b.q, 4);
+        snprintf(nm, sizeof(nm), "%s.R", bn[i]); P.pn(nm, b.R, 9);
+        snprintf(nm, sizeof(nm), "%s.lvel", bn[i]); P.p3(nm, b.lvel);
+        snprintf(nm, sizeof(nm), "%s.avel", bn[i]); P.p3(nm, b.avel);
+    }
+    const auto& c = car->controls;
+    P.p("ctrl.steer", c.steer); P.p("ctrl.clutch", c.clutch); P.p("ctrl.brake", c.brake);
+    P.p("ctrl.handBrake", c.handBrake); P.p("ctrl.gas", c.gas); P.p("ctrl.gearUp", c.gearUp); P.p("ctrl.gearDn", c.gearDn);
+    P.p("car.finalSteerAngleSignal", car->finalSteerAngleSignal);
+    P.p("car.smoothSteerValue", car->smoothSteerValue);
+    P.p3("car.accG", &car->accG.x);
+    P.p("car.sleepingFrames", car->sleepingFrames);
+    P.p("car.speed", car->speed.value);
+    P.p3("car.lastVelocity", &car->lastVelocity.x);
+    P.p("car.waterT", car->water->t);
+    P.p("car.fuel", car->fuel);
+    P.p("aero.airDensity", car->aeroMap->airDensity);
+    for (int i = 0; i < 4; ++i) {
+        Tyre* t = car->tyres[i].get();
+        const TyreStatus& st = t->status;
+#define TP(field, val) snprintf(nm, sizeof(nm), "tyre%d." field, i); P.p(nm, val)
+        TP("angularVelocity", st.angularVelocity); TP("slipAngleRAD", st.slipAngleRAD); TP("slipRatio", st.slipRatio);
+        TP("ndSlip", st.ndSlip); TP("load", st.load); TP("Fx", st.Fx); TP("Fy", st.Fy); TP("Mz", st.Mz);
+        TP("isLocked", st.isLocked ? 1 : 0); TP("dirtyLevel", st.dirtyLevel); TP("flatSpot", st.flatSpot);
+        TP("inflation", st.inflation); TP("pressureDynamic", st.pressureDynamic); TP("pressureStatic", st.pressureStatic);
+        TP("loadedRadius", st.loadedRadius); TP("effectiveRadius", st.effectiveRadius); TP("liveRadius", st.liveRadius);
+        TP("camberRAD", st.camberRAD); TP("D", st.D); TP("Dx", st.Dx); TP("Dy", st.Dy); TP("depth", st.depth);
+        TP("distToGround", st.distToGround); TP("feedbackTorque", st.feedbackTorque);
+        TP("rollingResistence", st.rollingResistence); TP("thermalInput", st.thermalInput);
+        TP("slipFactor", st.slipFactor); TP("virtualKM", st.virtualKM); TP("wearMult", st.wearMult);
+        TP("grain", st.grain); TP("blister", st.blister);
+        TP("localMX", t->localMX); TP("oldAngularVelocity", t->oldAngularVelocity);
+        TP("totalHubVelocity", t->totalHubVelocity); TP("slidingVelocityX", t->slidingVelocityX);
+        TP("slidingVelocityY", t->slidingVelocityY); TP("roadVelocityX", t->roadVelocityX);
+        TP("brakeTorque", t->inputs.brakeTorque); TP("handBrakeTorque", t->inputs.handBrakeTorque);
+        snprintf(nm, sizeof(nm), "tyre%d.contactPoint", i); P.p3(nm, &t->contactPoint.x);
+        snprintf(nm, sizeof(nm), "tyre%d.unmodifiedContactPoint", i); P.p3(nm, &t->unmodifiedContactPoint.x);
+        snprintf(nm, sizeof(nm), "tyre%d.contactNormal", i); P.p3(nm, &t->contactNormal.x);
+        TyreThermalModel* th = t->thermalModel.get();
+        TP("coreTemp", th->coreTemp); TP("phase", th->phase); TP("thermalMultD", th->thermalMultD);
+        TP("practicalTemp", th->practicalTemp);
+        for (int k = 0; k < 36; ++k) { snprintf(nm, sizeof(nm), "tyre%d.T[%d]", i, k); P.p(nm, th->patches[k].T); }
+        auto ss = car->suspensions[i]->getStatus();
+        TP("susp.travel", ss.travel); TP("susp.damperSpeedMS", ss.damperSpeedMS);
+#undef TP
+    }
+    Drivetrain* d = car->drivetrain.get();
+    Engine* e = d->engineModel.get();
+    P.p("dt.engine.velocity", d->engine.velocity); P.p("dt.drive.velocity", d->drive.velocity);
+    P.p("dt.outShaftL.velocity", d->outShaftL.velocity); P.p("dt.outShaftR.velocity", d->outShaftR.velocity);
+    P.p("dt.rootVelocity", d->rootVelocity); P.p("dt.locClutch", d->locClutch);
+    P.p("dt.currentClutchTorque", d->currentClutchTorque); P.p("dt.ratio", d->ratio); P.p("dt.lastRatio", d->lastRatio);
+    P.p("dt.cutOff", d->cutOff); P.p("dt.totalTorque", d->totalTorque); P.p("dt.currentGear", d->currentGear);
+    P.p("dt.isGearGrinding", d->isGearGrinding ? 1 : 0); P.p("dt.clutchOpenState", d->clutchOpenState ? 1 : 0);
+    P.p("dt.gearRequest.request", (int)d->gearRequest.request); P.p("dt.gearRequest.timeAccumulator", d->gearRequest.timeAccumulator);
+    P.p("dt.gearRequest.timeout", d->gearRequest.timeout); P.p("dt.gearRequest.requestedGear", d->gearRequest.requestedGear);
+    P.p("dt.validShiftRPMWindow", d->validShiftRPMWindow);
+    P.p("eng.outTorque", e->status.outTorque); P.p("eng.limiterOn", e->limiterOn); P.p("eng.lifeLeft", e->lifeLeft);
+    P.p("eng.gasUsage", e->gasUsage); P.p("eng.fuelPressure", e->fuelPressure); P.p("eng.turboBoost", e->status.turboBoost);
+    P.p("ac.clutchValueSignal", car->autoClutch->clutchValueSignal);
+    P.p("ac.seq.currentTime", car->autoClutch->clutchSequence.currentTime);
+    P.p("ac.seq.isDone", car->autoClutch->clutchSequence.isDone ? 1 : 0);
+    P.p("ac.seq.count", car->autoClutch->clutchSequence.clutchCurve.getCount());
+    P.p("ab.blipStartTime", car->autoBlip->blipStartTime);
+    P.p("as.gasCutoff", car->autoShift->gasCutoff);
+    P.p("gc.lastGearUp", car->gearChanger->lastGearUp ? 1 : 0); P.p("gc.lastGearDn", car->gearChanger->lastGearDn ? 1 : 0);
+    for (size_t i = 0; i < car->aeroMap->wings.size(); ++i) {
+        const WingState& ws = car->aeroMap->wings[i]->status;
+#define WP(field, val) snprintf(nm, sizeof(nm), "wing%d." field, (int)i); P.p(nm, val)
+        WP("aoa", ws.aoa); WP("yawAngle", ws.yawAngle); WP("cd", ws.cd); WP("cl", ws.cl);
+        WP("dragKG", ws.dragKG); WP("liftKG", ws.liftKG); WP("groundHeight", ws.groundHeight);
+#undef WP
+    }
+    P.p("trk.nearestTrackPointId", car->nearestTrackPointId); P.p("trk.oldTrackPointId", car->oldTrackPointId);
+    P.p("trk.splinePointId", car->splinePointId); P.p("trk.lastTrackPointTimestamp", car->lastTrackPointTimestamp);
+    P.p("trk.trackLocation", car->trackLocation); P.p("trk.oldTrackLocation", car->oldTrackLocation);
+    P.p("trk.bodyVsTrack", car->bodyVsTrack); P.p("trk.velocityVsTrack", car->velocityVsTrack);
+    for (int i = 0; i < 7; ++i) { snprintf(nm, sizeof(nm), "trk.probe[%d]", i); P.p(nm, car->probeHits[i]); }
+    for (int i = 0; i < 5; ++i) { snprintf(nm, sizeof(nm), "trk.lookAhead[%d]", i); P.p(nm, car->lookAhead[i]); }
+    ScoringSystem* sc = car->scoring.get();
+    P.p("sc.stepReward", sc->stepReward); P.p("sc.totalReward", sc->totalReward);
+    P.p("sc.oldPointId", sc->oldPointId); P.p("sc.oldSplinePointId", sc->oldSplinePointId);
+    P.p("sc.drifting", sc->drifting ? 1 : 0); P.p("sc.driftExtreme", sc->driftExtreme ? 1 : 0);
+    P.p("sc.driftInvalid", sc->driftInvalid ? 1 : 0); P.p("sc.currentDriftAngle", sc->currentDriftAngle);
+    P.p("sc.currentSpeedMultiplier", sc->currentSpeedMultiplier); P.p("sc.lastDriftDirection", sc->lastDriftDirection);
+    P.p("sc.driftStraightTimer", sc->driftStraightTimer); P.p("sc.instantDriftDelta", sc->instantDriftDelta);
+    P.p("sc.instantDrift", sc->instantDrift); P.p("sc.driftPoints", sc->driftPoints);
+    P.p("sc.driftComboCounter", sc->driftComboCounter);
+    P.p("car.collisionFlag", car->collisionFlag ? 1 : 0); P.p("car.outOfTrackFlag", car->outOfTrackFlag ? 1 : 0);
+    // CarState (what getCarState hands to python)
+    const CarState& cs = *car->state;
+    P.p("cs.timestamp", cs.timestamp); P.p("cs.engineRPM", cs.engineRPM); P.p("cs.speedMS", cs.speedMS);
+    P.p("cs.gear", cs.gear); P.p("cs.gearGrinding", cs.gearGrinding);
+    P.p("cs.trackPointId", cs.trackPointId); P.p("cs.lastTrackPointTimestamp", cs.lastTrackPointTimestamp);
+    P.p3("cs.bodyEuler", &cs.bodyEuler.x); P.p3("cs.accG", &cs.accG.x); P.p3("cs.velocity", &cs.velocity.x);
+    P.p3("cs.localVelocity", &cs.localVelocity.x); P.p3("cs.angularVelocity", &cs.angularVelocity.x);
+    P.p3("cs.localAngularVelocity", &cs.localAngularVelocity.x);
+    for (int i = 0; i < 4; ++i) { snprintf(nm, sizeof(nm), "cs.hubMatrix%d", i); P.pn(nm, cs.hubMatrix[i].dim1, 16); }
+    for (int i = 0; i < 4; ++i) { snprintf(nm, sizeof(nm), "cs.tyreContacts%d", i); P.p3(nm, &cs.tyreContacts[i].x); }
+    P.pn("cs.tyreLoad", cs.tyreLoad.data(), 4); P.pn("cs.tyreAngularSpeed", cs.tyreAngularSpeed.data(), 4);
+    P.pn("cs.tyreSlipRatio", cs.tyreSlipRatio.data(), 4); P.pn("cs.tyreNdSlip", cs.tyreNdSlip.data(), 4);
+    P.pn("cs.probes", cs.probes.data(), 7); P.pn("cs.lookAhead", cs.lookAhead.data(), 5);
+    P.p("cs.stepReward", cs.stepReward); P.p("cs.totalReward", cs.totalReward);
+}
+
+struct Env {
+    std::shared_ptr<Simulator> sim;
+    Car* car = nullptr;
+    double dt = 1.0 / 333.0;  // projectd_env.py:19
+    CarControls dcontrols;    // persistent python-side object (projectd_env.py:135)
+
+    void init(const std::string& base, const std::string& track, const std::string& model) {
+        // projectd_env.py:118-136, PyProjectD.cpp:111-137
+        sim = std::make_shared<Simulator>();
+        sim->simulatorId = 0;
+        sim->init(strw(base));
+        sim->loadTrack(strw(track));
+        car = sim->addCar(strw(model));
+        car->teleportByMode(TeleportMode::Start);
+        car->teleportOnCollision = false; car->teleportOnBadLocation = false; car->teleportMode = 0;
+        car->autoClutch->useAutoOnStart = true; car->autoClutch->useAutoOnChange = true;
+        car->autoShift->isActive = true; car->autoBlip->isActive = true;
+        const std::pair<const char*, float> tunes[] = {{"FRONT_BIAS", 55.0f}, {"DIFF_POWER", 30.0f}, {"DIFF_COAST", 30.0f},
+            {"FINAL_RATIO", 5.0f}, {"PRESSURE_LF", 28.0f}, {"PRESSURE_RF", 28.0f}, {"PRESSURE_LR", 28.0f}, {"PRESSURE_RR", 28.0f}};
+        if (model == "ks_toyota_ae86_drift")
+            for (auto& t : tunes) car->setup->setTune(t.first, t.second);
+        const std::pair<const char*, float> svars[] = {{"SmoothSteerSpeed", 10.0f}, {"MinBonusSpeed", 5.0f}, {"MaxBonusSpeed", 200.0f},
+            {"StallRpm", 300.0f}, {"DirectionThreshold", 0.75f}, {"OutOfTrackThreshold", 0.51f}, {"ApproachDistance", 3.5f},
+            {"CriticalDistance", 2.0f}, {"TravelBonus", 0.1f}, {"TravelSplineBonus", 0.01f}, {"DriftBonus", 0.0f}, {"SpeedBonus", 0.0f},
+            {"ThrottleBonus", 0.0f}, {"EngineRpmBonus", 0.0f}, {"DirectionBonus", 0.0f}, {"DirectionPenalty", 0.0f},
+            {"ObstApproachPenalty", 0.0f}, {"CollisionPenalty", 0.0f}, {"OffTrackPenalty", 0.0f}, {"GearGrindPenalty", 0.0f},
+            {"StallPenalty", 0.0f}};
+        for (auto& v : svars) car->scoring->config->setVar(v.first, v.second);
+    }
+    void step(float a0, float a1) {
+        // projectd_env.py:157-171, PyProjectD.cpp:160-180,297-305
+        dcontrols.steer = a0;
+        dcontrols.gas = pdoracle::envGas(a1);
+        car->controls = dcontrols;
+        car->smoothSteer = true;
+        sim->step((float)dt, sim->physicsTime, sim->gameTime);
+        sim->physicsTime += dt;
+        sim->gameTime += dt;
+    }
+    void reset() {
+        // projectd_env.py:216-227
+        car->teleportByMode(TeleportMode::Start);
+        step(0.0f, 0.0f);
+    }
+};
+
+int main(int argc, char** argv) {
+    if (argc < 4) { fprintf(stderr, "usage: %s <basePath> <track> <outDir> [car] [-v]\n", argv[0]); return 2; }
+    const std::string base = argv[1], track = argv[2], outDir = argv[3];
+    std::string model = "ks_toyota_ae86_drift";
+    for (int i = 4; i < argc; ++i) { if (!strcmp(argv[i], "-v")) ref_enable_log(true); else model = argv[i]; }
+    try {
+        for (int sid = 0; sid < pdoracle::kNumScenarios; ++sid) {
+            const auto& sc = pdoracle::kScenarios[sid];
+            INIReader::flushCache();
+            Env env;
+            env.init(base, track, model);
+            pdoracle::ProbeFile pf;
+            env.reset();
+            {
+                Probe P; P.names = &pf.names;
+                fillProbe(P, env.sim.get(), env.car);
+                pf.add(-1, 0.0f, 0.0f, P);
+            }
+            for (int t = 0; t < sc.ticks; ++t) {
+                float a0, a1;
+                pdoracle::scenarioAction(sid, t, a0, a1);
+                env.step(a0, a1);
+                if (pdoracle::scenarioRecord(sc, t)) {
+                    Probe P;
+                    fillProbe(P, env.sim.get(), env.car);
+                    pf.add(t, a0, a1, P);
+                }
+            }
+            const std::string path = outDir + "/" + track + "_" + sc.name + ".bin";
+            if (!pf.write(path.c_str())) { fprintf(stderr, "cannot write %s\n", path.c_str()); return 1; }
+            fprintf(stderr, "wrote %s: %d records x %d fields\n", path.c_str(), (int)pf.ticks.size(), pf.nfields);
+        }
+    } catch (const std::exception& ex) {
+        fprintf(stderr, "EXCEPTION: %s\n", ex.what());
+        return 1;
+    }
+    return 0;
+}
