@@ -1,0 +1,279 @@
+/* pdbatch -- MI355X-native batched vehicle-dynamics stepper (ProjectD-compatible).
+ *
+ * Plain-C data formats shared by the host library, the HIP kernels and (as documented input /
+ * output data) the test oracle.  All structs are POD with fixed layout; no pointers.
+ *
+ * Reference anchors (relative to /root/reference/src/ProjectD):
+ *   pdb_controls   <- Car/CarControls.h:9-20      (24 B, #pragma pack(4))
+ *   pdb_car_state  <- Car/CarState.h:11-56        (664 B, what getCarState copies to Python)
+ *   pdb_car_params <- every `// config` block of Car/*.h that Car::step reads
+ *   pdb_dyn_state  <- every `// runtime` member that survives from one tick to the next
+ */
+#ifndef PDB_TYPES_H
+#define PDB_TYPES_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PDB_MAX_CURVE 24
+#define PDB_MAX_BODIES 8
+#define PDB_MAX_JOINTS 16
+#define PDB_MAX_ROWS 40
+#define PDB_MAX_WINGS 4
+#define PDB_MAX_GEARS 10
+#define PDB_NUM_PROBES 7
+#define PDB_NUM_LOOKAHEAD 5
+#define PDB_OBS_DIM 24
+
+/* piecewise-linear LUT with clamped ends (Core/Curve.cpp:94-115) */
+typedef struct pdb_curve {
+    int32_t n;
+    float x[PDB_MAX_CURVE];
+    float y[PDB_MAX_CURVE];
+} pdb_curve;
+
+/* Car/CarControls.h:9-20 */
+#pragma pack(push, 4)
+typedef struct pdb_controls {
+    float steer, clutch, brake, handBrake, gas;
+    int8_t isShifterSupported, requestedGearIndex, gearUp, gearDn;
+} pdb_controls;
+
+/* Car/CarState.h:11-56 -- identical field order and packing */
+typedef struct pdb_car_state {
+    int32_t carId, simId;
+    float timestamp;
+    pdb_controls controls;
+    int32_t collisionFlag, outOfTrackFlag, trackPointId;
+    float lastTrackPointTimestamp, trackLocation, bodyVsTrack, velocityVsTrack;
+    float engineRPM, speedMS;
+    int32_t gear, gearGrinding;
+    float bodyMatrix[16];
+    float bodyPos[3], bodyEuler[3], accG[3], velocity[3], localVelocity[3], angularVelocity[3], localAngularVelocity[3];
+    float hubMatrix[4][16];
+    float tyreContacts[4][3];
+    float tyreLoad[4], tyreAngularSpeed[4], tyreSlipRatio[4], tyreNdSlip[4];
+    float probes[10];
+    float lookAhead[5];
+    float stepReward, totalReward;
+} pdb_car_state;
+#pragma pack(pop)
+
+/* ---------------------------------------------------------------------------------------------
+ * Per-model constant block
+ * ------------------------------------------------------------------------------------------- */
+enum { PDB_JOINT_FIXED = 0, PDB_JOINT_BALL = 1, PDB_JOINT_SLIDER = 2, PDB_JOINT_DBALL = 3 };
+enum { PDB_SUSP_DW = 0, PDB_SUSP_STRUT = 1, PDB_SUSP_AXLE = 2, PDB_SUSP_ML = 3 };
+/* body slots */
+enum { PDB_BODY_CHASSIS = 0, PDB_BODY_TANK = 1, PDB_BODY_AXLE = 2, PDB_BODY_HUB0 = 3, PDB_BODY_STRUT0 = 4,
+       PDB_BODY_HUB1 = 5, PDB_BODY_STRUT1 = 6 };
+
+typedef struct pdb_body_def {
+    float mass;
+    float inertia[3];   /* diagonal of the body-frame inertia (dMassSetBoxTotal) */
+} pdb_body_def;
+
+/* joints are stored in SOLVER ROW ORDER (ODE island traversal order) */
+typedef struct pdb_joint_def {
+    int32_t type, b0, b1;
+    int32_t suspErp;     /* 1: Car::step rewrites ERP/CFM each tick (Car.cpp:426-448) */
+    int32_t steerWheel;  /* 0/1: this is wheel i's tie-rod DBall re-seated each tick; else -1 */
+    float erp, cfm;
+    float anchor1[3], anchor2[3];
+    float axis1[3], offset[3], qrel[4];
+    float distance;      /* DBall stored distance (JointODE.cpp:59) */
+} pdb_joint_def;
+
+typedef struct pdb_damper {
+    float bumpSlow, reboundSlow, bumpFast, reboundFast, fastThresholdBump, fastThresholdRebound;
+} pdb_damper;
+
+typedef struct pdb_susp {
+    int32_t type;
+    int32_t hubBody, strutBody;          /* body slots (axle: hubBody = axle) */
+    float k, progressiveK, bumpStopUp, bumpStopDn, bumpStopRate, rodLength, toeOutLinear, staticCamber, packerRange;
+    pdb_damper damper;
+    float basePosition[3];
+    /* strut (Car/SuspensionStrut.h:9-21,53-67) */
+    float carStrut[3];                   /* dataRelToBody.carStrut   (body-local) */
+    float tyreStrut[3];                  /* dataRelToWheel.tyreStrut (hub-local)  */
+    float tyreSteer[3];                  /* dataRelToWheel.tyreSteer (hub-local)  */
+    float baseCarSteer[3];               /* baseCarSteerPosition     (body-local) */
+    float refPointY, refPointSignX;
+    float strutBaseLength, strutBodyLength;
+    /* axle (Car/SuspensionAxle.h:52-62) */
+    float axleTrack, referenceY, attachRelativePos, leafSpringKx;
+    float axleBasePos[3];
+    float sideSign;                      /* +1 left, -1 right */
+    float mass;                          /* ISuspension::getMass() */
+} pdb_susp;
+
+typedef struct pdb_tyre {
+    /* TyreData / TyreModelData of compound 0 (Car/TyreCompound.h:9-75), after Tyre::setCompound */
+    float radius, rimRadius, k, d, angularInertia, thermalFrictionK, thermalRollingK, thermalRollingSurfaceK;
+    float radiusRaiseK, softnessIndex;
+    float Fz0;        /* SCTM::Fz0 = [FRONT|REAR] FZ0 (Tyre.cpp:369) */
+    float modelFz0;   /* TyreModelData::Fz0: never assigned by Tyre::initCompounds, stays at its default 2000 (TyreCompound.h:37); used by the relaxation-length filter (TyreForces.cpp:49) */
+    float relaxationLength, rr0, rr1, rr_slip, pressureRef, pressureSpringGain, pressureRRGain, pressureGainD, idealPressure;
+    float flatSpotK, explosionTemperature, pressureTemperatureGain, pressureStatic;
+    int32_t version, driven;
+    /* SCTM (Car/TyreModel.h:18-39) */
+    float lsMultY, lsExpY, lsMultX, lsExpX, maxSlip0, maxSlip1, asy, falloffSpeed, speedSensitivity, camberGain;
+    float dcamber0, dcamber1, cfXmult, pressureCfGain, brakeDXMod, dCamberBlend, combinedFactor;
+    /* thermal (Car/TyreThermalModel.h, Car/TyreCompound.h:77-84) */
+    float surfaceTransfer, patchTransfer, patchCoreTransfer, internalCoreTransfer, coolFactorGain, camberSpreadK;
+    pdb_curve performanceCurve;
+    pdb_curve wearCurve;
+} pdb_tyre;
+
+typedef struct pdb_wing {
+    float position[3];
+    float area, cdGain, clGain, yawGain, angle;
+    int32_t isVertical;
+    pdb_curve lutAOA_CL, lutAOA_CD;
+} pdb_wing;
+
+typedef struct pdb_scoring {
+    float SmoothSteerSpeed, MinBonusSpeed, MaxBonusSpeed, StallRpm, DirectionThreshold, OutOfTrackThreshold,
+        ApproachDistance, CriticalDistance, TravelBonus, TravelSplineBonus, DriftBonus, SpeedBonus, ThrottleBonus,
+        EngineRpmBonus, DirectionBonus, DirectionPenalty, ObstApproachPenalty, CollisionPenalty, OffTrackPenalty,
+        GearGrindPenalty, StallPenalty;
+} pdb_scoring;
+
+typedef struct pdb_car_params {
+    int32_t magic;            /* 'PDCP' */
+    int32_t version;
+    /* rigid-body topology */
+    int32_t numBodies, numJoints, numRows;
+    pdb_body_def bodies[PDB_MAX_BODIES];
+    pdb_joint_def joints[PDB_MAX_JOINTS];
+    float worldErp, worldCfm;
+    float gravity[3];
+    /* car (Car/Car.h:118-147) */
+    int32_t suspTypeF, suspTypeR;
+    float mass, steerLock, steerRatio, steerLinearRatio, axleTorqueReaction;
+    float fuelTankPos[3];
+    float fuel, fuelKG, fuelConsumptionK;
+    float baseCarHeight;
+    float arbK[2];
+    float waterTmass, waterCoolSpeedK;
+    float probeDir[PDB_NUM_PROBES][3];
+    float probeLen[PDB_NUM_PROBES];
+    int32_t lookAheadCount;
+    float lookAheadStep;
+    /* sim (Sim/Simulator.cpp:33-60) */
+    float ambientTemperature, roadTemperature, mechanicalDamageRate, tyreConsumptionRate, fuelConsumptionRate;
+    float airDensity;          /* Simulator::getAirDensity() */
+    pdb_susp susp[4];
+    pdb_tyre tyre[4];
+    int32_t numWings;
+    pdb_wing wings[PDB_MAX_WINGS];
+    /* brakes (Car/BrakeSystem.h:44-52) */
+    float brakePower, brakePowerMultiplier, handBrakeTorque, frontBias, biasMin, biasMax;
+    /* drivetrain (Car/Drivetrain.h:103-121) -- doubles where the reference holds doubles */
+    int32_t tractionType, diffType, numGears, isShifterSupported;
+    double gearRatio[PDB_MAX_GEARS];
+    double finalRatio, diffPowerRamp, diffCoastRamp, diffPreLoad, gearUpTime, gearDnTime, autoCutOffTime;
+    double controlsWindowGain, validShiftRPMWindow, damageRpmWindow, clutchMaxTorque, clutchInertia;
+    double driveInertia, engineInertiaInit, outShaftInertiaL, outShaftInertiaR;
+    /* engine (Car/Engine.h:11-23,58-92) */
+    pdb_curve powerCurve, throttleCurve;
+    int32_t engMinimum, engLimiter, engLimiterCycles;
+    float engCoast1, engCoast2, engInertia, limiterMultiplier, rpmDamageThreshold, rpmDamageK, bovThreshold;
+    float maxPowerRPM, maxTorqueRPM;
+    /* assists */
+    float acRpmMin, acRpmMax, acClutchSpeed;
+    int32_t acUseOnChange, acUseOnStart, autoShiftActive, autoBlipActive, autoBlipElectronic;
+    pdb_curve upshiftProfile, downshiftProfile, blipProfile;
+    double blipPerformTime;
+    int32_t asChangeUpRpm, asChangeDnRpm;
+    float asSlipThreshold, asGasCutoffTime;
+    int32_t smoothSteer;
+    /* thermal patch connection table (Car/TyreThermalModel.cpp:31-58 build order) */
+    int8_t patchConnCount[36];
+    int8_t patchConn[36][4];
+    pdb_scoring scoring;
+} pdb_car_params;
+
+/* ---------------------------------------------------------------------------------------------
+ * Per-car persistent state (everything that lives from one tick to the next)
+ * ------------------------------------------------------------------------------------------- */
+typedef struct pdb_body_state {
+    float pos[3];
+    float q[4];
+    float R[9];
+    float lvel[3];
+    float avel[3];
+} pdb_body_state;   /* 22 floats */
+
+typedef struct pdb_tyre_state {
+    double flatSpot, virtualKM, phase;
+    float angularVelocity, slipAngleRAD, slipRatio, ndSlip, load, Fx, Fy, Mz;
+    float dirtyLevel, inflation, pressureDynamic, loadedRadius, effectiveRadius, camberRAD, D, localMX, oldAngularVelocity;
+    float contactPoint[3], unmodifiedContactPoint[3], contactNormal[3];
+    float coreTemp, thermalMultD, practicalTemp;
+    float T[36];
+    int32_t isLocked;
+    float inputT0;   /* TyreThermalPatch::inputT of every patch before the first thermal step (buildTyre sets it to ambient; 0 afterwards) */
+} pdb_tyre_state;
+
+typedef struct pdb_dyn_state {
+    /* doubles first (8-byte aligned) */
+    double physicsTime;
+    double engineVel, driveVel, outShaftLVel, outShaftRVel, rootVelocity;
+    double gearReqTimeAccumulator, gearReqTimeout, cutOff, lastRatio, validShiftRPMWindow;
+    double blipStartTime, fuel;
+    pdb_body_state body[PDB_MAX_BODIES];
+    pdb_tyre_state tyre[4];
+    /* car */
+    float smoothSteerValue, lastVelocity[3], waterT, lastTrackPointTimestamp, trackLocation, oldTrackLocation;
+    float bodyVsTrack, velocityVsTrack, pointCachePos[3], speed;
+    int32_t sleepingFrames, nearestTrackPointId, oldTrackPointId, splinePointId;
+    /* drivetrain / engine / assists */
+    int32_t currentGear, gearReqRequest, gearReqRequestedGear, clutchOpenState, isGearGrinding;
+    int32_t limiterOn, lastGearUp, lastGearDn, acSeqActive, acSeqIsDone;
+    float lifeLeft, fuelPressure, acClutchValueSignal, acSeqCurrentTime, asGasCutoff;
+    /* scoring */
+    float totalReward, stepReward, currentDriftAngle, currentSpeedMultiplier, lastDriftDirection, driftStraightTimer;
+    float instantDriftDelta, instantDrift, driftPoints;
+    int32_t oldPointId, oldSplinePointId, drifting, driftExtreme, driftInvalid, driftComboCounter;
+    int32_t collisionFlag, oldCollisionFlag, outOfTrackFlag;
+    int32_t _pad;
+} pdb_dyn_state;
+
+/* per-tick outputs (compact) */
+typedef struct pdb_step_out {
+    float obs[PDB_OBS_DIM];   /* projectd_env.py:237-275 order */
+    float reward;             /* CarState.stepReward */
+    int32_t flags;            /* bit0 collisionFlag, bit1 outOfTrackFlag, bit2 stuck (lastTrackPointTimestamp + 5 < timestamp) */
+} pdb_step_out;
+
+/* ---------------------------------------------------------------------------------------------
+ * Track blob: header followed by arrays (offsets in bytes from the start of the blob)
+ * ------------------------------------------------------------------------------------------- */
+typedef struct pdb_surface {
+    float gripMod, damping, sinHeight, sinLength, granularity, dirtAdditiveK;
+    int32_t collisionCategory, isValidTrack, triStart, triCount, sectorID, _pad;
+} pdb_surface;
+
+typedef struct pdb_track_header {
+    int32_t magic;   /* 'PDTK' */
+    int32_t version;
+    int32_t numSurfaces, numTris, numFat, numNodes;
+    int32_t interpolateStep, closedLoop;
+    float computedTrackLength, computedTrackWidth, dynamicGripLevel, hashCellSize;
+    uint64_t offSurfaces;   /* pdb_surface[numSurfaces] */
+    uint64_t offTris;       /* float[numTris][9]  (v0,v1,v2) */
+    uint64_t offFat;        /* float[numFat][15]  best,left,right,center,forwardDir (Sim/Track.h:18-25) */
+    uint64_t offFatDist;    /* float[numFat] */
+    uint64_t offNodes;      /* float[numNodes][3] interpolated B-spline nodes */
+    uint64_t offNodeDist;   /* float[numNodes] */
+    uint64_t totalBytes;
+} pdb_track_header;
+
+#ifdef __cplusplus
+}
+#endif
+#endif

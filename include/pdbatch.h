@@ -1,0 +1,91 @@
+/* pdbatch C ABI -- the drop-in boundary of the MI355X-native batched vehicle stepper.
+ *
+ * One pdb_batch = N independent (simulator, car) pairs of the reference, all on one track with one
+ * car model, resident on one GPU.  Each entry point names the reference interface it replaces
+ * (reference src/PyProjectD/PyProjectD.cpp unless stated otherwise):
+ *
+ *   pdb_build_car_model      addCar(simId, model)              :219-237 -> Car::init        (load-time half)
+ *   pdb_set_car_tune         setCarTune / setCarRawTune        :328-345 -> SetupManager::setTune/setRawTune
+ *   pdb_set_scoring_var      setScoringVar / getScoringVar     :347-365
+ *   pdb_build_track          loadTrack(simId, name)            :186-203 -> Track::init
+ *   pdb_initial_state        addCar + teleportCarByMode(Start) :219-237,283-290
+ *   pdb_teleport_to_spline   teleportCarToSpline               :274-281
+ *   pdb_create / pdb_destroy createSimulator / destroySimulator:111-149 (x N)
+ *   pdb_set_assists          setCarAssists                     :307-317
+ *   pdb_step / pdb_step_host setCarControls + stepSimulator + getCarState   :297-305,160-180,319-326
+ *   pdb_get_car_state        getCarState                       :319-326 (664-byte CarState per car)
+ *   pdb_reset                teleportCarByMode(mode=Start) for a mask of cars (projectd_env.py:216-227)
+ *
+ * Conventions: plain pointers and sizes, caller-owned buffers, no exceptions across the ABI.
+ * Functions returning int give 0 on success and a negative pdb_status on failure;
+ * pdb_last_error() returns the message of the calling thread's last failure.
+ * There is NO CPU fallback: device entry points fail with PDB_ERR_NO_DEVICE when no GPU is usable.
+ */
+#ifndef PDBATCH_H
+#define PDBATCH_H
+#include "pdb_types.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct pdb_batch pdb_batch;
+
+enum pdb_status {
+    PDB_OK = 0,
+    PDB_ERR_ARG = -1,        /* bad argument */
+    PDB_ERR_IO = -2,         /* missing / malformed content file, unsupported car feature */
+    PDB_ERR_NO_DEVICE = -3,  /* no usable HIP device */
+    PDB_ERR_HIP = -4         /* HIP runtime error */
+};
+
+enum pdb_action_mode {
+    PDB_ACTION_CONTROLS = 0, /* actions[i] = {steer, gas}          (CarControls fields) */
+    PDB_ACTION_ENV = 1       /* actions[i] = {a0, a1}: steer = a0, gas = linscale(a1,-1,1,0.1,1) (projectd_env.py:159-160) */
+};
+
+const char* pdb_last_error(void);
+const char* pdb_version(void);
+
+/* ---- host-side content (no device needed) ---- */
+int pdb_build_car_model(const char* base_path, const char* model_name, pdb_car_params* out);
+int pdb_set_car_tune(pdb_car_params* params, const char* base_path, const char* model_name, const char* name, float value, int raw);
+int pdb_set_scoring_var(pdb_car_params* params, const char* name, float value);
+float pdb_get_scoring_var(const pdb_car_params* params, const char* name);
+int pdb_set_assists(pdb_car_params* params, int auto_clutch, int auto_shift, int auto_blip, int smooth_steer);
+/* *blob is malloc'ed; release with pdb_free */
+int pdb_build_track(const char* base_path, const char* track_name, void** blob, uint64_t* bytes);
+void pdb_free(void* p);
+int pdb_initial_state(const pdb_car_params* params, const void* track_blob, pdb_dyn_state* out);
+int pdb_teleport_to_spline(const pdb_car_params* params, const void* track_blob, float distance_norm, pdb_dyn_state* inout);
+
+/* ---- device batch ---- */
+pdb_batch* pdb_create(int device, int n_cars, const pdb_car_params* params, const void* track_blob, uint64_t track_bytes,
+                      int action_mode);
+void pdb_destroy(pdb_batch* b);
+int pdb_num_cars(const pdb_batch* b);
+/* every car <- *state (broadcast) or states[first..first+count) */
+int pdb_set_state_all(pdb_batch* b, const pdb_dyn_state* state);
+int pdb_set_state(pdb_batch* b, int first, int count, const pdb_dyn_state* states);
+int pdb_get_state(pdb_batch* b, int first, int count, pdb_dyn_state* states);
+/* teleportCarByMode(Start) for cars with mask[i] != 0 (mask == NULL: all cars); host mask */
+int pdb_reset(pdb_batch* b, const uint8_t* mask);
+/* device pointers owned by the batch: float actions[N][2], pdb_step_out out[N] */
+float* pdb_actions_device(pdb_batch* b);
+pdb_step_out* pdb_out_device(pdb_batch* b);
+void* pdb_stream(pdb_batch* b);
+/* one tick of every car, reading pdb_actions_device and writing pdb_out_device; asynchronous on pdb_stream */
+int pdb_step(pdb_batch* b, float dt);
+/* n back-to-back ticks with the current actions (launch-overhead-free replay of a captured graph when n > 1) */
+int pdb_step_n(pdb_batch* b, float dt, int n);
+int pdb_sync(pdb_batch* b);
+/* convenience: upload actions, one tick, download outputs */
+int pdb_step_host(pdb_batch* b, const float* actions, float dt, pdb_step_out* out);
+int pdb_get_car_state(pdb_batch* b, int first, int count, pdb_car_state* out);
+/* average device time of the step kernel over the launches since the last call, in microseconds (HIP events) */
+int pdb_kernel_time_us(pdb_batch* b, double* avg_us, int* launches);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

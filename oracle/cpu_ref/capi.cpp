@@ -1,0 +1,86 @@
+// ORACLE / TEST INFRASTRUCTURE -- C API over cpu_ref for ctypes (tests, smoke, bench cpu_baseline leg).
+#include "cpu_ref.h"
+#include "../scenarios.h"
+#include <cstring>
+#include <vector>
+#include <string>
+#include <chrono>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+struct CpuRefHandle {
+    pdb_car_params P;
+    std::vector<uint8_t> blob;
+    cpuref::TrackData T;
+    pdb_dyn_state s0;
+    cpuref::Car car;
+};
+
+extern "C" {
+
+void* cpuref_create(const pdb_car_params* P, const void* trackBlob, uint64_t trackBytes, const pdb_dyn_state* s0) {
+    auto* h = new CpuRefHandle();
+    h->P = *P;
+    h->blob.assign((const uint8_t*)trackBlob, (const uint8_t*)trackBlob + trackBytes);
+    h->T.bind(h->blob.data());
+    h->s0 = *s0;
+    h->car.init(&h->P, &h->T, *s0);
+    return h;
+}
+void cpuref_destroy(void* hh) { delete (CpuRefHandle*)hh; }
+void cpuref_set_state(void* hh, const pdb_dyn_state* s) { ((CpuRefHandle*)hh)->car.loadState(*s); }
+void cpuref_get_state(void* hh, pdb_dyn_state* s) { *s = ((CpuRefHandle*)hh)->car.S; }
+// controls-level step: steer, gas
+void cpuref_step(void* hh, float steer, float gas) {
+    ((CpuRefHandle*)hh)->car.step(steer, gas, (float)(1.0 / 333.0), 1.0 / 333.0);
+}
+// env-level step: a0, a1 (projectd_env.py:157-160)
+void cpuref_step_env(void* hh, float a0, float a1) {
+    ((CpuRefHandle*)hh)->car.step(a0, pdoracle::envGas(a1), (float)(1.0 / 333.0), 1.0 / 333.0);
+}
+void cpuref_get_out(void* hh, pdb_step_out* o) { ((CpuRefHandle*)hh)->car.fillStepOut(*o); }
+void cpuref_get_car_state(void* hh, pdb_car_state* cs) { ((CpuRefHandle*)hh)->car.fillCarState(*cs); }
+float cpuref_env_gas(float a1) { return pdoracle::envGas(a1); }
+int cpuref_num_scenarios(void) { return pdoracle::kNumScenarios; }
+const char* cpuref_scenario_name(int sid) { return pdoracle::kScenarios[sid].name; }
+
+// run one scripted scenario exactly like oracle/refharness/ref_main.cpp and write the probe file
+int cpuref_run_scenario(void* hh, int sid, const char* outPath) {
+    auto* h = (CpuRefHandle*)hh;
+    const auto& sc = pdoracle::kScenarios[sid];
+    h->car = cpuref::Car();
+    h->car.init(&h->P, &h->T, h->s0);
+    pdoracle::ProbeFile pf;
+    h->car.step(0.0f, pdoracle::envGas(0.0f), (float)(1.0 / 333.0), 1.0 / 333.0);   // env.reset(): teleport (already in s0) + step([0,0])
+    { pdoracle::Probe P; P.names = &pf.names; h->car.fillProbe(P); pf.add(-1, 0.0f, 0.0f, P); }
+    for (int t = 0; t < sc.ticks; ++t) {
+        float a0, a1;
+        pdoracle::scenarioAction(sid, t, a0, a1);
+        h->car.step(a0, pdoracle::envGas(a1), (float)(1.0 / 333.0), 1.0 / 333.0);
+        if (pdoracle::scenarioRecord(sc, t)) { pdoracle::Probe P; h->car.fillProbe(P); pf.add(t, a0, a1, P); }
+    }
+    return pf.write(outPath) ? 0 : -1;
+}
+
+// CPU baseline: step `ncars` independent cars for `ticks` ticks with per-car constant env actions;
+// returns elapsed seconds.  threads <= 1: single thread.
+double cpuref_bench(void* hh, int ncars, int ticks, const float* actions, int threads, pdb_step_out* lastOut) {
+    auto* h = (CpuRefHandle*)hh;
+    std::vector<cpuref::Car> cars(ncars);
+    for (int i = 0; i < ncars; ++i) cars[i].init(&h->P, &h->T, h->s0);
+    const auto t0 = std::chrono::steady_clock::now();
+#ifdef _OPENMP
+    if (threads > 1) omp_set_num_threads(threads);
+#pragma omp parallel for schedule(static) if (threads > 1)
+#endif
+    for (int i = 0; i < ncars; ++i) {
+        const float steer = actions[2 * i], gas = pdoracle::envGas(actions[2 * i + 1]);
+        for (int t = 0; t < ticks; ++t) cars[i].step(steer, gas, (float)(1.0 / 333.0), 1.0 / 333.0);
+    }
+    const auto t1 = std::chrono::steady_clock::now();
+    if (lastOut) for (int i = 0; i < ncars; ++i) cars[i].fillStepOut(lastOut[i]);
+    return std::chrono::duration<double>(t1 - t0).count();
+}
+
+}  // extern "C"

@@ -1,0 +1,77 @@
+// ORACLE / TEST INFRASTRUCTURE -- not product code.  Only tests/, __graft_entry__.smoke() and
+// bench.py's cpu_baseline leg may link or run this.
+//
+// cpu_ref: scalar, one-car-at-a-time CPU restatement of the reference's per-tick vehicle step
+//   Simulator::step -> Car::step -> stepComponents -> IPhysicsEngine::step -> Car::postStep
+// (reference src/ProjectD/Sim/Simulator.cpp:168-237, Car/Car.cpp:414-865), arithmetic in the
+// reference's own types (float, double where the reference holds double).  Each function cites the
+// reference lines it follows.  Input data (pdb_car_params, the track blob, pdb_dyn_state) use the
+// product's documented formats from include/pdb_types.h.
+//
+// Pinning: every quantity above the IPhysicsEngine seam is compared tick-by-tick against golden
+// trajectories produced by the reference's own translation units (oracle/refharness ->
+// tests/golden/*.npz).  The rigid-body solve (oracle/rb) is PARITY UNPINNED: ODE is absent.
+#pragma once
+#include "pdb_types.h"
+#include "../rb/pdrb.h"
+#include "../probe.h"
+#include <vector>
+#include <cstdint>
+
+namespace cpuref {
+
+struct TrackData {
+    const pdb_track_header* h = nullptr;
+    const pdb_surface* surfaces = nullptr;
+    const float* tris = nullptr;
+    const float* fat = nullptr;
+    const float* fatDist = nullptr;
+    const float* nodes = nullptr;
+    const float* nodeDist = nullptr;
+    void bind(const uint8_t* blob);
+};
+
+// per-tick scratch that is not persistent state but is observable (probe / CarState)
+struct TyreScratch {
+    float brakeTorque = 0, handBrakeTorque = 0, feedbackTorque = 0, rollingResistence = 0, thermalInput = 0;
+    float slipFactor = 0, Dx = 0, Dy = 0, depth = 0, distToGround = 0, liveRadius = 0, wearMult = 0;
+    float totalHubVelocity = 0, slidingVelocityX = 0, slidingVelocityY = 0, roadVelocityX = 0;
+    float travel = 0, damperSpeedMS = 0;
+    int surface = -1;
+    float hubMatrix[16];
+};
+struct WingScratch { float aoa = 0, yawAngle = 0, cd = 0, cl = 0, dragKG = 0, liftKG = 0, groundHeight = 0; };
+
+struct Car {
+    const pdb_car_params* P = nullptr;
+    const TrackData* T = nullptr;
+    pdb_dyn_state S;
+    pdrb::World w;
+    // transient
+    pdb_controls controls;
+    float finalSteerAngleSignal = 0;
+    float accG[3] = {0, 0, 0};
+    float probeHits[7];
+    float lookAhead[5];
+    TyreScratch ts[4];
+    WingScratch ws[PDB_MAX_WINGS];
+    double locClutch = 1.0, currentClutchTorque = 0, ratio = 12.0, totalTorque = 0, engOutTorque = 0;
+    float gasUsage = 0;
+    double stepTime = 0;   // sim->physicsTime seen by the last step (before += dt)
+    int acSeqCount = 0;
+    std::vector<int> nearby;
+
+    void init(const pdb_car_params* P, const TrackData* T, const pdb_dyn_state& s0);
+    void loadState(const pdb_dyn_state& s);     // pdb_dyn_state -> bodies
+    void storeState();                          // bodies -> S
+    void step(float steer, float gas, float dt, double dtD);   // one env tick (setCarControls + stepSimulator)
+    void fillCarState(pdb_car_state& cs) const;
+    void fillStepOut(pdb_step_out& o) const;
+    void fillProbe(pdoracle::Probe& P) const;
+
+   private:
+    void carStep(float dt);
+    void postStep(float dt);
+};
+
+}  // namespace cpuref

@@ -5,8 +5,8 @@ Car data and sim.ini are copied from /root/reference into oracle/_ref (git-ignor
 nothing from the reference enters the repository history."""
 import os, shutil, sys
 here = os.path.dirname(os.path.abspath(__file__))
-sys.path.insert(0, here)
-import gen_track
+sys.path.insert(0, os.path.join(here, '..', 'projectd-core_amd'))
+import synthetic_tracks as gen_track
 REF = '/root/reference'
 def main():
     base = os.path.join(here, '_ref', 'base')

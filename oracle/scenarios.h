@@ -9,10 +9,10 @@ namespace pdoracle {
 struct Scenario { const char* name; int ticks; int denseTicks; int stride; };
 
 static const Scenario kScenarios[] = {
-    {"idle", 600, 600, 1},
-    {"launch", 2000, 500, 10},
-    {"circle", 1600, 400, 10},
-    {"slalom", 2400, 400, 10},
+    {"idle", 600, 200, 10},
+    {"launch", 2000, 450, 10},
+    {"circle", 1600, 300, 10},
+    {"slalom", 2400, 300, 10},
 };
 static const int kNumScenarios = 4;
 

@@ -1,0 +1,83 @@
+// pdbatch C ABI, host-side entry points (content loading, tunes, reset poses).  See include/pdbatch.h.
+#include "pdbatch.h"
+#include "model.hpp"
+#include <cstdlib>
+#include <cstring>
+#include <string>
+
+namespace pdb {
+thread_local std::string g_lastError;
+void setError(const std::string& s) { g_lastError = s; }
+}
+
+#define PDB_TRY try {
+#define PDB_CATCH(code) } catch (const std::exception& e) { pdb::setError(e.what()); return code; } catch (...) { pdb::setError("unknown error"); return code; }
+
+extern "C" {
+
+const char* pdb_last_error(void) { return pdb::g_lastError.c_str(); }
+const char* pdb_version(void) { return "pdbatch 0.1 (gfx950)"; }
+
+int pdb_build_car_model(const char* base_path, const char* model_name, pdb_car_params* out) {
+    if (!base_path || !model_name || !out) { pdb::setError("null argument"); return PDB_ERR_ARG; }
+    PDB_TRY
+    pdb::buildCarModel(base_path, model_name, *out);
+    return PDB_OK;
+    PDB_CATCH(PDB_ERR_IO)
+}
+int pdb_set_car_tune(pdb_car_params* params, const char* base_path, const char* model_name, const char* name, float value, int raw) {
+    if (!params || !base_path || !model_name || !name) { pdb::setError("null argument"); return PDB_ERR_ARG; }
+    PDB_TRY
+    pdb::setCarTune(*params, base_path, model_name, name, value, raw != 0);   // unknown names are ignored like the reference
+    return PDB_OK;
+    PDB_CATCH(PDB_ERR_IO)
+}
+int pdb_set_scoring_var(pdb_car_params* params, const char* name, float value) {
+    if (!params || !name) { pdb::setError("null argument"); return PDB_ERR_ARG; }
+    if (!pdb::setScoringVar(*params, name, value)) { pdb::setError(std::string("unknown scoring var ") + name); return PDB_ERR_ARG; }
+    return PDB_OK;
+}
+float pdb_get_scoring_var(const pdb_car_params* params, const char* name) {
+    float w = 0;
+    if (params && name) pdb::getScoringVar(*params, name, w);
+    return w;
+}
+int pdb_set_assists(pdb_car_params* params, int auto_clutch, int auto_shift, int auto_blip, int smooth_steer) {
+    if (!params) { pdb::setError("null argument"); return PDB_ERR_ARG; }
+    params->acUseOnStart = auto_clutch ? 1 : 0;
+    params->acUseOnChange = auto_clutch ? 1 : 0;
+    params->autoShiftActive = auto_shift ? 1 : 0;
+    params->autoBlipActive = auto_blip ? 1 : 0;
+    params->smoothSteer = smooth_steer ? 1 : 0;
+    return PDB_OK;
+}
+int pdb_build_track(const char* base_path, const char* track_name, void** blob, uint64_t* bytes) {
+    if (!base_path || !track_name || !blob || !bytes) { pdb::setError("null argument"); return PDB_ERR_ARG; }
+    PDB_TRY
+    std::vector<uint8_t> v = pdb::buildTrack(base_path, track_name);
+    void* p = malloc(v.size());
+    if (!p) { pdb::setError("out of memory"); return PDB_ERR_ARG; }
+    memcpy(p, v.data(), v.size());
+    *blob = p; *bytes = v.size();
+    return PDB_OK;
+    PDB_CATCH(PDB_ERR_IO)
+}
+void pdb_free(void* p) { free(p); }
+int pdb_initial_state(const pdb_car_params* params, const void* track_blob, pdb_dyn_state* out) {
+    if (!params || !track_blob || !out) { pdb::setError("null argument"); return PDB_ERR_ARG; }
+    PDB_TRY
+    pdb::TrackView tv(static_cast<const uint8_t*>(track_blob));
+    pdb::initialState(*params, tv, *out);
+    return PDB_OK;
+    PDB_CATCH(PDB_ERR_IO)
+}
+int pdb_teleport_to_spline(const pdb_car_params* params, const void* track_blob, float distance_norm, pdb_dyn_state* inout) {
+    if (!params || !track_blob || !inout) { pdb::setError("null argument"); return PDB_ERR_ARG; }
+    PDB_TRY
+    pdb::TrackView tv(static_cast<const uint8_t*>(track_blob));
+    pdb::teleportToSpline(*params, tv, distance_norm, *inout);
+    return PDB_OK;
+    PDB_CATCH(PDB_ERR_IO)
+}
+
+}  // extern "C"

@@ -1,0 +1,795 @@
+// pdbatch host side: builds the per-model constant block (pdb_car_params) from a car's data folder,
+// i.e. the load-time half of the reference's component init() routines evaluated once at the
+// identity pose (the reference creates every body at the origin with identity rotation and only
+// then teleports the car):
+//   Car::init / initCarData / initProbes / initLookAhead      Car/Car.cpp:31-314
+//   SuspensionStrut::init / attach / setPositions             Car/SuspensionStrut.cpp:17-228
+//   SuspensionAxle::init / attach                             Car/SuspensionAxle.cpp:15-118
+//   Tyre::initCompounds / setCompound                         Car/Tyre.cpp:48-391
+//   TyreThermalModel::buildTyre                               Car/TyreThermalModel.cpp:31-58
+//   Drivetrain::init, Engine::init(+precalculate)             Car/Drivetrain.cpp:18-152, Car/Engine.cpp:16-191
+//   AutoClutch/AutoBlip/AutoShifter::init                     Car/AutoClutch.cpp:25-89, AutoBlip.cpp:14-49, AutoShifter.cpp:14-29
+//   BrakeSystem::init, AeroMap::init, Wing::init              Car/BrakeSystem.cpp:14-73, AeroMap.cpp:15-81, Wing.cpp:19-69
+//   Simulator::init                                           Sim/Simulator.cpp:23-87
+// Joint anchors follow the ODE setters the reference calls (Physics/ODE/JointODE.cpp:21-60).
+// Only STRUT front / AXLE rear, RWD or FWD, no turbo is supported in this round; anything else
+// raises an error (no silent fallback).
+#include "model.hpp"
+#include "ini.hpp"
+#include "rbmath.hpp"
+#include <cstdio>
+#include <cstring>
+#include <cmath>
+#include <algorithm>
+#include <sys/stat.h>
+
+namespace pdb {
+
+static inline void v3set(float* o, float x, float y, float z) { o[0] = x; o[1] = y; o[2] = z; }
+static inline void v3add(float* o, const float* a, const float* b) { o[0] = a[0] + b[0]; o[1] = a[1] + b[1]; o[2] = a[2] + b[2]; }
+static inline void v3sub(float* o, const float* a, const float* b) { o[0] = a[0] - b[0]; o[1] = a[1] - b[1]; o[2] = a[2] - b[2]; }
+static inline float v3len(const float* a) { return sqrtf(a[0] * a[0] + a[1] * a[1] + a[2] * a[2]); }
+// vec3f::get_norm() (Core/Math.h:121-125)
+static inline void v3norm(float* a) { const float l = v3len(a); if (l != 0.0f) { const float s = 1.0f / l; a[0] *= s; a[1] *= s; a[2] *= s; } }
+
+static bool fileExists(const std::string& p) { struct stat st; return stat(p.c_str(), &st) == 0 && S_ISREG(st.st_mode); }
+
+struct RawJoint { pdb_joint_def d; };
+
+static void mkDBall(std::vector<RawJoint>& out, const HBody* B, int b0, int b1, const float* p1w, const float* p2w, float erp, float cfm) {
+    RawJoint j; memset(&j, 0, sizeof(j));
+    j.d.type = PDB_JOINT_DBALL; j.d.b0 = b0; j.d.b1 = b1; j.d.erp = erp; j.d.cfm = cfm; j.d.steerWheel = -1; j.d.suspErp = 1;
+    hWorldToLocal(B[b0], p1w, j.d.anchor1);
+    hWorldToLocal(B[b1], p2w, j.d.anchor2);
+    float g1[3], g2[3], d[3];
+    hLocalToWorld(B[b0], j.d.anchor1, g1);
+    hLocalToWorld(B[b1], j.d.anchor2, g2);
+    v3sub(d, g1, g2);
+    j.d.distance = sqrtf(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);
+    j.d.qrel[0] = 1;
+    out.push_back(j);
+}
+
+static void loadTyre(pdb_tyre& t, pdb_car_params& P, const std::string& dataPath, int index) {
+    Ini ini(dataPath + "tyres.ini");
+    if (!ini.ready) throw std::runtime_error("pdb: tyres.ini not found in " + dataPath);
+    const int iVer = ini.getInt("HEADER", "VERSION");
+    if (iVer < 10) throw std::runtime_error("pdb: tyres.ini VERSION < 10 unsupported (Tyre.cpp:54)");
+    const std::string sec = (index < 2) ? "FRONT" : "REAR";
+    memset(&t, 0, sizeof(t));
+    t.version = iVer;
+    // defaults (Car/Tyre.h:62-70, Car/TyreCompound.h)
+    t.flatSpotK = 0.15f; t.explosionTemperature = 350.0f; t.pressureTemperatureGain = 0.16f;
+    t.camberSpreadK = 1.4f;
+    t.surfaceTransfer = 0.3f; t.patchTransfer = 0.2f; t.patchCoreTransfer = 0.2f; t.internalCoreTransfer = 0.004f; t.coolFactorGain = 0;
+    t.thermalFrictionK = 0.03f; t.thermalRollingK = 0.5f; t.thermalRollingSurfaceK = 0;
+    t.dCamberBlend = 1.0f; t.brakeDXMod = 1.0f; t.combinedFactor = 0.0f; t.cfXmult = 1.0f;
+    if (ini.hasSection("EXPLOSION")) t.explosionTemperature = ini.getFloat("EXPLOSION", "TEMPERATURE");
+    if (ini.hasSection("ADDITIONAL1")) {
+        t.pressureTemperatureGain = ini.getFloat("ADDITIONAL1", "PRESSURE_TEMPERATURE_GAIN");
+        const float sp = ini.getFloat("ADDITIONAL1", "CAMBER_TEMP_SPREAD_K");
+        if (sp != 0.0f) t.camberSpreadK = sp;
+    }
+    if (ini.hasKey(sec, "DY_CURVE") || ini.hasKey(sec, "DX_CURVE") || ini.hasKey(sec, "DCAMBER_LUT"))
+        throw std::runtime_error("pdb: DY_CURVE/DX_CURVE/DCAMBER_LUT cubic-spline tyre paths unsupported this round");
+    float width = ini.getFloat(sec, "WIDTH"); (void)width;
+    t.radius = ini.getFloat(sec, "RADIUS");
+    t.rimRadius = ini.getFloat(sec, "RIM_RADIUS");
+    float fFLA = ini.getFloat(sec, "FRICTION_LIMIT_ANGLE");
+    if (fFLA == 0.0f) fFLA = 7.5f;
+    t.cfXmult = ini.getFloat(sec, "CX_MULT");
+    t.radiusRaiseK = ini.getFloat(sec, "RADIUS_ANGULAR_K") * 0.001f;
+    if (ini.hasKey(sec, "BRAKE_DX_MOD")) {
+        t.brakeDXMod = ini.getFloat(sec, "BRAKE_DX_MOD");
+        if (t.brakeDXMod == 0.0f) t.brakeDXMod = 1.0f; else t.brakeDXMod += 1.0f;
+    }
+    if (ini.hasKey(sec, "COMBINED_FACTOR")) t.combinedFactor = ini.getFloat(sec, "COMBINED_FACTOR");
+    const float fFZ0 = ini.getFloat(sec, "FZ0");
+    const float fFlexGain = ini.getFloat(sec, "FLEX_GAIN");
+    t.lsExpX = ini.getFloat(sec, "LS_EXPX");
+    t.lsExpY = ini.getFloat(sec, "LS_EXPY");
+    float Dx0 = ini.getFloat(sec, "DX_REF");
+    float Dy0 = ini.getFloat(sec, "DY_REF");
+    t.lsMultX = (Dx0 * fFZ0) / powf(fFZ0, t.lsExpX);   // calcLoadSensMult (TyreUtils.inl:32-35)
+    t.lsMultY = (Dy0 * fFZ0) / powf(fFZ0, t.lsExpY);
+    t.Fz0 = fFZ0;
+    t.modelFz0 = 2000.0f;
+    t.maxSlip0 = tanf(fFLA * 0.017453f);
+    t.maxSlip1 = tanf(((fFlexGain + 1.0f) * fFLA) * 0.017453f);
+    t.asy = ini.getFloat(sec, "FALLOFF_LEVEL");
+    t.falloffSpeed = ini.getFloat(sec, "FALLOFF_SPEED");
+    t.speedSensitivity = ini.getFloat(sec, "SPEED_SENSITIVITY");
+    t.relaxationLength = ini.getFloat(sec, "RELAXATION_LENGTH");
+    t.rr0 = ini.getFloat(sec, "ROLLING_RESISTANCE_0");
+    t.rr1 = ini.getFloat(sec, "ROLLING_RESISTANCE_1");
+    t.rr_slip = ini.getFloat(sec, "ROLLING_RESISTANCE_SLIP");
+    t.camberGain = ini.getFloat(sec, "CAMBER_GAIN");
+    t.dcamber0 = ini.getFloat(sec, "DCAMBER_0");
+    t.dcamber1 = ini.getFloat(sec, "DCAMBER_1");
+    if (t.dcamber0 == 0.0f || t.dcamber1 == 0.0f) { t.dcamber0 = 0.1f; t.dcamber1 = -0.8f; }
+    t.angularInertia = ini.getFloat(sec, "ANGULAR_INERTIA");
+    t.d = ini.getFloat(sec, "DAMP");
+    t.k = ini.getFloat(sec, "RATE");
+    if (t.angularInertia == 0.0f) t.angularInertia = 1.2f;
+    if (t.d == 0.0f) t.d = 400.0f;
+    if (t.k == 0.0f) t.k = 220000.0f;
+    t.pressureStatic = ini.getFloat(sec, "PRESSURE_STATIC");
+    if (t.pressureStatic == 0.0f) t.pressureStatic = 26.0f;
+    t.pressureRef = t.pressureStatic;
+    t.pressureSpringGain = ini.getFloat(sec, "PRESSURE_SPRING_GAIN");
+    if (t.pressureSpringGain == 0.0f) t.pressureSpringGain = 1000.0f;
+    t.pressureCfGain = ini.getFloat(sec, "PRESSURE_FLEX_GAIN");
+    t.pressureRRGain = ini.getFloat(sec, "PRESSURE_RR_GAIN");
+    t.pressureGainD = ini.getFloat(sec, "PRESSURE_D_GAIN");
+    t.idealPressure = ini.getFloat(sec, "PRESSURE_IDEAL");
+    if (t.idealPressure == 0.0f) t.idealPressure = 26.0f;
+    const std::string th = "THERMAL_" + sec;
+    if (ini.hasSection(th)) {
+        t.surfaceTransfer = ini.getFloat(th, "SURFACE_TRANSFER");
+        t.patchTransfer = ini.getFloat(th, "PATCH_TRANSFER");
+        t.patchCoreTransfer = ini.getFloat(th, "CORE_TRANSFER");
+        t.thermalFrictionK = ini.getFloat(th, "FRICTION_K");
+        t.thermalRollingK = ini.getFloat(th, "ROLLING_K");
+        t.internalCoreTransfer = ini.getFloat(th, "INTERNAL_CORE_TRANSFER");
+        if (ini.hasKey(th, "COOL_FACTOR")) t.coolFactorGain = (ini.getFloat(th, "COOL_FACTOR") - 1.0f) * 0.000324f;
+        t.thermalRollingSurfaceK = ini.getFloat(th, "SURFACE_ROLLING_K");
+        curveLoad(t.performanceCurve, dataPath + ini.getString(th, "PERFORMANCE_CURVE"));
+    }
+    curveLoad(t.wearCurve, dataPath + ini.getString(sec, "WEAR_CURVE"));
+    for (int i = 0; i < t.wearCurve.n; ++i) t.wearCurve.y[i] *= 0.01f;
+    // softnessIndex = max(0, loadSensExpD(lsExpY, lsMultY, 3000) - 1)  (Tyre.cpp:323-329)
+    const float sens = (powf(3000.0f, t.lsExpY) * t.lsMultY) / 3000.0f;
+    t.softnessIndex = std::max(0.0f, sens - 1.0f);
+    (void)P;
+}
+
+static void buildPatchConn(pdb_car_params& P) {
+    // Car/TyreThermalModel.cpp:31-58 with stripes = 3, elements = 12; patch index = y + x*elements
+    const int stripes = 3, elements = 12;
+    for (int k = 0; k < 36; ++k) P.patchConnCount[k] = 0;
+    auto connect = [&](int a, int b) {
+        P.patchConn[a][(int)P.patchConnCount[a]++] = (int8_t)b;
+        P.patchConn[b][(int)P.patchConnCount[b]++] = (int8_t)a;
+    };
+    for (int i = 0; i < stripes; ++i)
+        for (int j = 0; j < elements; ++j) {
+            const int p = j + i * elements;
+            if (i + 1 < stripes) connect(p, j + (i + 1) * elements);
+            if (j + 1 < elements) connect(p, (j + 1) + i * elements);
+            else if (j + 1 == elements) connect(p, 0 + i * elements);
+        }
+}
+
+// ODE island traversal order (util.cpp dxProcessIslands) -> solver row order
+static std::vector<int> islandOrder(const std::vector<RawJoint>& J, int nb) {
+    std::vector<std::vector<int>> bj(nb);
+    for (int j = 0; j < (int)J.size(); ++j) {
+        bj[J[j].d.b0].insert(bj[J[j].d.b0].begin(), j);
+        bj[J[j].d.b1].insert(bj[J[j].d.b1].begin(), j);
+    }
+    std::vector<char> bt(nb, 0), jt(J.size(), 0);
+    std::vector<int> order, stack;
+    for (int bb = nb - 1; bb >= 0; --bb) {
+        if (bt[bb]) continue;
+        bt[bb] = 1;
+        int b = bb;
+        stack.clear();
+        for (;;) {
+            for (int j : bj[b]) {
+                if (jt[j]) continue;
+                jt[j] = 1;
+                order.push_back(j);
+                const int other = (J[j].d.b0 == b) ? J[j].d.b1 : J[j].d.b0;
+                if (!bt[other]) { bt[other] = 1; stack.push_back(other); }
+            }
+            if (stack.empty()) break;
+            b = stack.back();
+            stack.pop_back();
+        }
+    }
+    return order;
+}
+
+void buildCarModel(const std::string& basePathIn, const std::string& modelName, pdb_car_params& P) {
+    std::string base = basePathIn;
+    std::replace(base.begin(), base.end(), '\\', '/');
+    if (!base.empty() && base.back() != '/') base += '/';
+    const std::string dataPath = base + "content/cars/" + modelName + "/data/";
+    memset(&P, 0, sizeof(P));
+    P.magic = 0x50434450;  // 'PDCP'
+    P.version = 1;
+
+    // ---- Simulator::init (Sim/Simulator.cpp:33-70, 346-349) ----
+    P.roadTemperature = 20.0f; P.ambientTemperature = 20.0f;
+    P.fuelConsumptionRate = 0.0f; P.tyreConsumptionRate = 0.0f; P.mechanicalDamageRate = 1.0f;
+    Ini simIni(base + "cfg/sim.ini");
+    if (simIni.ready) {
+        simIni.tryGetFloat("ENVIRONMENT", "ROAD_TEMP", P.roadTemperature);
+        simIni.tryGetFloat("ENVIRONMENT", "AMBIENT_TEMP", P.ambientTemperature);
+    }
+    P.airDensity = 1.2922f - (P.ambientTemperature * 0.0041f);
+    P.worldErp = 0.3f; P.worldCfm = 1.0e-7f;               // PhysicsEngineODE.cpp:24-25
+    v3set(P.gravity, 0.0f, -9.80665f, 0.0f);                // :23
+
+    // ---- Car::initCarData ----
+    Ini car(dataPath + "car.ini");
+    if (!car.ready) throw std::runtime_error("pdb: car.ini not found: " + dataPath);
+    if (car.hasSection("EXPLICIT_INERTIA")) throw std::runtime_error("pdb: EXPLICIT_INERTIA cars unsupported this round");
+    P.mass = car.getFloat("BASIC", "TOTALMASS");
+    float bodyInertia[3];
+    car.getFloat3("BASIC", "INERTIA", bodyInertia);
+    P.fuelKG = 0.74f;
+    if (car.hasSection("FUEL_EXT")) P.fuelKG = car.getFloat("FUEL_EXT", "KG_PER_LITER");
+    P.steerLock = car.getFloat("CONTROLS", "STEER_LOCK");
+    P.steerRatio = car.getFloat("CONTROLS", "STEER_RATIO");
+    P.steerLinearRatio = car.getFloat("CONTROLS", "LINEAR_STEER_ROD_RATIO");
+    if (P.steerLinearRatio == 0.0f) P.steerLinearRatio = 0.003f;
+    P.fuelConsumptionK = car.getFloat("FUEL", "CONSUMPTION");
+    P.fuel = car.getFloat("FUEL", "FUEL");
+    if (P.fuel == 0.0f) P.fuel = 30.0f;
+    car.getFloat3("FUELTANK", "POSITION", P.fuelTankPos);
+
+    // ---- probes / look-ahead (Car.cpp:285-314) ----
+    {
+        int n = 0;
+        for (int id = 1; id <= 10 && simIni.ready; ++id) {
+            char secn[32]; snprintf(secn, sizeof(secn), "CAR_PROBE_%d", id);
+            if (!simIni.hasSection(secn)) break;
+            if (n >= PDB_NUM_PROBES) throw std::runtime_error("pdb: more than 7 probes unsupported");
+            const float yaw = simIni.getFloat(secn, "YAW");
+            P.probeLen[n] = simIni.getFloat(secn, "LENGTH");
+            const float ax[3] = {0, 1, 0};
+            float M[9];
+            hAxisAngle(ax, yaw * (float)0.01745329251994329576923690768489, M);
+            // vec3f(0,0,1) * mat44f  (Core/Math.h:196-203): out.c = M4c + dot(v, column c)
+            const float v[3] = {0, 0, 1};
+            P.probeDir[n][0] = 0.0f + (v[0] * M[0] + v[1] * M[3] + v[2] * M[6]);
+            P.probeDir[n][1] = 0.0f + (v[0] * M[1] + v[1] * M[4] + v[2] * M[7]);
+            P.probeDir[n][2] = 0.0f + (v[0] * M[2] + v[1] * M[5] + v[2] * M[8]);
+            ++n;
+        }
+        if (n != PDB_NUM_PROBES) throw std::runtime_error("pdb: cfg/sim.ini must define exactly 7 CAR_PROBE_n sections");
+        P.lookAheadCount = 5; P.lookAheadStep = 10.0f;
+        if (simIni.ready) { simIni.tryGetInt("CAR_LOOK_AHEAD", "COUNT", P.lookAheadCount); simIni.tryGetFloat("CAR_LOOK_AHEAD", "STEP", P.lookAheadStep); }
+        if (P.lookAheadCount != PDB_NUM_LOOKAHEAD) throw std::runtime_error("pdb: CAR_LOOK_AHEAD COUNT must be 5");
+    }
+
+    // ---- bodies at the identity pose ----
+    HBody B[PDB_MAX_BODIES];
+    hBoxInertia(P.mass, bodyInertia[0], bodyInertia[1], bodyInertia[2], B[0].inertia); B[0].mass = P.mass;
+    hBoxInertia(1.0f, 0.5f, 0.5f, 0.5f, B[1].inertia); B[1].mass = 1.0f;   // Car.cpp:49
+    memcpy(B[1].pos, P.fuelTankPos, sizeof(float) * 3);                     // Car.cpp:50
+    std::vector<RawJoint> J;
+    {   // fixed joint (tank, chassis)  Car.cpp:51, JointODE.cpp:21-28
+        RawJoint j; memset(&j, 0, sizeof(j));
+        j.d.type = PDB_JOINT_FIXED; j.d.b0 = PDB_BODY_TANK; j.d.b1 = PDB_BODY_CHASSIS; j.d.erp = P.worldErp; j.d.cfm = P.worldCfm; j.d.steerWheel = -1;
+        float ofs[3]; v3sub(ofs, B[1].pos, B[0].pos);
+        hMul1(j.d.offset, B[1].R, ofs);
+        hQMul1(j.d.qrel, B[1].q, B[0].q);
+        J.push_back(j);
+    }
+
+    Ini sus(dataPath + "suspensions.ini");
+    if (!sus.ready) throw std::runtime_error("pdb: suspensions.ini not found");
+    const std::string typeF = sus.getString("FRONT", "TYPE"), typeR = sus.getString("REAR", "TYPE");
+    if (typeF != "STRUT" || typeR != "AXLE")
+        throw std::runtime_error("pdb: only FRONT=STRUT / REAR=AXLE suspensions are implemented this round (got " + typeF + "/" + typeR + ")");
+    P.suspTypeF = PDB_SUSP_STRUT; P.suspTypeR = PDB_SUSP_AXLE;
+    P.axleTorqueReaction = sus.getFloat("AXLE", "TORQUE_REACTION");
+    const int iVer = sus.getInt("HEADER", "VERSION");
+    const float wheelBase = sus.getFloat("BASIC", "WHEELBASE");
+    const float cg = sus.getFloat("BASIC", "CG_LOCATION");
+    const float frontBaseY = sus.getFloat("FRONT", "BASEY");
+    const float frontTrack = sus.getFloat("FRONT", "TRACK") * 0.5f;
+    const float rearBaseY = sus.getFloat("REAR", "BASEY");
+    const float rearTrack = sus.getFloat("REAR", "TRACK") * 0.5f;
+
+    auto loadDamper = [&](pdb_damper& d, const std::string& s) {
+        d.bumpSlow = sus.getFloat(s, "DAMP_BUMP"); d.reboundSlow = sus.getFloat(s, "DAMP_REBOUND");
+        d.bumpFast = sus.getFloat(s, "DAMP_FAST_BUMP"); d.reboundFast = sus.getFloat(s, "DAMP_FAST_REBOUND");
+        d.fastThresholdBump = sus.getFloat(s, "DAMP_FAST_BUMPTHRESHOLD"); d.fastThresholdRebound = sus.getFloat(s, "DAMP_FAST_REBOUNDTHRESHOLD");
+        if (d.fastThresholdBump == 0.0f) d.fastThresholdBump = 0.2f;
+        if (d.fastThresholdRebound == 0.0f) d.fastThresholdRebound = 0.2f;
+        if (d.bumpFast == 0.0f) d.bumpFast = d.bumpSlow;
+        if (d.reboundFast == 0.0f) d.reboundFast = d.reboundSlow;
+    };
+
+    // ---- front struts (SuspensionStrut.cpp:17-228) ----
+    for (int index = 0; index < 2; ++index) {
+        pdb_susp& S = P.susp[index];
+        memset(&S, 0, sizeof(S));
+        S.type = PDB_SUSP_STRUT;
+        const int hubB = (index == 0) ? PDB_BODY_HUB0 : PDB_BODY_HUB1;
+        const int strB = (index == 0) ? PDB_BODY_STRUT0 : PDB_BODY_STRUT1;
+        S.hubBody = hubB; S.strutBody = strB;
+        const std::string id = "FRONT";
+        float ref[3];
+        v3set(ref, (index == 0) ? frontTrack : -frontTrack, frontBaseY, (1.0f - cg) * wheelBase);
+        float carStrut[3], tyreStrut[3], carWBF[3], carWBR[3], tyreWB[3], tyreSteer[3], carSteer[3];
+        sus.getFloat3(id, "STRUT_CAR", carStrut); sus.getFloat3(id, "STRUT_TYRE", tyreStrut);
+        sus.getFloat3(id, "WBCAR_BOTTOM_FRONT", carWBF); sus.getFloat3(id, "WBCAR_BOTTOM_REAR", carWBR);
+        sus.getFloat3(id, "WBTYRE_BOTTOM", tyreWB); sus.getFloat3(id, "WBTYRE_STEER", tyreSteer); sus.getFloat3(id, "WBCAR_STEER", carSteer);
+        float* all[7] = {carStrut, tyreStrut, carWBF, carWBR, tyreWB, tyreSteer, carSteer};
+        if (iVer >= 2) {
+            const float rim = -sus.getFloat(id, "RIM_OFFSET");
+            if (rim != 0.0f) for (auto* p : all) p[0] += rim;
+        }
+        float hubMass = sus.getFloat(id, "HUB_MASS");
+        S.bumpStopUp = sus.getFloat(id, "BUMPSTOP_UP");
+        S.bumpStopDn = -sus.getFloat(id, "BUMPSTOP_DN");
+        S.rodLength = sus.getFloat(id, "ROD_LENGTH");
+        S.toeOutLinear = sus.getFloat(id, "TOE_OUT");
+        S.k = sus.getFloat(id, "SPRING_RATE");
+        S.progressiveK = sus.getFloat(id, "PROGRESSIVE_SPRING_RATE");
+        loadDamper(S.damper, id);
+        S.bumpStopRate = sus.getFloat(id, "BUMP_STOP_RATE");
+        if (S.bumpStopRate == 0.0f) S.bumpStopRate = 500000.0f;
+        S.staticCamber = -sus.getFloat(id, "STATIC_CAMBER") * 0.017453f;
+        if (index % 2) S.staticCamber *= -1.0f;
+        S.packerRange = sus.getFloat(id, "PACKER_RANGE");
+        if (ref[0] > 0.0f) for (auto* p : all) p[0] *= -1.0f;
+        if (hubMass <= 0.0f) hubMass = 20.0f;
+        B[hubB].mass = hubMass * 0.8f; hBoxInertia(B[hubB].mass, 0.2f, 0.6f, 0.6f, B[hubB].inertia);
+        B[strB].mass = hubMass * 0.2f; hBoxInertia(B[strB].mass, 0.05f, 0.5f, 0.2f, B[strB].inertia);
+        S.strutBodyLength = 0.2f;
+        S.mass = B[hubB].mass;
+        memcpy(S.basePosition, ref, sizeof(ref));
+        S.refPointY = ref[1];
+        S.refPointSignX = (ref[0] > 0.0f) ? 1.0f : ((ref[0] < 0.0f) ? -1.0f : 0.0f);
+        // attach(): dataRelToBody.X = carBody->localToWorld(dataRelToWheel.X + refPoint), body at identity
+        float rb_carWBF[3], rb_carWBR[3], rb_carStrut[3], rb_tyreWB[3], rb_tyreStrut[3], rb_carSteer[3], rb_tyreSteer[3], t3[3];
+        auto rel = [&](const float* p, float* o) { v3add(t3, p, ref); hLocalToWorld(B[0], t3, o); };
+        rel(carWBF, rb_carWBF); rel(carWBR, rb_carWBR); rel(carStrut, rb_carStrut); rel(tyreWB, rb_tyreWB);
+        rel(tyreStrut, rb_tyreStrut); rel(carSteer, rb_carSteer); rel(tyreSteer, rb_tyreSteer);
+        // setPositions()
+        float Mb[9]; hWorldMatrix3(B[0], Mb);
+        float vPos[3]; hLocalToWorld(B[0], S.basePosition, vPos);
+        hSetRotationM(B[hubB], Mb);
+        memcpy(B[hubB].pos, vPos, sizeof(vPos));
+        float vCarStrut[3], vTyreStrut[3], vNorm[3];
+        hLocalToWorld(B[0], rb_carStrut, vCarStrut);
+        hLocalToWorld(B[hubB], tyreStrut, vTyreStrut);
+        v3sub(vNorm, vTyreStrut, vCarStrut); v3norm(vNorm);
+        float vM3[3] = {Mb[6] * -1.0f, Mb[7] * -1.0f, Mb[8] * -1.0f};
+        float vM3N[3], vM3NN[3];
+        hCross(vM3N, vM3, vNorm);
+        hCross(vM3NN, vM3N, vNorm); v3norm(vM3NN);
+        const float Ms[9] = {vM3NN[0], vM3NN[1], vM3NN[2], -vM3N[0], -vM3N[1], -vM3N[2], -vNorm[0], -vNorm[1], -vNorm[2]};
+        hSetRotationM(B[strB], Ms);
+        B[strB].pos[0] = (vNorm[0] * S.strutBodyLength) * 0.5f + vCarStrut[0];
+        B[strB].pos[1] = (vNorm[1] * S.strutBodyLength) * 0.5f + vCarStrut[1];
+        B[strB].pos[2] = (vNorm[2] * S.strutBodyLength) * 0.5f + vCarStrut[2];
+        // joints 0..2 distance, 3 slider, 4 ball
+        mkDBall(J, B, PDB_BODY_CHASSIS, hubB, rb_carWBR, rb_tyreWB, P.worldErp, P.worldCfm);
+        mkDBall(J, B, PDB_BODY_CHASSIS, hubB, rb_carWBF, rb_tyreWB, P.worldErp, P.worldCfm);
+        mkDBall(J, B, PDB_BODY_CHASSIS, hubB, rb_carSteer, rb_tyreSteer, P.worldErp, P.worldCfm);
+        J.back().d.steerWheel = index;
+        {   // slider (strut, hub) along (vTyreStrut - vCarStrut)
+            hLocalToWorld(B[0], rb_carStrut, vCarStrut);
+            hLocalToWorld(B[hubB], tyreStrut, vTyreStrut);
+            RawJoint j; memset(&j, 0, sizeof(j));
+            j.d.type = PDB_JOINT_SLIDER; j.d.b0 = strB; j.d.b1 = hubB; j.d.erp = P.worldErp; j.d.cfm = P.worldCfm; j.d.steerWheel = -1;
+            float ax[3]; v3sub(ax, vTyreStrut, vCarStrut); hNorm3(ax);
+            hMul1(j.d.axis1, B[strB].R, ax);
+            float c[3]; v3sub(c, B[strB].pos, B[hubB].pos);
+            hMul1(j.d.offset, B[hubB].R, c);
+            hQMul1(j.d.qrel, B[strB].q, B[hubB].q);
+            J.push_back(j);
+            RawJoint b; memset(&b, 0, sizeof(b));
+            b.d.type = PDB_JOINT_BALL; b.d.b0 = PDB_BODY_CHASSIS; b.d.b1 = strB; b.d.erp = P.worldErp; b.d.cfm = P.worldCfm; b.d.steerWheel = -1;
+            hWorldToLocal(B[0], vCarStrut, b.d.anchor1);
+            hWorldToLocal(B[strB], vCarStrut, b.d.anchor2);
+            b.d.qrel[0] = 1;
+            J.push_back(b);
+            float dl[3]; v3sub(dl, vTyreStrut, vCarStrut);
+            S.strutBaseLength = v3len(dl);
+        }
+        memcpy(S.carStrut, rb_carStrut, sizeof(float) * 3);
+        memcpy(S.tyreStrut, tyreStrut, sizeof(float) * 3);
+        memcpy(S.tyreSteer, tyreSteer, sizeof(float) * 3);
+        memcpy(S.baseCarSteer, rb_carSteer, sizeof(float) * 3);
+    }
+
+    // ---- rear rigid axle (SuspensionAxle.cpp:15-118) ----
+    for (int index = 2; index < 4; ++index) {
+        pdb_susp& S = P.susp[index];
+        memset(&S, 0, sizeof(S));
+        S.type = PDB_SUSP_AXLE; S.hubBody = PDB_BODY_AXLE; S.strutBody = -1;
+        S.sideSign = (index == 2) ? 1.0f : -1.0f;
+        S.axleTrack = rearTrack; S.referenceY = rearBaseY;
+        v3set(S.axleBasePos, 0.0f, rearBaseY, -(cg * wheelBase));
+        S.attachRelativePos = 1.0f;
+        if (iVer >= 4) S.attachRelativePos = sus.getFloat("AXLE", "ATTACH_REL_POS");
+        if (index == 2) {
+            const float m = sus.getFloat("REAR", "HUB_MASS");
+            B[PDB_BODY_AXLE].mass = m; hBoxInertia(m, S.axleTrack * 2.0f, 0.2f, 0.5f, B[PDB_BODY_AXLE].inertia);
+            float Mb[9]; hWorldMatrix3(B[0], Mb);
+            hSetRotationM(B[PDB_BODY_AXLE], Mb);
+            hLocalToWorld(B[0], S.axleBasePos, B[PDB_BODY_AXLE].pos);
+            const int links = sus.getInt("AXLE", "LINK_COUNT");
+            for (int i = 0; i < links; ++i) {
+                char kc[32], ka[32]; snprintf(kc, sizeof(kc), "J%d_CAR", i); snprintf(ka, sizeof(ka), "J%d_AXLE", i);
+                float bc[3], ba[3], w[3], relCar[3], relAxle[3], vJ0[3], vJ1[3];
+                sus.getFloat3("AXLE", kc, bc); sus.getFloat3("AXLE", ka, ba);
+                hLocalToWorld(B[PDB_BODY_AXLE], bc, w); hWorldToLocal(B[0], w, relCar);
+                hLocalToWorld(B[PDB_BODY_AXLE], ba, w); hWorldToLocal(B[0], w, relAxle);
+                hLocalToWorld(B[0], relCar, vJ0); hLocalToWorld(B[0], relAxle, vJ1);
+                mkDBall(J, B, PDB_BODY_CHASSIS, PDB_BODY_AXLE, vJ0, vJ1, P.worldErp, P.worldCfm);
+            }
+        }
+        S.bumpStopUp = sus.getFloat("REAR", "BUMPSTOP_UP");
+        S.bumpStopDn = -sus.getFloat("REAR", "BUMPSTOP_DN");
+        S.rodLength = sus.getFloat("REAR", "ROD_LENGTH");
+        S.toeOutLinear = sus.getFloat("REAR", "TOE_OUT");
+        S.k = sus.getFloat("REAR", "SPRING_RATE");
+        S.progressiveK = sus.getFloat("REAR", "PROGRESSIVE_SPRING_RATE");
+        loadDamper(S.damper, "REAR");
+        S.bumpStopRate = sus.getFloat("REAR", "BUMP_STOP_RATE");
+        if (S.bumpStopRate == 0.0f) S.bumpStopRate = 500000.0f;
+        if (iVer >= 3) S.leafSpringKx = sus.getFloat("AXLE", "LEAF_SPRING_LAT_K");
+        v3set(S.basePosition, S.sideSign * S.axleTrack, S.axleBasePos[1], S.axleBasePos[2]);   // getBasePosition()
+        S.mass = B[PDB_BODY_AXLE].mass * 0.5f;
+    }
+
+    // ---- tyres ----
+    for (int i = 0; i < 4; ++i) loadTyre(P.tyre[i], P, dataPath, i);
+    buildPatchConn(P);
+    P.arbK[0] = sus.getFloat("ARB", "FRONT");
+    P.arbK[1] = sus.getFloat("ARB", "REAR");
+    P.waterTmass = 20.0f; P.waterCoolSpeedK = 0.002f;
+
+    // ---- aero (AeroMap.cpp:15-81, Wing.cpp:19-69) ----
+    {
+        Ini aero(dataPath + "aero.ini");
+        if (!aero.ready) throw std::runtime_error("pdb: aero.ini not found");
+        const int aver = aero.getInt("HEADER", "VERSION");
+        int n = 0;
+        for (int pass = 0; pass < 2; ++pass)
+            for (int id = 0;; ++id) {
+                char secn[32]; snprintf(secn, sizeof(secn), "%s_%d", pass ? "FIN" : "WING", id);
+                if (!aero.hasSection(secn)) break;
+                if (n >= PDB_MAX_WINGS) throw std::runtime_error("pdb: too many wings");
+                pdb_wing& W = P.wings[n++];
+                memset(&W, 0, sizeof(W));
+                W.isVertical = pass;
+                const float chord = aero.getFloat(secn, "CHORD"), span = aero.getFloat(secn, "SPAN");
+                W.area = chord * span;
+                aero.getFloat3(secn, "POSITION", W.position);
+                curveLoad(W.lutAOA_CL, dataPath + aero.getString(secn, "LUT_AOA_CL"));
+                curveLoad(W.lutAOA_CD, dataPath + aero.getString(secn, "LUT_AOA_CD"));
+                const std::string ghcl = aero.getString(secn, "LUT_GH_CL"), ghcd = aero.getString(secn, "LUT_GH_CD");
+                if ((!ghcl.empty() && fileExists(dataPath + ghcl)) || (!ghcd.empty() && fileExists(dataPath + ghcd)))
+                    throw std::runtime_error("pdb: wing ground-effect LUTs unsupported this round");
+                W.cdGain = aero.getFloat(secn, "CD_GAIN");
+                W.clGain = aero.getFloat(secn, "CL_GAIN");
+                W.angle = aero.getFloat(secn, "ANGLE");
+                if (aver >= 3) W.yawGain = aero.getFloat(secn, "YAW_CL_GAIN");
+            }
+        if (n == 0) throw std::runtime_error("pdb: cars without [WING_n] (AeroMap [DATA] path) unsupported this round");
+        if (aero.hasSection("DYNAMIC_CONTROLLER_0")) throw std::runtime_error("pdb: wing dynamic controllers unsupported this round");
+        P.numWings = n;
+    }
+
+    // ---- brakes (BrakeSystem.cpp:14-73) ----
+    {
+        Ini br(dataPath + "brakes.ini");
+        if (!br.ready) throw std::runtime_error("pdb: brakes.ini not found");
+        P.brakePower = br.getFloat("DATA", "MAX_TORQUE");
+        P.frontBias = br.getFloat("DATA", "FRONT_SHARE");
+        P.handBrakeTorque = br.getFloat("DATA", "HANDBRAKE_TORQUE");
+        P.brakePowerMultiplier = 1.0f;
+        P.biasMin = 0.0f; P.biasMax = 1.0f;
+        if (br.hasSection("EBB") || br.hasSection("TEMPS_FRONT") || fileExists(dataPath + "steer_brake_controller.ini") || fileExists(dataPath + "ctrl_ebb.ini"))
+            throw std::runtime_error("pdb: EBB / brake temps / steer-brake controllers unsupported this round");
+        Ini setup(dataPath + "setup.ini");
+        if (setup.ready && setup.hasSection("FRONT_BIAS")) {
+            P.biasMin = setup.getFloat("FRONT_BIAS", "MIN") * 0.01f;
+            P.biasMax = setup.getFloat("FRONT_BIAS", "MAX") * 0.01f;
+        }
+    }
+
+    // ---- engine (Engine.cpp:16-191) ----
+    Ini eng(dataPath + "engine.ini");
+    if (!eng.ready) throw std::runtime_error("pdb: engine.ini not found");
+    {
+        curveLoad(P.powerCurve, dataPath + eng.getString("HEADER", "POWER_CURVE"));
+        P.engMinimum = eng.getInt("ENGINE_DATA", "MINIMUM");
+        if (!P.engMinimum) P.engMinimum = 1000;
+        P.engCoast1 = 0.0f; P.engCoast2 = 0.000001f;   // EngineData defaults (Engine.h:18-20)
+        if (eng.getString("HEADER", "COAST_CURVE") == "FROM_COAST_REF") {
+            const float rpm = eng.getFloat("COAST_REF", "RPM"), tq = eng.getFloat("COAST_REF", "TORQUE"), nl = eng.getFloat("COAST_REF", "NON_LINEARITY");
+            const float v13 = ((1.0f - nl) * rpm) - P.engMinimum;
+            const float v14 = nl * rpm;
+            P.engCoast1 = (v13 == 0.0f) ? 0.0f : -(tq / v13);
+            P.engCoast2 = (v14 == 0.0f) ? 0.0f : tq / (v14 * v14);
+        }
+        P.engInertia = eng.getFloat("ENGINE_DATA", "INERTIA");
+        P.engLimiter = eng.getInt("ENGINE_DATA", "LIMITER");
+        if (P.engLimiter) { P.rpmDamageThreshold = P.engLimiter * 1.05f; P.rpmDamageK = 10.0f; }
+        int hz = eng.getInt("ENGINE_DATA", "LIMITER_HZ");
+        P.engLimiterCycles = hz ? (1000 / hz / 3) : 50;
+        if (eng.hasSection("COAST_SETTINGS")) throw std::runtime_error("pdb: [COAST_SETTINGS] unsupported this round");
+        if (eng.hasSection("TURBO_0")) throw std::runtime_error("pdb: turbo engines unsupported this round");
+        if (eng.hasSection("OVERLAP") && eng.getFloat("OVERLAP", "GAIN") != 0.0f) throw std::runtime_error("pdb: [OVERLAP] unsupported this round");
+        if (eng.hasSection("THROTTLE_RESPONSE")) throw std::runtime_error("pdb: [THROTTLE_RESPONSE] unsupported this round");
+        curveLoad(P.throttleCurve, dataPath + "throttle.lut");
+        if (eng.hasSection("DAMAGE")) {
+            P.rpmDamageThreshold = eng.getFloat("DAMAGE", "RPM_THRESHOLD");
+            P.rpmDamageK = eng.getFloat("DAMAGE", "RPM_DAMAGE_K");
+        }
+        P.bovThreshold = 0.2f;
+        if (eng.hasSection("BOV")) P.bovThreshold = eng.getFloat("BOV", "PRESSURE_THRESHOLD");
+        P.limiterMultiplier = 1.0f;
+        // precalculatePowerAndTorque (Engine.cpp:170-191)
+        const float maxRef = P.powerCurve.n ? P.powerCurve.x[P.powerCurve.n - 1] : 0.0f;
+        float maxTq = 0, maxPw = 0;
+        for (float rpm = 0; rpm <= maxRef; rpm += 50.0f) {
+            const float tq = curveValue(P.powerCurve, rpm);
+            if (tq > maxTq) { P.maxTorqueRPM = rpm; maxTq = tq; }
+            const float pw = rpm * tq * 0.1047f;
+            if (pw > maxPw) { P.maxPowerRPM = rpm; maxPw = pw; }
+        }
+    }
+
+    // ---- drivetrain (Drivetrain.cpp:18-152) ----
+    {
+        Ini dt(dataPath + "drivetrain.ini");
+        if (!dt.ready) throw std::runtime_error("pdb: drivetrain.ini not found");
+        const std::string tr = dt.getString("TRACTION", "TYPE");
+        if (tr != "RWD" && tr != "FWD") throw std::runtime_error("pdb: traction type " + tr + " unsupported (reference: TODO_NOT_IMPLEMENTED_FATAL)");
+        P.tractionType = (tr == "RWD") ? 0 : 1;
+        for (int i = 0; i < 4; ++i) P.tyre[i].driven = (P.tractionType == 0) ? (i >= 2) : (i < 2);
+        P.damageRpmWindow = dt.getFloat("DAMAGE", "RPM_WINDOW_K");
+        int ng = 0;
+        P.gearRatio[ng++] = dt.getFloat("GEARS", "GEAR_R");
+        P.gearRatio[ng++] = 0.0f;
+        const int cnt = dt.getInt("GEARS", "COUNT");
+        for (int i = 1; i <= cnt; ++i) {
+            char k[16]; snprintf(k, sizeof(k), "GEAR_%d", i);
+            if (ng >= PDB_MAX_GEARS) throw std::runtime_error("pdb: too many gears");
+            P.gearRatio[ng++] = dt.getFloat("GEARS", k);
+        }
+        P.numGears = ng;
+        P.finalRatio = dt.getFloat("GEARS", "FINAL");
+        P.diffPowerRamp = dt.getFloat("DIFFERENTIAL", "POWER");
+        P.diffCoastRamp = dt.getFloat("DIFFERENTIAL", "COAST");
+        P.diffPreLoad = dt.getFloat("DIFFERENTIAL", "PRELOAD");
+        P.diffType = (P.diffPowerRamp >= 1.0f && P.diffCoastRamp >= 1.0f) ? 1 : 0;
+        P.gearUpTime = dt.getFloat("GEARBOX", "CHANGE_UP_TIME") * 0.001f;
+        if (P.gearUpTime == 0.0f) P.gearUpTime = 0.1f;
+        P.gearDnTime = dt.getFloat("GEARBOX", "CHANGE_DN_TIME") * 0.001f;
+        if (P.gearDnTime == 0.0f) P.gearDnTime = 0.15f;
+        P.autoCutOffTime = dt.getFloat("GEARBOX", "AUTO_CUTOFF_TIME") * 0.001f;
+        P.isShifterSupported = dt.getInt("GEARBOX", "SUPPORTS_SHIFTER") != 0;
+        P.validShiftRPMWindow = dt.getFloat("GEARBOX", "VALID_SHIFT_RPM_WINDOW");
+        if (P.validShiftRPMWindow == 0.0) P.validShiftRPMWindow = 500.0;
+        P.controlsWindowGain = dt.getFloat("GEARBOX", "CONTROLS_WINDOW_GAIN");
+        P.engineInertiaInit = 0.01f; P.driveInertia = 0.01f; P.clutchInertia = 1.0;
+        const float gi = dt.getFloat("GEARBOX", "INERTIA");
+        if (gi != 0.0f) { P.clutchInertia = gi; P.driveInertia = gi; }
+        P.clutchMaxTorque = dt.getFloat("CLUTCH", "MAX_TORQUE");
+        if (P.clutchMaxTorque == 0.0) P.clutchMaxTorque = 450.0;
+        const int tl = (P.tractionType == 0) ? 2 : 0;
+        P.outShaftInertiaL = P.tyre[tl].angularInertia;
+        P.outShaftInertiaR = P.tyre[tl + 1].angularInertia;
+        if (P.tractionType == 0 && fileExists(dataPath + "ctrl_single_lock.ini")) throw std::runtime_error("pdb: ctrl_single_lock.ini unsupported this round");
+        // AutoClutch (AutoClutch.cpp:25-89)
+        const std::string up = dt.getString("AUTOCLUTCH", "UPSHIFT_PROFILE"), dn = dt.getString("AUTOCLUTCH", "DOWNSHIFT_PROFILE");
+        P.acUseOnChange = dt.getInt("AUTOCLUTCH", "USE_ON_CHANGES") != 0;
+        auto prof = [&](pdb_curve& c, const std::string& name) {
+            c.n = 0;
+            if (name != "NONE" && dt.hasSection(name)) {
+                curveAdd(c, 0.0f, 1.0f);
+                curveAdd(c, dt.getFloat(name, "POINT_0") * 0.001f, 0.0f);
+                curveAdd(c, dt.getFloat(name, "POINT_1") * 0.001f, 0.0f);
+                curveAdd(c, dt.getFloat(name, "POINT_2") * 0.001f, 1.0f);
+            }
+        };
+        prof(P.upshiftProfile, up); prof(P.downshiftProfile, dn);
+        P.acRpmMin = dt.getFloat("AUTOCLUTCH", "MIN_RPM"); P.acRpmMax = dt.getFloat("AUTOCLUTCH", "MAX_RPM");
+        if (P.acRpmMin == 0.0f || P.acRpmMax == 0.0f) { P.acRpmMin = 1500.0f; P.acRpmMax = 2500.0f; }
+        P.acClutchSpeed = 1.0f;
+        // AutoBlip (AutoBlip.cpp:14-49)
+        const float lvl = dt.getFloat("AUTOBLIP", "LEVEL");
+        P.blipProfile.n = 0;
+        curveAdd(P.blipProfile, 0.0f, 0.0f);
+        curveAdd(P.blipProfile, dt.getFloat("AUTOBLIP", "POINT_0"), lvl);
+        curveAdd(P.blipProfile, dt.getFloat("AUTOBLIP", "POINT_1"), lvl);
+        curveAdd(P.blipProfile, dt.getFloat("AUTOBLIP", "POINT_2"), 0.0f);
+        P.blipPerformTime = P.blipProfile.x[3];
+        P.autoBlipElectronic = dt.getInt("AUTOBLIP", "ELECTRONIC") != 0;
+        // AutoShifter (AutoShifter.cpp:14-29, defaults AutoShifter.h:16-20)
+        P.asChangeUpRpm = 0; P.asChangeDnRpm = 4000; P.asSlipThreshold = 0.8f; P.asGasCutoffTime = 0.5f;
+        if (dt.hasSection("AUTO_SHIFTER")) {
+            P.asChangeUpRpm = dt.getInt("AUTO_SHIFTER", "UP");
+            P.asChangeDnRpm = dt.getInt("AUTO_SHIFTER", "DOWN");
+            P.asSlipThreshold = dt.getFloat("AUTO_SHIFTER", "SLIP_THRESHOLD");
+            P.asGasCutoffTime = dt.getFloat("AUTO_SHIFTER", "GAS_CUTOFF_TIME");
+        }
+        if (!P.asChangeUpRpm) {   // lazy init in AutoShifter::step (AutoShifter.cpp:38-54)
+            const float lim = (float)(int)(P.engLimiter * P.limiterMultiplier);
+            const float mx = (lim >= P.maxPowerRPM) ? P.maxPowerRPM : lim;
+            P.asChangeUpRpm = (int)(mx * 0.98f);
+            P.asChangeDnRpm = (int)(P.maxTorqueRPM * 1.1f);
+        }
+    }
+    P.acUseOnStart = 0; P.autoShiftActive = 0; P.autoBlipActive = 0; P.smoothSteer = 0;
+
+    // ---- body masses (Car::updateBodyMass / calcBodyMass, Car.cpp:589-620) ----
+    {
+        float suspMass = 0;
+        for (int i = 0; i < 4; ++i) suspMass += P.susp[i].mass;
+        const float bodyMass = (P.mass - suspMass) + 0.0f;
+        B[0].mass = bodyMass; hBoxInertia(bodyMass, bodyInertia[0], bodyInertia[1], bodyInertia[2], B[0].inertia);
+        const float fuelMass = std::max(0.1f, P.fuelKG * (float)(double)P.fuel);
+        B[1].mass = fuelMass; hBoxInertia(fuelMass, 0.5f, 0.5f, 0.5f, B[1].inertia);
+    }
+    P.numBodies = 7;
+    for (int i = 0; i < P.numBodies; ++i) { P.bodies[i].mass = B[i].mass; memcpy(P.bodies[i].inertia, B[i].inertia, sizeof(float) * 3); }
+
+    // ---- joints into solver order ----
+    if ((int)J.size() > PDB_MAX_JOINTS) throw std::runtime_error("pdb: too many joints");
+    const std::vector<int> order = islandOrder(J, P.numBodies);
+    P.numJoints = (int)order.size();
+    int rows = 0;
+    for (int t = 0; t < P.numJoints; ++t) {
+        P.joints[t] = J[order[t]].d;
+        const int ty = P.joints[t].type;
+        rows += (ty == PDB_JOINT_FIXED) ? 6 : (ty == PDB_JOINT_BALL) ? 3 : (ty == PDB_JOINT_SLIDER) ? 5 : 1;
+    }
+    if (rows > PDB_MAX_ROWS) throw std::runtime_error("pdb: too many constraint rows");
+    P.numRows = rows;
+
+    // getBaseCarHeight (Car.cpp:1360-1365)
+    {
+        const float t0 = fabsf(P.susp[0].basePosition[1] - P.tyre[0].rimRadius);
+        const float t2 = fabsf(P.susp[2].basePosition[1] - P.tyre[2].rimRadius);
+        P.baseCarHeight = std::max(t0, t2);
+    }
+    // ScoringConfig defaults (ScoringSystem.cpp:46-71)
+    pdb_scoring& sc = P.scoring;
+    memset(&sc, 0, sizeof(sc));
+    sc.SmoothSteerSpeed = 10.0f; sc.MinBonusSpeed = 5.0f; sc.MaxBonusSpeed = 200.0f; sc.StallRpm = 300.0f;
+    sc.DirectionThreshold = 0.75f; sc.OutOfTrackThreshold = 0.51f; sc.ApproachDistance = 3.0f; sc.CriticalDistance = 2.0f;
+}
+
+// -------------------------------------------------------------------------------------------------
+// tunes (Car/SetupManager.cpp:10-120,355-444) -- the subset of SetupVar needed for float/double
+// variables; spinner semantics from setup.ini (SHOW_CLICKS, MIN, MAX, STEP) and final.rto.
+// -------------------------------------------------------------------------------------------------
+namespace {
+struct TuneVar { float* f; double* d; float mult; };
+static bool findTune(pdb_car_params& P, const std::string& name, TuneVar& v) {
+    v.f = nullptr; v.d = nullptr; v.mult = 1.0f;
+    static const char* types[] = {"LF", "RF", "LR", "RR"};
+    static const double sides[] = {-1, 1, -1, 1};
+    if (name == "FRONT_BIAS") { v.f = &P.frontBias; v.mult = (float)0.01; return true; }
+    if (name == "BRAKE_POWER_MULT") { v.f = &P.brakePowerMultiplier; v.mult = (float)0.01; return true; }
+    if (name == "DIFF_POWER") { v.d = &P.diffPowerRamp; v.mult = (float)0.01; return true; }
+    if (name == "DIFF_COAST") { v.d = &P.diffCoastRamp; v.mult = (float)0.01; return true; }
+    if (name == "DIFF_PRELOAD") { v.d = &P.diffPreLoad; return true; }
+    if (name == "FINAL_RATIO") { v.d = &P.finalRatio; return true; }
+    if (name == "ARB_FRONT") { v.f = &P.arbK[0]; return true; }
+    if (name == "ARB_REAR") { v.f = &P.arbK[1]; return true; }
+    if (name == "ENGINE_LIMITER") { v.f = &P.limiterMultiplier; v.mult = (float)0.01; return true; }
+    for (int g = 0; g < P.numGears; ++g) {
+        char b[32]; snprintf(b, sizeof(b), "INTERNAL_GEAR_%d", g);
+        if (name == b) { v.d = &P.gearRatio[g]; return true; }
+    }
+    for (int w = 0; w < P.numWings; ++w) {
+        char b[32]; snprintf(b, sizeof(b), "WING_%d", w);
+        if (name == b) { v.f = &P.wings[w].angle; return true; }
+    }
+    for (int i = 0; i < 4; ++i) {
+        const std::string t = types[i];
+        pdb_susp& S = P.susp[i];
+        if (name == "DAMP_FAST_BUMP_" + t) { v.f = &S.damper.bumpFast; return true; }
+        if (name == "DAMP_BUMP_" + t) { v.f = &S.damper.bumpSlow; return true; }
+        if (name == "DAMP_FAST_REBOUND_" + t) { v.f = &S.damper.reboundFast; return true; }
+        if (name == "DAMP_REBOUND_" + t) { v.f = &S.damper.reboundSlow; return true; }
+        if (name == "BUMP_STOP_RATE_" + t) { v.f = &S.bumpStopRate; v.mult = (float)1000.0; return true; }
+        if (name == "SPRING_RATE_" + t) { v.f = &S.k; v.mult = (float)1000.0; return true; }
+        if (name == "PROGRESSIVE_SPRING_RATE_" + t) { v.f = &S.progressiveK; v.mult = (float)1000.0; return true; }
+        if (name == "ROD_LENGTH_" + t) { v.f = &S.rodLength; v.mult = (float)0.0001; return true; }
+        if (name == "CAMBER_" + t) { v.f = &S.staticCamber; v.mult = (float)(0.0017453292 * sides[i]); return true; }
+        if (name == "TOE_OUT_" + t) { v.f = &S.toeOutLinear; v.mult = (float)0.00001; return true; }
+        if (name == "PACKER_RANGE_" + t) { v.f = &S.packerRange; v.mult = (float)0.001; return true; }
+        if (name == "PRESSURE_" + t) { v.f = &P.tyre[i].pressureStatic; return true; }
+    }
+    return false;
+}
+static inline float truncF(float x) { return (float)(int)x; }
+}  // namespace
+
+bool setCarTune(pdb_car_params& P, const std::string& basePathIn, const std::string& modelName, const std::string& name, float value, bool raw) {
+    TuneVar v;
+    if (!findTune(P, name, v)) return false;   // PyProjectD.cpp:328-345: unknown names are ignored
+    auto setRaw = [&](float x) { if (v.f) *v.f = x; else *v.d = x; };
+    if (raw) { setRaw(value); return true; }
+    std::string base = basePathIn;
+    std::replace(base.begin(), base.end(), '\\', '/');
+    if (!base.empty() && base.back() != '/') base += '/';
+    const std::string dataPath = base + "content/cars/" + modelName + "/data/";
+    // SetupVar defaults (SetupManager.h:29-44)
+    float minV = -3.402823466e+38f, maxV = 3.402823466e+38f, step = 0.01f;
+    int spinner = 3;  // RawFloat
+    bool tunable = false;
+    std::vector<float> predefined;
+    Ini ini(dataPath + "setup.ini");
+    if (ini.ready) {
+        if (name == "FINAL_RATIO" && ini.hasKey("FINAL_GEAR_RATIO", "RATIOS")) {
+            std::ifstream fs(dataPath + ini.getString("FINAL_GEAR_RATIO", "RATIOS"));
+            std::string line;
+            while (fs.is_open() && std::getline(fs, line)) {
+                if (!line.empty() && line.back() == '\r') line.pop_back();
+                if (line.empty()) continue;
+                auto kv = splitStr(line, "|");
+                if (kv.size() == 2) predefined.push_back(toFloat(kv[1]));
+            }
+            if (!predefined.empty()) {
+                std::sort(predefined.begin(), predefined.end());
+                spinner = 4;  // RawPredefined
+                minV = predefined.front(); maxV = predefined.back(); step = 0.01f; tunable = true;
+            }
+        }
+        if (ini.hasSection(name)) {
+            const bool t = ini.tryGetFloat(name, "MIN", minV) && ini.tryGetFloat(name, "MAX", maxV) && ini.tryGetFloat(name, "STEP", step);
+            int sc = 0;
+            if (ini.tryGetInt(name, "SHOW_CLICKS", sc) && sc >= 0 && sc <= 4) spinner = sc;
+            if (t) tunable = true;
+        }
+    }
+    if (tunable && (minV >= maxV || fabs(maxV - minV) < 0.01)) { minV = 0; maxV = 0; tunable = false; }
+    if (tunable && step < 0.0f) { step = 0.0f; tunable = false; }
+    if (!tunable) spinner = 3;
+    // getSpinner(type) limits, then setValue (SetupManager.cpp:355-421)
+    float smin, smax;
+    switch (spinner) {
+        case 0: smin = truncF(minV); smax = truncF(maxV); break;
+        case 1: smin = truncF(minV / step); smax = truncF(maxV / step); break;
+        case 2: smin = 0.0f; smax = truncF((maxV - minV) / step); break;
+        default: smin = minV; smax = maxV; break;
+    }
+    const float val = (value < smin) ? smin : ((value > smax) ? smax : value);
+    float rawV;
+    switch (spinner) {
+        case 0: rawV = val * v.mult; break;
+        case 1: rawV = (val * step) * v.mult; break;
+        case 2: rawV = (val * step + minV) * v.mult; break;
+        default: rawV = val; break;
+    }
+    if (spinner == 4 && !predefined.empty()) {
+        int best = 0; float bd = 3.402823466e+38f;
+        for (int i = 0; i < (int)predefined.size(); ++i) {
+            const float d = fabsf(predefined[i] - rawV);
+            if (d < bd) { bd = d; best = i; }
+        }
+        rawV = predefined[best];
+    }
+    setRaw(rawV);
+    return true;
+}
+
+bool setScoringVar(pdb_car_params& P, const std::string& name, float w) {
+    pdb_scoring& s = P.scoring;
+#define SV(n) if (name == #n) { s.n = w; return true; }
+    SV(SmoothSteerSpeed) SV(MinBonusSpeed) SV(MaxBonusSpeed) SV(StallRpm) SV(DirectionThreshold) SV(OutOfTrackThreshold)
+    SV(ApproachDistance) SV(CriticalDistance) SV(TravelBonus) SV(TravelSplineBonus) SV(DriftBonus) SV(SpeedBonus)
+    SV(ThrottleBonus) SV(EngineRpmBonus) SV(DirectionBonus) SV(DirectionPenalty) SV(ObstApproachPenalty) SV(CollisionPenalty)
+    SV(OffTrackPenalty) SV(GearGrindPenalty) SV(StallPenalty)
+#undef SV
+    return false;
+}
+bool getScoringVar(const pdb_car_params& P, const std::string& name, float& w) {
+    const pdb_scoring& s = P.scoring;
+#define SV(n) if (name == #n) { w = s.n; return true; }
+    SV(SmoothSteerSpeed) SV(MinBonusSpeed) SV(MaxBonusSpeed) SV(StallRpm) SV(DirectionThreshold) SV(OutOfTrackThreshold)
+    SV(ApproachDistance) SV(CriticalDistance) SV(TravelBonus) SV(TravelSplineBonus) SV(DriftBonus) SV(SpeedBonus)
+    SV(ThrottleBonus) SV(EngineRpmBonus) SV(DirectionBonus) SV(DirectionPenalty) SV(ObstApproachPenalty) SV(CollisionPenalty)
+    SV(OffTrackPenalty) SV(GearGrindPenalty) SV(StallPenalty)
+#undef SV
+    w = 0;
+    return false;
+}
+
+}  // namespace pdb

@@ -1,0 +1,287 @@
+// pdbatch host side: track loader.  Reads the reference's on-disk track formats and emits the
+// packed blob the kernels consume.
+//   surfaces.bin  Sim/Track.cpp:97-150 (58-byte packed BlobSurface, Sim/Surface.h:25-45)
+//   spline.bin    Sim/Track.cpp:274-293 (SlimTrackPoint, Sim/Track.h:12-17)
+//   spline.cache  Sim/Track.cpp:294-311 (FatTrackPoint, Sim/Track.h:18-25)
+//   spline.ini    Sim/Track.cpp:158-186
+// and restates the load-time geometry: computeFatPoints (Track.cpp:366-434, untraced sides),
+// initTrackPoints (Track.cpp:188-272) and BSpline3d::init_from_array (Core/Spline3d.cpp:79-162).
+#include "model.hpp"
+#include "ini.hpp"
+#include <cstdio>
+#include <cstring>
+#include <cmath>
+#include <algorithm>
+
+namespace pdb {
+
+#pragma pack(push, 1)
+struct BlobSurface {
+    uint32_t magic, numVertices, numIndices, sectorID, collisionCategory;
+    float gripMod, damping, sinHeight, sinLength, granularity, dirtAdditiveK, vibrationGain, vibrationLength, wavPitchSpeed;
+    uint8_t isValidTrack, isPitlane;
+};
+#pragma pack(pop)
+static_assert(sizeof(BlobSurface) == 58, "BlobSurface layout");
+
+// One vertical-or-general ray against the triangle soup.  Moeller-Trumbore in OPCODE's culling form
+// (det = e1 . (dir x e2) must exceed 1e-6); per surface mesh the nearest hit, across meshes a
+// strictly nearer hit replaces the current one (PhysicsEngineODE.cpp:196-211); normal =
+// normalise((v1-v0) x (v2-v0)).
+static inline bool rayTri(const float* o, const float* d, float maxDist, const float* v0, const float* v1, const float* v2, float& tOut) {
+    const float e1[3] = {v1[0] - v0[0], v1[1] - v0[1], v1[2] - v0[2]};
+    const float e2[3] = {v2[0] - v0[0], v2[1] - v0[1], v2[2] - v0[2]};
+    const float p[3] = {d[1] * e2[2] - d[2] * e2[1], d[2] * e2[0] - d[0] * e2[2], d[0] * e2[1] - d[1] * e2[0]};
+    const float det = e1[0] * p[0] + e1[1] * p[1] + e1[2] * p[2];
+    if (det < 1.0e-6f) return false;
+    const float tv[3] = {o[0] - v0[0], o[1] - v0[1], o[2] - v0[2]};
+    const float u = tv[0] * p[0] + tv[1] * p[1] + tv[2] * p[2];
+    if (u < 0.0f || u > det) return false;
+    const float q[3] = {tv[1] * e1[2] - tv[2] * e1[1], tv[2] * e1[0] - tv[0] * e1[2], tv[0] * e1[1] - tv[1] * e1[0]};
+    const float v = d[0] * q[0] + d[1] * q[1] + d[2] * q[2];
+    if (v < 0.0f || u + v > det) return false;
+    float t = e2[0] * q[0] + e2[1] * q[1] + e2[2] * q[2];
+    t *= 1.0f / det;
+    if (t < 0.0f || !(t < maxDist)) return false;
+    tOut = t;
+    return true;
+}
+
+static RayHitH rayCastRaw(const pdb_surface* surfaces, int numSurfaces, const float* tris, const float* o, const float* d, float maxDist) {
+    RayHitH best;
+    for (int s = 0; s < numSurfaces; ++s) {
+        float bt = -1.0f; int btri = -1;
+        for (int t = surfaces[s].triStart; t < surfaces[s].triStart + surfaces[s].triCount; ++t) {
+            float tt;
+            if (rayTri(o, d, maxDist, tris + 9 * t, tris + 9 * t + 3, tris + 9 * t + 6, tt))
+                if (bt < 0.0f || tt < bt) { bt = tt; btri = t; }
+        }
+        if (btri >= 0 && (best.depth < 0.0f || best.depth > bt)) {
+            const float* v0 = tris + 9 * btri; const float* v1 = v0 + 3; const float* v2 = v0 + 6;
+            const float vu[3] = {v1[0] - v0[0], v1[1] - v0[1], v1[2] - v0[2]};
+            const float vv[3] = {v2[0] - v0[0], v2[1] - v0[1], v2[2] - v0[2]};
+            float n[3] = {vu[1] * vv[2] - vu[2] * vv[1], vu[2] * vv[0] - vu[0] * vv[2], vu[0] * vv[1] - vu[1] * vv[0]};
+            const float l = n[0] * n[0] + n[1] * n[1] + n[2] * n[2];
+            if (l > 0.0f) {
+                const float sc = 1.0f / sqrtf(l);
+                best.has = true; best.depth = bt; best.surface = s;
+                for (int k = 0; k < 3; ++k) { best.pos[k] = o[k] + d[k] * bt; best.normal[k] = n[k] * sc; }
+            }
+        }
+    }
+    return best;
+}
+
+RayHitH rayCastTrack(const TrackView& tv, const float* origin, const float* dir, float maxDist) {
+    return rayCastRaw(tv.surfaces, tv.h->numSurfaces, tv.tris, origin, dir, maxDist);
+}
+
+static std::vector<uint8_t> readFile(const std::string& p) {
+    std::vector<uint8_t> d;
+    FILE* f = fopen(p.c_str(), "rb");
+    if (!f) return d;
+    fseek(f, 0, SEEK_END);
+    const long n = ftell(f);
+    fseek(f, 0, SEEK_SET);
+    d.resize((size_t)n);
+    if (n > 0 && fread(d.data(), 1, (size_t)n, f) != (size_t)n) d.clear();
+    fclose(f);
+    return d;
+}
+
+struct V3 { float x, y, z; };
+static inline V3 operator+(V3 a, V3 b) { return {a.x + b.x, a.y + b.y, a.z + b.z}; }
+static inline V3 operator-(V3 a, V3 b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
+static inline V3 operator*(V3 a, float f) { return {a.x * f, a.y * f, a.z * f}; }
+static inline V3 operator*(float f, V3 a) { return {a.x * f, a.y * f, a.z * f}; }
+static inline V3 operator/(V3 a, float f) { return {a.x / f, a.y / f, a.z / f}; }
+static inline float len(V3 a) { return sqrtf(a.x * a.x + a.y * a.y + a.z * a.z); }
+static inline V3 norm(V3 a) { const float l = len(a); if (l != 0.0f) return a * (1.0f / l); return a; }
+static inline V3 cross(V3 a, V3 v) { return {a.y * v.z - a.z * v.y, a.z * v.x - a.x * v.z, a.x * v.y - a.y * v.x}; }
+
+// Core/Spline3d.cpp:154-162
+static V3 bsInterp(float u, V3 P0, V3 P1, V3 P2, V3 P3) {
+    V3 p = u * u * u * ((-1.0f) * P0 + 3.0f * P1 - 3.0f * P2 + P3) / 6.0f;
+    p = p + u * u * (3.0f * P0 - 6.0f * P1 + 3.0f * P2) / 6.0f;
+    p = p + u * (-3.0f * P0 + 3.0f * P2) / 6.0f;
+    p = p + (P0 + 4.0f * P1 + P2) / 6.0f;
+    return p;
+}
+
+std::vector<uint8_t> buildTrack(const std::string& basePathIn, const std::string& trackName) {
+    std::string base = basePathIn;
+    std::replace(base.begin(), base.end(), '\\', '/');
+    if (!base.empty() && base.back() != '/') base += '/';
+    const std::string dir = base + "content/tracks/" + trackName + "/";
+
+    float grip = 1.0f, cellSize = 50.0f;
+    Ini simIni(base + "cfg/sim.ini");
+    if (simIni.ready) { simIni.tryGetFloat("ENVIRONMENT", "TRACK_GRIP", grip); simIni.tryGetFloat("VERTEX_HASH", "CELL_SIZE", cellSize); }
+
+    // ---- surfaces ----
+    std::vector<pdb_surface> surfaces;
+    std::vector<float> tris;
+    {
+        const std::vector<uint8_t> d = readFile(dir + "surfaces.bin");
+        if (d.empty()) throw std::runtime_error("pdb: cannot read " + dir + "surfaces.bin");
+        size_t pos = 0;
+        while (pos + sizeof(BlobSurface) <= d.size()) {
+            BlobSurface b;
+            memcpy(&b, d.data() + pos, sizeof(b));
+            pos += sizeof(b);
+            if (b.magic != 0xAABBCCDD || !b.numVertices || !b.numIndices) throw std::runtime_error("pdb: bad surface blob");
+            const size_t vb = (size_t)b.numVertices * 12, ib = (size_t)b.numIndices * 2;
+            if (pos + vb + ib > d.size()) throw std::runtime_error("pdb: truncated surface blob");
+            const float* v = reinterpret_cast<const float*>(d.data() + pos);
+            const uint16_t* ix = reinterpret_cast<const uint16_t*>(d.data() + pos + vb);
+            pdb_surface s;
+            memset(&s, 0, sizeof(s));
+            s.gripMod = b.gripMod; s.damping = b.damping; s.sinHeight = b.sinHeight; s.sinLength = b.sinLength;
+            s.granularity = b.granularity; s.dirtAdditiveK = b.dirtAdditiveK;
+            s.collisionCategory = (int32_t)b.collisionCategory; s.isValidTrack = b.isValidTrack; s.sectorID = (int32_t)b.sectorID;
+            s.triStart = (int32_t)(tris.size() / 9);
+            s.triCount = (int32_t)(b.numIndices / 3);
+            for (uint32_t t = 0; t < b.numIndices / 3; ++t)
+                for (int k = 0; k < 3; ++k) {
+                    float vv[3];
+                    memcpy(vv, reinterpret_cast<const uint8_t*>(v) + (size_t)ix[3 * t + k] * 12, 12);
+                    tris.push_back(vv[0]); tris.push_back(vv[1]); tris.push_back(vv[2]);
+                }
+            surfaces.push_back(s);
+            pos += vb + ib;
+        }
+    }
+
+    // ---- spline ----
+    bool closedLoop = false, traceSides = false;
+    float traceRayOffsetY = 20.0f, traceRayLength = 100.0f;
+    Ini spl(dir + "spline.ini");
+    if (spl.ready) {
+        closedLoop = spl.getInt("SPLINE", "CLOSED_LOOP") != 0;
+        traceSides = spl.getInt("SPLINE", "TRACE_SIDES") != 0;
+        spl.tryGetFloat("SPLINE", "TRACE_RAY_OFFSET_Y", traceRayOffsetY);
+        spl.tryGetFloat("SPLINE", "TRACE_RAY_LENGTH", traceRayLength);
+    }
+    struct Slim { float best[3]; float sides[2]; };
+    struct Fat { V3 best, left, right, center, forwardDir; };
+    std::vector<Slim> slim;
+    {
+        const std::vector<uint8_t> d = readFile(dir + "spline.bin");
+        slim.resize(d.size() / sizeof(Slim));
+        if (!slim.empty()) memcpy(slim.data(), d.data(), slim.size() * sizeof(Slim));
+    }
+    std::vector<Fat> fat;
+    {
+        const std::vector<uint8_t> d = readFile(dir + "spline.cache");
+        fat.resize(d.size() / sizeof(Fat));
+        if (!fat.empty()) memcpy(fat.data(), d.data(), fat.size() * sizeof(Fat));
+        if (fat.size() != slim.size()) fat.clear();
+    }
+    if (fat.empty() && !slim.empty()) {
+        if (traceSides) throw std::runtime_error("pdb: TRACE_SIDES=1 tracks need their spline.cache (side tracing not implemented)");
+        fat.resize(slim.size());
+        memset(fat.data(), 0, fat.size() * sizeof(Fat));
+        const float down[3] = {0, -1, 0};
+        for (size_t i = 0; i < slim.size(); ++i) {
+            const V3 sb = {slim[i].best[0], slim[i].best[1], slim[i].best[2]};
+            const V3 rs = sb + V3{0, traceRayOffsetY, 0};
+            RayHitH h = rayCastRaw(surfaces.data(), (int)surfaces.size(), tris.data(), &rs.x, down, traceRayLength);
+            if (!h.has) continue;
+            Fat& f = fat[i];
+            f.best = {h.pos[0], h.pos[1], h.pos[2]};
+            if (i + 1 < slim.size()) f.forwardDir = norm(V3{slim[i + 1].best[0], slim[i + 1].best[1], slim[i + 1].best[2]} - sb);
+            else if (i > 0) f.forwardDir = norm(sb - V3{slim[i - 1].best[0], slim[i - 1].best[1], slim[i - 1].best[2]});
+            const V3 leftDir = norm(cross(f.forwardDir, V3{0, -1, 0}));
+            const V3 rightDir = leftDir * -1.0f;
+            f.left = f.best + leftDir * slim[i].sides[0];
+            f.right = f.best + rightDir * slim[i].sides[1];
+            V3 o = f.left + V3{0, traceRayOffsetY, 0};
+            h = rayCastRaw(surfaces.data(), (int)surfaces.size(), tris.data(), &o.x, down, traceRayLength);
+            if (h.has) f.left = {h.pos[0], h.pos[1], h.pos[2]};
+            o = f.right + V3{0, traceRayOffsetY, 0};
+            h = rayCastRaw(surfaces.data(), (int)surfaces.size(), tris.data(), &o.x, down, traceRayLength);
+            if (h.has) f.right = {h.pos[0], h.pos[1], h.pos[2]};
+            f.center = (f.left + f.right) * 0.5f;
+        }
+    }
+
+    // ---- initTrackPoints (Track.cpp:200-271) ----
+    float trackWidth = 0.1f, trackLength = 0.1f;
+    std::vector<float> fatDist(fat.size());
+    std::vector<V3> nodes;
+    std::vector<float> nodeDist;
+    int steps = 0;
+    if (!fat.empty()) {
+        const size_t n = fat.size();
+        for (size_t id = 0; id < n; ++id) {
+            const float w = len(fat[id].left - fat[id].right);
+            if (trackWidth < w) trackWidth = w;
+            fatDist[id] = trackLength;
+            if (id + 1 < n) trackLength += len(fat[id].best - fat[id + 1].best);
+        }
+        steps = (int)(trackLength / 0.1f) / (int)n;
+        auto addNode = [&](V3 p) {
+            nodes.push_back(p);
+            if (nodes.size() == 1) nodeDist.push_back(0);
+            else { const size_t k = nodes.size() - 1; nodeDist.push_back(len(nodes[k] - nodes[k - 1]) + nodeDist[k - 1]); }
+        };
+        const int np = (int)n;
+        if (np >= 4) {
+            std::vector<V3> pts(n);
+            for (size_t i = 0; i < n; ++i) pts[i] = fat[i].best;
+            auto wrap = [&](int id) { return id < np ? id : id - np; };
+            if (!closedLoop) {
+                const float d0 = len(pts[1] - pts[0]);
+                const V3 n0 = (pts[1] - pts[0]) / d0;
+                for (int i = 0; i < steps; ++i) { const float u = (float)i / (float)steps; addNode(pts[0] + n0 * (u * d0)); }
+            }
+            for (int pt = 0; pt + 4 < np; ++pt)
+                for (int i = 0; i < steps; ++i) { const float u = (float)i / (float)steps; addNode(bsInterp(u, pts[pt], pts[pt + 1], pts[pt + 2], pts[pt + 3])); }
+            if (closedLoop) {
+                for (int pt = np - 4; pt < np; ++pt)
+                    for (int i = 0; i < steps; ++i) {
+                        const float u = (float)i / (float)steps;
+                        addNode(bsInterp(u, pts[pt], pts[wrap(pt + 1)], pts[wrap(pt + 2)], pts[wrap(pt + 3)]));
+                    }
+            } else {
+                for (int pt = np - 3; pt + 1 < np; ++pt) {
+                    const float dx = len(pts[pt + 1] - pts[pt]);
+                    const V3 nx = (pts[pt + 1] - pts[pt]) / dx;
+                    for (int i = 0; i < steps; ++i) { const float u = (float)i / (float)steps; addNode(pts[pt] + nx * (u * dx)); }
+                }
+                addNode(pts[np - 1]);
+            }
+        }
+        if (nodeDist.empty()) throw std::runtime_error("pdb: spline needs at least 4 points");
+        trackLength = nodeDist.back();
+    }
+
+    // ---- pack ----
+    pdb_track_header h;
+    memset(&h, 0, sizeof(h));
+    h.magic = 0x4B544450; h.version = 1;
+    h.numSurfaces = (int32_t)surfaces.size(); h.numTris = (int32_t)(tris.size() / 9);
+    h.numFat = (int32_t)fat.size(); h.numNodes = (int32_t)nodes.size();
+    h.interpolateStep = steps; h.closedLoop = closedLoop ? 1 : 0;
+    h.computedTrackLength = trackLength; h.computedTrackWidth = trackWidth; h.dynamicGripLevel = grip; h.hashCellSize = cellSize;
+    auto align = [](uint64_t x) { return (x + 15) & ~uint64_t(15); };
+    uint64_t off = align(sizeof(h));
+    h.offSurfaces = off; off = align(off + surfaces.size() * sizeof(pdb_surface));
+    h.offTris = off; off = align(off + tris.size() * 4);
+    h.offFat = off; off = align(off + fat.size() * 60);
+    h.offFatDist = off; off = align(off + fat.size() * 4);
+    h.offNodes = off; off = align(off + nodes.size() * 12);
+    h.offNodeDist = off; off = align(off + nodes.size() * 4);
+    h.totalBytes = off;
+    std::vector<uint8_t> blob(off, 0);
+    memcpy(blob.data(), &h, sizeof(h));
+    if (!surfaces.empty()) memcpy(blob.data() + h.offSurfaces, surfaces.data(), surfaces.size() * sizeof(pdb_surface));
+    if (!tris.empty()) memcpy(blob.data() + h.offTris, tris.data(), tris.size() * 4);
+    if (!fat.empty()) memcpy(blob.data() + h.offFat, fat.data(), fat.size() * 60);
+    if (!fat.empty()) memcpy(blob.data() + h.offFatDist, fatDist.data(), fat.size() * 4);
+    if (!nodes.empty()) memcpy(blob.data() + h.offNodes, nodes.data(), nodes.size() * 12);
+    if (!nodes.empty()) memcpy(blob.data() + h.offNodeDist, nodeDist.data(), nodes.size() * 4);
+    return blob;
+}
+
+}  // namespace pdb

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""ORACLE / TEST INFRASTRUCTURE.  Writes a synthetic track in the reference's on-disk formats:
+"""Synthetic benchmark / test tracks written in the reference's on-disk formats:
 surfaces.bin (58-byte packed BlobSurface header + float[3] verts + uint16 indices,
 Sim/Surface.h:25-45, Sim/Track.cpp:97-150), spline.bin (SlimTrackPoint = float[3] best +
 float[2] sides, Sim/Track.h:12-17), spline.ini (Sim/Track.cpp:158-186).
@@ -37,6 +37,63 @@ def gen_flat(out, half=2000.0, z0=-1500.0, z1=1500.0, step=10.0, side=6.0):
     c = os.path.join(out, 'spline.cache')
     if os.path.exists(c):
         os.remove(c)
+
+SIM_INI = '''[SIM]
+STEP_HZ=333
+MAX_CARS=2
+
+[ENVIRONMENT]
+ROAD_TEMP=20.0
+AMBIENT_TEMP=20.0
+TRACK_GRIP=0.98
+
+[VERTEX_HASH]
+CELL_SIZE=50.0
+TABLE_SIZE=4096
+
+[CAR_LOOK_AHEAD]
+COUNT=5
+STEP=10.0
+
+[CAR_PROBE_1]
+YAW=0.0
+LENGTH=50.0
+
+[CAR_PROBE_2]
+YAW=25.0
+LENGTH=50.0
+
+[CAR_PROBE_3]
+YAW=-25.0
+LENGTH=50.0
+
+[CAR_PROBE_4]
+YAW=90.0
+LENGTH=10.0
+
+[CAR_PROBE_5]
+YAW=-90.0
+LENGTH=10.0
+
+[CAR_PROBE_6]
+YAW=-145.0
+LENGTH=10.0
+
+[CAR_PROBE_7]
+YAW=145.0
+LENGTH=10.0
+'''
+
+def make_base(base, tracks=('flat',)):
+    """Create <base>/cfg/sim.ini (same keys/values as the reference's shipped cfg/sim.ini that the
+    hot path reads: Sim/Simulator.cpp:62-75, Sim/Track.cpp:38-42,212-216, Car/Car.cpp:285-314) and the
+    requested synthetic tracks under <base>/content/tracks/."""
+    os.makedirs(os.path.join(base, 'cfg'), exist_ok=True)
+    with open(os.path.join(base, 'cfg', 'sim.ini'), 'w') as f:
+        f.write(SIM_INI)
+    for t in tracks:
+        {'flat': gen_flat}[t](os.path.join(base, 'content', 'tracks', t))
+    return base
 
 if __name__ == '__main__':
     kind, out = sys.argv[1], sys.argv[2]
