@@ -6,7 +6,7 @@
  * Reference anchors (relative to /root/reference/src/ProjectD):
  *   pdb_controls   <- Car/CarControls.h:9-20      (24 B, #pragma pack(4))
  *   pdb_car_state  <- Car/CarState.h:11-56        (664 B, what getCarState copies to Python)
- *   pdb_car_params <- every `// config` block of Car/*.h that Car::step reads
+ *   pdb_car_params <- every "config" block of the Car/ headers that Car::step reads
  *   pdb_dyn_state  <- every `// runtime` member that survives from one tick to the next
  */
 #ifndef PDB_TYPES_H
@@ -240,7 +240,8 @@ typedef struct pdb_dyn_state {
     float instantDriftDelta, instantDrift, driftPoints;
     int32_t oldPointId, oldSplinePointId, drifting, driftExtreme, driftInvalid, driftComboCounter;
     int32_t collisionFlag, oldCollisionFlag, outOfTrackFlag;
-    int32_t _pad;
+    float gasUsage;          /* Engine::gasUsage of the previous tick (fuel burn input, Car.cpp:478) */
+    int32_t _pad[2];         /* record size is a multiple of 16 bytes (coalesced 16-byte-per-lane copies) */
 } pdb_dyn_state;
 
 /* per-tick outputs (compact) */

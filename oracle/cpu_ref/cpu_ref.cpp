@@ -950,6 +950,7 @@ static void engineStep(Car& c, float gasInput, float rpm) {
     if (S.lifeLeft <= 0.0f) S.fuelPressure = 0;
     const float fGas = gas * 1.0f;
     c.gasUsage = fGas;
+    S.gasUsage = fGas;
     float fPower = curve(P.powerCurve, rpm);
     float fCoastTorq = 0;
     if (P.engCoast1 != 0.0f) fCoastTorq = (rpm - (float)P.engMinimum) * P.engCoast1;
@@ -1132,7 +1133,7 @@ void Car::carStep(float dt) {
     } else S.smoothSteerValue = smoothSteerTarget;
     {   // fuel (:476-489); fuelConsumptionRate = 0
         const float fRpmAbs = fabsf(engineRpm(*this));
-        const double fNewFuel = S.fuel - (fRpmAbs * dt * gasUsage) * (0.0f + 1.0) * Pm.fuelConsumptionK * 0.001 * Pm.fuelConsumptionRate;
+        const double fNewFuel = S.fuel - (fRpmAbs * dt * S.gasUsage) * (0.0f + 1.0) * Pm.fuelConsumptionK * 0.001 * Pm.fuelConsumptionRate;
         S.fuel = fNewFuel;
         if (fNewFuel > 0.0f) S.fuelPressure = 1.0f; else { S.fuel = 0; S.fuelPressure = 0; }
     }

@@ -1,0 +1,248 @@
+// pdbatch device batch: owns the HBM-resident car records of one GPU and launches the step kernel.
+// See include/pdbatch.h for the reference interfaces each entry point replaces.
+#include <hip/hip_runtime.h>
+#include "pdbatch.h"
+#include "model.hpp"
+#include <cmath>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "step_kernel.hip.inc"
+
+namespace pdb { void setError(const std::string& s); }
+
+#define HIPCHK(expr)                                                                                 \
+    do {                                                                                             \
+        hipError_t _e = (expr);                                                                      \
+        if (_e != hipSuccess) {                                                                      \
+            pdb::setError(std::string(#expr) + ": " + hipGetErrorString(_e));                        \
+            return PDB_ERR_HIP;                                                                      \
+        }                                                                                            \
+    } while (0)
+
+struct pdb_batch {
+    int device = 0;
+    int n = 0;
+    pdb_car_params params;
+    std::vector<uint8_t> track;
+    DevConst K;
+    hipStream_t stream = nullptr;
+    pdb_dyn_state* dStates = nullptr;
+    float* dActions = nullptr;
+    pdb_step_out* dOut = nullptr;
+    pdb_car_state* dCarStates = nullptr;
+    pdb_car_params* dParams = nullptr;
+    DevConst* dK = nullptr;
+    uint8_t* dTrack = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    double kernelMs = 0;
+    int kernelLaunches = 0;
+    // graph of `graphTicks` back-to-back ticks
+    hipGraphExec_t graphExec = nullptr;
+    int graphTicks = 0;
+    float graphDt = 0;
+    pdb_dyn_state resetTemplate;   // state of a fresh car teleported to the spline start
+};
+
+static void fillConst(const pdb_car_params& P, DevConst& K, int actionMode) {
+    memset(&K, 0, sizeof(K));
+    for (int i = 0; i < 4; ++i) {
+        // mat44f::createFromAxisAngle((0,0,1), staticCamber): M11 = M22 = c, M12 = s, M21 = -s, M33 = (1-c)+c
+        const float s = sinf(P.susp[i].staticCamber), c = cosf(P.susp[i].staticCamber), o = 1.0f - c;
+        K.camC[i] = ((0.0f * 0.0f) * o) + c;
+        K.camS[i] = (1.0f * s) + (0.0f * 0.0f) * o;
+        K.camM33[i] = ((1.0f * 1.0f) * o) + c;
+    }
+    K.acos096 = acosf(0.96f);
+    int r = 0;
+    for (int j = 0; j < P.numJoints; ++j) {
+        K.rowStart[j] = r;
+        const int t = P.joints[j].type;
+        r += (t == PDB_JOINT_FIXED) ? 6 : (t == PDB_JOINT_BALL) ? 3 : (t == PDB_JOINT_SLIDER) ? 5 : 1;
+    }
+    for (int j = P.numJoints; j <= PDB_MAX_JOINTS; ++j) K.rowStart[j] = r;
+    K.actionMode = actionMode;
+    K.wantCarState = 0;
+}
+
+static int launch(pdb_batch* b, float dt, bool wantCarState) {
+    if (b->K.dt != dt || b->K.wantCarState != (wantCarState ? 1 : 0)) {
+        b->K.dt = dt;
+        b->K.dtD = (dt == (float)(1.0 / 333.0)) ? (1.0 / 333.0) : (double)dt;   // PyProjectD.cpp:160-173: double dt, float step
+        b->K.wantCarState = wantCarState ? 1 : 0;
+        HIPCHK(hipMemcpyAsync(b->dK, &b->K, sizeof(DevConst), hipMemcpyHostToDevice, b->stream));
+    }
+    hipLaunchKernelGGL(pdb_step_kernel, dim3(b->n), dim3(PDB_WAVE), 0, b->stream, b->dStates, b->dActions, b->dOut, b->dCarStates, b->dParams, b->dK,
+                       b->dTrack, b->n);
+    HIPCHK(hipGetLastError());
+    return PDB_OK;
+}
+
+extern "C" {
+
+pdb_batch* pdb_create(int device, int n_cars, const pdb_car_params* params, const void* track_blob, uint64_t track_bytes, int action_mode) {
+    if (!params || !track_blob || n_cars <= 0) { pdb::setError("pdb_create: bad argument"); return nullptr; }
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count <= 0 || device < 0 || device >= count) {
+        pdb::setError("pdb_create: no usable HIP device (there is no CPU fallback)");
+        return nullptr;
+    }
+    if (hipSetDevice(device) != hipSuccess) { pdb::setError("hipSetDevice failed"); return nullptr; }
+    pdb_batch* b = new pdb_batch();
+    b->device = device; b->n = n_cars; b->params = *params;
+    b->track.assign((const uint8_t*)track_blob, (const uint8_t*)track_blob + track_bytes);
+    fillConst(b->params, b->K, action_mode);
+    b->K.dt = (float)(1.0 / 333.0); b->K.dtD = 1.0 / 333.0;
+    bool ok = true;
+    ok = ok && hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking) == hipSuccess;
+    ok = ok && hipMalloc(&b->dStates, sizeof(pdb_dyn_state) * (size_t)n_cars) == hipSuccess;
+    ok = ok && hipMalloc(&b->dActions, sizeof(float) * 2 * (size_t)n_cars) == hipSuccess;
+    ok = ok && hipMalloc(&b->dOut, sizeof(pdb_step_out) * (size_t)n_cars) == hipSuccess;
+    ok = ok && hipMalloc(&b->dCarStates, sizeof(pdb_car_state) * (size_t)n_cars) == hipSuccess;
+    ok = ok && hipMalloc(&b->dParams, sizeof(pdb_car_params)) == hipSuccess;
+    ok = ok && hipMalloc(&b->dK, sizeof(DevConst)) == hipSuccess;
+    ok = ok && hipMalloc(&b->dTrack, track_bytes) == hipSuccess;
+    ok = ok && hipEventCreate(&b->ev0) == hipSuccess && hipEventCreate(&b->ev1) == hipSuccess;
+    if (ok) {
+        ok = ok && hipMemcpy(b->dParams, &b->params, sizeof(pdb_car_params), hipMemcpyHostToDevice) == hipSuccess;
+        ok = ok && hipMemcpy(b->dK, &b->K, sizeof(DevConst), hipMemcpyHostToDevice) == hipSuccess;
+        ok = ok && hipMemcpy(b->dTrack, b->track.data(), track_bytes, hipMemcpyHostToDevice) == hipSuccess;
+        ok = ok && hipMemset(b->dActions, 0, sizeof(float) * 2 * (size_t)n_cars) == hipSuccess;
+        ok = ok && hipMemset(b->dOut, 0, sizeof(pdb_step_out) * (size_t)n_cars) == hipSuccess;
+    }
+    if (!ok) { pdb::setError("pdb_create: HIP allocation / upload failed"); pdb_destroy(b); return nullptr; }
+    try {
+        pdb::TrackView tv(b->track.data());
+        pdb::initialState(b->params, tv, b->resetTemplate);
+    } catch (const std::exception& e) { pdb::setError(e.what()); pdb_destroy(b); return nullptr; }
+    if (pdb_set_state_all(b, &b->resetTemplate) != PDB_OK) { pdb_destroy(b); return nullptr; }
+    return b;
+}
+
+void pdb_destroy(pdb_batch* b) {
+    if (!b) return;
+    (void)hipSetDevice(b->device);
+    if (b->graphExec) (void)hipGraphExecDestroy(b->graphExec);
+    if (b->stream) (void)hipStreamSynchronize(b->stream);
+    (void)hipFree(b->dStates); (void)hipFree(b->dActions); (void)hipFree(b->dOut); (void)hipFree(b->dCarStates); (void)hipFree(b->dParams); (void)hipFree(b->dK); (void)hipFree(b->dTrack);
+    if (b->ev0) (void)hipEventDestroy(b->ev0);
+    if (b->ev1) (void)hipEventDestroy(b->ev1);
+    if (b->stream) (void)hipStreamDestroy(b->stream);
+    delete b;
+}
+
+int pdb_num_cars(const pdb_batch* b) { return b ? b->n : 0; }
+
+int pdb_set_state_all(pdb_batch* b, const pdb_dyn_state* state) {
+    if (!b || !state) { pdb::setError("null argument"); return PDB_ERR_ARG; }
+    std::vector<pdb_dyn_state> tmp((size_t)b->n, *state);
+    HIPCHK(hipMemcpyAsync(b->dStates, tmp.data(), sizeof(pdb_dyn_state) * (size_t)b->n, hipMemcpyHostToDevice, b->stream));
+    HIPCHK(hipStreamSynchronize(b->stream));
+    return PDB_OK;
+}
+int pdb_set_state(pdb_batch* b, int first, int count, const pdb_dyn_state* states) {
+    if (!b || !states || first < 0 || count < 0 || first + count > b->n) { pdb::setError("bad range"); return PDB_ERR_ARG; }
+    HIPCHK(hipMemcpyAsync(b->dStates + first, states, sizeof(pdb_dyn_state) * (size_t)count, hipMemcpyHostToDevice, b->stream));
+    HIPCHK(hipStreamSynchronize(b->stream));
+    return PDB_OK;
+}
+int pdb_get_state(pdb_batch* b, int first, int count, pdb_dyn_state* states) {
+    if (!b || !states || first < 0 || count < 0 || first + count > b->n) { pdb::setError("bad range"); return PDB_ERR_ARG; }
+    HIPCHK(hipMemcpyAsync(states, b->dStates + first, sizeof(pdb_dyn_state) * (size_t)count, hipMemcpyDeviceToHost, b->stream));
+    HIPCHK(hipStreamSynchronize(b->stream));
+    return PDB_OK;
+}
+
+int pdb_reset(pdb_batch* b, const uint8_t* mask) {
+    if (!b) { pdb::setError("null argument"); return PDB_ERR_ARG; }
+    // teleportCarByMode(Start): Car::teleportToSpline(0) edits applied to each masked car's current record
+    std::vector<pdb_dyn_state> st((size_t)b->n);
+    int rc = pdb_get_state(b, 0, b->n, st.data());
+    if (rc != PDB_OK) return rc;
+    pdb::TrackView tv(b->track.data());
+    for (int i = 0; i < b->n; ++i)
+        if (!mask || mask[i]) pdb::teleportToSpline(b->params, tv, 0.0f, st[i]);
+    return pdb_set_state(b, 0, b->n, st.data());
+}
+
+float* pdb_actions_device(pdb_batch* b) { return b ? b->dActions : nullptr; }
+pdb_step_out* pdb_out_device(pdb_batch* b) { return b ? b->dOut : nullptr; }
+void* pdb_stream(pdb_batch* b) { return b ? (void*)b->stream : nullptr; }
+
+int pdb_step(pdb_batch* b, float dt) {
+    if (!b) { pdb::setError("null argument"); return PDB_ERR_ARG; }
+    HIPCHK(hipEventRecord(b->ev0, b->stream));
+    int rc = launch(b, dt, false);
+    if (rc != PDB_OK) return rc;
+    HIPCHK(hipEventRecord(b->ev1, b->stream));
+    HIPCHK(hipEventSynchronize(b->ev1));
+    float ms = 0;
+    HIPCHK(hipEventElapsedTime(&ms, b->ev0, b->ev1));
+    b->kernelMs += ms; b->kernelLaunches += 1;
+    return PDB_OK;
+}
+
+int pdb_step_n(pdb_batch* b, float dt, int n) {
+    if (!b || n <= 0) { pdb::setError("bad argument"); return PDB_ERR_ARG; }
+    if (n == 1) return pdb_step(b, dt);
+    if (!b->graphExec || b->graphTicks != n || b->graphDt != dt) {
+        if (b->graphExec) { (void)hipGraphExecDestroy(b->graphExec); b->graphExec = nullptr; }
+        // make sure the constants are current before capture (the capture must not contain the H2D copy)
+        if (b->K.dt != dt || b->K.wantCarState != 0) {
+            b->K.dt = dt; b->K.dtD = (dt == (float)(1.0 / 333.0)) ? (1.0 / 333.0) : (double)dt; b->K.wantCarState = 0;
+            HIPCHK(hipMemcpyAsync(b->dK, &b->K, sizeof(DevConst), hipMemcpyHostToDevice, b->stream));
+            HIPCHK(hipStreamSynchronize(b->stream));
+        }
+        hipGraph_t g = nullptr;
+        HIPCHK(hipStreamBeginCapture(b->stream, hipStreamCaptureModeThreadLocal));
+        for (int i = 0; i < n; ++i)
+            hipLaunchKernelGGL(pdb_step_kernel, dim3(b->n), dim3(PDB_WAVE), 0, b->stream, b->dStates, b->dActions, b->dOut, b->dCarStates, b->dParams,
+                               b->dK, b->dTrack, b->n);
+        HIPCHK(hipStreamEndCapture(b->stream, &g));
+        HIPCHK(hipGraphInstantiate(&b->graphExec, g, nullptr, nullptr, 0));
+        (void)hipGraphDestroy(g);
+        b->graphTicks = n; b->graphDt = dt;
+    }
+    HIPCHK(hipEventRecord(b->ev0, b->stream));
+    HIPCHK(hipGraphLaunch(b->graphExec, b->stream));
+    HIPCHK(hipEventRecord(b->ev1, b->stream));
+    HIPCHK(hipEventSynchronize(b->ev1));
+    float ms = 0;
+    HIPCHK(hipEventElapsedTime(&ms, b->ev0, b->ev1));
+    b->kernelMs += ms; b->kernelLaunches += n;
+    return PDB_OK;
+}
+
+int pdb_sync(pdb_batch* b) {
+    if (!b) { pdb::setError("null argument"); return PDB_ERR_ARG; }
+    HIPCHK(hipStreamSynchronize(b->stream));
+    return PDB_OK;
+}
+
+int pdb_step_host(pdb_batch* b, const float* actions, float dt, pdb_step_out* out) {
+    if (!b || !actions) { pdb::setError("null argument"); return PDB_ERR_ARG; }
+    HIPCHK(hipMemcpyAsync(b->dActions, actions, sizeof(float) * 2 * (size_t)b->n, hipMemcpyHostToDevice, b->stream));
+    int rc = launch(b, dt, true);
+    if (rc != PDB_OK) return rc;
+    if (out) HIPCHK(hipMemcpyAsync(out, b->dOut, sizeof(pdb_step_out) * (size_t)b->n, hipMemcpyDeviceToHost, b->stream));
+    HIPCHK(hipStreamSynchronize(b->stream));
+    return PDB_OK;
+}
+
+int pdb_get_car_state(pdb_batch* b, int first, int count, pdb_car_state* out) {
+    if (!b || !out || first < 0 || count < 0 || first + count > b->n) { pdb::setError("bad range"); return PDB_ERR_ARG; }
+    HIPCHK(hipMemcpyAsync(out, b->dCarStates + first, sizeof(pdb_car_state) * (size_t)count, hipMemcpyDeviceToHost, b->stream));
+    HIPCHK(hipStreamSynchronize(b->stream));
+    return PDB_OK;
+}
+
+int pdb_kernel_time_us(pdb_batch* b, double* avg_us, int* launches) {
+    if (!b) { pdb::setError("null argument"); return PDB_ERR_ARG; }
+    if (avg_us) *avg_us = b->kernelLaunches ? (b->kernelMs * 1000.0 / b->kernelLaunches) : 0.0;
+    if (launches) *launches = b->kernelLaunches;
+    b->kernelMs = 0; b->kernelLaunches = 0;
+    return PDB_OK;
+}
+
+}  // extern "C"

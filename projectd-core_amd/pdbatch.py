@@ -1,0 +1,92 @@
+"""Python surface of the pdbatch C ABI (include/pdbatch.h): ctypes bindings + a batched environment mirroring
+pyprojectd/projectd_env.py (ProjectDEnv.step/reset) for N cars at once.  PyTorch is used only for device
+buffers / streams by callers that want zero-copy actions and observations; nothing here computes physics."""
+import ctypes as C, os, sys, tempfile
+import numpy as np
+
+PKG = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(PKG)
+sys.path.insert(0, os.path.join(ROOT, 'tests'))
+import pdb_ctypes as pc  # ctypes views of include/pdb_types.h  # noqa: E402
+
+SIM_DT = 1.0 / 333.0   # projectd_env.py:19
+
+
+class Batch:
+    """N (simulator, car) pairs resident on one GPU."""
+
+    def __init__(self, n_cars, params, track_blob, device=0, action_mode=1):
+        self.lib = pc.load_product()
+        self.n = n_cars
+        self.params = params
+        self.track = track_blob
+        self.h = self.lib.pdb_create(device, n_cars, C.byref(params), track_blob, len(track_blob), action_mode)
+        if not self.h:
+            raise RuntimeError('pdb_create failed: %s' % self.lib.pdb_last_error().decode())
+
+    def close(self):
+        if self.h:
+            self.lib.pdb_destroy(self.h)
+            self.h = None
+
+    def _chk(self, rc):
+        if rc != 0:
+            raise RuntimeError(self.lib.pdb_last_error().decode())
+
+    def step_host(self, actions, want_out=True):
+        a = np.ascontiguousarray(actions, dtype=np.float32).reshape(self.n, 2)
+        out = (pc.StepOut * self.n)()
+        self._chk(self.lib.pdb_step_host(self.h, a.ctypes.data_as(C.c_void_p), C.c_float(SIM_DT), C.byref(out)))
+        o = np.frombuffer(out, dtype=np.dtype(pc.StepOut))
+        return o
+
+    def set_actions(self, actions):
+        import torch  # device plumbing only
+        a = np.ascontiguousarray(actions, dtype=np.float32).reshape(self.n, 2)
+        self._chk(self.lib.pdb_step_host(self.h, a.ctypes.data_as(C.c_void_p), C.c_float(SIM_DT), None))
+
+    def step(self, ticks=1):
+        self._chk(self.lib.pdb_step_n(self.h, C.c_float(SIM_DT), ticks))
+
+    def get_state(self, first=0, count=None):
+        count = self.n - first if count is None else count
+        st = (pc.DynState * count)()
+        self._chk(self.lib.pdb_get_state(self.h, first, count, C.byref(st)))
+        return st
+
+    def set_state(self, states, first=0):
+        self._chk(self.lib.pdb_set_state(self.h, first, len(states), C.byref(states)))
+
+    def get_car_state(self, first=0, count=None):
+        count = self.n - first if count is None else count
+        cs = (pc.CarState * count)()
+        self._chk(self.lib.pdb_get_car_state(self.h, first, count, C.byref(cs)))
+        return cs
+
+    def reset(self, mask=None):
+        if mask is None:
+            self._chk(self.lib.pdb_reset(self.h, None))
+        else:
+            m = np.ascontiguousarray(mask, dtype=np.uint8)
+            self._chk(self.lib.pdb_reset(self.h, m.ctypes.data_as(C.c_void_p)))
+
+    def kernel_time_us(self):
+        us = C.c_double(); n = C.c_int()
+        self._chk(self.lib.pdb_kernel_time_us(self.h, C.byref(us), C.byref(n)))
+        return us.value, n.value
+
+
+def packed_params(name='ks_toyota_ae86_drift.env'):
+    P = pc.CarParams()
+    data = open(os.path.join(PKG, 'data', name + '.pdcar'), 'rb').read()
+    assert len(data) == C.sizeof(P)
+    C.memmove(C.byref(P), data, len(data))
+    return P
+
+
+def synthetic_track(kind='flat'):
+    import synthetic_tracks
+    lib = pc.load_product()
+    d = tempfile.mkdtemp(prefix='pdb_base_')
+    synthetic_tracks.make_base(d, tracks=(kind,))
+    return pc.build_track(lib, d, kind)

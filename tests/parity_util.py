@@ -1,0 +1,127 @@
+"""GPU-vs-oracle parity helpers shared by tests/test_gpu_parity.py, __graft_entry__.smoke() and bench.py."""
+import ctypes as C, os, sys
+import numpy as np
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+sys.path.insert(0, HERE); sys.path.insert(0, os.path.join(ROOT, 'projectd-core_amd'))
+import pdb_ctypes as pc
+
+_DT = np.dtype(pc.DynState)
+
+
+def state_vectors(st):
+    """Flatten one DynState into (float vector, int vector, names) for comparison."""
+    arr = np.frombuffer(bytes(st), dtype=_DT)[0]
+    fl, it, fn, inn = [], [], [], []
+    def walk(prefix, v, dt):
+        if dt.names:
+            for n in dt.names:
+                if n.startswith('_pad'):
+                    continue
+                walk(prefix + '.' + n if prefix else n, v[n], dt[n])
+        elif dt.subdtype:
+            base, shape = dt.subdtype
+            vv = np.asarray(v).reshape(-1) if not base.names else None
+            if base.names:
+                flat = np.asarray(v).reshape(-1)
+                for i in range(flat.shape[0]):
+                    walk('%s[%d]' % (prefix, i), flat[i], base)
+            else:
+                for i, x in enumerate(vv):
+                    (fl if base.kind == 'f' else it).append(float(x) if base.kind == 'f' else int(x))
+                    (fn if base.kind == 'f' else inn).append('%s[%d]' % (prefix, i))
+        else:
+            if dt.kind == 'f':
+                fl.append(float(v)); fn.append(prefix)
+            else:
+                it.append(int(v)); inn.append(prefix)
+    walk('', arr, _DT)
+    return np.array(fl), np.array(it, dtype=np.int64), fn, inn
+
+
+# per-field scale floor for the relative error: max(|ref|, 1e-3 * scale)
+def field_scale(name):
+    if '.pos' in name or 'contactPoint' in name or 'ContactPoint' in name or 'pointCachePos' in name:
+        return 1.0          # metres
+    if '.R[' in name or '.q[' in name or 'contactNormal' in name:
+        return 1.0
+    if 'lvel' in name or 'lastVelocity' in name or name == 'speed':
+        return 10.0         # m/s
+    if 'avel' in name:
+        return 1.0          # rad/s
+    if name.endswith('.load') or 'Fx' in name or 'Fy' in name:
+        return 1000.0       # N
+    if 'Mz' in name or 'localMX' in name:
+        return 100.0
+    if 'angularVelocity' in name or 'oldAngularVelocity' in name or 'Vel' in name or 'rootVelocity' in name:
+        return 10.0         # rad/s
+    if '.T[' in name or 'coreTemp' in name or 'practicalTemp' in name or 'waterT' in name:
+        return 20.0
+    return 1.0
+
+
+def compare_states(sg, sc):
+    """max relative float deviation, number of integer mismatches, worst field name."""
+    fg, ig, fn, inn = state_vectors(sg)
+    fc, ic, _, _ = state_vectors(sc)
+    scale = np.array([field_scale(n) for n in fn])
+    den = np.maximum(np.abs(fc), 1e-3 * scale)
+    rel = np.abs(fg - fc) / den
+    rel[np.isnan(fg) != np.isnan(fc)] = np.inf
+    rel[np.isnan(fg) & np.isnan(fc)] = 0
+    w = int(np.argmax(rel))
+    bad_int = [(inn[i], int(ig[i]), int(ic[i])) for i in np.where(ig != ic)[0]]
+    return float(rel[w]), fn[w], float(fg[w]), float(fc[w]), bad_int
+
+
+def make_actions(n, seed, lo=-0.3, hi=0.3):
+    """config-2 style: per-car constant action, steer ~ U(-0.3,0.3), a1 ~ U(-1,1), PCG-free numpy."""
+    rng = np.random.RandomState(seed)
+    a = np.empty((n, 2), dtype=np.float32)
+    a[:, 0] = rng.uniform(lo, hi, n)
+    a[:, 1] = rng.uniform(-1.0, 1.0, n)
+    return a
+
+
+def run_parity(n_cars=8, ticks=200, seed=1234, resync=False, verbose=False, check_every=1, actions_fn=None):
+    """Step `n_cars` cars for `ticks` ticks on the GPU (through the C ABI) and in the CPU oracle, from the same
+    initial state.  resync=True re-injects the oracle state into the GPU before every tick (single-tick parity).
+    Returns the worst relative deviation over all cars, ticks and float fields; raises on integer mismatches."""
+    import pdbatch
+    P = pdbatch.packed_params()
+    trk = pdbatch.synthetic_track('flat')
+    lib = pc.load_product(); orc = pc.load_oracle()
+    S0 = pc.DynState()
+    assert lib.pdb_initial_state(C.byref(P), trk, C.byref(S0)) == 0
+    b = pdbatch.Batch(n_cars, P, trk, device=0, action_mode=1)
+    hs = [orc.cpuref_create(C.byref(P), trk, len(trk), C.byref(S0)) for _ in range(n_cars)]
+    acts = make_actions(n_cars, seed)
+    worst = 0.0; worst_info = None
+    try:
+        for t in range(ticks):
+            a = acts if actions_fn is None else actions_fn(t, acts)
+            if resync and t > 0:
+                arr = (pc.DynState * n_cars)()
+                for i in range(n_cars):
+                    orc.cpuref_get_state(hs[i], C.byref(arr[i]))
+                b.set_state(arr)
+            b.step_host(a)
+            for i in range(n_cars):
+                orc.cpuref_step_env(hs[i], float(a[i, 0]), float(a[i, 1]))
+            if (t % check_every) == 0 or t == ticks - 1:
+                sg = b.get_state()
+                for i in range(n_cars):
+                    sc = pc.DynState()
+                    orc.cpuref_get_state(hs[i], C.byref(sc))
+                    rel, name, vg, vc, bad_int = compare_states(sg[i], sc)
+                    if bad_int:
+                        raise AssertionError('integer state mismatch car %d tick %d: %s' % (i, t, bad_int[:5]))
+                    if rel > worst:
+                        worst = rel; worst_info = (t, i, name, vg, vc)
+    finally:
+        b.close()
+        for h in hs:
+            orc.cpuref_destroy(h)
+    if verbose:
+        print('parity: n=%d ticks=%d resync=%s worst rel=%.3e at %s' % (n_cars, ticks, resync, worst, worst_info))
+    return worst

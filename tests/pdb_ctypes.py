@@ -96,7 +96,9 @@ class DynState(C.Structure):
         [(n, C.c_float) for n in ('lifeLeft', 'fuelPressure', 'acClutchValueSignal', 'acSeqCurrentTime', 'asGasCutoff', 'totalReward', 'stepReward', 'currentDriftAngle',
                                   'currentSpeedMultiplier', 'lastDriftDirection', 'driftStraightTimer', 'instantDriftDelta', 'instantDrift', 'driftPoints')] + \
         [(n, C.c_int32) for n in ('oldPointId', 'oldSplinePointId', 'drifting', 'driftExtreme', 'driftInvalid', 'driftComboCounter', 'collisionFlag', 'oldCollisionFlag',
-                                  'outOfTrackFlag', '_pad')]
+                                  'outOfTrackFlag')] + \
+        [('gasUsage', C.c_float), ('_pad', C.c_int32 * 2)]
+assert C.sizeof(DynState) % 16 == 0
 class StepOut(C.Structure):
     _fields_ = [('obs', C.c_float * 24), ('reward', C.c_float), ('flags', C.c_int32)]
 
