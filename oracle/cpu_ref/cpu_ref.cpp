@@ -1,6 +1,7 @@
 // ORACLE / TEST INFRASTRUCTURE -- see cpu_ref.h.  Citations are relative to
 // /root/reference/src/ProjectD unless stated otherwise.
 #include "cpu_ref.h"
+#include "mathsel.h"
 #include "../rb/pdray.h"
 #include <cmath>
 #include <cstring>
@@ -47,7 +48,7 @@ struct M44 {
 // Core/Math.cpp:87-115
 static M44 axisAngle(const V3& a, float angle) {
     M44 r;
-    const float s = sinf(angle), c = cosf(angle), o = 1.0f - c;
+    const float s = m_sinf(angle), c = m_cosf(angle), o = 1.0f - c;
     r.m[0] = ((a.x * a.x) * o) + c; r.m[5] = ((a.y * a.y) * o) + c; r.m[10] = ((a.z * a.z) * o) + c;
     r.m[1] = (a.z * s) + (a.y * a.x) * o; r.m[6] = (a.x * s) + (a.z * a.y) * o; r.m[8] = (a.y * s) + (a.z * a.x) * o;
     r.m[2] = (a.z * a.x) * o - (a.y * s); r.m[4] = (a.y * a.x) * o - (a.z * s); r.m[9] = (a.z * a.y) * o - (a.x * s);
@@ -340,8 +341,8 @@ static void axleStep(const pdb_susp& su, pdrb::World& w, TyreScratch& sc) {
 struct TMI { float load, slipAngleRAD, slipRatio, camberRAD, speed, u, cpLength, grain, blister, pressureRatio; bool useSimpleModel; };
 struct TMO { float Fy = 0, Fx = 0, Mz = 0, trail = 0, ndSlip = 0, Dy = 0, Dx = 0; };
 
-static float sctmStaticDX(const pdb_tyre& t, float load) { if (load != 0.0) return (powf(load, t.lsExpX) * t.lsMultX) / load; return 0; }
-static float sctmStaticDY(const pdb_tyre& t, float load) { if (load != 0.0f) return (powf(load, t.lsExpY) * t.lsMultY) / load; return 0; }
+static float sctmStaticDX(const pdb_tyre& t, float load) { if (load != 0.0) return (m_powf(load, t.lsExpX) * t.lsMultX) / load; return 0; }
+static float sctmStaticDY(const pdb_tyre& t, float load) { if (load != 0.0f) return (m_powf(load, t.lsExpY) * t.lsMultY) / load; return 0; }
 static float sctmPureFY(const pdb_tyre& t, float asy, float /*D*/, float cf, float /*load*/, float slip) {
     const float v5 = (cf * 2.0f) * 0.0064f;
     const float v6 = 1.0f / (v5 / 3.0f);
@@ -355,9 +356,9 @@ static TMO sctmSolve(const pdb_tyre& t, const TMI& tmi) {
     if (tmi.load <= 0.0f || (tmi.slipAngleRAD == 0.0f && tmi.slipRatio == 0.0f && tmi.camberRAD == 0.0f)) return tmo;
     const float asy = tmi.useSimpleModel ? 1.0f : t.asy;
     const float fSlipAngle = tmi.slipAngleRAD;
-    const float fUnk1 = (sinf(tmi.camberRAD) * t.camberGain) + fSlipAngle;
-    const float fUnk1Tan = tanf(fUnk1);
-    const float fSlipAngleSin = sinf(fSlipAngle);
+    const float fUnk1 = (m_sinf(tmi.camberRAD) * t.camberGain) + fSlipAngle;
+    const float fUnk1Tan = m_tanf(fUnk1);
+    const float fSlipAngleSin = m_sinf(fSlipAngle);
     const float fBlister1 = tclamp(tmi.blister * 0.01f, 0.0f, 1.0f);
     const float fBlister2 = (fBlister1 * 0.2f) + 1.0f;
     const float fStaticDy = sctmStaticDY(t, tmi.load);
@@ -375,7 +376,7 @@ static TMO sctmSolve(const pdb_tyre& t, const TMI& tmi) {
         fUDy += (((fUDy / (fCamberUnk + 1.0f)) - fUDy) * t.dCamberBlend);
     }
     const float fSlipRatio = tmi.slipRatio;
-    const float fSlipAngleCos = cosf(tmi.slipAngleRAD);
+    const float fSlipAngleCos = m_cosf(tmi.slipAngleRAD);
     const float fSlipRatioClamped = (fSlipRatio > -0.9999999f ? fSlipRatio : -0.9999999f);
     const float fSpeed = tmi.speed;
     const float a = fSpeed * fSlipAngleSin;
@@ -393,8 +394,8 @@ static TMO sctmSolve(const pdb_tyre& t, const TMI& tmi) {
     const float fCombFactor = t.combinedFactor;
     if (fCombFactor <= 0.0f || fCombFactor == 2.0f) fSlip = sqrtf((fUnk4 * fUnk4) + (fUnk3 * fUnk3));
     else {
-        const float c = powf(fabsf(fUnk4), fCombFactor) + powf(fabsf(fUnk3), fCombFactor);
-        fSlip = powf(c, 1.0f / fCombFactor);
+        const float c = m_powf(fabsf(fUnk4), fCombFactor) + m_powf(fabsf(fUnk3), fCombFactor);
+        fSlip = m_powf(c, 1.0f / fCombFactor);
     }
     const float fPureFyDx = sctmPureFY(t, asy, fDx, fCF * t.cfXmult, tmi.load, fSlip) * fDx;
     const float fPureFyDy = sctmPureFY(t, asy, fDy, fCF, tmi.load, fSlip);
@@ -464,11 +465,11 @@ static void thermalStep(const pdb_car_params& P, const pdb_tyre& tp, pdb_tyre_st
 }
 
 // TyreUtils.inl:7-30
-static float calcSlipAngleRAD(float vy, float vx) { if (vx != 0.0f) return atanf(-(vy / fabsf(vx))); return 0; }
+static float calcSlipAngleRAD(float vy, float vx) { if (vx != 0.0f) return m_atanf(-(vy / fabsf(vx))); return 0; }
 static float calcCamberRAD(const V3& n, const M44& m) {
     const float f = ((m.m[1] * n.y) + (m.m[0] * n.x)) + (m.m[2] * n.z);
     if (f <= -1.0f || f >= 1.0f) return -1.5707964f;
-    return -asinf(f);
+    return -m_asinf(f);
 }
 static float calcContactPatchLength(float radius, float deflection) {
     const float v = radius - deflection;
@@ -527,8 +528,8 @@ static void tyreStep(Car& c, int i, float dt) {
         const float fTest = vHitNorm * vWorldM2;
         if (fTest <= 0.96f) {
             float fTestAcos;
-            if (fTest <= -1.0f || fTest >= 1.0f) fTestAcos = 0; else fTestAcos = acosf(fTest);
-            const float fAngle = fTestAcos - acosf(0.96f);
+            if (fTest <= -1.0f || fTest >= 1.0f) fTestAcos = 0; else fTestAcos = m_acosf(fTest);
+            const float fAngle = fTestAcos - m_acosf(0.96f);
             const V3 vAxis((vWorldM2.z * vHitNorm.y) - (vWorldM2.y * vHitNorm.z), (vWorldM2.x * vHitNorm.z) - (vWorldM2.z * vHitNorm.x),
                            (vWorldM2.y * vHitNorm.x) - (vWorldM2.x * vHitNorm.y));
             const M44 mh = axisAngle(vAxis.get_norm(), fAngle);
@@ -546,14 +547,14 @@ static void tyreStep(Car& c, int i, float dt) {
             const float fSinHeight = surf->sinHeight;
             if (fSinHeight != 0.0f) {
                 const float fSinLength = surf->sinLength;
-                contactPoint.y -= (((sinf(fSinLength * contactPoint.x) * cosf(fSinLength * contactPoint.z)) + 1.0f) * fSinHeight);
+                contactPoint.y -= (((m_sinf(fSinLength * contactPoint.x) * m_cosf(fSinLength * contactPoint.z)) + 1.0f) * fSinHeight);
             }
             if (surf->granularity != 0.0f) {
                 const float v1[3] = {1.0f, 5.8f, 11.4f};
                 const float v2[3] = {0.005f, 0.005f, 0.01f};
                 const float cx = contactPoint.x, cz = contactPoint.z;
                 float cy = contactPoint.y;
-                for (int id = 0; id < 3; ++id) { const float v = v1[id]; cy = cy + ((((sinf(v * cx) * cosf(v * cz)) + 1.0f) * v2[id]) * -0.6f); }
+                for (int id = 0; id < 3; ++id) { const float v = v1[id]; cy = cy + ((((m_sinf(v * cx) * m_cosf(v * cz)) + 1.0f) * v2[id]) * -0.6f); }
                 contactPoint.y = cy;
             }
         }
@@ -821,8 +822,8 @@ static void wingStep(Car& c, int wi) {
     }
     const float angle = wg.angle;
     if (vLocalVel.z == 0.0f) { ws.aoa = 0; ws.yawAngle = 0; ws.cd = 0; ws.cl = 0; return; }
-    ws.aoa = atanf((1.0f / vLocalVel.z) * vLocalVel.y) * 57.29578f;
-    ws.yawAngle = atanf((1.0f / vLocalVel.z) * vLocalVel.x) * 57.29578f;
+    ws.aoa = m_atanf((1.0f / vLocalVel.z) * vLocalVel.y) * 57.29578f;
+    ws.yawAngle = m_atanf((1.0f / vLocalVel.z) * vLocalVel.x) * 57.29578f;
     const V3& lv = vLocalVel;
     {   // addDrag
         const float off = wg.isVertical ? ws.yawAngle : ws.aoa;
@@ -838,7 +839,7 @@ static void wingStep(Car& c, int wi) {
         ws.cl = curve(wg.lutAOA_CL, (1.0f * angle) + off) * wg.clGain;
         if (lv.z < 0.0f) ws.cl = 0;
         if (!wg.isVertical && wg.yawGain != 0.0f) {
-            const float v8 = (sinf(fabsf(ws.yawAngle) * 0.017453f) * wg.yawGain) + 1.0f;
+            const float v8 = (m_sinf(fabsf(ws.yawAngle) * 0.017453f) * wg.yawGain) + 1.0f;
             ws.cl *= tclamp(v8, 0.0f, 1.0f);
         }
         const float fDot = (fAxis * fAxis) + (lv.z * lv.z);
@@ -995,7 +996,7 @@ static void drivetrainStep(Car& c, float dt) {
     pdb_tyre_state& TR = S.tyre[tr];
     TyreScratch& SL = c.ts[tl];
     TyreScratch& SR = c.ts[tr];
-    c.locClutch = powf(c.controls.clutch, 1.5f);
+    c.locClutch = m_powf(c.controls.clutch, 1.5f);
     c.currentClutchTorque = 0;
     // step2WD
     const int gr = S.gearReqRequest - 1;
@@ -1416,7 +1417,7 @@ void Car::postStep(float dt) {
         for (int i = 0; i < PDB_NUM_LOOKAHEAD; ++i) {
             const float distanceNorm = S.trackLocation + ((Pm.lookAheadStep * (float)(i + 1)) / Tk.h->computedTrackLength) * driveDir;
             const V3 dir = trackDirAtDistance(Tk, distanceNorm);
-            lookAhead[i] = atan2f(dir.cross(curTrackDir) * up, curTrackDir * dir);
+            lookAhead[i] = m_atan2f(dir.cross(curTrackDir) * up, curTrackDir * dir);
         }
     }
     // ScoringSystem::step: computeDriftScore then computeAgentReward
@@ -1434,7 +1435,7 @@ void Car::postStep(float dt) {
             V3 vel = lvel;
             const float fLen = vel.len();
             if (fLen != 0.0f) vel.x /= fLen;
-            if (vel.x <= -1.0f || vel.x >= 1.0f) fBeta = 1.5707964f; else fBeta = asinf(vel.x);
+            if (vel.x <= -1.0f || vel.x >= 1.0f) fBeta = 1.5707964f; else fBeta = m_asinf(vel.x);
             fBeta = fabsf(fBeta);
         }
         const float fSpeedKmh = kmh(S.speed);
@@ -1535,13 +1536,13 @@ void Car::fillCarState(pdb_car_state& cs) const {
     memcpy(cs.bodyMatrix, bm.m, sizeof(bm.m));
     cs.bodyPos[0] = bm.m[12]; cs.bodyPos[1] = bm.m[13]; cs.bodyPos[2] = bm.m[14];
     {   // mat44f::getEulerAngles (Core/Math.cpp:60-85)
-        float rx = atan2f(-bm.m[8], bm.m[10]);
+        float rx = m_atan2f(-bm.m[8], bm.m[10]);
         float v7 = 1, v8 = bm.m[9];
         if (v8 > 1.0 || (v7 = -1, v8 < -1.0)) v8 = v7;
-        const float ry = asinf(v8);
+        const float ry = m_asinf(v8);
         float v10, v11;
         if (bm.m[1] == 0.0f && bm.m[5] == 0.0f) { v11 = bm.m[4]; v10 = bm.m[0]; rx = 0.0f; } else { v11 = -bm.m[1]; v10 = bm.m[5]; }
-        const float rz = atan2f(v11, v10);
+        const float rz = m_atan2f(v11, v10);
         cs.bodyEuler[0] = ry * -57.295779513082323f; cs.bodyEuler[1] = rx * -57.295779513082323f; cs.bodyEuler[2] = rz * -57.295779513082323f;
     }
     memcpy(cs.accG, accG, 12);

@@ -1,0 +1,91 @@
+// ORACLE / TEST INFRASTRUCTURE.  Independent implementation of the product's "reproducible
+// elementary functions" specification (projectd-core_amd/csrc/device/pmath.hpp header comment):
+// IEEE double +,-,*,/ and sqrt only, one final rounding to float.  Used when the oracle is built
+// with -DCPUREF_PORTABLE_MATH (liboracle_pm.so) so that GPU results can be compared bit for bit;
+// the default build (liboracle.so) calls glibc like the reference does and is the one pinned
+// against the reference-TU golden trajectories.
+#pragma once
+#include <cmath>
+#include <cstdint>
+#include <cstring>
+
+namespace pmref {
+
+static inline double fl(double x) { double t = (double)(long long)x; if (t > x) t = t - 1.0; return t; }
+
+static inline void sc(double x, double* s, double* c) {
+    double k = fl(x * 0.63661977236758134308 + 0.5);
+    double r = (x - k * 1.57079632673412561417e+00) - k * 6.07710050650619224932e-11;
+    double z = r * r;
+    double sp = r * (1.0 - z / 6.0 * (1.0 - z / 20.0 * (1.0 - z / 42.0 * (1.0 - z / 72.0 * (1.0 - z / 110.0 * (1.0 - z / 156.0 * (1.0 - z / 210.0)))))));
+    double cp = 1.0 - z / 2.0 * (1.0 - z / 12.0 * (1.0 - z / 30.0 * (1.0 - z / 56.0 * (1.0 - z / 90.0 * (1.0 - z / 132.0 * (1.0 - z / 182.0 * (1.0 - z / 240.0)))))));
+    switch (((long long)k) & 3) {
+        case 0: *s = sp; *c = cp; break;
+        case 1: *s = cp; *c = -sp; break;
+        case 2: *s = -sp; *c = -cp; break;
+        default: *s = -cp; *c = sp; break;
+    }
+}
+static inline float r_sinf(float x) { double s, c; sc((double)x, &s, &c); return (float)s; }
+static inline float r_cosf(float x) { double s, c; sc((double)x, &s, &c); return (float)c; }
+static inline float r_tanf(float x) { double s, c; sc((double)x, &s, &c); return (float)(s / c); }
+
+static inline double at(double x) {
+    bool neg = x < 0.0;
+    double a = neg ? -x : x;
+    bool inv = a > 1.0;
+    if (inv) a = 1.0 / a;
+    a = a / (1.0 + sqrt(1.0 + a * a));
+    a = a / (1.0 + sqrt(1.0 + a * a));
+    double z = a * a;
+    static const double odd[13] = {25.0, 23.0, 21.0, 19.0, 17.0, 15.0, 13.0, 11.0, 9.0, 7.0, 5.0, 3.0, 1.0};
+    double p = 1.0 / 27.0;
+    for (int i = 0; i < 13; ++i) p = 1.0 / odd[i] - z * p;
+    double r = 4.0 * (a * p);
+    if (inv) r = 1.57079632679489661923 - r;
+    return neg ? -r : r;
+}
+static inline double at2(double y, double x) {
+    if (x > 0.0) return at(y / x);
+    if (x < 0.0) return (y >= 0.0) ? at(y / x) + 3.14159265358979323846 : at(y / x) - 3.14159265358979323846;
+    if (y > 0.0) return 1.57079632679489661923;
+    if (y < 0.0) return -1.57079632679489661923;
+    return 0.0;
+}
+static inline float r_atanf(float x) { return (float)at((double)x); }
+static inline float r_atan2f(float y, float x) { return (float)at2((double)y, (double)x); }
+static inline float r_asinf(float x) { double d = (double)x; return (float)at2(d, sqrt((1.0 - d) * (1.0 + d))); }
+static inline float r_acosf(float x) { double d = (double)x; return (float)at2(sqrt((1.0 - d) * (1.0 + d)), d); }
+
+static inline double lg(double x) {
+    uint64_t u; memcpy(&u, &x, 8);
+    int e = (int)((u >> 52) & 0x7ff) - 1023;
+    u = (u & 0x000fffffffffffffULL) | 0x3ff0000000000000ULL;
+    double m; memcpy(&m, &u, 8);
+    if (m > 1.41421356237309504880) { m = m * 0.5; e += 1; }
+    double s = (m - 1.0) / (m + 1.0), z = s * s;
+    static const double odd[11] = {21.0, 19.0, 17.0, 15.0, 13.0, 11.0, 9.0, 7.0, 5.0, 3.0, 1.0};
+    double p = 1.0 / 23.0;
+    for (int i = 0; i < 11; ++i) p = 1.0 / odd[i] + z * p;
+    return (double)e * 0.69314718055994530942 + 2.0 * (s * p);
+}
+static inline double ex(double z) {
+    if (z > 700.0) z = 700.0;
+    if (z < -700.0) return 0.0;
+    double k = fl(z * 1.44269504088896340736 + 0.5);
+    double r = (z - k * 6.93147180369123816490e-01) - k * 1.90821492927058770002e-10;
+    double p = 1.0 + r / 13.0;
+    for (int n = 12; n >= 2; --n) p = 1.0 + r / (double)n * p;
+    p = 1.0 + r * p;
+    uint64_t u = (uint64_t)((long long)k + 1023) << 52;
+    double s2; memcpy(&s2, &u, 8);
+    return p * s2;
+}
+static inline float r_powf(float x, float y) {
+    if (y == 0.0f) return 1.0f;
+    if (!(x > 0.0f)) return 0.0f;
+    if (x == 1.0f) return 1.0f;
+    return (float)ex((double)y * lg((double)x));
+}
+
+}  // namespace pmref

@@ -1,5 +1,6 @@
 // ORACLE / TEST INFRASTRUCTURE -- see pdrb.h header comment.  PARITY UNPINNED (ODE library absent).
 #include "pdrb.h"
+#include "../cpu_ref/mathsel.h"
 #include <cmath>
 #include <cstring>
 #include <algorithm>
@@ -483,7 +484,7 @@ static int jointRows(const World& w, const Joint& j, float fps, Row* rows) {
 // ---------------------------------------------------------------------------------------------
 static inline float sinc_ode(float x) {
     if (fabsf(x) < 1.0e-4f) return 1.0f - x * x * 0.166666666666666666667f;
-    return sinf(x) / x;
+    return m_sinf(x) / x;
 }
 
 void World::step(float h) {
@@ -666,7 +667,7 @@ void World::step(float h) {
             const float hh = h * 0.5f;
             const float theta = wlen * hh;
             float qr[4], q2[4];
-            qr[0] = cosf(theta);
+            qr[0] = m_cosf(theta);
             const float s = sinc_ode(theta) * hh;
             qr[1] = b.avel[0] * s; qr[2] = b.avel[1] * s; qr[3] = b.avel[2] * s;
             qmul0(q2, qr, b.q);

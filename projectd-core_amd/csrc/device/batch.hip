@@ -49,12 +49,12 @@ static void fillConst(const pdb_car_params& P, DevConst& K, int actionMode) {
     memset(&K, 0, sizeof(K));
     for (int i = 0; i < 4; ++i) {
         // mat44f::createFromAxisAngle((0,0,1), staticCamber): M11 = M22 = c, M12 = s, M21 = -s, M33 = (1-c)+c
-        const float s = sinf(P.susp[i].staticCamber), c = cosf(P.susp[i].staticCamber), o = 1.0f - c;
+        const float s = pm::sinf_(P.susp[i].staticCamber), c = pm::cosf_(P.susp[i].staticCamber), o = 1.0f - c;
         K.camC[i] = ((0.0f * 0.0f) * o) + c;
         K.camS[i] = (1.0f * s) + (0.0f * 0.0f) * o;
         K.camM33[i] = ((1.0f * 1.0f) * o) + c;
     }
-    K.acos096 = acosf(0.96f);
+    K.acos096 = pm::acosf_(0.96f);
     int r = 0;
     for (int j = 0; j < P.numJoints; ++j) {
         K.rowStart[j] = r;

@@ -136,8 +136,10 @@ def load_product(host_only=False):
         lib.pdb_kernel_time_us.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
     return lib
 
-def load_oracle():
-    lib = _load(os.path.join(ROOT, 'oracle', 'liboracle.so'))
+def load_oracle(portable_math=False):
+    """portable_math=False: glibc build, pinned against tests/golden (reference-TU trajectories);
+    portable_math=True: same restatement with the product's reproducible elementary functions (bit-comparable with the GPU)."""
+    lib = _load(os.path.join(ROOT, 'oracle', 'liboracle_pm.so' if portable_math else 'liboracle.so'))
     lib.cpuref_create.restype = C.c_void_p
     lib.cpuref_create.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p]
     lib.cpuref_destroy.argtypes = [C.c_void_p]
