@@ -1,0 +1,149 @@
+#!/usr/bin/env python3
+"""Headline benchmark: env-steps/s of the batched 333 Hz vehicle step (BASELINE.json metric).
+
+    python bench.py --gpus N --steps K --warmup W
+    (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+
+One "step" = one physics tick (dt = 1/333 s) of every car resident on the GPU = one launch of the HIP step kernel.
+Workload = BASELINE.json configs[1]: 4096 AE86 cars per GPU on the synthetic flat-plane track, per-car constant random
+actions (steer ~ U(-0.3,0.3), a1 ~ U(-1,1), numpy RandomState(1234) indexed by GLOBAL car id).  State, actions and
+outputs are resident in HBM before the timed region.  Multi-GPU: cars are sharded contiguously (weak scaling, 4096 per
+GPU); the only collective is the per-tick RCCL all-gather of the [N,26] observation/reward/flag block to the learner.
+Prints ONE JSON line on rank 0.
+"""
+import argparse, ctypes as C, json, os, sys, time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(ROOT, 'projectd-core_amd'))
+sys.path.insert(0, os.path.join(ROOT, 'tests'))
+
+CARS_PER_GPU = 4096
+# algorithmic bytes per car-tick (DESIGN.md "Algorithmic bytes"): record read + record write + action + output row
+B_ALG = 2208 + 2208 + 8 + 104
+HBM_PEAK_GBS = 8000.0
+
+
+def cpu_baseline(P, trk, S0, actions, seconds_target=15.0):
+    """oracle (CPU restatement, glibc build) timed on this host: 1 core, bounded sample of the same workload"""
+    import numpy as np
+    import pdb_ctypes as pc
+    orc = pc.load_oracle(portable_math=False)
+    h = orc.cpuref_create(C.byref(P), trk, len(trk), C.byref(S0))
+    n, ticks = 16, 333
+    a = np.ascontiguousarray(actions[:n], dtype=np.float32)
+    t = orc.cpuref_bench(h, n, ticks, a.ctypes.data_as(C.c_void_p), 1, None)
+    rate1 = n * ticks / t
+    # size the sample for ~seconds_target of CPU work
+    n2 = int(max(16, min(512, rate1 * seconds_target / 333)))
+    a2 = np.ascontiguousarray(actions[:n2], dtype=np.float32)
+    t2 = orc.cpuref_bench(h, n2, 333, a2.ctypes.data_as(C.c_void_p), 1, None)
+    ncores = os.cpu_count() or 1
+    n3 = min(len(actions), max(ncores * 4, 64))
+    a3 = np.ascontiguousarray(actions[:n3], dtype=np.float32)
+    t3 = orc.cpuref_bench(h, n3, 333, a3.ctypes.data_as(C.c_void_p), ncores, None)
+    orc.cpuref_destroy(h)
+    return {"value": n2 * 333 / t2, "unit": "env-steps/s", "cores": 1, "kind": "port",
+            "sample": "%d cars x 333 ticks of the bench workload (first %d cars), CPU restatement of Car::step + ODE-equivalent solve, single thread" % (n2, n2),
+            "all_cores_value": n3 * 333 / t3, "all_cores": ncores}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=3000)
+    ap.add_argument('--warmup', type=int, default=333)
+    ap.add_argument('--cars', type=int, default=CARS_PER_GPU)
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import pdbatch, pdb_ctypes as pc, parity_util
+
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if args.gpus > 1 and world != args.gpus:
+        raise SystemExit('launch with torch.distributed.run --nproc-per-node %d' % args.gpus)
+    if not torch.cuda.is_available():
+        raise SystemExit('bench.py needs an MI355X: there is no CPU fallback for the product path')
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group('nccl', init_method='env://')
+
+    n = args.cars
+    P = pdbatch.packed_params()
+    trk = pdbatch.synthetic_track('flat')
+    lib = pc.load_product()
+    S0 = pc.DynState()
+    assert lib.pdb_initial_state(C.byref(P), trk, C.byref(S0)) == 0
+    all_actions = parity_util.make_actions(n * world, 1234)          # indexed by global car id => invariant to the sharding
+    actions = all_actions[rank * n:(rank + 1) * n]
+    b = pdbatch.Batch(n, P, trk, device=local_rank, action_mode=1)
+    stream = torch.cuda.current_stream()
+    b.set_stream(stream.cuda_stream)
+    b.upload_actions(actions)
+
+    class _Arr:   # zero-copy torch view of the library-owned output block
+        def __init__(self, ptr, shape):
+            self.__cuda_array_interface__ = {'shape': shape, 'typestr': '<f4', 'data': (ptr, False), 'version': 2}
+    out_t = torch.as_tensor(_Arr(b.out_device_ptr(), (n, 26)), device='cuda:%d' % local_rank)
+    gathered = torch.empty((world * n, 26), dtype=torch.float32, device='cuda:%d' % local_rank) if world > 1 else None
+
+    def tick():
+        b.step_async()
+        if world > 1:
+            dist.all_gather_into_tensor(gathered, out_t)
+
+    for _ in range(args.warmup):
+        tick()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    b.event_record(0)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        tick()
+    b.event_record(1)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    elapsed = t1 - t0
+    region_ms = b.event_elapsed_ms()
+    if world > 1:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device='cuda:%d' % local_rank)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+
+    if rank == 0:
+        kernel_us = region_ms * 1000.0 / args.steps          # HIP events on the kernel's stream around the timed region
+        achieved = B_ALG * n / (kernel_us * 1e-6) / 1e9
+        res = {
+            "metric": "env-steps/sec (333 Hz tick, 4-wheel car)",
+            "value": n * world * args.steps / elapsed,
+            "unit": "env-steps/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed * 1000.0 / args.steps,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32 (+f64 drivetrain)", "data": "synthetic",
+            "config": {"workload": "configs[1]: %d cars/GPU, AE86, flat-plane track, per-car constant random actions, dt=1/333 s" % n,
+                       "cars_per_gpu": n, "collective": "per-tick RCCL all-gather of [N,26] obs/reward/flags" if world > 1 else "none",
+                       "parity": "bit-exact vs CPU oracle (tests/test_gpu_parity.py)"},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                         "traffic": None, "kernel": "pdb_step_kernel", "kernel_avg_us": kernel_us, "alg_bytes_per_car_tick": B_ALG},
+        }
+        if not args.no_cpu_baseline:
+            res["cpu_baseline"] = cpu_baseline(P, trk, S0, all_actions)
+        print(json.dumps(res))
+    b.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

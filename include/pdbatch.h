@@ -78,6 +78,14 @@ void* pdb_stream(pdb_batch* b);
 int pdb_step(pdb_batch* b, float dt);
 /* n back-to-back ticks with the current actions (launch-overhead-free replay of a captured graph when n > 1) */
 int pdb_step_n(pdb_batch* b, float dt, int n);
+/* same as pdb_step but returns right after the launch (no host wait) */
+int pdb_step_async(pdb_batch* b, float dt);
+/* run the batch on a caller-owned HIP stream (e.g. torch's current stream) instead of its own */
+int pdb_set_stream(pdb_batch* b, void* hip_stream);
+/* HIP events on the batch stream bracketing a timed region: which = 0 (begin) / 1 (end) */
+int pdb_event_record(pdb_batch* b, int which);
+/* waits for the end event and returns the elapsed milliseconds between the two events */
+int pdb_event_elapsed_ms(pdb_batch* b, float* ms);
 int pdb_sync(pdb_batch* b);
 /* convenience: upload actions, one tick, download outputs */
 int pdb_step_host(pdb_batch* b, const float* actions, float dt, pdb_step_out* out);

@@ -35,7 +35,8 @@ struct pdb_batch {
     pdb_car_params* dParams = nullptr;
     DevConst* dK = nullptr;
     uint8_t* dTrack = nullptr;
-    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr, tev0 = nullptr, tev1 = nullptr;
+    bool ownStream = true;
     double kernelMs = 0;
     int kernelLaunches = 0;
     // graph of `graphTicks` back-to-back ticks
@@ -104,6 +105,7 @@ pdb_batch* pdb_create(int device, int n_cars, const pdb_car_params* params, cons
     ok = ok && hipMalloc(&b->dK, sizeof(DevConst)) == hipSuccess;
     ok = ok && hipMalloc(&b->dTrack, track_bytes) == hipSuccess;
     ok = ok && hipEventCreate(&b->ev0) == hipSuccess && hipEventCreate(&b->ev1) == hipSuccess;
+    ok = ok && hipEventCreate(&b->tev0) == hipSuccess && hipEventCreate(&b->tev1) == hipSuccess;
     if (ok) {
         ok = ok && hipMemcpy(b->dParams, &b->params, sizeof(pdb_car_params), hipMemcpyHostToDevice) == hipSuccess;
         ok = ok && hipMemcpy(b->dK, &b->K, sizeof(DevConst), hipMemcpyHostToDevice) == hipSuccess;
@@ -128,7 +130,9 @@ void pdb_destroy(pdb_batch* b) {
     (void)hipFree(b->dStates); (void)hipFree(b->dActions); (void)hipFree(b->dOut); (void)hipFree(b->dCarStates); (void)hipFree(b->dParams); (void)hipFree(b->dK); (void)hipFree(b->dTrack);
     if (b->ev0) (void)hipEventDestroy(b->ev0);
     if (b->ev1) (void)hipEventDestroy(b->ev1);
-    if (b->stream) (void)hipStreamDestroy(b->stream);
+    if (b->tev0) (void)hipEventDestroy(b->tev0);
+    if (b->tev1) (void)hipEventDestroy(b->tev1);
+    if (b->stream && b->ownStream) (void)hipStreamDestroy(b->stream);
     delete b;
 }
 
@@ -211,6 +215,33 @@ int pdb_step_n(pdb_batch* b, float dt, int n) {
     float ms = 0;
     HIPCHK(hipEventElapsedTime(&ms, b->ev0, b->ev1));
     b->kernelMs += ms; b->kernelLaunches += n;
+    return PDB_OK;
+}
+
+int pdb_step_async(pdb_batch* b, float dt) {
+    if (!b) { pdb::setError("null argument"); return PDB_ERR_ARG; }
+    return launch(b, dt, false);
+}
+
+int pdb_set_stream(pdb_batch* b, void* hip_stream) {
+    if (!b) { pdb::setError("null argument"); return PDB_ERR_ARG; }
+    HIPCHK(hipStreamSynchronize(b->stream));
+    if (b->graphExec) { (void)hipGraphExecDestroy(b->graphExec); b->graphExec = nullptr; b->graphTicks = 0; }
+    if (b->ownStream) { (void)hipStreamDestroy(b->stream); b->ownStream = false; }
+    b->stream = (hipStream_t)hip_stream;
+    return PDB_OK;
+}
+
+int pdb_event_record(pdb_batch* b, int which) {
+    if (!b) { pdb::setError("null argument"); return PDB_ERR_ARG; }
+    HIPCHK(hipEventRecord(which ? b->tev1 : b->tev0, b->stream));
+    return PDB_OK;
+}
+
+int pdb_event_elapsed_ms(pdb_batch* b, float* ms) {
+    if (!b || !ms) { pdb::setError("null argument"); return PDB_ERR_ARG; }
+    HIPCHK(hipEventSynchronize(b->tev1));
+    HIPCHK(hipEventElapsedTime(ms, b->tev0, b->tev1));
     return PDB_OK;
 }
 

@@ -45,6 +45,38 @@ class Batch:
         a = np.ascontiguousarray(actions, dtype=np.float32).reshape(self.n, 2)
         self._chk(self.lib.pdb_step_host(self.h, a.ctypes.data_as(C.c_void_p), C.c_float(SIM_DT), None))
 
+    def step_async(self):
+        self._chk(self.lib.pdb_step_async(self.h, C.c_float(SIM_DT)))
+
+    def sync(self):
+        self._chk(self.lib.pdb_sync(self.h))
+
+    def set_stream(self, stream_ptr):
+        self._chk(self.lib.pdb_set_stream(self.h, C.c_void_p(stream_ptr)))
+
+    def event_record(self, which):
+        self._chk(self.lib.pdb_event_record(self.h, which))
+
+    def event_elapsed_ms(self):
+        ms = C.c_float()
+        self._chk(self.lib.pdb_event_elapsed_ms(self.h, C.byref(ms)))
+        return ms.value
+
+    def upload_actions(self, actions):
+        """host -> device copy of the action array without stepping (hipMemcpy through a torch-free ctypes call)"""
+        a = np.ascontiguousarray(actions, dtype=np.float32).reshape(self.n, 2)
+        hip = C.CDLL('libamdhip64.so')
+        hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+        rc = hip.hipMemcpy(self.lib.pdb_actions_device(self.h), a.ctypes.data_as(C.c_void_p), a.nbytes, 1)
+        if rc != 0:
+            raise RuntimeError('hipMemcpy failed: %d' % rc)
+
+    def out_device_ptr(self):
+        return self.lib.pdb_out_device(self.h)
+
+    def actions_device_ptr(self):
+        return self.lib.pdb_actions_device(self.h)
+
     def step(self, ticks=1):
         self._chk(self.lib.pdb_step_n(self.h, C.c_float(SIM_DT), ticks))
 

@@ -131,6 +131,10 @@ def load_product(host_only=False):
         lib.pdb_step.argtypes = [C.c_void_p, C.c_float]
         lib.pdb_step_n.argtypes = [C.c_void_p, C.c_float, C.c_int]
         lib.pdb_sync.argtypes = [C.c_void_p]
+        lib.pdb_step_async.argtypes = [C.c_void_p, C.c_float]
+        lib.pdb_set_stream.argtypes = [C.c_void_p, C.c_void_p]
+        lib.pdb_event_record.argtypes = [C.c_void_p, C.c_int]
+        lib.pdb_event_elapsed_ms.argtypes = [C.c_void_p, C.c_void_p]
         lib.pdb_step_host.argtypes = [C.c_void_p, C.c_void_p, C.c_float, C.c_void_p]
         lib.pdb_get_car_state.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]
         lib.pdb_kernel_time_us.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
