@@ -17,8 +17,14 @@ static inline void sc(double x, double* s, double* c) {
     double k = fl(x * 0.63661977236758134308 + 0.5);
     double r = (x - k * 1.57079632673412561417e+00) - k * 6.07710050650619224932e-11;
     double z = r * r;
-    double sp = r * (1.0 - z / 6.0 * (1.0 - z / 20.0 * (1.0 - z / 42.0 * (1.0 - z / 72.0 * (1.0 - z / 110.0 * (1.0 - z / 156.0 * (1.0 - z / 210.0)))))));
-    double cp = 1.0 - z / 2.0 * (1.0 - z / 12.0 * (1.0 - z / 30.0 * (1.0 - z / 56.0 * (1.0 - z / 90.0 * (1.0 - z / 132.0 * (1.0 - z / 182.0 * (1.0 - z / 240.0)))))));
+    static const double S[7] = {-1.0 / 6.0, 1.0 / 120.0, -1.0 / 5040.0, 1.0 / 362880.0, -1.0 / 39916800.0, 1.0 / 6227020800.0, -1.0 / 1307674368000.0};
+    static const double Cc[8] = {-1.0 / 2.0, 1.0 / 24.0, -1.0 / 720.0, 1.0 / 40320.0, -1.0 / 3628800.0, 1.0 / 479001600.0, -1.0 / 87178291200.0, 1.0 / 20922789888000.0};
+    double ps = S[6];
+    for (int i = 5; i >= 0; --i) ps = S[i] + z * ps;
+    double sp = r + r * (z * ps);
+    double pc = Cc[7];
+    for (int i = 6; i >= 0; --i) pc = Cc[i] + z * pc;
+    double cp = 1.0 + z * pc;
     switch (((long long)k) & 3) {
         case 0: *s = sp; *c = cp; break;
         case 1: *s = cp; *c = -sp; break;
@@ -74,9 +80,10 @@ static inline double ex(double z) {
     if (z < -700.0) return 0.0;
     double k = fl(z * 1.44269504088896340736 + 0.5);
     double r = (z - k * 6.93147180369123816490e-01) - k * 1.90821492927058770002e-10;
-    double p = 1.0 + r / 13.0;
-    for (int n = 12; n >= 2; --n) p = 1.0 + r / (double)n * p;
-    p = 1.0 + r * p;
+    static const double F[14] = {1.0, 1.0, 0.5, 1.0 / 6.0, 1.0 / 24.0, 1.0 / 120.0, 1.0 / 720.0, 1.0 / 5040.0, 1.0 / 40320.0, 1.0 / 362880.0,
+                                 1.0 / 3628800.0, 1.0 / 39916800.0, 1.0 / 479001600.0, 1.0 / 6227020800.0};
+    double p = F[13];
+    for (int n = 12; n >= 0; --n) p = F[n] + r * p;
     uint64_t u = (uint64_t)((long long)k + 1023) << 52;
     double s2; memcpy(&s2, &u, 8);
     return p * s2;

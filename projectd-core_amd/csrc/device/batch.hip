@@ -44,6 +44,7 @@ struct pdb_batch {
     int graphTicks = 0;
     float graphDt = 0;
     pdb_dyn_state resetTemplate;   // state of a fresh car teleported to the spline start
+    unsigned long long* dStamps = nullptr;
 };
 
 static void fillConst(const pdb_car_params& P, DevConst& K, int actionMode) {
@@ -113,6 +114,13 @@ pdb_batch* pdb_create(int device, int n_cars, const pdb_car_params* params, cons
         ok = ok && hipMemset(b->dActions, 0, sizeof(float) * 2 * (size_t)n_cars) == hipSuccess;
         ok = ok && hipMemset(b->dOut, 0, sizeof(pdb_step_out) * (size_t)n_cars) == hipSuccess;
     }
+#ifdef PDB_STAMPS
+    if (ok) {
+        ok = ok && hipMalloc(&b->dStamps, sizeof(unsigned long long) * 16 * (size_t)n_cars) == hipSuccess;
+        b->K.stamps = b->dStamps;
+        ok = ok && hipMemcpy(b->dK, &b->K, sizeof(DevConst), hipMemcpyHostToDevice) == hipSuccess;
+    }
+#endif
     if (!ok) { pdb::setError("pdb_create: HIP allocation / upload failed"); pdb_destroy(b); return nullptr; }
     try {
         pdb::TrackView tv(b->track.data());
@@ -267,6 +275,14 @@ int pdb_get_car_state(pdb_batch* b, int first, int count, pdb_car_state* out) {
     HIPCHK(hipStreamSynchronize(b->stream));
     return PDB_OK;
 }
+
+#ifdef PDB_STAMPS
+int pdb_debug_stamps(pdb_batch* b, unsigned long long* out) {
+    HIPCHK(hipStreamSynchronize(b->stream));
+    HIPCHK(hipMemcpy(out, b->dStamps, sizeof(unsigned long long) * 16 * (size_t)b->n, hipMemcpyDeviceToHost));
+    return PDB_OK;
+}
+#endif
 
 int pdb_kernel_time_us(pdb_batch* b, double* avg_us, int* launches) {
     if (!b) { pdb::setError("null argument"); return PDB_ERR_ARG; }

@@ -43,10 +43,9 @@ PM_FN void sincos_k(double x, double& s, double& c) {
     // pi/2 split: hi has 33 significant bits so k*hi is exact for |k| < 2^20
     const double r = (x - k * 1.57079632673412561417e+00) - k * 6.07710050650619224932e-11;
     const double z = r * r;
-    // sin r = r (1 - z/6 (1 - z/20 (1 - z/42 (1 - z/72 (1 - z/110 (1 - z/156 (1 - z/210)))))))
-    const double sp = r * (1.0 - z / 6.0 * (1.0 - z / 20.0 * (1.0 - z / 42.0 * (1.0 - z / 72.0 * (1.0 - z / 110.0 * (1.0 - z / 156.0 * (1.0 - z / 210.0)))))));
-    // cos r = 1 - z/2 (1 - z/12 (1 - z/30 (1 - z/56 (1 - z/90 (1 - z/132 (1 - z/182 (1 - z/240)))))))
-    const double cp = 1.0 - z / 2.0 * (1.0 - z / 12.0 * (1.0 - z / 30.0 * (1.0 - z / 56.0 * (1.0 - z / 90.0 * (1.0 - z / 132.0 * (1.0 - z / 182.0 * (1.0 - z / 240.0)))))));
+    // Taylor kernels in Horner form; the reciprocal factorials are compile-time constants (no run-time division)
+    const double sp = r + r * (z * (-1.0 / 6.0 + z * (1.0 / 120.0 + z * (-1.0 / 5040.0 + z * (1.0 / 362880.0 + z * (-1.0 / 39916800.0 + z * (1.0 / 6227020800.0 + z * (-1.0 / 1307674368000.0))))))));
+    const double cp = 1.0 + z * (-1.0 / 2.0 + z * (1.0 / 24.0 + z * (-1.0 / 720.0 + z * (1.0 / 40320.0 + z * (-1.0 / 3628800.0 + z * (1.0 / 479001600.0 + z * (-1.0 / 87178291200.0 + z * (1.0 / 20922789888000.0))))))));
     const long long q = ((long long)k) & 3;
     if (q == 0) { s = sp; c = cp; }
     else if (q == 1) { s = cp; c = -sp; }
@@ -103,10 +102,11 @@ PM_FN double exp_k(double z) {
     if (z < -700.0) return 0.0;
     const double k = pm_floor(z * 1.44269504088896340736 + 0.5);
     const double r = (z - k * 6.93147180369123816490e-01) - k * 1.90821492927058770002e-10;
-    // e^r = 1 + r (1 + r/2 (1 + r/3 ( ... (1 + r/13))))
-    double p = 1.0 + r / 13.0;
-    p = 1.0 + r / 12.0 * p; p = 1.0 + r / 11.0 * p; p = 1.0 + r / 10.0 * p; p = 1.0 + r / 9.0 * p; p = 1.0 + r / 8.0 * p; p = 1.0 + r / 7.0 * p;
-    p = 1.0 + r / 6.0 * p; p = 1.0 + r / 5.0 * p; p = 1.0 + r / 4.0 * p; p = 1.0 + r / 3.0 * p; p = 1.0 + r / 2.0 * p; p = 1.0 + r * p;
+    // e^r = sum r^n / n!, n <= 13, Horner with compile-time reciprocal factorials
+    double p = 1.0 / 6227020800.0;
+    p = 1.0 / 479001600.0 + r * p; p = 1.0 / 39916800.0 + r * p; p = 1.0 / 3628800.0 + r * p; p = 1.0 / 362880.0 + r * p;
+    p = 1.0 / 40320.0 + r * p; p = 1.0 / 5040.0 + r * p; p = 1.0 / 720.0 + r * p; p = 1.0 / 120.0 + r * p; p = 1.0 / 24.0 + r * p;
+    p = 1.0 / 6.0 + r * p; p = 0.5 + r * p; p = 1.0 + r * p; p = 1.0 + r * p;
     const uint64_t u = (uint64_t)((long long)k + 1023) << 52;
     double sc; memcpy(&sc, &u, 8);
     return p * sc;
