@@ -26,8 +26,8 @@ HBM_PEAK_GBS = 8000.0
 def cpu_baseline(P, trk, S0, actions, seconds_target=15.0):
     """oracle (CPU restatement, glibc build) timed on this host: 1 core, bounded sample of the same workload"""
     import numpy as np
-    import pdb_ctypes as pc
-    orc = pc.load_oracle(portable_math=False)
+    import oracle_ctypes   # test infrastructure: only this cpu_baseline leg touches the oracle
+    orc = oracle_ctypes.load_oracle(portable_math=False)
     h = orc.cpuref_create(C.byref(P), trk, len(trk), C.byref(S0))
     n, ticks = 16, 333
     a = np.ascontiguousarray(actions[:n], dtype=np.float32)
@@ -58,7 +58,7 @@ def main():
 
     import numpy as np
     import torch
-    import pdbatch, pdb_ctypes as pc, parity_util
+    import pdbatch, pdb_ctypes as pc, sharding
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
@@ -79,8 +79,9 @@ def main():
     lib = pc.load_product()
     S0 = pc.DynState()
     assert lib.pdb_initial_state(C.byref(P), trk, C.byref(S0)) == 0
-    all_actions = parity_util.make_actions(n * world, 1234)          # indexed by global car id => invariant to the sharding
-    actions = all_actions[rank * n:(rank + 1) * n]
+    all_actions = sharding.global_actions(n * world, 1234)          # indexed by global car id => invariant to the sharding
+    first, last = sharding.shard_bounds(n * world, world, rank)
+    actions = all_actions[first:last]
     b = pdbatch.Batch(n, P, trk, device=local_rank, action_mode=1)
     stream = torch.cuda.current_stream()
     b.set_stream(stream.cuda_stream)
@@ -90,12 +91,11 @@ def main():
         def __init__(self, ptr, shape):
             self.__cuda_array_interface__ = {'shape': shape, 'typestr': '<f4', 'data': (ptr, False), 'version': 2}
     out_t = torch.as_tensor(_Arr(b.out_device_ptr(), (n, 26)), device='cuda:%d' % local_rank)
-    gathered = torch.empty((world * n, 26), dtype=torch.float32, device='cuda:%d' % local_rank) if world > 1 else None
+    gather = sharding.ObsGather(n, world, 'cuda:%d' % local_rank, dist)
 
     def tick():
         b.step_async()
-        if world > 1:
-            dist.all_gather_into_tensor(gathered, out_t)
+        gather(out_t)
 
     for _ in range(args.warmup):
         tick()
@@ -115,10 +115,7 @@ def main():
     t1 = time.perf_counter()
     elapsed = t1 - t0
     region_ms = b.event_elapsed_ms()
-    if world > 1:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device='cuda:%d' % local_rank)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
+    elapsed = sharding.max_over_ranks(elapsed, 'cuda:%d' % local_rank, dist, world)
 
     if rank == 0:
         kernel_us = region_ms * 1000.0 / args.steps          # HIP events on the kernel's stream around the timed region

@@ -276,5 +276,10 @@ typedef struct pdb_track_header {
 
 #ifdef __cplusplus
 }
+/* sizes are part of the ABI (tests/test_abi.py reads these numbers) */
+static_assert(sizeof(pdb_car_state) == 664, "pdb_car_state must equal the reference CarState (pack 4)");
+static_assert(sizeof(pdb_car_params) == 8352, "pdb_car_params layout");
+static_assert(sizeof(pdb_dyn_state) == 2208, "pdb_dyn_state layout (multiple of 16 bytes)");
+static_assert(sizeof(pdb_step_out) == 104, "pdb_step_out layout");
 #endif
 #endif

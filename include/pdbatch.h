@@ -54,6 +54,9 @@ int pdb_set_scoring_var(pdb_car_params* params, const char* name, float value);
 float pdb_get_scoring_var(const pdb_car_params* params, const char* name);
 int pdb_set_assists(pdb_car_params* params, int auto_clutch, int auto_shift, int auto_blip, int smooth_steer);
 /* *blob is malloc'ed; release with pdb_free */
+/* diagnostic: the step's reproducible elementary functions evaluated on the host, fn = 0 sin, 1 cos, 2 tan, 3 atan,
+ * 4 atan2(x,y), 5 asin, 6 acos, 7 pow(x,y); y may be NULL for the one-argument functions */
+int pdb_math_eval(int fn, const float* x, const float* y, float* out, int n);
 int pdb_build_track(const char* base_path, const char* track_name, void** blob, uint64_t* bytes);
 void pdb_free(void* p);
 int pdb_initial_state(const pdb_car_params* params, const void* track_blob, pdb_dyn_state* out);

@@ -1,6 +1,8 @@
 // ORACLE / TEST INFRASTRUCTURE -- C API over cpu_ref for ctypes (tests, smoke, bench cpu_baseline leg).
 #include "cpu_ref.h"
 #include "../scenarios.h"
+#include "pm_ref.h"
+#include <cmath>
 #include <cstring>
 #include <vector>
 #include <string>
@@ -43,6 +45,20 @@ void cpuref_get_out(void* hh, pdb_step_out* o) { ((CpuRefHandle*)hh)->car.fillSt
 void cpuref_get_car_state(void* hh, pdb_car_state* cs) { ((CpuRefHandle*)hh)->car.fillCarState(*cs); }
 float cpuref_env_gas(float a1) { return pdoracle::envGas(a1); }
 int cpuref_num_scenarios(void) { return pdoracle::kNumScenarios; }
+// elementary functions of the portable-math specification (pm_ref.h) and of glibc, for tests/test_pmath.py
+int cpuref_math_eval(int fn, int glibc, const float* x, const float* y, float* out, int n) {
+    for (int i = 0; i < n; ++i) {
+        const float a = x[i], b = y ? y[i] : 0.0f;
+        if (glibc) {
+            switch (fn) { case 0: out[i] = sinf(a); break; case 1: out[i] = cosf(a); break; case 2: out[i] = tanf(a); break; case 3: out[i] = atanf(a); break;
+                          case 4: out[i] = atan2f(a, b); break; case 5: out[i] = asinf(a); break; case 6: out[i] = acosf(a); break; default: out[i] = powf(a, b); break; }
+        } else {
+            switch (fn) { case 0: out[i] = pmref::r_sinf(a); break; case 1: out[i] = pmref::r_cosf(a); break; case 2: out[i] = pmref::r_tanf(a); break; case 3: out[i] = pmref::r_atanf(a); break;
+                          case 4: out[i] = pmref::r_atan2f(a, b); break; case 5: out[i] = pmref::r_asinf(a); break; case 6: out[i] = pmref::r_acosf(a); break; default: out[i] = pmref::r_powf(a, b); break; }
+        }
+    }
+    return 0;
+}
 const char* cpuref_scenario_name(int sid) { return pdoracle::kScenarios[sid].name; }
 
 // run one scripted scenario exactly like oracle/refharness/ref_main.cpp and write the probe file

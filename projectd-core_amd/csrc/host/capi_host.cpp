@@ -1,6 +1,7 @@
 // pdbatch C ABI, host-side entry points (content loading, tunes, reset poses).  See include/pdbatch.h.
 #include "pdbatch.h"
 #include "model.hpp"
+#include "../device/pmath.hpp"
 #include <cstdlib>
 #include <cstring>
 #include <string>
@@ -78,6 +79,25 @@ int pdb_teleport_to_spline(const pdb_car_params* params, const void* track_blob,
     pdb::teleportToSpline(*params, tv, distance_norm, *inout);
     return PDB_OK;
     PDB_CATCH(PDB_ERR_IO)
+}
+
+// reproducible elementary functions of the step (device/pmath.hpp compiled for the host): lets a maintainer check,
+// on any platform, that host and device evaluate them identically (the kernel's constants come from these too)
+int pdb_math_eval(int fn, const float* x, const float* y, float* out, int n) {
+    if (!x || !out || n < 0 || fn < 0 || fn > 7 || ((fn == 4 || fn == 7) && !y)) { pdb::setError("pdb_math_eval: bad argument"); return PDB_ERR_ARG; }
+    for (int i = 0; i < n; ++i) {
+        switch (fn) {
+            case 0: out[i] = pm::sinf_(x[i]); break;
+            case 1: out[i] = pm::cosf_(x[i]); break;
+            case 2: out[i] = pm::tanf_(x[i]); break;
+            case 3: out[i] = pm::atanf_(x[i]); break;
+            case 4: out[i] = pm::atan2f_(x[i], y[i]); break;
+            case 5: out[i] = pm::asinf_(x[i]); break;
+            case 6: out[i] = pm::acosf_(x[i]); break;
+            default: out[i] = pm::powf_(x[i], y[i]); break;
+        }
+    }
+    return PDB_OK;
 }
 
 }  // extern "C"

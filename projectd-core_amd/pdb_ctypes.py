@@ -1,9 +1,9 @@
-"""ctypes views of include/pdb_types.h + loaders for the product library and the test oracle."""
+"""ctypes views of include/pdb_types.h and include/pdbatch.h (the product library only)."""
 import ctypes as C, os, sys
 import numpy as np
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-PKG = os.path.join(ROOT, 'projectd-core_amd')
+PKG = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(PKG)
 
 MAX_CURVE, MAX_BODIES, MAX_JOINTS, MAX_WINGS, MAX_GEARS = 24, 8, 16, 4, 10
 
@@ -138,26 +138,6 @@ def load_product(host_only=False):
         lib.pdb_step_host.argtypes = [C.c_void_p, C.c_void_p, C.c_float, C.c_void_p]
         lib.pdb_get_car_state.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]
         lib.pdb_kernel_time_us.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
-    return lib
-
-def load_oracle(portable_math=False):
-    """portable_math=False: glibc build, pinned against tests/golden (reference-TU trajectories);
-    portable_math=True: same restatement with the product's reproducible elementary functions (bit-comparable with the GPU)."""
-    lib = _load(os.path.join(ROOT, 'oracle', 'liboracle_pm.so' if portable_math else 'liboracle.so'))
-    lib.cpuref_create.restype = C.c_void_p
-    lib.cpuref_create.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p]
-    lib.cpuref_destroy.argtypes = [C.c_void_p]
-    lib.cpuref_set_state.argtypes = [C.c_void_p, C.c_void_p]
-    lib.cpuref_get_state.argtypes = [C.c_void_p, C.c_void_p]
-    lib.cpuref_step.argtypes = [C.c_void_p, C.c_float, C.c_float]
-    lib.cpuref_step_env.argtypes = [C.c_void_p, C.c_float, C.c_float]
-    lib.cpuref_get_out.argtypes = [C.c_void_p, C.c_void_p]
-    lib.cpuref_get_car_state.argtypes = [C.c_void_p, C.c_void_p]
-    lib.cpuref_env_gas.restype = C.c_float; lib.cpuref_env_gas.argtypes = [C.c_float]
-    lib.cpuref_scenario_name.restype = C.c_char_p
-    lib.cpuref_run_scenario.argtypes = [C.c_void_p, C.c_int, C.c_char_p]
-    lib.cpuref_bench.restype = C.c_double
-    lib.cpuref_bench.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p]
     return lib
 
 ENV_TUNES = {'FRONT_BIAS': 55.0, 'DIFF_POWER': 30.0, 'DIFF_COAST': 30.0, 'FINAL_RATIO': 5.0,

@@ -6,7 +6,7 @@ import numpy as np
 
 PKG = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(PKG)
-sys.path.insert(0, os.path.join(ROOT, 'tests'))
+sys.path.insert(0, PKG)
 import pdb_ctypes as pc  # ctypes views of include/pdb_types.h  # noqa: E402
 
 SIM_DT = 1.0 / 333.0   # projectd_env.py:19

@@ -1,0 +1,54 @@
+"""Worker for tests/test_sharding.py: one rank of a world_size-2 gloo job.  The stepper on each rank is the CPU oracle
+(test infrastructure) standing in for the GPU batch -- what is under test is the host-side sharding/gather logic of
+projectd-core_amd/sharding.py, which is the code bench.py runs over RCCL."""
+import ctypes as C, os, sys
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+sys.path.insert(0, HERE); sys.path.insert(0, os.path.join(ROOT, 'projectd-core_amd'))
+
+
+def step_block(orc, handles, actions):
+    import pdb_ctypes as pc
+    out = np.zeros((len(handles), 26), dtype=np.float32)
+    so = pc.StepOut()
+    for i, h in enumerate(handles):
+        orc.cpuref_step_env(h, float(actions[i, 0]), float(actions[i, 1]))
+        orc.cpuref_get_out(h, C.byref(so))
+        out[i, :24] = so.obs[:]
+        out[i, 24] = so.reward
+        out[i, 25:26].view(np.int32)[0] = so.flags
+    return out
+
+
+def main(rank, world, port, n_global, ticks, out_path):
+    import torch, torch.distributed as dist
+    import pdb_ctypes as pc, oracle_ctypes, pdbatch, sharding
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group('gloo', init_method='env://')
+    P = pdbatch.packed_params(); trk = pdbatch.synthetic_track('flat')
+    lib = pc.load_product(host_only=True); orc = oracle_ctypes.load_oracle(True)
+    S0 = pc.DynState(); assert lib.pdb_initial_state(C.byref(P), trk, C.byref(S0)) == 0
+    first, last = sharding.shard_bounds(n_global, world, rank)
+    n_local = last - first
+    # learner (rank 0) owns the global actions and scatters each rank's slice
+    all_a = torch.from_numpy(sharding.global_actions(n_global, 1234)) if rank == 0 else None
+    mine = sharding.scatter_actions(all_a, n_local, world, rank, 'cpu', dist).numpy()
+    hs = [orc.cpuref_create(C.byref(P), trk, len(trk), C.byref(S0)) for _ in range(n_local)]
+    gather = sharding.ObsGather(n_local, world, 'cpu', dist)
+    g = None
+    for t in range(ticks):
+        block = torch.from_numpy(step_block(orc, hs, mine))
+        g = gather(block)
+    slow = sharding.max_over_ranks(1.0 + rank, 'cpu', dist, world)
+    if rank == 0:
+        np.save(out_path, np.concatenate([g.numpy().reshape(-1), [slow]]))
+    for h in hs:
+        orc.cpuref_destroy(h)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main(int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4]), int(sys.argv[5]), sys.argv[6])

@@ -9,6 +9,7 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, 'projectd-core_amd'))
 
 import pdb_ctypes as pc  # noqa: E402
+import oracle_ctypes  # noqa: E402
 
 
 def pytest_configure(config):
@@ -29,7 +30,7 @@ def hostlib(built):
 
 @pytest.fixture(scope='session')
 def oracle(built):
-    return pc.load_oracle()
+    return oracle_ctypes.load_oracle()
 
 
 @pytest.fixture(scope='session')

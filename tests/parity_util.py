@@ -5,6 +5,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 sys.path.insert(0, HERE); sys.path.insert(0, os.path.join(ROOT, 'projectd-core_amd'))
 import pdb_ctypes as pc
+import oracle_ctypes
 
 _DT = np.dtype(pc.DynState)
 
@@ -98,11 +99,8 @@ def compare_states(sg, sc):
 
 def make_actions(n, seed, lo=-0.3, hi=0.3):
     """config-2 style: per-car constant action, steer ~ U(-0.3,0.3), a1 ~ U(-1,1), PCG-free numpy."""
-    rng = np.random.RandomState(seed)
-    a = np.empty((n, 2), dtype=np.float32)
-    a[:, 0] = rng.uniform(lo, hi, n)
-    a[:, 1] = rng.uniform(-1.0, 1.0, n)
-    return a
+    import sharding
+    return sharding.global_actions(n, seed, lo, hi)
 
 
 def run_parity(n_cars=8, ticks=200, seed=1234, resync=False, verbose=False, check_every=1, actions_fn=None):
@@ -112,7 +110,7 @@ def run_parity(n_cars=8, ticks=200, seed=1234, resync=False, verbose=False, chec
     import pdbatch
     P = pdbatch.packed_params()
     trk = pdbatch.synthetic_track('flat')
-    lib = pc.load_product(); orc = pc.load_oracle(portable_math=True)
+    lib = pc.load_product(); orc = oracle_ctypes.load_oracle(portable_math=True)
     S0 = pc.DynState()
     assert lib.pdb_initial_state(C.byref(P), trk, C.byref(S0)) == 0
     b = pdbatch.Batch(n_cars, P, trk, device=0, action_mode=1)

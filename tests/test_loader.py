@@ -1,0 +1,158 @@
+"""Host logic behind the boundary: car-model / track builders, tunes, scoring vars, reset poses (csrc/host/*).
+Tests that need the reference's shipped car data run only where /root/reference exists (the build container);
+the packed AE86 block they check (projectd-core_amd/data/*.pdcar) is what travels to the GPU box."""
+import ctypes as C, os, struct
+import numpy as np
+import pytest
+import pdb_ctypes as pc
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF = '/root/reference'
+needs_ref = pytest.mark.skipif(not os.path.isdir(os.path.join(REF, 'content', 'cars')), reason='reference content not present')
+AE86 = 'ks_toyota_ae86_drift'
+
+
+def header(blob):
+    return pc.TrackHeader.from_buffer_copy(blob[:C.sizeof(pc.TrackHeader)]) if hasattr(pc, 'TrackHeader') else None
+
+
+@needs_ref
+def test_packed_ae86_block_is_reproducible(hostlib):
+    """the committed .pdcar blocks are exactly what the loader produces from the shipped car data + env settings"""
+    P = pc.env_params(hostlib, REF)
+    packed = open(os.path.join(ROOT, 'projectd-core_amd', 'data', AE86 + '.env.pdcar'), 'rb').read()
+    assert bytes(P) == packed
+    D = pc.CarParams()
+    assert hostlib.pdb_build_car_model(REF.encode(), AE86.encode(), C.byref(D)) == 0
+    assert bytes(D) == open(os.path.join(ROOT, 'projectd-core_amd', 'data', AE86 + '.default.pdcar'), 'rb').read()
+
+
+@needs_ref
+def test_ae86_topology(hostlib):
+    """7 bodies, 16 joints, 33 constraint rows; RWD, 5 forward gears + R + N"""
+    P = pc.CarParams()
+    assert hostlib.pdb_build_car_model(REF.encode(), AE86.encode(), C.byref(P)) == 0
+    assert (P.numBodies, P.numJoints, P.numRows) == (7, 16, 33)
+    rows = {0: 6, 1: 3, 2: 5, 3: 1}   # fixed, ball, slider, dball (pdb_types.h joint types)
+    assert sum(rows[P.joints[j].type] for j in range(P.numJoints)) == 33
+    total = sum(P.bodies[b].mass for b in range(P.numBodies))
+    assert 900.0 < total < 1400.0
+    assert P.numGears >= 6 and P.gearRatio[1] == 0.0      # [R, N, 1..]
+    assert P.powerCurve.n > 4 and P.numWings >= 1
+    assert abs(P.gravity[1] + 9.80665) < 1e-3 or abs(P.gravity[1] + 9.81) < 0.05
+
+
+@needs_ref
+def test_tunes_follow_setup_spinner_semantics(hostlib):
+    """projectd_env.py:127-130 tunes -> SetupManager::setTune (Car/SetupManager.cpp): FINAL_RATIO is a ratio index-free
+    value, FRONT_BIAS a percentage, DIFF_* percentages, PRESSURE_* psi"""
+    P = pc.CarParams()
+    assert hostlib.pdb_build_car_model(REF.encode(), AE86.encode(), C.byref(P)) == 0
+    before = (P.finalRatio, P.frontBias, P.diffPowerRamp, P.tyre[0].pressureStatic)
+    for k, v in pc.ENV_TUNES.items():
+        assert hostlib.pdb_set_car_tune(C.byref(P), REF.encode(), AE86.encode(), k.encode(), v, 0) == 0
+    assert P.finalRatio == 5.0
+    assert abs(P.frontBias - 0.55) < 1e-6
+    assert abs(P.diffPowerRamp - 0.30) < 1e-6 and abs(P.diffCoastRamp - 0.30) < 1e-6
+    assert all(abs(P.tyre[i].pressureStatic - 28.0) < 1e-6 for i in range(4))
+    assert before != (P.finalRatio, P.frontBias, P.diffPowerRamp, P.tyre[0].pressureStatic)
+    # unknown tune names are ignored, like the reference (SetupManager::setTune looks the name up and returns)
+    snap = bytes(P)
+    assert hostlib.pdb_set_car_tune(C.byref(P), REF.encode(), AE86.encode(), b'NO_SUCH_TUNE', 1.0, 0) == 0
+    assert bytes(P) == snap
+
+
+@needs_ref
+def test_unsupported_or_missing_models_fail_with_a_message(hostlib):
+    P = pc.CarParams()
+    assert hostlib.pdb_build_car_model(REF.encode(), b'no_such_car', C.byref(P)) < 0
+    assert hostlib.pdb_last_error()
+    ok = 0
+    for m in sorted(os.listdir(os.path.join(REF, 'content', 'cars'))):
+        rc = hostlib.pdb_build_car_model(REF.encode(), m.encode(), C.byref(P))
+        if rc == 0:
+            ok += 1
+            assert P.numRows <= 40 and P.numBodies <= 8
+        else:   # e.g. double-wishbone / turbo cars: refused loudly, never half-loaded
+            assert len(hostlib.pdb_last_error()) > 0
+    assert ok >= 1
+
+
+def test_scoring_vars_roundtrip(hostlib, env_params):
+    P = pc.CarParams.from_buffer_copy(bytes(env_params))
+    for k, v in pc.ENV_SCORING.items():
+        assert hostlib.pdb_get_scoring_var(C.byref(P), k.encode()) == np.float32(v)
+    assert hostlib.pdb_set_scoring_var(C.byref(P), b'DriftBonus', 2.5) == 0
+    assert hostlib.pdb_get_scoring_var(C.byref(P), b'DriftBonus') == 2.5
+    assert hostlib.pdb_set_scoring_var(C.byref(P), b'NoSuchVar', 1.0) < 0
+    assert b'NoSuchVar' in hostlib.pdb_last_error()
+
+
+def test_assists_switches(hostlib, env_params):
+    P = pc.CarParams.from_buffer_copy(bytes(env_params))
+    assert (P.acUseOnStart, P.acUseOnChange, P.autoShiftActive, P.autoBlipActive, P.smoothSteer) == (1, 1, 1, 1, 1)
+    hostlib.pdb_set_assists(C.byref(P), 0, 1, 0, 0)
+    assert (P.acUseOnStart, P.acUseOnChange, P.autoShiftActive, P.autoBlipActive, P.smoothSteer) == (0, 0, 1, 0, 0)
+
+
+def test_flat_track_blob(hostlib, flat_track):
+    """synthetic config-1/2 track: 1 surface, 2 triangles, 301 slim points -> fat points, B-spline nodes"""
+    magic, version, nsurf, ntris, nfat, nnodes, istep, closed = struct.unpack_from('<8i', flat_track, 0)
+    tlen, twidth, grip, cell = struct.unpack_from('<4f', flat_track, 32)
+    offs = struct.unpack_from('<7Q', flat_track, 48)
+    assert magic == int.from_bytes(b'PDTK', 'little') or magic == int.from_bytes(b'KTDP', 'little')
+    assert (nsurf, ntris, nfat, closed) == (1, 2, 301, 0)
+    assert nnodes > nfat
+    assert abs(tlen - 3000.0) < 1.0 and abs(twidth - 12.0) < 1e-3
+    assert offs[-1] == len(flat_track)
+    fat = np.frombuffer(flat_track, dtype='<f4', count=nfat * 15, offset=offs[2]).reshape(nfat, 15)
+    assert np.allclose(fat[:, 0], 0) and np.allclose(np.diff(fat[:, 2]), 10.0)          # best line along +z every 10 m
+    assert np.allclose(np.abs(fat[:, 3] - fat[:, 6]), 12.0, atol=1e-3)                  # left/right 6 m each side
+    assert np.allclose(fat[:-1, 12:15], [0, 0, 1], atol=1e-6)                           # forwardDir
+    dist = np.frombuffer(flat_track, dtype='<f4', count=nfat, offset=offs[3])
+    assert dist[0] == np.float32(0.1) and np.all(np.diff(dist) > 0)   # Track::initTrackPoints starts the running length at 0.1 (Track.cpp:200-271)
+
+
+def test_missing_track_fails_with_a_message(hostlib, base_dir):
+    blob = C.c_void_p(); n = C.c_uint64()
+    assert hostlib.pdb_build_track(base_dir.encode(), b'no_such_track', C.byref(blob), C.byref(n)) < 0
+    assert len(hostlib.pdb_last_error()) > 0
+    assert hostlib.pdb_build_track(None, b'flat', C.byref(blob), C.byref(n)) == -1
+
+
+@needs_ref
+def test_driftplayground_mesh_counts(hostlib):
+    """510 surfaces (490 WALL + 20 TRACK), 112 411 triangles"""
+    import tempfile, shutil, synthetic_tracks
+    d = tempfile.mkdtemp(prefix='pdb_dp_')
+    try:
+        synthetic_tracks.make_base(d, tracks=())
+        os.makedirs(os.path.join(d, 'content', 'tracks'), exist_ok=True)
+        shutil.copytree(os.path.join(REF, 'content', 'tracks', 'driftplayground'), os.path.join(d, 'content', 'tracks', 'driftplayground'))
+        os.system('chmod -R u+w "%s"' % d)
+        blob = pc.build_track(hostlib, d, 'driftplayground')
+    finally:
+        shutil.rmtree(d, ignore_errors=True)
+    magic, version, nsurf, ntris, nfat, nnodes = struct.unpack_from('<6i', blob, 0)
+    assert (nsurf, ntris) == (510, 112411)
+    assert nfat > 100
+
+
+def test_initial_state_and_spline_teleport(hostlib, env_params, flat_track, state0):
+    """teleportCarByMode(Start) with no pits falls back to spline start; teleportToSpline(d) puts the chassis on the
+    best line facing forwardDir (Car::teleportToSpline -> forceRotation + forcePosition, Car.cpp)"""
+    s = state0
+    ch = s.body[0]
+    assert abs(ch.pos[0]) < 1e-4 and ch.pos[1] > 0.0
+    assert abs(np.linalg.norm(ch.q[:]) - 1.0) < 1e-6
+    for b in range(env_params.numBodies):
+        assert np.all(np.array(s.body[b].lvel[:]) == 0) and np.all(np.array(s.body[b].avel[:]) == 0)
+    assert s.currentGear == 1 or s.currentGear == 2   # neutral (index 1) before the autoshifter engages
+    t = pc.DynState.from_buffer_copy(bytes(s))
+    assert hostlib.pdb_teleport_to_spline(C.byref(env_params), flat_track, 0.5, C.byref(t)) == 0
+    dz = t.body[0].pos[2] - s.body[0].pos[2]
+    assert 1400.0 < dz < 1600.0
+    # all bodies moved rigidly
+    for b in range(env_params.numBodies):
+        assert abs((t.body[b].pos[2] - s.body[b].pos[2]) - dz) < 1e-2
+        assert abs(t.body[b].pos[1] - s.body[b].pos[1]) < 1e-3

@@ -3,10 +3,10 @@ import ctypes as C, os, sys
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, 'tests')); sys.path.insert(0, os.path.join(ROOT, 'projectd-core_amd'))
-import pdb_ctypes as pc, parity_util as pu, pdbatch
+import pdb_ctypes as pc, parity_util as pu, pdbatch, oracle_ctypes
 n, ticks = int(sys.argv[1]), int(sys.argv[2])
 P = pdbatch.packed_params(); trk = pdbatch.synthetic_track('flat')
-lib = pc.load_product(); orc = pc.load_oracle(portable_math=True)
+lib = pc.load_product(); orc = oracle_ctypes.load_oracle(portable_math=True)
 S0 = pc.DynState(); assert lib.pdb_initial_state(C.byref(P), trk, C.byref(S0)) == 0
 b = pdbatch.Batch(n, P, trk, 0, 1)
 hs = [orc.cpuref_create(C.byref(P), trk, len(trk), C.byref(S0)) for _ in range(n)]

@@ -35,7 +35,10 @@ a = pu.make_actions(n, 1234)
 for _ in range(400): b.step_host(a)
 st = np.zeros((n, 16), dtype=np.uint64)
 lib.pdb_debug_stamps(b.h, st.ctypes.data_as(C.c_void_p))
-d = np.diff(st[:, :14].astype(np.int64), axis=1)
+sti = st.astype(np.int64)
+print('solveRows detail (median cycles): setup(JM,rhs) %d | A rows %d | factorisation %d | fwd+bwd %d' % (np.median(sti[:,14]-sti[:,7]), np.median(sti[:,8]-sti[:,14]), np.median(sti[:,15]-sti[:,8]), np.median(sti[:,9]-sti[:,15])))
+sti[:, 8] = sti[:, 9]
+d = np.diff(sti[:, :14], axis=1)
 names = ['load', 'phase1 lane0 pre-step', 'susp (lane=wheel)', 'tyre (lane=wheel)', 'wings/steer/assists/drivetrain/ARB', 'accumulate', 'bodies+joint rows+JinvM+rhs', 'A assembly', 'LDLT', 'substitution', 'cforce+integrate', 'postStep track+scoring', 'outputs+store']
 tot = d.sum(1)
 print('cars %d: median wave lifetime %.0f shader clocks (= %.1f us at 100 MHz memtime?)' % (n, np.median(tot), np.median(tot) / 100.0))
