@@ -241,7 +241,8 @@ typedef struct pdb_dyn_state {
     int32_t oldPointId, oldSplinePointId, drifting, driftExtreme, driftInvalid, driftComboCounter;
     int32_t collisionFlag, oldCollisionFlag, outOfTrackFlag;
     float gasUsage;          /* Engine::gasUsage of the previous tick (fuel burn input, Car.cpp:478) */
-    int32_t _pad[2];         /* record size is a multiple of 16 bytes (coalesced 16-byte-per-lane copies) */
+    float locClutch;         /* Drivetrain::locClutch of the previous tick (read by the H-shifter gear select, Drivetrain.cpp:189) */
+    int32_t _pad[1];         /* record size is a multiple of 16 bytes (coalesced 16-byte-per-lane copies) */
 } pdb_dyn_state;
 
 /* per-tick outputs (compact) */

@@ -41,7 +41,9 @@ enum pdb_status {
 
 enum pdb_action_mode {
     PDB_ACTION_CONTROLS = 0, /* actions[i] = {steer, gas}          (CarControls fields) */
-    PDB_ACTION_ENV = 1       /* actions[i] = {a0, a1}: steer = a0, gas = linscale(a1,-1,1,0.1,1) (projectd_env.py:159-160) */
+    PDB_ACTION_ENV = 1,      /* actions[i] = {a0, a1}: steer = a0, gas = linscale(a1,-1,1,0.1,1) (projectd_env.py:159-160) */
+    PDB_ACTION_FULL = 2      /* actions[i] = 8 floats: steer, clutch, brake, handBrake, gas, requestedGearIndex (-1 = none),
+                              * gearUp, gearDn -- every CarControls field of setCarControls (PyProjectD.cpp:297-305) */
 };
 
 const char* pdb_last_error(void);

@@ -41,6 +41,27 @@ void cpuref_step(void* hh, float steer, float gas) {
 void cpuref_step_env(void* hh, float a0, float a1) {
     ((CpuRefHandle*)hh)->car.step(a0, pdoracle::envGas(a1), (float)(1.0 / 333.0), 1.0 / 333.0);
 }
+// full-controls step: 8 floats laid out like PDB_ACTION_FULL (include/pdbatch.h)
+static pdb_controls ctlOf(const float* a) {
+    pdb_controls c; memset(&c, 0, sizeof(c));
+    c.steer = a[0]; c.clutch = a[1]; c.brake = a[2]; c.handBrake = a[3]; c.gas = a[4];
+    c.isShifterSupported = 1; c.requestedGearIndex = (int8_t)(int)a[5]; c.gearUp = a[6] != 0.0f; c.gearDn = a[7] != 0.0f;
+    return c;
+}
+void cpuref_step_controls(void* hh, const float* a) {
+    ((CpuRefHandle*)hh)->car.stepControls(ctlOf(a), (float)(1.0 / 333.0), 1.0 / 333.0);
+}
+// the scripted controls of oracle/scenarios.h as PDB_ACTION_FULL rows (tests drive the GPU with the same script)
+void cpuref_scenario_controls(int sid, int tick, float* a) {
+    pdoracle::Ctl c; pdoracle::scenarioControls(sid, tick, c);
+    a[0] = c.steer; a[1] = c.clutch; a[2] = c.brake; a[3] = c.handBrake; a[4] = c.gas; a[5] = (float)c.requestedGearIndex; a[6] = (float)c.gearUp; a[7] = (float)c.gearDn;
+}
+int cpuref_scenario_info(int sid, int* ticks, int* full, int* assists3) {
+    if (sid < 0 || sid >= pdoracle::kNumScenarios) return -1;
+    const auto& sc = pdoracle::kScenarios[sid];
+    *ticks = sc.ticks; *full = sc.full; assists3[0] = sc.autoClutch; assists3[1] = sc.autoShift; assists3[2] = sc.autoBlip;
+    return 0;
+}
 void cpuref_get_out(void* hh, pdb_step_out* o) { ((CpuRefHandle*)hh)->car.fillStepOut(*o); }
 void cpuref_get_car_state(void* hh, pdb_car_state* cs) { ((CpuRefHandle*)hh)->car.fillCarState(*cs); }
 float cpuref_env_gas(float a1) { return pdoracle::envGas(a1); }
@@ -65,6 +86,8 @@ const char* cpuref_scenario_name(int sid) { return pdoracle::kScenarios[sid].nam
 int cpuref_run_scenario(void* hh, int sid, const char* outPath) {
     auto* h = (CpuRefHandle*)hh;
     const auto& sc = pdoracle::kScenarios[sid];
+    // setCarAssists (PyProjectD.cpp:307-317) per scenario; smooth steering stays on like the env
+    h->P.acUseOnStart = sc.autoClutch; h->P.acUseOnChange = sc.autoClutch; h->P.autoShiftActive = sc.autoShift; h->P.autoBlipActive = sc.autoBlip;
     h->car = cpuref::Car();
     h->car.init(&h->P, &h->T, h->s0);
     pdoracle::ProbeFile pf;
@@ -72,8 +95,14 @@ int cpuref_run_scenario(void* hh, int sid, const char* outPath) {
     { pdoracle::Probe P; P.names = &pf.names; h->car.fillProbe(P); pf.add(-1, 0.0f, 0.0f, P); }
     for (int t = 0; t < sc.ticks; ++t) {
         float a0, a1;
-        pdoracle::scenarioAction(sid, t, a0, a1);
-        h->car.step(a0, pdoracle::envGas(a1), (float)(1.0 / 333.0), 1.0 / 333.0);
+        if (sc.full) {
+            float a[8]; cpuref_scenario_controls(sid, t, a);
+            a0 = a[0]; a1 = a[4];
+            h->car.stepControls(ctlOf(a), (float)(1.0 / 333.0), 1.0 / 333.0);
+        } else {
+            pdoracle::scenarioAction(sid, t, a0, a1);
+            h->car.step(a0, pdoracle::envGas(a1), (float)(1.0 / 333.0), 1.0 / 333.0);
+        }
         if (pdoracle::scenarioRecord(sc, t)) { pdoracle::Probe P; h->car.fillProbe(P); pf.add(t, a0, a1, P); }
     }
     return pf.write(outPath) ? 0 : -1;

@@ -181,6 +181,7 @@ void Car::loadState(const pdb_dyn_state& s) {
     const V3 cp(S.pointCachePos);
     for (int id = 0; id < T->h->numFat; ++id) { const V3 p(T->fat + 15 * id); if ((cp - p).sqlen() < md2) nearby.push_back(id); }
     stepTime = S.physicsTime;
+    locClutch = S.locClutch;
 }
 void Car::storeState() {
     for (int i = 0; i < P->numBodies; ++i) {
@@ -997,6 +998,7 @@ static void drivetrainStep(Car& c, float dt) {
     TyreScratch& SL = c.ts[tl];
     TyreScratch& SR = c.ts[tr];
     c.locClutch = m_powf(c.controls.clutch, 1.5f);
+    S.locClutch = (float)c.locClutch;   // exact: the value is a float
     c.currentClutchTorque = 0;
     // step2WD
     const int gr = S.gearReqRequest - 1;
@@ -1253,6 +1255,22 @@ void Car::carStep(float dt) {
         if (controls.gearDn && !S.lastGearDn) gearDown(*this);
         S.lastGearUp = controls.gearUp ? 1 : 0;
         S.lastGearDn = controls.gearDn ? 1 : 0;
+    } else {
+        // Drivetrain::setCurrentGear(gearId, false) (Drivetrain.cpp:174-207); isGearboxLocked is never set on this path
+        const int index = controls.requestedGearIndex;
+        S.isGearGrinding = 0;
+        if (index >= 0 && index < Pm.numGears && index != S.currentGear) {
+            const double v8 = fabs(S.engineVel - Pm.gearRatio[index] * S.driveVel * Pm.finalRatio);
+            const double v9 = ((controls.gas * locClutch * v8 - locClutch * v8) * Pm.controlsWindowGain + locClutch * v8) * (1.0 / (2.0 * 3.14159265358979323846)) * 60.0;
+            if (index == 1 || v9 < S.validShiftRPMWindow) S.currentGear = index;
+            else {
+                S.isGearGrinding = 1;
+                if (S.validShiftRPMWindow > 0.0) {
+                    const double fRate = Pm.mechanicalDamageRate;
+                    if (fRate > 0.0) S.validShiftRPMWindow -= Pm.damageRpmWindow * fRate * 0.003;
+                }
+            }
+        }
     }
     drivetrainStep(*this, dt);
     // AntirollBar::step (AntirollBar.cpp:19-46)
@@ -1510,8 +1528,13 @@ void Car::postStep(float dt) {
 
 // PyProjectD.cpp:297-305 (setCarControls) + :160-180 (stepSimulator) + Simulator::step (Simulator.cpp:168-201)
 void Car::step(float steer, float gas, float dt, double dtD) {
-    memset(&controls, 0, sizeof(controls));
-    controls.steer = steer; controls.gas = gas; controls.isShifterSupported = 1; controls.requestedGearIndex = -1;
+    pdb_controls c;
+    memset(&c, 0, sizeof(c));
+    c.steer = steer; c.gas = gas; c.isShifterSupported = 1; c.requestedGearIndex = -1;
+    stepControls(c, dt, dtD);
+}
+void Car::stepControls(const pdb_controls& c, float dt, double dtD) {
+    controls = c;
     stepTime = S.physicsTime;
     S.speed = getVelocity(w.bodies[PDB_BODY_CHASSIS]).len();   // Car::stepPreCacheValues (Car.cpp:414-417)
     carStep(dt);

@@ -65,6 +65,7 @@ struct Car {
     void loadState(const pdb_dyn_state& s);     // pdb_dyn_state -> bodies
     void storeState();                          // bodies -> S
     void step(float steer, float gas, float dt, double dtD);   // one env tick (setCarControls + stepSimulator)
+    void stepControls(const pdb_controls& c, float dt, double dtD);   // same with every CarControls field given
     void fillCarState(pdb_car_state& cs) const;
     void fillStepOut(pdb_step_out& o) const;
     void fillProbe(pdoracle::Probe& P) const;

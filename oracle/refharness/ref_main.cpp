@@ -143,7 +143,7 @@ struct Env {
     double dt = 1.0 / 333.0;  // projectd_env.py:19
     CarControls dcontrols;    // persistent python-side object (projectd_env.py:135)
 
-    void init(const std::string& base, const std::string& track, const std::string& model) {
+    void init(const std::string& base, const std::string& track, const std::string& model, bool autoClutch = true, bool autoShift = true, bool autoBlip = true) {
         // projectd_env.py:118-136, PyProjectD.cpp:111-137
         sim = std::make_shared<Simulator>();
         sim->simulatorId = 0;
@@ -152,8 +152,8 @@ struct Env {
         car = sim->addCar(strw(model));
         car->teleportByMode(TeleportMode::Start);
         car->teleportOnCollision = false; car->teleportOnBadLocation = false; car->teleportMode = 0;
-        car->autoClutch->useAutoOnStart = true; car->autoClutch->useAutoOnChange = true;
-        car->autoShift->isActive = true; car->autoBlip->isActive = true;
+        car->autoClutch->useAutoOnStart = autoClutch; car->autoClutch->useAutoOnChange = autoClutch;   // PyProjectD.cpp:307-317
+        car->autoShift->isActive = autoShift; car->autoBlip->isActive = autoBlip;
         const std::pair<const char*, float> tunes[] = {{"FRONT_BIAS", 55.0f}, {"DIFF_POWER", 30.0f}, {"DIFF_COAST", 30.0f},
             {"FINAL_RATIO", 5.0f}, {"PRESSURE_LF", 28.0f}, {"PRESSURE_RF", 28.0f}, {"PRESSURE_LR", 28.0f}, {"PRESSURE_RR", 28.0f}};
         if (model == "ks_toyota_ae86_drift")
@@ -170,6 +170,16 @@ struct Env {
         // projectd_env.py:157-171, PyProjectD.cpp:160-180,297-305
         dcontrols.steer = a0;
         dcontrols.gas = pdoracle::envGas(a1);
+        car->controls = dcontrols;
+        car->smoothSteer = true;
+        sim->step((float)dt, sim->physicsTime, sim->gameTime);
+        sim->physicsTime += dt;
+        sim->gameTime += dt;
+    }
+    void stepControls(const pdoracle::Ctl& c) {
+        // PyProjectD.cpp:297-305 with every field of the python-side CarControls object written
+        dcontrols.steer = c.steer; dcontrols.clutch = c.clutch; dcontrols.brake = c.brake; dcontrols.handBrake = c.handBrake; dcontrols.gas = c.gas;
+        dcontrols.requestedGearIndex = (int8_t)c.requestedGearIndex; dcontrols.gearUp = c.gearUp != 0; dcontrols.gearDn = c.gearDn != 0;
         car->controls = dcontrols;
         car->smoothSteer = true;
         sim->step((float)dt, sim->physicsTime, sim->gameTime);
@@ -193,7 +203,7 @@ int main(int argc, char** argv) {
             const auto& sc = pdoracle::kScenarios[sid];
             INIReader::flushCache();
             Env env;
-            env.init(base, track, model);
+            env.init(base, track, model, sc.autoClutch != 0, sc.autoShift != 0, sc.autoBlip != 0);
             pdoracle::ProbeFile pf;
             env.reset();
             {
@@ -203,8 +213,14 @@ int main(int argc, char** argv) {
             }
             for (int t = 0; t < sc.ticks; ++t) {
                 float a0, a1;
-                pdoracle::scenarioAction(sid, t, a0, a1);
-                env.step(a0, a1);
+                if (sc.full) {
+                    pdoracle::Ctl c; pdoracle::scenarioControls(sid, t, c);
+                    a0 = c.steer; a1 = c.gas;
+                    env.stepControls(c);
+                } else {
+                    pdoracle::scenarioAction(sid, t, a0, a1);
+                    env.step(a0, a1);
+                }
                 if (pdoracle::scenarioRecord(sc, t)) {
                     Probe P;
                     fillProbe(P, env.sim.get(), env.car);

@@ -30,6 +30,7 @@ struct pdb_batch {
     hipStream_t stream = nullptr;
     pdb_dyn_state* dStates = nullptr;
     float* dActions = nullptr;
+    int actionStride = 2;   // floats per car: 2 (CONTROLS / ENV) or 8 (FULL)
     pdb_step_out* dOut = nullptr;
     pdb_car_state* dCarStates = nullptr;
     pdb_car_params* dParams = nullptr;
@@ -99,7 +100,9 @@ pdb_batch* pdb_create(int device, int n_cars, const pdb_car_params* params, cons
     bool ok = true;
     ok = ok && hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking) == hipSuccess;
     ok = ok && hipMalloc(&b->dStates, sizeof(pdb_dyn_state) * (size_t)n_cars) == hipSuccess;
-    ok = ok && hipMalloc(&b->dActions, sizeof(float) * 2 * (size_t)n_cars) == hipSuccess;
+    if (action_mode < PDB_ACTION_CONTROLS || action_mode > PDB_ACTION_FULL) { pdb::setError("pdb_create: unknown action mode"); delete b; return nullptr; }
+    b->actionStride = (action_mode == PDB_ACTION_FULL) ? 8 : 2;
+    ok = ok && hipMalloc(&b->dActions, sizeof(float) * b->actionStride * (size_t)n_cars) == hipSuccess;
     ok = ok && hipMalloc(&b->dOut, sizeof(pdb_step_out) * (size_t)n_cars) == hipSuccess;
     ok = ok && hipMalloc(&b->dCarStates, sizeof(pdb_car_state) * (size_t)n_cars) == hipSuccess;
     ok = ok && hipMalloc(&b->dParams, sizeof(pdb_car_params)) == hipSuccess;
@@ -111,7 +114,7 @@ pdb_batch* pdb_create(int device, int n_cars, const pdb_car_params* params, cons
         ok = ok && hipMemcpy(b->dParams, &b->params, sizeof(pdb_car_params), hipMemcpyHostToDevice) == hipSuccess;
         ok = ok && hipMemcpy(b->dK, &b->K, sizeof(DevConst), hipMemcpyHostToDevice) == hipSuccess;
         ok = ok && hipMemcpy(b->dTrack, b->track.data(), track_bytes, hipMemcpyHostToDevice) == hipSuccess;
-        ok = ok && hipMemset(b->dActions, 0, sizeof(float) * 2 * (size_t)n_cars) == hipSuccess;
+        ok = ok && hipMemset(b->dActions, 0, sizeof(float) * b->actionStride * (size_t)n_cars) == hipSuccess;
         ok = ok && hipMemset(b->dOut, 0, sizeof(pdb_step_out) * (size_t)n_cars) == hipSuccess;
     }
 #ifdef PDB_STAMPS
@@ -261,7 +264,7 @@ int pdb_sync(pdb_batch* b) {
 
 int pdb_step_host(pdb_batch* b, const float* actions, float dt, pdb_step_out* out) {
     if (!b || !actions) { pdb::setError("null argument"); return PDB_ERR_ARG; }
-    HIPCHK(hipMemcpyAsync(b->dActions, actions, sizeof(float) * 2 * (size_t)b->n, hipMemcpyHostToDevice, b->stream));
+    HIPCHK(hipMemcpyAsync(b->dActions, actions, sizeof(float) * b->actionStride * (size_t)b->n, hipMemcpyHostToDevice, b->stream));
     int rc = launch(b, dt, true);
     if (rc != PDB_OK) return rc;
     if (out) HIPCHK(hipMemcpyAsync(out, b->dOut, sizeof(pdb_step_out) * (size_t)b->n, hipMemcpyDeviceToHost, b->stream));

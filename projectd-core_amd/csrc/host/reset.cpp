@@ -146,6 +146,7 @@ void initialState(const pdb_car_params& P, const TrackView& tv, pdb_dyn_state& S
     S.gearReqTimeout = 200; S.gearReqRequestedGear = -1; S.lastRatio = -1.0;
     S.validShiftRPMWindow = P.validShiftRPMWindow;
     S.acSeqIsDone = 1;
+    S.locClutch = 1.0f;                              // Drivetrain.h:137
     S.pointCachePos[0] = 0; S.pointCachePos[1] = -10000.0f; S.pointCachePos[2] = 0;   // Track.cpp:203
     teleportToSpline(P, tv, 0.0f, S);
 }

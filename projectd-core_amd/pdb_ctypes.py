@@ -97,7 +97,7 @@ class DynState(C.Structure):
                                   'currentSpeedMultiplier', 'lastDriftDirection', 'driftStraightTimer', 'instantDriftDelta', 'instantDrift', 'driftPoints')] + \
         [(n, C.c_int32) for n in ('oldPointId', 'oldSplinePointId', 'drifting', 'driftExtreme', 'driftInvalid', 'driftComboCounter', 'collisionFlag', 'oldCollisionFlag',
                                   'outOfTrackFlag')] + \
-        [('gasUsage', C.c_float), ('_pad', C.c_int32 * 2)]
+        [('gasUsage', C.c_float), ('locClutch', C.c_float), ('_pad', C.c_int32 * 1)]
 assert C.sizeof(DynState) % 16 == 0
 class StepOut(C.Structure):
     _fields_ = [('obs', C.c_float * 24), ('reward', C.c_float), ('flags', C.c_int32)]

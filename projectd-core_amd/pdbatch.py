@@ -18,6 +18,8 @@ class Batch:
     def __init__(self, n_cars, params, track_blob, device=0, action_mode=1):
         self.lib = pc.load_product()
         self.n = n_cars
+        self.action_mode = action_mode
+        self.stride = 8 if action_mode == 2 else 2   # floats per car (include/pdbatch.h pdb_action_mode)
         self.params = params
         self.track = track_blob
         self.h = self.lib.pdb_create(device, n_cars, C.byref(params), track_blob, len(track_blob), action_mode)
@@ -34,7 +36,7 @@ class Batch:
             raise RuntimeError(self.lib.pdb_last_error().decode())
 
     def step_host(self, actions, want_out=True):
-        a = np.ascontiguousarray(actions, dtype=np.float32).reshape(self.n, 2)
+        a = np.ascontiguousarray(actions, dtype=np.float32).reshape(self.n, self.stride)
         out = (pc.StepOut * self.n)()
         self._chk(self.lib.pdb_step_host(self.h, a.ctypes.data_as(C.c_void_p), C.c_float(SIM_DT), C.byref(out)))
         o = np.frombuffer(out, dtype=np.dtype(pc.StepOut))
@@ -42,7 +44,7 @@ class Batch:
 
     def set_actions(self, actions):
         import torch  # device plumbing only
-        a = np.ascontiguousarray(actions, dtype=np.float32).reshape(self.n, 2)
+        a = np.ascontiguousarray(actions, dtype=np.float32).reshape(self.n, self.stride)
         self._chk(self.lib.pdb_step_host(self.h, a.ctypes.data_as(C.c_void_p), C.c_float(SIM_DT), None))
 
     def step_async(self):
@@ -64,7 +66,7 @@ class Batch:
 
     def upload_actions(self, actions):
         """host -> device copy of the action array without stepping (hipMemcpy through a torch-free ctypes call)"""
-        a = np.ascontiguousarray(actions, dtype=np.float32).reshape(self.n, 2)
+        a = np.ascontiguousarray(actions, dtype=np.float32).reshape(self.n, self.stride)
         hip = C.CDLL('libamdhip64.so')
         hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
         rc = hip.hipMemcpy(self.lib.pdb_actions_device(self.h), a.ctypes.data_as(C.c_void_p), a.nbytes, 1)

@@ -124,3 +124,80 @@ def test_reset_mask_and_graph_replay(built):
         b2.close()
     finally:
         b.close()
+
+
+def _full_mode_run(P, n_cars, ticks, controls_fn):
+    """GPU (PDB_ACTION_FULL) vs portable-math oracle, free running from the initial state: returns worst rel deviation"""
+    import pdbatch, oracle_ctypes
+    trk = pdbatch.synthetic_track('flat')
+    lib = pc.load_product(); orc = oracle_ctypes.load_oracle(portable_math=True)
+    S0 = pc.DynState()
+    assert lib.pdb_initial_state(C.byref(P), trk, C.byref(S0)) == 0
+    b = pdbatch.Batch(n_cars, P, trk, device=0, action_mode=2)
+    hs = [orc.cpuref_create(C.byref(P), trk, len(trk), C.byref(S0)) for _ in range(n_cars)]
+    worst = 0.0
+    try:
+        for t in range(ticks):
+            a = np.ascontiguousarray(controls_fn(t), dtype=np.float32).reshape(n_cars, 8)
+            b.step_host(a)
+            for i in range(n_cars):
+                orc.cpuref_step_controls(hs[i], a[i].ctypes.data_as(C.c_void_p))
+            if t % 20 == 0 or t == ticks - 1:
+                sg = b.get_state()
+                for i in range(n_cars):
+                    sc = pc.DynState(); orc.cpuref_get_state(hs[i], C.byref(sc))
+                    rel, name, vg, vc, bad_int = parity_util.compare_states(sg[i], sc)
+                    assert not bad_int, (t, i, bad_int[:4])
+                    assert rel < TOL, (t, i, name, vg, vc)
+                    worst = max(worst, rel)
+    finally:
+        b.close()
+        for h in hs:
+            orc.cpuref_destroy(h)
+    return worst
+
+
+@pytest.mark.parametrize('sid', [4, 5])
+def test_full_controls_scenarios(built, sid):
+    """every CarControls field driven (PDB_ACTION_FULL): the brake / handbrake scenario with assists, and the manual
+    scenario without (clutch pedal, gearUp/gearDn pulses, H-pattern select with grinding) -- the scripts whose
+    reference-TU trajectories pin the oracle in tests/test_oracle_golden.py"""
+    import pdbatch, oracle_ctypes
+    orc = oracle_ctypes.load_oracle(portable_math=True)
+    ticks, full, assists = C.c_int(), C.c_int(), (C.c_int * 3)()
+    assert orc.cpuref_scenario_info(sid, C.byref(ticks), C.byref(full), assists) == 0 and full.value == 1
+    P = pc.CarParams.from_buffer_copy(bytes(pdbatch.packed_params()))
+    lib = pc.load_product()
+    lib.pdb_set_assists(C.byref(P), assists[0], assists[1], assists[2], 1)
+    n = 4
+
+    def controls(t):
+        a = np.zeros((n, 8), np.float32)
+        for i in range(n):   # car i runs the script shifted by 7 i ticks so the four cars are in different phases
+            orc.cpuref_scenario_controls(sid, max(t - 7 * i, 0), a[i].ctypes.data_as(C.c_void_p))
+        return a
+    worst = _full_mode_run(P, n, ticks.value, controls)
+    print('full-controls scenario %d: worst rel = %.3e' % (sid, worst))
+    assert worst == 0.0
+
+
+def test_full_controls_random(built):
+    """32 cars, piecewise-constant random values of every control incl. brake, handbrake, clutch and shifter requests, with
+    assists on for even cars' parameter set and off for the second batch"""
+    import pdbatch
+    lib = pc.load_product()
+    for assists in ((1, 1, 1), (0, 0, 0)):
+        P = pc.CarParams.from_buffer_copy(bytes(pdbatch.packed_params()))
+        lib.pdb_set_assists(C.byref(P), assists[0], assists[1], assists[2], 1)
+        n = 32
+        rng = np.random.RandomState(11 + assists[0])
+        cur = np.zeros((n, 8), np.float32)
+
+        def controls(t):
+            if t % 40 == 0:
+                cur[:, 0] = rng.uniform(-1, 1, n); cur[:, 1] = rng.choice([0.0, 0.3, 1.0], n); cur[:, 2] = rng.choice([0.0, 0.0, 0.5, 1.0], n)
+                cur[:, 3] = rng.choice([0.0, 0.0, 0.0, 1.0], n); cur[:, 4] = rng.uniform(0, 1, n)
+                cur[:, 5] = rng.choice([-1, -1, -1, 0, 1, 2, 3, 4], n); cur[:, 6] = rng.choice([0, 1], n); cur[:, 7] = rng.choice([0, 0, 1], n)
+            return cur
+        worst = _full_mode_run(P, n, 800, controls)
+        assert worst == 0.0
