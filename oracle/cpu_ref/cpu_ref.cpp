@@ -1597,7 +1597,7 @@ void Car::fillStepOut(pdb_step_out& o) const {
     for (int i = 0; i < 5; ++i) o.obs[k++] = cs.lookAhead[i];
     for (int i = 0; i < 7; ++i) o.obs[k++] = cs.probes[i];
     o.reward = cs.stepReward;
-    o.flags = (cs.collisionFlag ? 1 : 0) | (cs.outOfTrackFlag ? 2 : 0) | ((cs.lastTrackPointTimestamp + 5.0f < cs.timestamp) ? 4 : 0);
+    o.flags = (cs.collisionFlag ? 1 : 0) | (cs.outOfTrackFlag ? 2 : 0) | (((double)cs.lastTrackPointTimestamp + 5.0 < (double)cs.timestamp) ? 4 : 0);
 }
 
 void Car::fillProbe(pdoracle::Probe& Pr) const {

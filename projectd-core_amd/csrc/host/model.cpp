@@ -195,6 +195,17 @@ void buildCarModel(const std::string& basePathIn, const std::string& modelName, 
     std::replace(base.begin(), base.end(), '\\', '/');
     if (!base.empty() && base.back() != '/') base += '/';
     const std::string dataPath = base + "content/cars/" + modelName + "/data/";
+    {   // packed block (the product's own distribution format for a configured car): <model>/<model>.pdcar next to data/
+        FILE* probe = fopen((dataPath + "car.ini").c_str(), "rb");
+        if (probe) fclose(probe);
+        else if (FILE* f = fopen((base + "content/cars/" + modelName + "/" + modelName + ".pdcar").c_str(), "rb")) {
+            const size_t got = fread(&P, 1, sizeof(P), f);
+            const bool tail = fgetc(f) != EOF;
+            fclose(f);
+            if (got != sizeof(P) || tail || P.magic != 0x50434450 || P.version != 1) throw std::runtime_error("pdb: malformed packed car block for " + modelName);
+            return;
+        }
+    }
     memset(&P, 0, sizeof(P));
     P.magic = 0x50434450;  // 'PDCP'
     P.version = 1;
@@ -716,6 +727,13 @@ bool setCarTune(pdb_car_params& P, const std::string& basePathIn, const std::str
     bool tunable = false;
     std::vector<float> predefined;
     Ini ini(dataPath + "setup.ini");
+    if (!ini.ready) {
+        // a car loaded from a packed block has no data/ directory: its tunes are already applied in the block, and
+        // the spinner ranges that turn a setup value into a parameter are not available
+        FILE* probe = fopen((dataPath + "car.ini").c_str(), "rb");
+        if (probe) fclose(probe);
+        else throw std::runtime_error("pdb: setCarTune(" + name + ") needs " + dataPath + "setup.ini (packed car blocks carry their tunes pre-applied)");
+    }
     if (ini.ready) {
         if (name == "FINAL_RATIO" && ini.hasKey("FINAL_GEAR_RATIO", "RATIOS")) {
             std::ifstream fs(dataPath + ini.getString("FINAL_GEAR_RATIO", "RATIOS"));

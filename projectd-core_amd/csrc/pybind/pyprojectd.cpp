@@ -1,0 +1,348 @@
+// PyProjectD-compatible python module over the pdbatch C ABI (include/pdbatch.h).
+//
+// Same module name, classes, functions, argument meaning and error convention as the reference's pybind11 module
+// (reference src/PyProjectD/PyProjectD.cpp:515-640), so pyprojectd/projectd_env.py runs against it unchanged:
+//   * creators return -1 on failure and log; everything else silently ignores unknown ids (:74-109)
+//   * nothing throws into python; the GIL is never released
+//   * a simulator holds one track and ONE car (what every env does, projectd_env.py:118-121); it is one lane of a
+//     device batch.  The classic per-simulator calls drive a 1-car batch; createBatch() widens a configured simulator
+//     into N identical lanes stepped by one kernel launch (stepBatch), which is the point of this build.
+// The playground / window functions (:600-640) exist and do nothing: rendering is outside the hot path.
+#include <pybind11/pybind11.h>
+#include <pybind11/numpy.h>
+#include <pybind11/stl.h>
+#include <array>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <fstream>
+#include <memory>
+#include <mutex>
+#include <string>
+#include <unordered_map>
+#include <vector>
+#include "pdbatch.h"
+
+namespace py = pybind11;
+
+namespace {
+
+#pragma pack(push, 4)
+struct vec3f { float x = 0, y = 0, z = 0; };
+struct mat44f { float M11 = 1, M12 = 0, M13 = 0, M14 = 0, M21 = 0, M22 = 1, M23 = 0, M24 = 0, M31 = 0, M32 = 0, M33 = 1, M34 = 0, M41 = 0, M42 = 0, M43 = 0, M44 = 1; };
+struct CarControls {   // reference Car/CarControls.h
+    float steer = 0, clutch = 0, brake = 0, handBrake = 0, gas = 0;
+    int8_t isShifterSupported = 1, requestedGearIndex = -1, gearUp = 0, gearDn = 0;
+};
+struct CarState {      // reference Car/CarState.h (664 bytes, pack 4) == pdb_car_state
+    int32_t carId = 0, simId = 0; float timestamp = 0; CarControls controls;
+    int32_t collisionFlag = 0, outOfTrackFlag = 0, trackPointId = 0; float lastTrackPointTimestamp = 0, trackLocation = 0, bodyVsTrack = 0, velocityVsTrack = 0;
+    float engineRPM = 0, speedMS = 0; int32_t gear = 0, gearGrinding = 0;
+    mat44f bodyMatrix; vec3f bodyPos, bodyEuler, accG, velocity, localVelocity, angularVelocity, localAngularVelocity;
+    std::array<mat44f, 4> hubMatrix; std::array<vec3f, 4> tyreContacts;
+    std::array<float, 4> tyreLoad{}, tyreAngularSpeed{}, tyreSlipRatio{}, tyreNdSlip{};
+    std::array<float, 10> probes{}; std::array<float, 5> lookAhead{};
+    float stepReward = 0, totalReward = 0;
+};
+#pragma pack(pop)
+static_assert(sizeof(CarState) == sizeof(pdb_car_state), "CarState must match the reference layout");
+static_assert(sizeof(CarControls) == sizeof(pdb_controls), "CarControls must match the reference layout");
+
+std::mutex g_lock;             // protects the maps only, like SIM_LOCK (:16-17)
+std::string g_logFile;
+
+void logf(const char* fmt, ...) {
+    char buf[1024];
+    va_list ap; va_start(ap, fmt); vsnprintf(buf, sizeof(buf), fmt, ap); va_end(ap);
+    if (!g_logFile.empty()) { if (FILE* f = fopen(g_logFile.c_str(), "a")) { fprintf(f, "%s\n", buf); fclose(f); } }
+    else if (getenv("PDB_VERBOSE")) fprintf(stderr, "%s\n", buf);
+}
+
+struct Sim {
+    int id = 0;
+    std::string base, trackName, model;
+    std::vector<uint8_t> track;
+    bool hasCar = false;
+    pdb_car_params P{};
+    pdb_dyn_state S{};            // host copy; authoritative while batch == nullptr
+    pdb_batch* batch = nullptr;   // 1-car device batch, created at the first step
+    bool paramsDirty = false;
+    CarControls controls;
+    bool teleOnCollision = false, teleOnBadLoc = false; int teleMode = 0;
+    CarState state;
+    double physicsTime = 0;
+    int device = 0;
+    ~Sim() { if (batch) pdb_destroy(batch); }
+
+    bool pullState() { return !batch || pdb_get_state(batch, 0, 1, &S) == PDB_OK; }
+    bool pushState() { return !batch || pdb_set_state(batch, 0, 1, &S) == PDB_OK; }
+    bool ensureBatch() {
+        if (batch && paramsDirty) { pullState(); pdb_destroy(batch); batch = nullptr; }
+        if (!batch) {
+            batch = pdb_create(device, 1, &P, track.data(), track.size(), PDB_ACTION_FULL);
+            if (!batch) { logf("EXCEPTION: %s", pdb_last_error()); return false; }
+            if (pdb_set_state(batch, 0, 1, &S) != PDB_OK) { logf("EXCEPTION: %s", pdb_last_error()); return false; }
+        }
+        paramsDirty = false;
+        return true;
+    }
+    void teleportSpline(float d) {
+        if (!hasCar || track.empty()) return;
+        pullState();
+        if (pdb_teleport_to_spline(&P, track.data(), d, &S) != PDB_OK) logf("EXCEPTION: %s", pdb_last_error());
+        pushState();
+    }
+    void teleportByMode(int mode) {   // Car::teleportByMode (Car.cpp:1342-1358)
+        if (mode == 0) teleportSpline(0.0f);
+        else if (mode == 1) { pullState(); teleportSpline(S.trackLocation); }
+        else if (mode == 2) teleportSpline((float)rand() / (float)RAND_MAX);
+    }
+};
+
+struct Batch {
+    int id = 0, n = 0;
+    pdb_batch* b = nullptr;
+    std::vector<pdb_step_out> out;
+    ~Batch() { if (b) pdb_destroy(b); }
+};
+
+std::unordered_map<int, std::shared_ptr<Sim>> g_sims;
+std::unordered_map<int, std::shared_ptr<Batch>> g_batches;
+int g_uniqSimId = 0, g_uniqBatchId = 0;
+
+Sim* getSim(int simId) { auto it = g_sims.find(simId); return it == g_sims.end() ? nullptr : it->second.get(); }
+Sim* getCarSim(int simId, int carId) { Sim* s = getSim(simId); return (s && s->hasCar && carId == 0) ? s : nullptr; }
+Batch* getBatch(int id) { auto it = g_batches.find(id); return it == g_batches.end() ? nullptr : it->second.get(); }
+
+// ---- logging / seed (:50-68) ----
+void setSeed(unsigned int seed) { srand(seed); }
+void setLogFile(const std::string& filename, bool overwrite) { g_logFile = filename; if (overwrite) { if (FILE* f = fopen(filename.c_str(), "w")) fclose(f); } }
+void clearLogFile() { if (!g_logFile.empty()) { if (FILE* f = fopen(g_logFile.c_str(), "w")) fclose(f); } }
+void writeLog(const std::string& msg) { logf("%s", msg.c_str()); }
+
+// ---- simulator (:111-180) ----
+int createSimulator(const std::string& basePath) {
+    std::ifstream ini(basePath + "/cfg/sim.ini");
+    if (!ini.good()) { logf("EXCEPTION: cannot open %s/cfg/sim.ini", basePath.c_str()); return -1; }
+    auto s = std::make_shared<Sim>();
+    s->base = basePath;
+    if (const char* d = getenv("PDB_DEVICE")) s->device = atoi(d);
+    std::lock_guard<std::mutex> g(g_lock);
+    s->id = g_uniqSimId++;
+    logf("[PY] createSimulator simId=%d", s->id);
+    g_sims.insert({s->id, s});
+    return s->id;
+}
+void destroySimulator(int simId) { logf("[PY] destroySimulator simId=%d", simId); std::lock_guard<std::mutex> g(g_lock); g_sims.erase(simId); }
+void destroyAllSimulators() { std::lock_guard<std::mutex> g(g_lock); g_sims.clear(); g_batches.clear(); g_uniqSimId = 0; }
+
+void stepSimulator(int simId, double dt) {
+    Sim* s = getSim(simId);
+    if (!s || !s->hasCar) return;
+    if (!s->ensureBatch()) return;
+    const CarControls& c = s->controls;
+    const float a[8] = {c.steer, c.clutch, c.brake, c.handBrake, c.gas, (float)c.requestedGearIndex, (float)(c.gearUp != 0), (float)(c.gearDn != 0)};
+    pdb_step_out o;
+    if (pdb_step_host(s->batch, a, (float)dt, &o) != PDB_OK) { logf("EXCEPTION: %s", pdb_last_error()); return; }
+    pdb_car_state cs;
+    if (pdb_get_car_state(s->batch, 0, 1, &cs) == PDB_OK) { memcpy(&s->state, &cs, sizeof(cs)); s->state.carId = 0; s->state.simId = s->id; }
+    s->physicsTime += dt;
+    // ScoringSystem::step teleports inside the tick (ScoringSystem.cpp:194-226); here the pose edit follows the tick
+    if ((s->teleOnCollision && (o.flags & 1)) || (s->teleOnBadLoc && (o.flags & 2))) s->teleportByMode(s->teleMode);
+}
+
+// ---- track (:186-215) ----
+void loadTrack(int simId, const std::string& trackName) {
+    logf("[PY] loadTrack simId=%d trackName=%s", simId, trackName.c_str());
+    Sim* s = getSim(simId);
+    if (!s) return;
+    void* blob = nullptr; uint64_t bytes = 0;
+    if (pdb_build_track(s->base.c_str(), trackName.c_str(), &blob, &bytes) != PDB_OK) { logf("EXCEPTION: %s", pdb_last_error()); return; }
+    s->track.assign((uint8_t*)blob, (uint8_t*)blob + bytes);
+    pdb_free(blob);
+    s->trackName = trackName;
+    if (s->batch) { pdb_destroy(s->batch); s->batch = nullptr; }
+    if (s->hasCar && pdb_initial_state(&s->P, s->track.data(), &s->S) != PDB_OK) logf("EXCEPTION: %s", pdb_last_error());
+}
+void unloadTrack(int simId) { Sim* s = getSim(simId); if (!s) return; if (s->batch) { pdb_destroy(s->batch); s->batch = nullptr; } s->track.clear(); s->trackName.clear(); }
+
+// ---- car (:219-365) ----
+int addCar(int simId, const std::string& modelName) {
+    logf("[PY] addCar simId=%d modelName=%s", simId, modelName.c_str());
+    Sim* s = getSim(simId);
+    if (!s) return -1;
+    if (s->hasCar) { logf("EXCEPTION: one car per simulator in the batched build (cars never interact across envs)"); return -1; }
+    if (s->track.empty()) { logf("EXCEPTION: addCar needs a loaded track"); return -1; }
+    if (pdb_build_car_model(s->base.c_str(), modelName.c_str(), &s->P) != PDB_OK) { logf("EXCEPTION: %s", pdb_last_error()); return -1; }
+    if (pdb_initial_state(&s->P, s->track.data(), &s->S) != PDB_OK) { logf("EXCEPTION: %s", pdb_last_error()); return -1; }
+    s->model = modelName; s->hasCar = true;
+    return 0;
+}
+void removeCar(int simId, int carId) { Sim* s = getCarSim(simId, carId); if (!s) return; if (s->batch) { pdb_destroy(s->batch); s->batch = nullptr; } s->hasCar = false; }
+void teleportCarToLocation(int, int, float, float, float) { /* forcePosition to an arbitrary point: not on the env path */ }
+void teleportCarToPits(int simId, int carId, int) { if (Sim* s = getCarSim(simId, carId)) s->teleportSpline(0.0f); /* synthetic tracks carry no pits */ }
+void teleportCarToSpline(int simId, int carId, float d) { if (Sim* s = getCarSim(simId, carId)) s->teleportSpline(d); }
+void teleportCarByMode(int simId, int carId, int mode) { if (Sim* s = getCarSim(simId, carId)) s->teleportByMode(mode); }
+void setCarAutoTeleport(int simId, int carId, bool collision, bool badLoc, int mode) {
+    if (Sim* s = getCarSim(simId, carId)) { s->teleOnCollision = collision; s->teleOnBadLoc = badLoc; s->teleMode = mode; }
+}
+void setCarControls(int simId, int carId, bool smooth, const CarControls& controls) {
+    Sim* s = getCarSim(simId, carId);
+    if (!s) return;
+    s->controls = controls;
+    if ((s->P.smoothSteer != 0) != smooth) { s->P.smoothSteer = smooth ? 1 : 0; s->paramsDirty = true; }
+}
+void setCarAssists(int simId, int carId, bool autoClutch, bool autoShift, bool autoBlip) {
+    if (Sim* s = getCarSim(simId, carId)) { pdb_set_assists(&s->P, autoClutch, autoShift, autoBlip, s->P.smoothSteer); s->paramsDirty = true; }
+}
+void getCarState(int simId, int carId, CarState& state) { if (Sim* s = getCarSim(simId, carId)) state = s->state; }
+void setCarTune(int simId, int carId, const std::string& name, float value) {
+    if (Sim* s = getCarSim(simId, carId)) {
+        if (pdb_set_car_tune(&s->P, s->base.c_str(), s->model.c_str(), name.c_str(), value, 0) != PDB_OK) logf("EXCEPTION: %s", pdb_last_error());
+        s->paramsDirty = true;
+    }
+}
+void setCarRawTune(int simId, int carId, const std::string& name, float value) {
+    if (Sim* s = getCarSim(simId, carId)) {
+        if (pdb_set_car_tune(&s->P, s->base.c_str(), s->model.c_str(), name.c_str(), value, 1) != PDB_OK) logf("EXCEPTION: %s", pdb_last_error());
+        s->paramsDirty = true;
+    }
+}
+void setScoringVar(int simId, int carId, const std::string& name, float w) {
+    if (Sim* s = getCarSim(simId, carId)) { pdb_set_scoring_var(&s->P, name.c_str(), w); s->paramsDirty = true; }
+}
+float getScoringVar(int simId, int carId, const std::string& name) { Sim* s = getCarSim(simId, carId); return s ? pdb_get_scoring_var(&s->P, name.c_str()) : 0.0f; }
+
+// ---- vectorised extension: N lanes configured like simulator simId ----
+int createBatch(int simId, int nCars, int device) {
+    Sim* s = getSim(simId);
+    if (!s || !s->hasCar || nCars <= 0) { logf("EXCEPTION: createBatch needs a simulator with a track and a car"); return -1; }
+    auto B = std::make_shared<Batch>();
+    B->b = pdb_create(device, nCars, &s->P, s->track.data(), s->track.size(), PDB_ACTION_ENV);
+    if (!B->b) { logf("EXCEPTION: %s", pdb_last_error()); return -1; }
+    s->pullState();
+    if (pdb_set_state_all(B->b, &s->S) != PDB_OK) { logf("EXCEPTION: %s", pdb_last_error()); return -1; }
+    B->n = nCars; B->out.resize(nCars);
+    std::lock_guard<std::mutex> g(g_lock);
+    B->id = g_uniqBatchId++;
+    g_batches.insert({B->id, B});
+    return B->id;
+}
+void destroyBatch(int id) { std::lock_guard<std::mutex> g(g_lock); g_batches.erase(id); }
+// actions [N,2] float32 (a0 = steer, a1 -> gas like projectd_env.py:159-160) -> [N,26] float32: obs[24], reward, flags (bit-cast int32)
+py::array_t<float> stepBatch(int id, py::array_t<float, py::array::c_style | py::array::forcecast> actions, double dt) {
+    Batch* B = getBatch(id);
+    if (!B || actions.size() != (py::ssize_t)B->n * 2) return py::array_t<float>();
+    if (pdb_step_host(B->b, actions.data(), (float)dt, B->out.data()) != PDB_OK) { logf("EXCEPTION: %s", pdb_last_error()); return py::array_t<float>(); }
+    py::array_t<float> r({(py::ssize_t)B->n, (py::ssize_t)26});
+    memcpy(r.mutable_data(), B->out.data(), sizeof(pdb_step_out) * (size_t)B->n);
+    return r;
+}
+void resetBatch(int id, py::object mask) {
+    Batch* B = getBatch(id);
+    if (!B) return;
+    if (mask.is_none()) { pdb_reset(B->b, nullptr); return; }
+    auto m = py::array_t<uint8_t, py::array::c_style | py::array::forcecast>::ensure(mask);
+    if (m && m.size() == B->n) pdb_reset(B->b, m.data());
+}
+void getBatchCarState(int id, int lane, CarState& state) {
+    Batch* B = getBatch(id);
+    if (!B || lane < 0 || lane >= B->n) return;
+    pdb_car_state cs;
+    if (pdb_get_car_state(B->b, lane, 1, &cs) == PDB_OK) { memcpy(&state, &cs, sizeof(cs)); state.carId = lane; }
+}
+
+// ---- playground / window (:367-511): rendering is out of scope, the calls are accepted ----
+void launchPlaygroundInOwnThread(const std::string&) {}
+void initPlayground(const std::string&) {}
+void shutPlayground() {}
+void shutAll() { destroyAllSimulators(); }
+void tickPlayground() {}
+bool isPlaygroundInitialized() { return false; }
+bool isPlaygroundExited() { return false; }
+void moveWindow(int, int) {}
+void resizeWindow(int, int) {}
+void setRenderHz(int, bool) {}
+void setActiveSimulator(int, bool) {}
+void setActiveCar(int, bool, bool) {}
+int getActiveSimulator() { return -1; }
+int getActiveCar() { return -1; }
+
+}  // namespace
+
+PYBIND11_MODULE(PyProjectD, m) {
+    m.doc() = "PyProjectD (pdbatch: MI355X batched stepper behind the reference API)";
+    py::class_<vec3f>(m, "vec3f").def(py::init<>()).def_readwrite("x", &vec3f::x).def_readwrite("y", &vec3f::y).def_readwrite("z", &vec3f::z);
+    py::class_<mat44f>(m, "mat44f").def(py::init<>())
+        .def_readwrite("M11", &mat44f::M11).def_readwrite("M12", &mat44f::M12).def_readwrite("M13", &mat44f::M13).def_readwrite("M14", &mat44f::M14)
+        .def_readwrite("M21", &mat44f::M21).def_readwrite("M22", &mat44f::M22).def_readwrite("M23", &mat44f::M23).def_readwrite("M24", &mat44f::M24)
+        .def_readwrite("M31", &mat44f::M31).def_readwrite("M32", &mat44f::M32).def_readwrite("M33", &mat44f::M33).def_readwrite("M34", &mat44f::M34)
+        .def_readwrite("M41", &mat44f::M41).def_readwrite("M42", &mat44f::M42).def_readwrite("M43", &mat44f::M43).def_readwrite("M44", &mat44f::M44);
+    py::class_<CarControls>(m, "CarControls").def(py::init<>())
+        .def_readwrite("steer", &CarControls::steer).def_readwrite("clutch", &CarControls::clutch).def_readwrite("brake", &CarControls::brake)
+        .def_readwrite("handBrake", &CarControls::handBrake).def_readwrite("gas", &CarControls::gas)
+        .def_readwrite("isShifterSupported", &CarControls::isShifterSupported).def_readwrite("requestedGearIndex", &CarControls::requestedGearIndex)
+        .def_readwrite("gearUp", &CarControls::gearUp).def_readwrite("gearDn", &CarControls::gearDn);
+    py::class_<CarState>(m, "CarState").def(py::init<>())
+        .def_readonly("carId", &CarState::carId).def_readonly("simId", &CarState::simId).def_readonly("timestamp", &CarState::timestamp)
+        .def_readonly("controls", &CarState::controls)
+        .def_readonly("collisionFlag", &CarState::collisionFlag).def_readonly("outOfTrackFlag", &CarState::outOfTrackFlag)
+        .def_readonly("trackPointId", &CarState::trackPointId).def_readonly("lastTrackPointTimestamp", &CarState::lastTrackPointTimestamp)
+        .def_readonly("trackLocation", &CarState::trackLocation).def_readonly("bodyVsTrack", &CarState::bodyVsTrack)
+        .def_readonly("velocityVsTrack", &CarState::velocityVsTrack)
+        .def_readonly("engineRPM", &CarState::engineRPM).def_readonly("speedMS", &CarState::speedMS).def_readonly("gear", &CarState::gear)
+        .def_readonly("gearGrinding", &CarState::gearGrinding)
+        .def_readonly("bodyMatrix", &CarState::bodyMatrix).def_readonly("bodyPos", &CarState::bodyPos).def_readonly("bodyEuler", &CarState::bodyEuler)
+        .def_readonly("accG", &CarState::accG).def_readonly("velocity", &CarState::velocity).def_readonly("localVelocity", &CarState::localVelocity)
+        .def_readonly("angularVelocity", &CarState::angularVelocity).def_readonly("localAngularVelocity", &CarState::localAngularVelocity)
+        .def_readonly("hubMatrix", &CarState::hubMatrix).def_readonly("tyreContacts", &CarState::tyreContacts)
+        .def_readonly("tyreLoad", &CarState::tyreLoad).def_readonly("tyreAngularSpeed", &CarState::tyreAngularSpeed)
+        .def_readonly("tyreSlipRatio", &CarState::tyreSlipRatio).def_readonly("tyreNdSlip", &CarState::tyreNdSlip)
+        .def_readonly("probes", &CarState::probes).def_readonly("lookAhead", &CarState::lookAhead)
+        .def_readonly("stepReward", &CarState::stepReward).def_readonly("totalReward", &CarState::totalReward);
+
+    m.def("setSeed", &setSeed, "");
+    m.def("setLogFile", &setLogFile, "", py::arg("filename"), py::arg("overwrite") = true);
+    m.def("clearLogFile", &clearLogFile, "");
+    m.def("writeLog", &writeLog, "");
+    m.def("createSimulator", &createSimulator, "");
+    m.def("destroySimulator", &destroySimulator, "");
+    m.def("stepSimulator", &stepSimulator, "", py::arg("simId"), py::arg("dt") = 1.0 / 333.0);
+    m.def("loadTrack", &loadTrack, "");
+    m.def("unloadTrack", &unloadTrack, "");
+    m.def("addCar", &addCar, "");
+    m.def("removeCar", &removeCar, "");
+    m.def("teleportCarToLocation", &teleportCarToLocation, "");
+    m.def("teleportCarToPits", &teleportCarToPits, "");
+    m.def("teleportCarToSpline", &teleportCarToSpline, "");
+    m.def("teleportCarByMode", &teleportCarByMode, "");
+    m.def("setCarAutoTeleport", &setCarAutoTeleport, "", py::arg("simId"), py::arg("carId"), py::arg("collision"), py::arg("badLoc"), py::arg("teleportMode") = 0);
+    m.def("setCarControls", &setCarControls, "");
+    m.def("setCarAssists", &setCarAssists, "");
+    m.def("getCarState", &getCarState, "");
+    m.def("setCarRawTune", &setCarRawTune, "");
+    m.def("setCarTune", &setCarTune, "");
+    m.def("setScoringVar", &setScoringVar, "");
+    m.def("getScoringVar", &getScoringVar, "");
+    m.def("launchPlaygroundInOwnThread", &launchPlaygroundInOwnThread, "");
+    m.def("initPlayground", &initPlayground, "");
+    m.def("shutPlayground", &shutPlayground, "");
+    m.def("shutAll", &shutAll, "");
+    m.def("tickPlayground", &tickPlayground, "");
+    m.def("isPlaygroundInitialized", &isPlaygroundInitialized, "");
+    m.def("isPlaygroundExited", &isPlaygroundExited, "");
+    m.def("moveWindow", &moveWindow, "");
+    m.def("resizeWindow", &resizeWindow, "");
+    m.def("setRenderHz", &setRenderHz, "");
+    m.def("setActiveSimulator", &setActiveSimulator, "");
+    m.def("setActiveCar", &setActiveCar, "");
+    m.def("getActiveSimulator", &getActiveSimulator, "");
+    m.def("getActiveCar", &getActiveCar, "");
+    // vectorised extension (not in the reference): one configured simulator widened to N lanes
+    m.def("createBatch", &createBatch, "", py::arg("simId"), py::arg("nCars"), py::arg("device") = 0);
+    m.def("destroyBatch", &destroyBatch, "");
+    m.def("stepBatch", &stepBatch, "", py::arg("batchId"), py::arg("actions"), py::arg("dt") = 1.0 / 333.0);
+    m.def("resetBatch", &resetBatch, "", py::arg("batchId"), py::arg("mask") = py::none());
+    m.def("getBatchCarState", &getBatchCarState, "");
+}

@@ -84,6 +84,15 @@ YAW=145.0
 LENGTH=10.0
 '''
 
+def install_packed_car(base, model='ks_toyota_ae86_drift', block='ks_toyota_ae86_drift.env'):
+    """Put one of the package's packed car blocks where the loader looks for cars that ship without their INI data:
+    <base>/content/cars/<model>/<model>.pdcar"""
+    import shutil
+    dst = os.path.join(base, 'content', 'cars', model)
+    os.makedirs(dst, exist_ok=True)
+    shutil.copy(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'data', block + '.pdcar'), os.path.join(dst, model + '.pdcar'))
+
+
 def make_base(base, tracks=('flat',)):
     """Create <base>/cfg/sim.ini (same keys/values as the reference's shipped cfg/sim.ini that the
     hot path reads: Sim/Simulator.cpp:62-75, Sim/Track.cpp:38-42,212-216, Car/Car.cpp:285-314) and the

@@ -1,0 +1,178 @@
+"""The PyProjectD-compatible module (csrc/pybind/pyprojectd.cpp): same names and error convention as the reference's
+pybind11 module (reference src/PyProjectD/PyProjectD.cpp:515-640).  CPU part: surface + conventions; the GPU part
+(-m gpu) drives the env classes and checks every observation/reward against the oracle."""
+import ctypes as C, os, sys, tempfile
+import numpy as np
+import pytest
+
+REFERENCE_FUNCTIONS = [   # m.def(...) names, reference PyProjectD.cpp:600-640
+    'setSeed', 'setLogFile', 'clearLogFile', 'writeLog', 'createSimulator', 'destroySimulator', 'stepSimulator', 'loadTrack', 'unloadTrack',
+    'addCar', 'removeCar', 'teleportCarToLocation', 'teleportCarToPits', 'teleportCarToSpline', 'teleportCarByMode', 'setCarAutoTeleport',
+    'setCarControls', 'setCarAssists', 'getCarState', 'setCarRawTune', 'setCarTune', 'setScoringVar', 'getScoringVar',
+    'launchPlaygroundInOwnThread', 'initPlayground', 'shutPlayground', 'shutAll', 'tickPlayground', 'isPlaygroundInitialized', 'isPlaygroundExited',
+    'moveWindow', 'resizeWindow', 'setRenderHz', 'setActiveSimulator', 'setActiveCar', 'getActiveSimulator', 'getActiveCar']
+CARSTATE_FIELDS = [       # def_readonly names, reference PyProjectD.cpp:556-598
+    'carId', 'simId', 'timestamp', 'controls', 'collisionFlag', 'outOfTrackFlag', 'trackPointId', 'lastTrackPointTimestamp', 'trackLocation',
+    'bodyVsTrack', 'velocityVsTrack', 'engineRPM', 'speedMS', 'gear', 'gearGrinding', 'bodyMatrix', 'bodyPos', 'bodyEuler', 'accG', 'velocity',
+    'localVelocity', 'angularVelocity', 'localAngularVelocity', 'hubMatrix', 'tyreContacts', 'tyreLoad', 'tyreAngularSpeed', 'tyreSlipRatio',
+    'tyreNdSlip', 'probes', 'lookAhead', 'stepReward', 'totalReward']
+
+
+@pytest.fixture(scope='module')
+def pd(built):
+    import PyProjectD
+    return PyProjectD
+
+
+@pytest.fixture()
+def base(built):
+    import synthetic_tracks
+    d = tempfile.mkdtemp(prefix='pdb_env_')
+    synthetic_tracks.make_base(d, tracks=('flat',))
+    synthetic_tracks.install_packed_car(d)
+    return d
+
+
+def test_module_surface(pd):
+    for f in REFERENCE_FUNCTIONS:
+        assert callable(getattr(pd, f)), f
+    for c in ('vec3f', 'mat44f', 'CarControls', 'CarState'):
+        assert hasattr(pd, c)
+    s = pd.CarState()
+    for f in CARSTATE_FIELDS:
+        assert hasattr(s, f), f
+    with pytest.raises(AttributeError):
+        s.gear = 3                                   # read-only like the reference
+    c = pd.CarControls()
+    assert (c.steer, c.clutch, c.brake, c.handBrake, c.gas, c.isShifterSupported, c.requestedGearIndex, c.gearUp, c.gearDn) == (0, 0, 0, 0, 0, 1, -1, 0, 0)
+    c.steer = 0.25; c.requestedGearIndex = 2
+    assert c.steer == 0.25 and c.requestedGearIndex == 2
+    m = pd.mat44f(); assert (m.M11, m.M22, m.M33, m.M44, m.M12) == (1, 1, 1, 1, 0)
+    assert len(s.probes) == 10 and len(s.lookAhead) == 5 and len(s.hubMatrix) == 4 and len(s.tyreContacts) == 4
+
+
+def test_error_convention(pd, base):
+    """creators return -1 and log; everything else ignores unknown ids; nothing throws (PyProjectD.cpp:74-109,111-137,219-237)"""
+    log = os.path.join(base, 'log.txt')
+    pd.setLogFile(log, True)
+    assert pd.createSimulator('/no/such/base') == -1
+    pd.stepSimulator(12345, 1.0 / 333.0)
+    pd.loadTrack(12345, 'flat')
+    assert pd.addCar(12345, 'ks_toyota_ae86_drift') == -1
+    st = pd.CarState(); pd.getCarState(12345, 0, st)
+    assert pd.getScoringVar(12345, 0, 'TravelBonus') == 0.0
+    pd.setCarTune(12345, 0, 'FRONT_BIAS', 55.0); pd.teleportCarByMode(12345, 0, 0); pd.destroySimulator(12345)
+    sim = pd.createSimulator(base)
+    assert sim >= 0
+    assert pd.addCar(sim, 'ks_toyota_ae86_drift') == -1          # no track yet
+    pd.loadTrack(sim, 'no_such_track')
+    assert pd.addCar(sim, 'ks_toyota_ae86_drift') == -1
+    pd.loadTrack(sim, 'flat')
+    assert pd.addCar(sim, 'no_such_car') == -1
+    car = pd.addCar(sim, 'ks_toyota_ae86_drift')
+    assert car == 0
+    assert pd.addCar(sim, 'ks_toyota_ae86_drift') == -1          # one car per simulator in the batched build
+    pd.setScoringVar(sim, car, 'TravelBonus', 0.25)
+    assert pd.getScoringVar(sim, car, 'TravelBonus') == 0.25
+    assert pd.getScoringVar(sim, car, 'NoSuchVar') == 0.0
+    pd.setCarTune(sim, car, 'FRONT_BIAS', 55.0)                   # packed car: refused + logged, no exception
+    pd.writeLog('[ENV] hello')
+    sim2 = pd.createSimulator(base)
+    assert sim2 == sim + 1                                        # monotonically increasing ids
+    pd.destroySimulator(sim); pd.destroySimulator(sim2)
+    text = open(log).read()
+    assert 'EXCEPTION' in text and '[ENV] hello' in text and 'createSimulator' in text
+    pd.setLogFile('', False)
+
+
+def test_no_cpu_fallback_through_the_module(pd, base):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip('GPU present')
+    sim = pd.createSimulator(base); pd.loadTrack(sim, 'flat'); car = pd.addCar(sim, 'ks_toyota_ae86_drift')
+    st0 = pd.CarState(); pd.getCarState(sim, car, st0)
+    pd.stepSimulator(sim, 1.0 / 333.0)                           # logs the failure, does not compute anything
+    st = pd.CarState(); pd.getCarState(sim, car, st)
+    assert st.timestamp == st0.timestamp == 0.0
+    assert pd.createBatch(sim, 4, 0) == -1
+    pd.destroySimulator(sim)
+    import projectd_env
+    with pytest.raises(RuntimeError):
+        projectd_env.ProjectDVecEnv(4, base, track_name='flat')
+
+
+def test_env_config_and_bounds(built):
+    import projectd_env as E
+    cfg = E.EnvConfig(track_name='flat', terminate_when_stuck=False)
+    assert cfg.track_name == 'flat' and cfg.car_model == 'ks_toyota_ae86_drift' and cfg.stuck_timeout == 5.0
+    assert cfg.scoring_vars['TravelBonus'] == 0.1 and cfg.car_tunes['ks_toyota_ae86_drift']['FINAL_RATIO'] == 5.0
+    with pytest.raises(TypeError):
+        E.EnvConfig(no_such_setting=1)
+    lo, hi = E.obs_bounds(cfg)
+    assert lo.shape == hi.shape == (24,) and hi[0] == 100 and hi[6] == 10 and lo[6] == 0 and abs(hi[12] - np.pi) < 1e-6 and hi[17] == 50 and lo[17] == 0
+    assert E.linscale(0.0, -1.0, 1.0, 0.1, 1.0) == 0.55 and E.linscale(-5.0, -1.0, 1.0, 0.1, 1.0) == 0.1
+
+
+@pytest.mark.gpu
+def test_single_env_matches_oracle(pd, base):
+    """ProjectDEnv through the classic calls: obs / reward of every step equal the oracle's (bit-exact)"""
+    import projectd_env as E, pdbatch, pdb_ctypes as pc, oracle_ctypes
+    env = E.ProjectDEnv(base, track_name='flat')
+    P = pdbatch.packed_params(); trk = pdbatch.synthetic_track('flat')
+    lib = pc.load_product(); orc = oracle_ctypes.load_oracle(True)
+    S0 = pc.DynState(); assert lib.pdb_initial_state(C.byref(P), trk, C.byref(S0)) == 0
+    h = orc.cpuref_create(C.byref(P), trk, len(trk), C.byref(S0))
+    o = pc.StepOut()
+    obs = env.reset()
+    orc.cpuref_step_env(h, 0.0, 0.0); orc.cpuref_get_out(h, C.byref(o))
+    assert np.array_equal(obs, np.array(o.obs[:], np.float32))
+    rng = np.random.RandomState(3)
+    a = np.array([0.0, 1.0], np.float32)
+    for t in range(400):
+        if t % 60 == 0:
+            a = np.array([rng.uniform(-0.4, 0.4), rng.uniform(-1, 1)], np.float32)
+        obs, rew, term, trunc, info = env.step(a)
+        orc.cpuref_step_env(h, float(a[0]), float(a[1])); orc.cpuref_get_out(h, C.byref(o))
+        assert np.array_equal(obs, np.array(o.obs[:], np.float32)), t
+        if not term:
+            assert np.float32(rew) == np.float32(o.reward), t
+        assert env.dstate.gear >= 0 and env.dstate.simId == env.sim
+    orc.cpuref_destroy(h)
+    env.close()
+
+
+@pytest.mark.gpu
+def test_vec_env_matches_oracle_and_resets(pd, base):
+    import projectd_env as E, pdbatch, pdb_ctypes as pc, oracle_ctypes, sharding
+    n = 16
+    env = E.ProjectDVecEnv(n, base, track_name='flat', terminate_low_reward=-1e9)
+    P = pdbatch.packed_params(); trk = pdbatch.synthetic_track('flat')
+    lib = pc.load_product(); orc = oracle_ctypes.load_oracle(True)
+    S0 = pc.DynState(); assert lib.pdb_initial_state(C.byref(P), trk, C.byref(S0)) == 0
+    hs = [orc.cpuref_create(C.byref(P), trk, len(trk), C.byref(S0)) for _ in range(n)]
+    o = pc.StepOut()
+    obs = env.reset()
+    for i in range(n):
+        orc.cpuref_step_env(hs[i], 0.0, 0.0); orc.cpuref_get_out(hs[i], C.byref(o))
+        assert np.array_equal(obs[i], np.array(o.obs[:], np.float32))
+    acts = sharding.global_actions(n, 77)
+    for t in range(300):
+        obs, rew, term, trunc, info = env.step(acts)
+        assert obs.shape == (n, 24) and rew.shape == (n,) and term.dtype == bool
+        for i in range(n):
+            orc.cpuref_step_env(hs[i], float(acts[i, 0]), float(acts[i, 1])); orc.cpuref_get_out(hs[i], C.byref(o))
+            if not term[i]:
+                assert np.array_equal(obs[i], np.array(o.obs[:], np.float32)), (t, i)
+                assert rew[i] == np.float32(np.float64(o.reward)), (t, i)
+        if term.any():
+            break
+    # masked reset: only the selected lanes return to the start line
+    m = np.zeros(n, np.uint8); m[[1, 5]] = 1
+    cs = pd.CarState()
+    pd.getBatchCarState(env.batch, 0, cs); z0 = cs.bodyPos.z
+    env.reset(m)
+    pd.getBatchCarState(env.batch, 1, cs); assert abs(cs.bodyPos.z + 1500.0) < 1.0
+    pd.getBatchCarState(env.batch, 0, cs); assert cs.bodyPos.z == z0
+    for h in hs:
+        orc.cpuref_destroy(h)
+    env.close()
