@@ -20,7 +20,7 @@ extern "C" {
 #define PDB_MAX_CURVE 24
 #define PDB_MAX_BODIES 8
 #define PDB_MAX_JOINTS 16
-#define PDB_MAX_ROWS 40
+#define PDB_MAX_ROWS 33   /* strut-front / live-axle-rear topology: 2 x (3 dball + 5 slider + 3 ball) + 5 dball + 6 fixed */
 #define PDB_MAX_WINGS 4
 #define PDB_MAX_GEARS 10
 #define PDB_NUM_PROBES 7

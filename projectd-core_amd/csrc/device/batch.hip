@@ -69,6 +69,9 @@ static void fillConst(const pdb_car_params& P, DevConst& K, int actionMode) {
     K.wantCarState = 0;
 }
 
+typedef void (*StepKernel)(pdb_dyn_state*, const float*, pdb_step_out*, pdb_car_state*, const pdb_car_params*, const DevConst*, const uint8_t*, int);
+static StepKernel stepKernelFor(const pdb_batch* b) { return (b->params.numRows == 33) ? pdb_step_kernel : pdb_step_kernel_generic; }
+
 static int launch(pdb_batch* b, float dt, bool wantCarState) {
     if (b->K.dt != dt || b->K.wantCarState != (wantCarState ? 1 : 0)) {
         b->K.dt = dt;
@@ -76,7 +79,7 @@ static int launch(pdb_batch* b, float dt, bool wantCarState) {
         b->K.wantCarState = wantCarState ? 1 : 0;
         HIPCHK(hipMemcpyAsync(b->dK, &b->K, sizeof(DevConst), hipMemcpyHostToDevice, b->stream));
     }
-    hipLaunchKernelGGL(pdb_step_kernel, dim3(b->n), dim3(PDB_WAVE), 0, b->stream, b->dStates, b->dActions, b->dOut, b->dCarStates, b->dParams, b->dK,
+    hipLaunchKernelGGL(stepKernelFor(b), dim3((b->n + PDB_CPB - 1) / PDB_CPB), dim3(PDB_BLOCK_THREADS), 0, b->stream, b->dStates, b->dActions, b->dOut, b->dCarStates, b->dParams, b->dK,
                        b->dTrack, b->n);
     HIPCHK(hipGetLastError());
     return PDB_OK;
@@ -212,7 +215,7 @@ int pdb_step_n(pdb_batch* b, float dt, int n) {
         hipGraph_t g = nullptr;
         HIPCHK(hipStreamBeginCapture(b->stream, hipStreamCaptureModeThreadLocal));
         for (int i = 0; i < n; ++i)
-            hipLaunchKernelGGL(pdb_step_kernel, dim3(b->n), dim3(PDB_WAVE), 0, b->stream, b->dStates, b->dActions, b->dOut, b->dCarStates, b->dParams,
+            hipLaunchKernelGGL(stepKernelFor(b), dim3((b->n + PDB_CPB - 1) / PDB_CPB), dim3(PDB_BLOCK_THREADS), 0, b->stream, b->dStates, b->dActions, b->dOut, b->dCarStates, b->dParams,
                                b->dK, b->dTrack, b->n);
         HIPCHK(hipStreamEndCapture(b->stream, &g));
         HIPCHK(hipGraphInstantiate(&b->graphExec, g, nullptr, nullptr, 0));

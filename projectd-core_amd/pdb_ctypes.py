@@ -108,7 +108,8 @@ def _load(path):
     return C.CDLL(path)
 
 def load_product(host_only=False):
-    lib = _load(os.path.join(PKG, 'libpdbhost.so' if host_only else 'libpdbatch.so'))
+    # PDB_LIB: experiment hook (tools/): load a differently-built variant of the device library
+    lib = _load(os.path.join(PKG, 'libpdbhost.so' if host_only else os.environ.get('PDB_LIB', 'libpdbatch.so')))
     lib.pdb_last_error.restype = C.c_char_p
     lib.pdb_version.restype = C.c_char_p
     lib.pdb_get_scoring_var.restype = C.c_float

@@ -36,12 +36,17 @@ for _ in range(400): b.step_host(a)
 st = np.zeros((n, 16), dtype=np.uint64)
 lib.pdb_debug_stamps(b.h, st.ctypes.data_as(C.c_void_p))
 sti = st.astype(np.int64)
-print('solveRows detail (median cycles): setup(JM,rhs) %d | A rows %d | factorisation %d | fwd+bwd %d' % (np.median(sti[:,14]-sti[:,7]), np.median(sti[:,8]-sti[:,14]), np.median(sti[:,15]-sti[:,8]), np.median(sti[:,9]-sti[:,15])))
-sti[:, 8] = sti[:, 9]
-d = np.diff(sti[:, :14], axis=1)
-names = ['load', 'phase1 lane0 pre-step', 'susp (lane=wheel)', 'tyre (lane=wheel)', 'wings/steer/assists/drivetrain/ARB', 'accumulate', 'bodies+joint rows+JinvM+rhs', 'A assembly', 'LDLT', 'substitution', 'cforce+integrate', 'postStep track+scoring', 'outputs+store']
-tot = d.sum(1)
-print('cars %d: median wave lifetime %.0f shader clocks (= %.1f us at 100 MHz memtime?)' % (n, np.median(tot), np.median(tot) / 100.0))
-for i, nm in enumerate(names):
-    print('%-40s median %8.0f  share %5.1f%%' % (nm, np.median(d[:, i]), 100.0 * np.median(d[:, i]) / np.median(tot)))
+CPB = 3
+first = sti[::CPB]                      # first car of each block also carries the pack wave's stamps (4, 14, 15)
+med = lambda x: float(np.median(x))
+t0 = sti[:, 0]
+print('cars %d (car wave, median shader clocks since wave start):' % n)
+for nm, k in (('record loaded, ERP set', 1), ('world inertia + non-steer joint rows done (barrier 1)', 2), ('steer rows done, A assembly starts', 7),
+              ('A assembled', 8), ('LDL^T done', 3), ('barrier 2 passed (forces ready)', 5), ('late bodies done, rhs starts', 6), ('lambda solved', 9),
+              ('integration done', 11), ('post scans + pack scoring done', 12), ('record stored', 13)):
+    print('  %-58s %8.0f' % (nm, med(sti[:, k] - t0)))
+print('pack wave (median, relative to the block\'s first car wave start):')
+for nm, k in (('pre-step + steering rods done', 4), ('suspensions + tyres done', 14), ('wings, drivetrain, ARB done', 15)):
+    print('  %-58s %8.0f' % (nm, med(first[:, k] - first[:, 0])))
+print('wave lifetime median %.0f clocks' % med(sti[:, 13] - t0))
 b.close()
