@@ -65,7 +65,6 @@ int cpuref_scenario_info(int sid, int* ticks, int* full, int* assists3) {
 void cpuref_get_out(void* hh, pdb_step_out* o) { ((CpuRefHandle*)hh)->car.fillStepOut(*o); }
 void cpuref_get_car_state(void* hh, pdb_car_state* cs) { ((CpuRefHandle*)hh)->car.fillCarState(*cs); }
 float cpuref_env_gas(float a1) { return pdoracle::envGas(a1); }
-int cpuref_num_scenarios(void) { return pdoracle::kNumScenarios; }
 // elementary functions of the portable-math specification (pm_ref.h) and of glibc, for tests/test_pmath.py
 int cpuref_math_eval(int fn, int glibc, const float* x, const float* y, float* out, int n) {
     for (int i = 0; i < n; ++i) {
@@ -81,6 +80,9 @@ int cpuref_math_eval(int fn, int glibc, const float* x, const float* y, float* o
     return 0;
 }
 const char* cpuref_scenario_name(int sid) { return pdoracle::kScenarios[sid].name; }
+const char* cpuref_scenario_track(int sid) { return pdoracle::kScenarios[sid].track; }
+int cpuref_num_scenarios(void) { return pdoracle::kNumScenarios; }
+void cpuref_scenario_feedback(int sid, int tick, const float* obs, float* a) { pdoracle::scenarioFeedback(sid, tick, obs, a[0], a[1]); }
 
 // run one scripted scenario exactly like oracle/refharness/ref_main.cpp and write the probe file
 int cpuref_run_scenario(void* hh, int sid, const char* outPath) {
@@ -95,7 +97,11 @@ int cpuref_run_scenario(void* hh, int sid, const char* outPath) {
     { pdoracle::Probe P; P.names = &pf.names; h->car.fillProbe(P); pf.add(-1, 0.0f, 0.0f, P); }
     for (int t = 0; t < sc.ticks; ++t) {
         float a0, a1;
-        if (sc.full) {
+        if (sc.feedback) {
+            pdb_step_out o; h->car.fillStepOut(o);
+            pdoracle::scenarioFeedback(sid, t, o.obs, a0, a1);
+            h->car.step(a0, pdoracle::envGas(a1), (float)(1.0 / 333.0), 1.0 / 333.0);
+        } else if (sc.full) {
             float a[8]; cpuref_scenario_controls(sid, t, a);
             a0 = a[0]; a1 = a[4];
             h->car.stepControls(ctlOf(a), (float)(1.0 / 333.0), 1.0 / 333.0);

@@ -19,6 +19,7 @@ def main():
         shutil.copytree(os.path.join(REF, 'content', 'cars', model, 'data'), dst)
         os.system('chmod -R u+w "%s"' % dst)
     gen_track.gen_flat(os.path.join(base, 'content', 'tracks', 'flat'))
+    gen_track.gen_touge(os.path.join(base, 'content', 'tracks', 'touge'))
     for trk in ('driftplayground',):
         dst = os.path.join(base, 'content', 'tracks', trk)
         if os.path.isdir(dst):

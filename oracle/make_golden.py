@@ -11,7 +11,7 @@ def main():
     subprocess.check_call(['make', '-C', os.path.join(here, 'refharness')])
     subprocess.check_call([sys.executable, os.path.join(here, 'make_base.py')])
     out = os.path.join(here, '_ref', 'out'); os.makedirs(out, exist_ok=True)
-    subprocess.check_call([os.path.join(here, '_ref', 'refharness'), os.path.join(here, '_ref', 'base'), 'flat', out])
+    subprocess.check_call([os.path.join(here, '_ref', 'refharness'), os.path.join(here, '_ref', 'base'), 'all', out])
     gold = os.path.join(here, '..', 'tests', 'golden'); os.makedirs(gold, exist_ok=True)
     for f in sorted(os.listdir(out)):
         if not f.endswith('.bin'): continue

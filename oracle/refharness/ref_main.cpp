@@ -137,6 +137,17 @@ static void fillProbe(Probe& P, Simulator* sim, Car* car) {
     P.p("cs.stepReward", cs.stepReward); P.p("cs.totalReward", cs.totalReward);
 }
 
+// the env's 24-slot observation (projectd_env.py:239-273) from the CarState python reads
+static void obsOf(const CarState& s, float* o) {
+    int k = 0;
+    o[k++] = s.localVelocity.x; o[k++] = s.localVelocity.y; o[k++] = s.localVelocity.z;
+    o[k++] = s.localAngularVelocity.x; o[k++] = s.localAngularVelocity.y; o[k++] = s.localAngularVelocity.z;
+    for (int i = 0; i < 4; ++i) o[k++] = s.tyreNdSlip[i];
+    o[k++] = s.bodyVsTrack; o[k++] = s.velocityVsTrack;
+    for (int i = 0; i < 5; ++i) o[k++] = s.lookAhead[i];
+    for (int i = 0; i < 7; ++i) o[k++] = s.probes[i];
+}
+
 struct Env {
     std::shared_ptr<Simulator> sim;
     Car* car = nullptr;
@@ -195,7 +206,7 @@ struct Env {
 
 int main(int argc, char** argv) {
     if (argc < 4) { fprintf(stderr, "usage: %s <basePath> <track> <outDir> [car] [-v]\n", argv[0]); return 2; }
-    const std::string base = argv[1], track = argv[2], outDir = argv[3];
+    const std::string base = argv[1], only = (std::string(argv[2]) == "all") ? std::string() : std::string(argv[2]), outDir = argv[3];
     std::string model = "ks_toyota_ae86_drift";
     for (int i = 4; i < argc; ++i) { if (!strcmp(argv[i], "-v")) ref_enable_log(true); else model = argv[i]; }
     try {
@@ -203,6 +214,8 @@ int main(int argc, char** argv) {
             const auto& sc = pdoracle::kScenarios[sid];
             INIReader::flushCache();
             Env env;
+            const std::string track = sc.track;
+            if (!only.empty() && only != track) continue;
             env.init(base, track, model, sc.autoClutch != 0, sc.autoShift != 0, sc.autoBlip != 0);
             pdoracle::ProbeFile pf;
             env.reset();
@@ -213,7 +226,11 @@ int main(int argc, char** argv) {
             }
             for (int t = 0; t < sc.ticks; ++t) {
                 float a0, a1;
-                if (sc.full) {
+                if (sc.feedback) {
+                    float obs[24]; obsOf(*env.car->state, obs);
+                    pdoracle::scenarioFeedback(sid, t, obs, a0, a1);
+                    env.step(a0, a1);
+                } else if (sc.full) {
                     pdoracle::Ctl c; pdoracle::scenarioControls(sid, t, c);
                     a0 = c.steer; a1 = c.gas;
                     env.stepControls(c);

@@ -8,17 +8,37 @@ namespace pdoracle {
 
 // full: 0 = env 2-vector (steer, a1) with the env's assists (all on); 1 = every CarControls field scripted
 // (PyProjectD.cpp:297-305 setCarControls) with the scenario's own assist switches (setCarAssists :307-317)
-struct Scenario { const char* name; int ticks; int denseTicks; int stride; int full; int autoClutch, autoShift, autoBlip; };
+// track: synthetic track the scenario runs on (projectd-core_amd/synthetic_tracks.py); feedback: 1 = the action is a function of the
+// previous tick's 24-slot observation (scenarioFeedback), i.e. a closed loop like an RL policy
+struct Scenario { const char* name; int ticks; int denseTicks; int stride; int full; int autoClutch, autoShift, autoBlip; const char* track; int feedback; };
 
 static const Scenario kScenarios[] = {
-    {"idle", 600, 200, 10, 0, 1, 1, 1},
-    {"launch", 2000, 450, 10, 0, 1, 1, 1},
-    {"circle", 1600, 300, 10, 0, 1, 1, 1},
-    {"slalom", 2400, 300, 10, 0, 1, 1, 1},
-    {"brake", 2400, 200, 10, 1, 1, 1, 1},    // pedal brake to a stop, handbrake turn (BrakeSystem, tyre lock)
-    {"manual", 2600, 300, 10, 1, 0, 0, 0},   // no assists: manual clutch, gearUp/gearDn pulses, H-shifter gear select, grinding
+    {"idle", 600, 200, 10, 0, 1, 1, 1, "flat", 0},
+    {"launch", 2000, 450, 10, 0, 1, 1, 1, "flat", 0},
+    {"circle", 1600, 300, 10, 0, 1, 1, 1, "flat", 0},
+    {"slalom", 2400, 300, 10, 0, 1, 1, 1, "flat", 0},
+    {"brake", 2400, 200, 10, 1, 1, 1, 1, "flat", 0},    // pedal brake to a stop, handbrake turn (BrakeSystem, tyre lock)
+    {"manual", 2600, 300, 10, 1, 0, 0, 0, "flat", 0},   // no assists: manual clutch, gearUp/gearDn pulses, H-shifter gear select, grinding
+    {"drive", 7000, 300, 10, 0, 1, 1, 1, "touge", 1},   // closed hilly, banked mountain road driven by a probe-feedback controller (configs[2] shape)
 };
-static const int kNumScenarios = 6;
+static const int kNumScenarios = 7;
+
+// closed-loop action from the previous observation (projectd_env.py:239-273 slot order): centre between the side probes,
+// align with the +-25 degree probes, damp with the yaw rate, hold ~12 m/s.  Plain float arithmetic, fixed order.
+inline void scenarioFeedback(int sid, int tick, const float* obs, float& a0, float& a1) {
+    (void)sid; (void)tick;
+    const float lat = obs[21] - obs[20];      // probes[4] - probes[3]  (-90 / +90 degrees, 10 m)
+    const float head = obs[19] - obs[18];     // probes[2] - probes[1]  (-25 / +25 degrees, 50 m)
+    const float yaw = obs[4];                 // localAngularVelocity.y
+    const float v = obs[2];                   // localVelocity.z
+    float s = (0.03f * lat + 0.015f * head) + 0.15f * yaw;
+    if (s < -1.0f) s = -1.0f;
+    if (s > 1.0f) s = 1.0f;
+    float g = 0.3f * (12.0f - v);
+    if (g < -1.0f) g = -1.0f;
+    if (g > 1.0f) g = 1.0f;
+    a0 = s; a1 = g;
+}
 
 struct Ctl { float steer, clutch, brake, handBrake, gas; int requestedGearIndex, gearUp, gearDn; };
 

@@ -38,6 +38,84 @@ def gen_flat(out, half=2000.0, z0=-1500.0, z1=1500.0, step=10.0, side=6.0):
     if os.path.exists(c):
         os.remove(c)
 
+def touge_centreline(step=5.0, radius=600.0):
+    """Closed mountain-road centreline: a wobbly ring (3- and 5-lobed) with +-40 m of elevation, resampled at `step` metres.
+    Pure float64 math with fixed constants => the same bytes on every machine."""
+    m = 20000
+    pts = []
+    for k in range(m):
+        th = 2.0 * math.pi * k / m
+        r = radius * (1.0 + 0.25 * math.sin(3.0 * th) + 0.10 * math.sin(5.0 * th + 1.0))
+        pts.append((r * math.cos(th), 30.0 * math.sin(2.0 * th) + 10.0 * math.sin(7.0 * th + 0.5), r * math.sin(th)))
+    cum = [0.0]
+    for k in range(m):
+        a, b = pts[k], pts[(k + 1) % m]
+        cum.append(cum[-1] + math.sqrt(sum((b[i] - a[i]) ** 2 for i in range(3))))
+    total = cum[-1]
+    n = int(round(total / step))
+    out = []
+    j = 0
+    for i in range(n):
+        s = total * i / n
+        while cum[j + 1] < s:
+            j += 1
+        t = (s - cum[j]) / (cum[j + 1] - cum[j])
+        a, b = pts[j], pts[(j + 1) % m]
+        out.append(tuple(a[c] + t * (b[c] - a[c]) for c in range(3)))
+    return out
+
+
+def gen_touge(out, step=5.0, side=5.0, margin=4.0, bank_gain=6.0, bank_max=0.08, points_per_surface=400):
+    """Synthetic "Akina-like" closed mountain road (BASELINE configs[2] shape): curvy ring with hills and curvature-
+    proportional banking; ribbon mesh (two triangles per spline interval, TRACK surfaces of <= points_per_surface
+    intervals so that uint16 indices suffice), spline every `step` metres with symmetric sides, CLOSED_LOOP=1."""
+    os.makedirs(out, exist_ok=True)
+    c = touge_centreline(step)
+    n = len(c)
+    lat, bank = [], []
+    for i in range(n):
+        p0, p1, p2 = c[i - 1], c[i], c[(i + 1) % n]
+        fx, fz = p2[0] - p0[0], p2[2] - p0[2]
+        fl = math.hypot(fx, fz)
+        fx, fz = fx / fl, fz / fl
+        lat.append((fz, -fx))                      # unit lateral vector in the xz plane (to the right of travel for +z forward... sign is irrelevant: symmetric)
+        ax, az = p1[0] - p0[0], p1[2] - p0[2]
+        bx, bz = p2[0] - p1[0], p2[2] - p1[2]
+        turn = (ax * bz - az * bx) / (math.hypot(ax, az) * math.hypot(bx, bz))   # sin of the heading change per interval
+        kappa = turn / step
+        bank.append(max(-bank_max, min(bank_max, bank_gain * kappa)))
+    half = side + margin
+
+    def edge(i, sgn):
+        p = c[i]; l = lat[i]
+        return (p[0] + sgn * half * l[0], p[1] - sgn * half * math.sin(bank[i]), p[2] + sgn * half * l[1])
+    with open(os.path.join(out, 'surfaces.bin'), 'wb') as f:
+        i0 = 0
+        while i0 < n:
+            cnt = min(points_per_surface, n - i0)
+            verts, idx = [], []
+            for k in range(cnt + 1):
+                i = (i0 + k) % n
+                verts.append(edge(i, -1.0)); verts.append(edge(i, +1.0))
+            for k in range(cnt):
+                a, b, cc, d = 2 * k, 2 * k + 1, 2 * k + 2, 2 * k + 3          # a,b at interval start (left,right); cc,d at its end
+                for tri in ((a, cc, d), (a, d, b)):
+                    v0, v1, v2 = verts[tri[0]], verts[tri[1]], verts[tri[2]]
+                    ny = (v1[2] - v0[2]) * (v2[0] - v0[0]) - (v1[0] - v0[0]) * (v2[2] - v0[2])
+                    idx.extend(tri if ny > 0 else (tri[0], tri[2], tri[1]))      # front face up
+            write_surface(f, [tuple(float(x) for x in v) for v in verts], idx)
+            i0 += cnt
+    with open(os.path.join(out, 'spline.bin'), 'wb') as f:
+        for p in c:
+            f.write(struct.pack('<5f', p[0], p[1], p[2], side, side))
+    with open(os.path.join(out, 'spline.ini'), 'w') as f:
+        f.write('[SPLINE]\nCLOSED_LOOP=1\nTRACE_SIDES=0\n')
+    cch = os.path.join(out, 'spline.cache')
+    if os.path.exists(cch):
+        os.remove(cch)
+    return n
+
+
 SIM_INI = '''[SIM]
 STEP_HZ=333
 MAX_CARS=2
@@ -101,9 +179,9 @@ def make_base(base, tracks=('flat',)):
     with open(os.path.join(base, 'cfg', 'sim.ini'), 'w') as f:
         f.write(SIM_INI)
     for t in tracks:
-        {'flat': gen_flat}[t](os.path.join(base, 'content', 'tracks', t))
+        {'flat': gen_flat, 'touge': gen_touge}[t](os.path.join(base, 'content', 'tracks', t))
     return base
 
 if __name__ == '__main__':
     kind, out = sys.argv[1], sys.argv[2]
-    {'flat': gen_flat}[kind](out)
+    {'flat': gen_flat, 'touge': gen_touge}[kind](out)

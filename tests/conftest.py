@@ -37,7 +37,7 @@ def oracle(built):
 def base_dir(built):
     import synthetic_tracks
     d = tempfile.mkdtemp(prefix='pdb_base_')
-    synthetic_tracks.make_base(d, tracks=('flat',))
+    synthetic_tracks.make_base(d, tracks=('flat', 'touge'))
     return d
 
 
@@ -55,6 +55,11 @@ def env_params():
 @pytest.fixture(scope='session')
 def flat_track(hostlib, base_dir):
     return pc.build_track(hostlib, base_dir, 'flat')
+
+
+@pytest.fixture(scope='session')
+def touge_track(hostlib, base_dir):
+    return pc.build_track(hostlib, base_dir, 'touge')
 
 
 @pytest.fixture(scope='session')

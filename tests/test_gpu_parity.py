@@ -201,3 +201,53 @@ def test_full_controls_random(built):
             return cur
         worst = _full_mode_run(P, n, 800, controls)
         assert worst == 0.0
+
+
+def test_touge_closed_loop_feedback(built):
+    """BASELINE configs[2] shape: closed, hilly, banked mountain road (1782 triangles, 891 spline points, CLOSED_LOOP=1), 16 cars
+    spread around the lap, each steered by the probe-feedback controller of oracle/scenarios.h from its own observations
+    (the script whose reference-TU trajectory pins the oracle in tests/test_oracle_golden.py).  Bit-exact state parity."""
+    import pdbatch, oracle_ctypes
+    n, ticks = 16, 1500
+    P = pdbatch.packed_params(); trk = pdbatch.synthetic_track('touge')
+    lib = pc.load_product(); orc = oracle_ctypes.load_oracle(portable_math=True)
+    S0 = pc.DynState()
+    assert lib.pdb_initial_state(C.byref(P), trk, C.byref(S0)) == 0
+    starts = (pc.DynState * n)()
+    for i in range(n):
+        s = pc.DynState.from_buffer_copy(bytes(S0))
+        assert lib.pdb_teleport_to_spline(C.byref(P), trk, C.c_float(i / n), C.byref(s)) == 0
+        C.memmove(C.byref(starts[i]), C.byref(s), C.sizeof(s))
+    b = pdbatch.Batch(n, P, trk, device=0, action_mode=1)
+    b.set_state(starts)
+    hs = []
+    for i in range(n):
+        h = orc.cpuref_create(C.byref(P), trk, len(trk), C.byref(S0)); orc.cpuref_set_state(h, C.byref(starts[i])); hs.append(h)
+    try:
+        a = np.zeros((n, 2), np.float32)
+        og = pc.StepOut()
+        ys = []
+        for t in range(ticks):
+            out = b.step_host(a)
+            for i in range(n):
+                orc.cpuref_step_env(hs[i], float(a[i, 0]), float(a[i, 1]))
+            obs = np.ascontiguousarray(out['obs'], dtype=np.float32)
+            for i in range(n):
+                orc.cpuref_scenario_feedback(6, t, obs[i].ctypes.data_as(C.c_void_p), a[i].ctypes.data_as(C.c_void_p))
+            if t % 25 == 0 or t == ticks - 1:
+                sg = b.get_state()
+                for i in range(n):
+                    sc = pc.DynState(); orc.cpuref_get_state(hs[i], C.byref(sc))
+                    rel, name, vg, vc, bad_int = parity_util.compare_states(sg[i], sc)
+                    assert not bad_int, (t, i, bad_int[:4])
+                    assert rel == 0.0, (t, i, name, vg, vc)
+                    orc.cpuref_get_out(hs[i], C.byref(og))
+                    assert np.array_equal(obs[i], np.array(og.obs[:], np.float32)) and out['flags'][i] == og.flags
+                ys.append([s.body[0].pos[1] for s in sg])
+        ys = np.array(ys)
+        assert np.ptp(ys[0]) > 20.0                      # the cars really are at different elevations of the hills
+        assert (out['flags'] & 3).sum() <= 2             # the controller keeps (nearly) every car on the road
+    finally:
+        b.close()
+        for h in hs:
+            orc.cpuref_destroy(h)
