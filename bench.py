@@ -54,6 +54,8 @@ def main():
     ap.add_argument('--warmup', type=int, default=333)
     ap.add_argument('--cars', type=int, default=CARS_PER_GPU)
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--workload', choices=['flat', 'touge'], default='flat',
+                    help='flat = BASELINE configs[1] (the bench line); touge = configs[2] shape: closed hilly road, cars spread around the lap, probe-feedback steering computed on the GPU each tick')
     args = ap.parse_args()
 
     import numpy as np
@@ -75,7 +77,7 @@ def main():
 
     n = args.cars
     P = pdbatch.packed_params()
-    trk = pdbatch.synthetic_track('flat')
+    trk = pdbatch.synthetic_track(args.workload)
     lib = pc.load_product()
     S0 = pc.DynState()
     assert lib.pdb_initial_state(C.byref(P), trk, C.byref(S0)) == 0
@@ -86,15 +88,27 @@ def main():
     stream = torch.cuda.current_stream()
     b.set_stream(stream.cuda_stream)
     b.upload_actions(actions)
+    if args.workload == 'touge':   # spread the cars around the lap (host-side teleports, once)
+        st = (pc.DynState * n)()
+        for i in range(n):
+            s = pc.DynState.from_buffer_copy(bytes(S0))
+            lib.pdb_teleport_to_spline(C.byref(P), trk, C.c_float(((first + i) % 4096) / 4096.0), C.byref(s))
+            C.memmove(C.byref(st[i]), C.byref(s), C.sizeof(s))
+        b.set_state(st)
 
     class _Arr:   # zero-copy torch view of the library-owned output block
         def __init__(self, ptr, shape):
             self.__cuda_array_interface__ = {'shape': shape, 'typestr': '<f4', 'data': (ptr, False), 'version': 2}
     out_t = torch.as_tensor(_Arr(b.out_device_ptr(), (n, 26)), device='cuda:%d' % local_rank)
     gather = sharding.ObsGather(n, world, 'cuda:%d' % local_rank, dist)
+    act_t = torch.as_tensor(_Arr(b.actions_device_ptr(), (n, 2)), device='cuda:%d' % local_rank)
 
     def tick():
         b.step_async()
+        if args.workload == 'touge':   # the policy: oracle/scenarios.h scenarioFeedback as elementwise device ops on the observation block
+            o = out_t
+            act_t[:, 0] = torch.clamp(0.03 * (o[:, 21] - o[:, 20]) + 0.015 * (o[:, 19] - o[:, 18]) + 0.15 * o[:, 4], -1.0, 1.0)
+            act_t[:, 1] = torch.clamp(0.3 * (12.0 - o[:, 2]), -1.0, 1.0)
         gather(out_t)
 
     for _ in range(args.warmup):
@@ -128,7 +142,8 @@ def main():
             "ms_per_step": elapsed * 1000.0 / args.steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32 (+f64 drivetrain)", "data": "synthetic",
-            "config": {"workload": "configs[1]: %d cars/GPU, AE86, flat-plane track, per-car constant random actions, dt=1/333 s" % n,
+            "config": {"workload": ("configs[1]: %d cars/GPU, AE86, flat-plane track, per-car constant random actions, dt=1/333 s" % n) if args.workload == 'flat' else
+                                   ("configs[2] shape: %d cars/GPU, AE86, synthetic closed mountain road (1782 triangles, 891 spline points), probe-feedback steering on the GPU, dt=1/333 s" % n),
                        "cars_per_gpu": n, "collective": "per-tick RCCL all-gather of [N,26] obs/reward/flags" if world > 1 else "none",
                        "parity": "bit-exact vs CPU oracle (tests/test_gpu_parity.py)"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,

@@ -273,6 +273,14 @@ typedef struct pdb_track_header {
     uint64_t offNodes;      /* float[numNodes][3] interpolated B-spline nodes */
     uint64_t offNodeDist;   /* float[numNodes] */
     uint64_t totalBytes;
+    /* version >= 2: uniform xz grid over the surface triangles for the (vertical) wheel rays.  Cell (ix, iz) lists, in
+     * ascending triangle order, every triangle whose xz bounding box overlaps it; a vertical ray at (x, z) needs only the
+     * list of its own cell and finds exactly the hits of a scan over all triangles. */
+    int32_t gridNx, gridNz;
+    float gridMinX, gridMinZ, gridCell, _gridPad;
+    uint64_t offGridStart;  /* int32[gridNx*gridNz + 1] */
+    uint64_t offGridTris;   /* int32[...]  triangle ids */
+    uint64_t offTriSurf;    /* int32[numTris] surface of each triangle */
 } pdb_track_header;
 
 #ifdef __cplusplus

@@ -259,7 +259,7 @@ std::vector<uint8_t> buildTrack(const std::string& basePathIn, const std::string
     // ---- pack ----
     pdb_track_header h;
     memset(&h, 0, sizeof(h));
-    h.magic = 0x4B544450; h.version = 1;
+    h.magic = 0x4B544450; h.version = 2;
     h.numSurfaces = (int32_t)surfaces.size(); h.numTris = (int32_t)(tris.size() / 9);
     h.numFat = (int32_t)fat.size(); h.numNodes = (int32_t)nodes.size();
     h.interpolateStep = steps; h.closedLoop = closedLoop ? 1 : 0;
@@ -272,6 +272,37 @@ std::vector<uint8_t> buildTrack(const std::string& basePathIn, const std::string
     h.offFatDist = off; off = align(off + fat.size() * 4);
     h.offNodes = off; off = align(off + nodes.size() * 12);
     h.offNodeDist = off; off = align(off + nodes.size() * 4);
+    // ---- xz grid over the triangles (see pdb_track_header) ----
+    std::vector<int32_t> gridStart, gridTris, triSurf((size_t)h.numTris, 0);
+    for (size_t s = 0; s < surfaces.size(); ++s)
+        for (int t = surfaces[s].triStart; t < surfaces[s].triStart + surfaces[s].triCount; ++t) triSurf[(size_t)t] = (int32_t)s;
+    if (h.numTris > 0) {
+        float mnx = tris[0], mxx = tris[0], mnz = tris[2], mxz = tris[2];
+        for (size_t v = 0; v < tris.size(); v += 3) { mnx = std::min(mnx, tris[v]); mxx = std::max(mxx, tris[v]); mnz = std::min(mnz, tris[v + 2]); mxz = std::max(mxz, tris[v + 2]); }
+        // cell edge: about two triangles per cell on average, at most 2^20 cells
+        float cell = sqrtf(((mxx - mnx) * (mxz - mnz)) / (float)h.numTris * 2.0f);
+        if (!(cell > 0.5f)) cell = 0.5f;
+        while ((double)((mxx - mnx) / cell + 1.0f) * (double)((mxz - mnz) / cell + 1.0f) > 1048576.0) cell *= 2.0f;
+        h.gridMinX = mnx; h.gridMinZ = mnz; h.gridCell = cell;
+        auto cellOf = [&](float x, float mn) { return (int)floorf((x - mn) / cell); };   // the kernel uses the same expression
+        h.gridNx = cellOf(mxx, mnx) + 1; h.gridNz = cellOf(mxz, mnz) + 1;
+        const size_t nc = (size_t)h.gridNx * (size_t)h.gridNz;
+        std::vector<int32_t> count(nc + 1, 0);
+        auto span = [&](int t, int& x0, int& x1, int& z0, int& z1) {
+            const float* p = tris.data() + 9 * (size_t)t;
+            x0 = cellOf(std::min(p[0], std::min(p[3], p[6])), mnx); x1 = cellOf(std::max(p[0], std::max(p[3], p[6])), mnx);
+            z0 = cellOf(std::min(p[2], std::min(p[5], p[8])), mnz); z1 = cellOf(std::max(p[2], std::max(p[5], p[8])), mnz);
+        };
+        for (int t = 0; t < h.numTris; ++t) { int x0, x1, z0, z1; span(t, x0, x1, z0, z1); for (int z = z0; z <= z1; ++z) for (int x = x0; x <= x1; ++x) count[(size_t)z * h.gridNx + x + 1]++; }
+        for (size_t c = 0; c < nc; ++c) count[c + 1] += count[c];
+        gridStart = count;
+        gridTris.assign((size_t)gridStart[nc], 0);
+        std::vector<int32_t> fill(gridStart.begin(), gridStart.end() - 1);
+        for (int t = 0; t < h.numTris; ++t) { int x0, x1, z0, z1; span(t, x0, x1, z0, z1); for (int z = z0; z <= z1; ++z) for (int x = x0; x <= x1; ++x) gridTris[(size_t)fill[(size_t)z * h.gridNx + x]++] = t; }   // ascending t per cell
+    }
+    h.offGridStart = off; off = align(off + gridStart.size() * 4);
+    h.offGridTris = off; off = align(off + gridTris.size() * 4);
+    h.offTriSurf = off; off = align(off + triSurf.size() * 4);
     h.totalBytes = off;
     std::vector<uint8_t> blob(off, 0);
     memcpy(blob.data(), &h, sizeof(h));
@@ -281,6 +312,9 @@ std::vector<uint8_t> buildTrack(const std::string& basePathIn, const std::string
     if (!fat.empty()) memcpy(blob.data() + h.offFatDist, fatDist.data(), fat.size() * 4);
     if (!nodes.empty()) memcpy(blob.data() + h.offNodes, nodes.data(), nodes.size() * 12);
     if (!nodes.empty()) memcpy(blob.data() + h.offNodeDist, nodeDist.data(), nodes.size() * 4);
+    if (!gridStart.empty()) memcpy(blob.data() + h.offGridStart, gridStart.data(), gridStart.size() * 4);
+    if (!gridTris.empty()) memcpy(blob.data() + h.offGridTris, gridTris.data(), gridTris.size() * 4);
+    if (!triSurf.empty()) memcpy(blob.data() + h.offTriSurf, triSurf.data(), triSurf.size() * 4);
     return blob;
 }
 
