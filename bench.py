@@ -132,6 +132,13 @@ def main():
     elapsed = sharding.max_over_ranks(elapsed, 'cuda:%d' % local_rank, dist, world)
 
     if rank == 0:
+        traffic = None
+        try:   # memory-side bytes per launch from the committed PMC passes of this same command (profiles/, tools/profile_round.sh)
+            pm = json.load(open(os.path.join(ROOT, 'profiles', 'r01_pmc.json')))
+            if args.workload == 'flat' and n == CARS_PER_GPU and pm.get('bench', {}).get('config', {}).get('cars_per_gpu') == n:
+                traffic = pm.get('traffic_bytes_per_launch')
+        except Exception:
+            traffic = None
         kernel_us = region_ms * 1000.0 / args.steps          # HIP events on the kernel's stream around the timed region
         achieved = B_ALG * n / (kernel_us * 1e-6) / 1e9
         res = {
@@ -147,7 +154,8 @@ def main():
                        "cars_per_gpu": n, "collective": "per-tick RCCL all-gather of [N,26] obs/reward/flags" if world > 1 else "none",
                        "parity": "bit-exact vs CPU oracle (tests/test_gpu_parity.py)"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": None, "kernel": "pdb_step_kernel", "kernel_avg_us": kernel_us, "alg_bytes_per_car_tick": B_ALG},
+                         "traffic": traffic, "traffic_source": ("profiles/r01_pmc.json: (2*FETCH_SIZE + WRITE_SIZE)*1024 per launch, rocprofv3 --pmc passes of this command" if traffic else None),
+                         "kernel": "pdb_step_kernel", "kernel_avg_us": kernel_us, "alg_bytes_per_car_tick": B_ALG},
         }
         if not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(P, trk, S0, all_actions)
