@@ -19,7 +19,7 @@ extern "C" {
 
 #define PDB_MAX_CURVE 24
 #define PDB_MAX_BODIES 8
-#define PDB_MAX_JOINTS 16
+#define PDB_MAX_JOINTS 24
 #define PDB_MAX_ROWS 33   /* strut-front / live-axle-rear topology: 2 x (3 dball + 5 slider + 3 ball) + 5 dball + 6 fixed */
 #define PDB_MAX_WINGS 4
 #define PDB_MAX_GEARS 10
@@ -108,7 +108,15 @@ typedef struct pdb_susp {
     float axleBasePos[3];
     float sideSign;                      /* +1 left, -1 right */
     float mass;                          /* ISuspension::getMass() */
+    /* double wishbone (Car/SuspensionDW.h): spring / damper / bump stops act between basePosition and the hub along the body's up axis */
+    float bumpStopProgressive;
 } pdb_susp;
+
+#define PDB_MAX_TURBOS 3
+typedef struct pdb_turbo {               /* Car/Turbo.h TurboDef + Turbo::userSetting */
+    float lagDN, lagUP, maxBoost, wastegate, rpmRef, gamma, userSetting;
+    int32_t isAdjustable;
+} pdb_turbo;
 
 typedef struct pdb_tyre {
     /* TyreData / TyreModelData of compound 0 (Car/TyreCompound.h:9-75), after Tyre::setCompound */
@@ -183,6 +191,10 @@ typedef struct pdb_car_params {
     int32_t engMinimum, engLimiter, engLimiterCycles;
     float engCoast1, engCoast2, engInertia, limiterMultiplier, rpmDamageThreshold, rpmDamageK, bovThreshold;
     float maxPowerRPM, maxTorqueRPM;
+    int32_t numTurbos;
+    pdb_turbo turbos[PDB_MAX_TURBOS];
+    float turboBoostDamageThreshold, turboBoostDamageK;
+    int32_t _padEngine;
     /* assists */
     float acRpmMin, acRpmMax, acClutchSpeed;
     int32_t acUseOnChange, acUseOnStart, autoShiftActive, autoBlipActive, autoBlipElectronic;
@@ -242,7 +254,8 @@ typedef struct pdb_dyn_state {
     int32_t collisionFlag, oldCollisionFlag, outOfTrackFlag;
     float gasUsage;          /* Engine::gasUsage of the previous tick (fuel burn input, Car.cpp:478) */
     float locClutch;         /* Drivetrain::locClutch of the previous tick (read by the H-shifter gear select, Drivetrain.cpp:189) */
-    int32_t _pad[1];         /* record size is a multiple of 16 bytes (coalesced 16-byte-per-lane copies) */
+    float turboRotation[PDB_MAX_TURBOS];   /* Turbo::rotation */
+    int32_t _pad[2];         /* record size is a multiple of 16 bytes (coalesced 16-byte-per-lane copies) */
 } pdb_dyn_state;
 
 /* per-tick outputs (compact) */
@@ -287,8 +300,8 @@ typedef struct pdb_track_header {
 }
 /* sizes are part of the ABI (tests/test_abi.py reads these numbers) */
 static_assert(sizeof(pdb_car_state) == 664, "pdb_car_state must equal the reference CarState (pack 4)");
-static_assert(sizeof(pdb_car_params) == 8352, "pdb_car_params layout");
-static_assert(sizeof(pdb_dyn_state) == 2208, "pdb_dyn_state layout (multiple of 16 bytes)");
+static_assert(sizeof(pdb_car_params) == 9248, "pdb_car_params layout");
+static_assert(sizeof(pdb_dyn_state) == 2224, "pdb_dyn_state layout (multiple of 16 bytes)");
 static_assert(sizeof(pdb_step_out) == 104, "pdb_step_out layout");
 #endif
 #endif

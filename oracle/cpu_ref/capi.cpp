@@ -81,6 +81,7 @@ int cpuref_math_eval(int fn, int glibc, const float* x, const float* y, float* o
 }
 const char* cpuref_scenario_name(int sid) { return pdoracle::kScenarios[sid].name; }
 const char* cpuref_scenario_track(int sid) { return pdoracle::kScenarios[sid].track; }
+const char* cpuref_scenario_car(int sid) { return pdoracle::kScenarios[sid].car ? pdoracle::kScenarios[sid].car : PDORACLE_DEFAULT_CAR; }
 int cpuref_num_scenarios(void) { return pdoracle::kNumScenarios; }
 void cpuref_scenario_feedback(int sid, int tick, const float* obs, float* a) { pdoracle::scenarioFeedback(sid, tick, obs, a[0], a[1]); }
 

@@ -210,7 +210,7 @@ static float damperForce(const pdb_damper& d, float speed) {
 // ISuspension::getHubWorldMatrix (SuspensionStrut.cpp:367-373, SuspensionAxle.cpp:224-232)
 static M44 hubWorldMatrix(const pdb_car_params& P, const pdrb::World& w, int i) {
     const pdb_susp& su = P.susp[i];
-    if (su.type == PDB_SUSP_STRUT) {
+    if (su.type == PDB_SUSP_STRUT || su.type == PDB_SUSP_DW) {   // SuspensionDW.cpp:343-346: mat44f::rotate == the same product
         const M44 m0 = worldMatrix(w.bodies[su.hubBody]);
         const M44 rot = axisAngle(V3(0, 0, 1), su.staticCamber);
         return mult44(rot, m0);
@@ -271,6 +271,55 @@ static void strutStep(const pdb_susp& su, pdrb::World& w, TyreScratch& sc) {
     hub.addForceAtPos(&vDamperForce.x, &vTyreStrut.x);
     const V3 negd = vDamperForce * -1.0f;
     body.addForceAtPos(&negd.x, &vCarStrut.x);
+}
+
+// SuspensionDW::step (SuspensionDW.cpp:214-283), no active actuator
+static void dwStep(const pdb_susp& su, pdrb::World& w, TyreScratch& sc) {
+    Body& body = w.bodies[PDB_BODY_CHASSIS];
+    Body& hub = w.bodies[su.hubBody];
+    const M44 mb = worldMatrix(body);
+    const V3 vBodyM2(mb.m[4], mb.m[5], mb.m[6]);
+    const V3 vHubWorldPos = getPos(hub);
+    const V3 vHubLocalPos = w2l(body, vHubWorldPos);
+    const V3 refPoint(su.basePosition);
+    const float fHubDeltaY = vHubLocalPos.y - refPoint.y;
+    const float fTravel = fHubDeltaY + su.rodLength;
+    sc.travel = fTravel;
+    float fForce = ((fTravel * su.progressiveK) + su.k) * fTravel;
+    if (su.packerRange != 0.0f && fTravel > su.packerRange && su.k != 0.0f)
+        fForce += (((fTravel - su.packerRange) * su.bumpStopProgressive) + su.bumpStopRate) * (fTravel - su.packerRange);
+    if (fForce > 0.0f) {
+        const V3 f = vBodyM2 * -fForce;
+        hub.addForceAtPos(&f.x, &vHubWorldPos.x);
+        const V3 lf(0, fForce, 0);
+        body.addRelForceAtRelPos(&lf.x, &refPoint.x);
+    }
+    const V3 vHubVel = getVelocity(hub);
+    const V3 vPointVel = localPointVel(body, refPoint);
+    const V3 vDeltaVel = vHubVel - vPointVel;
+    const float fDamperSpeed = vDeltaVel * vBodyM2;
+    sc.damperSpeedMS = fDamperSpeed;
+    const float fDamperForce = damperForce(su.damper, fDamperSpeed);
+    {
+        const V3 vForce = vBodyM2 * fDamperForce;
+        hub.addForceAtPos(&vForce.x, &vHubWorldPos.x);
+        const V3 neg = vForce * -1.0f;
+        body.addForceAtRelPos(&neg.x, &refPoint.x);
+    }
+    if (su.bumpStopUp != 0.0f && fHubDeltaY > su.bumpStopUp && 0.0f != su.k) {
+        fForce = (((fHubDeltaY - su.bumpStopUp) * su.bumpStopProgressive) + su.bumpStopRate) * (fHubDeltaY - su.bumpStopUp);
+        const V3 f = vBodyM2 * -fForce;
+        hub.addForceAtPos(&f.x, &vHubWorldPos.x);
+        const V3 lf(0, fForce, 0);
+        body.addRelForceAtRelPos(&lf.x, &vHubLocalPos.x);
+    }
+    if (su.bumpStopDn != 0.0f && fHubDeltaY < su.bumpStopDn && 0.0f != su.k) {
+        fForce = (((fHubDeltaY - su.bumpStopDn) * su.bumpStopProgressive) + su.bumpStopRate) * (fHubDeltaY - su.bumpStopDn);
+        const V3 f = vBodyM2 * -fForce;
+        hub.addForceAtPos(&f.x, &vHubWorldPos.x);
+        const V3 lf(0, fForce, 0);
+        body.addRelForceAtRelPos(&lf.x, &vHubLocalPos.x);
+    }
 }
 
 // SuspensionAxle::step (SuspensionAxle.cpp:120-185)
@@ -956,9 +1005,30 @@ static void engineStep(Car& c, float gasInput, float rpm) {
     float fPower = curve(P.powerCurve, rpm);
     float fCoastTorq = 0;
     if (P.engCoast1 != 0.0f) fCoastTorq = (rpm - (float)P.engMinimum) * P.engCoast1;
+    // stepTurbos (Engine.cpp:368-384) -> Turbo::step (Turbo.cpp:11-38) with the fixed 0.003 s step of the reference
+    float turboBoost = 0;
+    for (int t = 0; t < P.numTurbos; ++t) {
+        const pdb_turbo& tb = P.turbos[t];
+        float rot = S.turboRotation[t];
+        float fNewRotation = 0, fLag;
+        if (rpm > 0.0f && fGas > 0.0f) fNewRotation = m_powf(tclamp(((fGas * rpm) / tb.rpmRef), 0.0f, 1.0f), tb.gamma);
+        if (fNewRotation <= rot) fLag = tclamp((0.003f * tb.lagDN), 0.0f, 1.0f);
+        else fLag = tclamp((0.003f * tb.lagUP), 0.0f, 1.0f);
+        rot += ((fNewRotation - rot) * fLag);
+        if (tb.wastegate != 0.0f) {
+            const float fUserWG = tb.wastegate * tb.userSetting;
+            if ((tb.maxBoost * rot) > fUserWG) rot = fUserWG / tb.maxBoost;
+        }
+        S.turboRotation[t] = rot;
+        turboBoost += ((tb.maxBoost * rot) * S.fuelPressure);
+    }
+    c.turboBoost = turboBoost;
+    if (turboBoost != 0.0f) fPower *= (turboBoost + 1.0f);
     if (P.engCoast2 != 0.0f) { const float d = rpm - (float)P.engMinimum; fCoastTorq -= (((d * d) * P.engCoast2) * signf_(rpm)); }
     fCoastTorq += (float)0.0;
     if (rpm <= (float)P.engMinimum) fCoastTorq = 0;
+    if (P.turboBoostDamageThreshold != 0.0f && turboBoost > P.turboBoostDamageThreshold)
+        S.lifeLeft -= ((((turboBoost - P.turboBoostDamageThreshold) * P.turboBoostDamageK) * 0.003f) * P.mechanicalDamageRate);
     if (P.rpmDamageThreshold != 0.0f && rpm > P.rpmDamageThreshold)
         S.lifeLeft -= ((((rpm - P.rpmDamageThreshold) * P.rpmDamageK) * 0.003f) * P.mechanicalDamageRate);
     const float fAirAmount = P.airDensity * 0.82630974f;
@@ -1103,7 +1173,7 @@ static void drivetrainStep(Car& c, float dt) {
         const float fAxleTorq = fGearTorque * P.axleTorqueReaction;
         const V3 a(0, 0, fAxleTorq), b(0, 0, -fAxleTorq);
         c.w.bodies[PDB_BODY_CHASSIS].addRelTorque(&a.x);
-        c.w.bodies[PDB_BODY_AXLE].addRelTorque(&b.x);
+        c.w.bodies[P.susp[2].hubBody].addRelTorque(&b.x);
     }
 }
 
@@ -1189,7 +1259,11 @@ void Car::carStep(float dt) {
         ts[2].handBrakeTorque = controls.handBrake * Pm.handBrakeTorque;
         ts[3].handBrakeTorque = controls.handBrake * Pm.handBrakeTorque;
     }
-    for (int i = 0; i < 4; ++i) { if (Pm.susp[i].type == PDB_SUSP_STRUT) strutStep(Pm.susp[i], w, ts[i]); else axleStep(Pm.susp[i], w, ts[i]); }
+    for (int i = 0; i < 4; ++i) {
+        if (Pm.susp[i].type == PDB_SUSP_STRUT) strutStep(Pm.susp[i], w, ts[i]);
+        else if (Pm.susp[i].type == PDB_SUSP_DW) dwStep(Pm.susp[i], w, ts[i]);
+        else axleStep(Pm.susp[i], w, ts[i]);
+    }
     for (int i = 0; i < 4; ++i) tyreStep(*this, i, dt);
     for (int wi = 0; wi < Pm.numWings; ++wi) wingStep(*this, wi);
     {   // SteeringSystem::step (SteeringSystem.cpp:17-24) -> setSteerLengthOffset (SuspensionStrut.cpp:340-350)
@@ -1603,15 +1677,18 @@ void Car::fillStepOut(pdb_step_out& o) const {
 void Car::fillProbe(pdoracle::Probe& Pr) const {
     const double tPre = S.physicsTime;   // the harness samples after `physicsTime += dt`
     Pr.p("time", tPre);
-    const char* bn[7] = {"chassis", "tank", "axle", "hub0", "strut0", "hub1", "strut1"};
-    char nm[96];
-    for (int i = 0; i < 7; ++i) {
+    const bool legacy = P->susp[0].type == PDB_SUSP_STRUT && P->susp[2].type == PDB_SUSP_AXLE;
+    const char* bnl[7] = {"chassis", "tank", "axle", "hub0", "strut0", "hub1", "strut1"};
+    char nm[96], bname[16];
+    for (int i = 0; i < P->numBodies; ++i) {
         const Body& b = w.bodies[i];
-        snprintf(nm, sizeof(nm), "%s.pos", bn[i]); Pr.p3(nm, b.pos);
-        snprintf(nm, sizeof(nm), "%s.q", bn[i]); Pr.pn(nm, b.q, 4);
-        snprintf(nm, sizeof(nm), "%s.R", bn[i]); Pr.pn(nm, b.R, 9);
-        snprintf(nm, sizeof(nm), "%s.lvel", bn[i]); Pr.p3(nm, b.lvel);
-        snprintf(nm, sizeof(nm), "%s.avel", bn[i]); Pr.p3(nm, b.avel);
+        if (!legacy) snprintf(bname, sizeof(bname), "body%d", i);
+        const char* bn = legacy ? bnl[i] : bname;
+        snprintf(nm, sizeof(nm), "%s.pos", bn); Pr.p3(nm, b.pos);
+        snprintf(nm, sizeof(nm), "%s.q", bn); Pr.pn(nm, b.q, 4);
+        snprintf(nm, sizeof(nm), "%s.R", bn); Pr.pn(nm, b.R, 9);
+        snprintf(nm, sizeof(nm), "%s.lvel", bn); Pr.p3(nm, b.lvel);
+        snprintf(nm, sizeof(nm), "%s.avel", bn); Pr.p3(nm, b.avel);
     }
     Pr.p("ctrl.steer", controls.steer); Pr.p("ctrl.clutch", controls.clutch); Pr.p("ctrl.brake", controls.brake);
     Pr.p("ctrl.handBrake", controls.handBrake); Pr.p("ctrl.gas", controls.gas); Pr.p("ctrl.gearUp", controls.gearUp); Pr.p("ctrl.gearDn", controls.gearDn);
@@ -1661,7 +1738,7 @@ void Car::fillProbe(pdoracle::Probe& Pr) const {
     Pr.p("dt.gearRequest.timeout", S.gearReqTimeout); Pr.p("dt.gearRequest.requestedGear", S.gearReqRequestedGear);
     Pr.p("dt.validShiftRPMWindow", S.validShiftRPMWindow);
     Pr.p("eng.outTorque", engOutTorque); Pr.p("eng.limiterOn", S.limiterOn); Pr.p("eng.lifeLeft", S.lifeLeft);
-    Pr.p("eng.gasUsage", gasUsage); Pr.p("eng.fuelPressure", S.fuelPressure); Pr.p("eng.turboBoost", 0.0);
+    Pr.p("eng.gasUsage", gasUsage); Pr.p("eng.fuelPressure", S.fuelPressure); Pr.p("eng.turboBoost", turboBoost);
     Pr.p("ac.clutchValueSignal", S.acClutchValueSignal);
     Pr.p("ac.seq.currentTime", S.acSeqCurrentTime);
     Pr.p("ac.seq.isDone", S.acSeqIsDone ? 1 : 0);

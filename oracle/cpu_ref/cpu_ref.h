@@ -55,6 +55,7 @@ struct Car {
     float lookAhead[5];
     TyreScratch ts[4];
     WingScratch ws[PDB_MAX_WINGS];
+    float turboBoost = 0;
     double locClutch = 1.0, currentClutchTorque = 0, ratio = 12.0, totalTorque = 0, engOutTorque = 0;
     float gasUsage = 0;
     double stepTime = 0;   // sim->physicsTime seen by the last step (before += dt)

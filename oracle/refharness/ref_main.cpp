@@ -23,20 +23,22 @@ using pdoracle::Probe;
 static void fillProbe(Probe& P, Simulator* sim, Car* car) {
     pdrb::World* w = ref_get_world(sim->physics.get());
     P.p("time", sim->physicsTime);
-    auto* s0 = (SuspensionStrut*)car->suspensions[0];
-    auto* s1 = (SuspensionStrut*)car->suspensions[1];
-    IRigidBody* bodies[7] = {car->body.get(), car->fuelTankBody.get(), car->rigidAxle.get(), s0->hub.get(),
-                             s0->strutBody.get(), s1->hub.get(), s1->strutBody.get()};
+    // rigid bodies in creation order (= world order): chassis, tank, [axle], then per wheel hub (+ strut body)
+    const bool legacy = car->suspensions[0]->getType() == SuspensionType::Strut && car->suspensions[2]->getType() == SuspensionType::Axle;
     const char* bn[7] = {"chassis", "tank", "axle", "hub0", "strut0", "hub1", "strut1"};
-    char nm[96];
-    for (int i = 0; i < 7; ++i) {
-        const pdrb::Body& b = w->bodies[ref_body_id(bodies[i])];
-        snprintf(nm, sizeof(nm), "%s.pos", bn[i]); P.p3(nm, b.pos);
-        snprintf(nm, sizeof(nm), "%s.q", bn[i]); P.pn(nm, b.q, 4);
-        snprintf(nm, sizeof(nm), "%s.R", bn[i]); P.pn(nm, b.R, 9);
-        snprintf(nm, sizeof(nm), "%s.lvel", bn[i]); P.p3(nm, b.lvel);
-        snprintf(nm, sizeof(nm), "%s.avel", bn[i]); P.p3(nm, b.avel);
+    char nm[96], bname[16];
+    for (int i = 0; i < (int)w->bodies.size(); ++i) {
+        const pdrb::Body& b = w->bodies[i];
+        if (!legacy) { snprintf(bname, sizeof(bname), "body%d", i); }
+        const char* bni = legacy ? bn[i] : bname;
+#define bn_i bni
+        snprintf(nm, sizeof(nm), "%s.pos", bn_i); P.p3(nm, b.pos);
+        snprintf(nm, sizeof(nm), "%s.q", bn_i); P.pn(nm, b.q, 4);
+        snprintf(nm, sizeof(nm), "%s.R", bn_i); P.pn(nm, b.R, 9);
+        snprintf(nm, sizeof(nm), "%s.lvel", bn_i); P.p3(nm, b.lvel);
+        snprintf(nm, sizeof(nm), "%s.avel", bn_i); P.p3(nm, b.avel);
     }
+#undef bn_i
     const auto& c = car->controls;
     P.p("ctrl.steer", c.steer); P.p("ctrl.clutch", c.clutch); P.p("ctrl.brake", c.brake);
     P.p("ctrl.handBrake", c.handBrake); P.p("ctrl.gas", c.gas); P.p("ctrl.gearUp", c.gearUp); P.p("ctrl.gearDn", c.gearDn);
@@ -216,7 +218,7 @@ int main(int argc, char** argv) {
             Env env;
             const std::string track = sc.track;
             if (!only.empty() && only != track) continue;
-            env.init(base, track, model, sc.autoClutch != 0, sc.autoShift != 0, sc.autoBlip != 0);
+            env.init(base, track, sc.car ? std::string(sc.car) : model, sc.autoClutch != 0, sc.autoShift != 0, sc.autoBlip != 0);
             pdoracle::ProbeFile pf;
             env.reset();
             {

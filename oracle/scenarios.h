@@ -10,18 +10,22 @@ namespace pdoracle {
 // (PyProjectD.cpp:297-305 setCarControls) with the scenario's own assist switches (setCarAssists :307-317)
 // track: synthetic track the scenario runs on (projectd-core_amd/synthetic_tracks.py); feedback: 1 = the action is a function of the
 // previous tick's 24-slot observation (scenarioFeedback), i.e. a closed loop like an RL policy
-struct Scenario { const char* name; int ticks; int denseTicks; int stride; int full; int autoClutch, autoShift, autoBlip; const char* track; int feedback; };
+// car: model directory under content/cars (nullptr = the env default, ks_toyota_ae86_drift)
+struct Scenario { const char* name; int ticks; int denseTicks; int stride; int full; int autoClutch, autoShift, autoBlip; const char* track; int feedback; const char* car; };
 
 static const Scenario kScenarios[] = {
-    {"idle", 600, 200, 10, 0, 1, 1, 1, "flat", 0},
-    {"launch", 2000, 450, 10, 0, 1, 1, 1, "flat", 0},
-    {"circle", 1600, 300, 10, 0, 1, 1, 1, "flat", 0},
-    {"slalom", 2400, 300, 10, 0, 1, 1, 1, "flat", 0},
-    {"brake", 2400, 200, 10, 1, 1, 1, 1, "flat", 0},    // pedal brake to a stop, handbrake turn (BrakeSystem, tyre lock)
-    {"manual", 2600, 300, 10, 1, 0, 0, 0, "flat", 0},   // no assists: manual clutch, gearUp/gearDn pulses, H-shifter gear select, grinding
-    {"drive", 7000, 300, 10, 0, 1, 1, 1, "touge", 1},   // closed hilly, banked mountain road driven by a probe-feedback controller (configs[2] shape)
+    {"idle", 600, 200, 10, 0, 1, 1, 1, "flat", 0, nullptr},
+    {"launch", 2000, 450, 10, 0, 1, 1, 1, "flat", 0, nullptr},
+    {"circle", 1600, 300, 10, 0, 1, 1, 1, "flat", 0, nullptr},
+    {"slalom", 2400, 300, 10, 0, 1, 1, 1, "flat", 0, nullptr},
+    {"brake", 2400, 200, 10, 1, 1, 1, 1, "flat", 0, nullptr},    // pedal brake to a stop, handbrake turn (BrakeSystem, tyre lock)
+    {"manual", 2600, 300, 10, 1, 0, 0, 0, "flat", 0, nullptr},   // no assists: manual clutch, gearUp/gearDn pulses, H-shifter gear select, grinding
+    {"drive", 7000, 300, 10, 0, 1, 1, 1, "touge", 1, nullptr},   // closed hilly, banked mountain road driven by a probe-feedback controller (configs[2] shape)
+    {"rx7", 2400, 300, 10, 0, 1, 1, 1, "flat", 0, "ks_mazda_rx7_tuned"},          // double wishbones all round, one turbo: the slalom script
+    {"supra", 5000, 300, 10, 0, 1, 1, 1, "touge", 1, "ks_toyota_supra_mkiv_drift"},   // double wishbones, two turbos, 6 gears, on the mountain road
 };
-static const int kNumScenarios = 7;
+static const int kNumScenarios = 9;
+#define PDORACLE_DEFAULT_CAR "ks_toyota_ae86_drift"
 
 // closed-loop action from the previous observation (projectd_env.py:239-273 slot order): centre between the side probes,
 // align with the +-25 degree probes, damp with the yaw rate, hold ~12 m/s.  Plain float arithmetic, fixed order.
@@ -48,7 +52,7 @@ inline void scenarioAction(int sid, int tick, float& a0, float& a1) {
     case 0: a0 = 0.0f; a1 = -1.0f; break;
     case 1: a0 = 0.0f; a1 = 1.0f; break;
     case 2: a0 = 0.35f; a1 = 0.2f; break;
-    default:
+    default:   // slalom (3) and the rx7 run (7)
         a0 = (float)(0.4 * sin(6.283185307179586 * t / 2.0));
         a1 = (float)(0.6 * sin(6.283185307179586 * t / 5.0 + 1.0));
         break;
@@ -60,7 +64,7 @@ inline float envGas(float a1);
 inline void scenarioControls(int sid, int tick, Ctl& c) {
     c.steer = 0; c.clutch = 0; c.brake = 0; c.handBrake = 0; c.gas = 0; c.requestedGearIndex = -1; c.gearUp = 0; c.gearDn = 0;
     const double t = (double)tick * (1.0 / 333.0);
-    if (sid < 4) { float a0, a1; scenarioAction(sid, tick, a0, a1); c.steer = a0; c.gas = envGas(a1); return; }
+    if (sid < 4 || sid == 7) { float a0, a1; scenarioAction(sid, tick, a0, a1); c.steer = a0; c.gas = envGas(a1); return; }
     if (sid == 4) {
         if (t < 3.0) { c.gas = 1.0f; }
         else if (t < 5.0) { c.brake = 0.8f; }

@@ -283,10 +283,26 @@ void buildCarModel(const std::string& basePathIn, const std::string& modelName, 
     Ini sus(dataPath + "suspensions.ini");
     if (!sus.ready) throw std::runtime_error("pdb: suspensions.ini not found");
     const std::string typeF = sus.getString("FRONT", "TYPE"), typeR = sus.getString("REAR", "TYPE");
-    if (typeF != "STRUT" || typeR != "AXLE")
-        throw std::runtime_error("pdb: only FRONT=STRUT / REAR=AXLE suspensions are implemented this round (got " + typeF + "/" + typeR + ")");
-    P.suspTypeF = PDB_SUSP_STRUT; P.suspTypeR = PDB_SUSP_AXLE;
-    P.axleTorqueReaction = sus.getFloat("AXLE", "TORQUE_REACTION");
+    if ((typeF != "STRUT" && typeF != "DWB") || (typeR != "AXLE" && typeR != "DWB"))
+        throw std::runtime_error("pdb: suspension types " + typeF + "/" + typeR + " are not implemented (front STRUT|DWB, rear AXLE|DWB)");
+    if (sus.hasSection("HEAVE_FRONT") || sus.hasSection("HEAVE_REAR")) throw std::runtime_error("pdb: heave springs are not implemented");
+    P.suspTypeF = (typeF == "STRUT") ? PDB_SUSP_STRUT : PDB_SUSP_DW;
+    P.suspTypeR = (typeR == "AXLE") ? PDB_SUSP_AXLE : PDB_SUSP_DW;
+    if (typeR == "AXLE") P.axleTorqueReaction = sus.getFloat("AXLE", "TORQUE_REACTION");
+    // body slots in the reference's creation order (Car.cpp:38-39,63-107): chassis, tank, [rigid axle], then per wheel
+    // hub (+ strut body for struts)
+    int nextBody = 2;
+    const int axleB = (typeR == "AXLE") ? nextBody++ : -1;
+    int hubOf[4], strutOf[4];
+    for (int index = 0; index < 4; ++index) {
+        const bool front = index < 2;
+        const std::string& ty = front ? typeF : typeR;
+        strutOf[index] = -1;
+        if (ty == "AXLE") { hubOf[index] = axleB; continue; }
+        hubOf[index] = nextBody++;
+        if (ty == "STRUT") strutOf[index] = nextBody++;
+    }
+    if (nextBody > PDB_MAX_BODIES) throw std::runtime_error("pdb: too many rigid bodies for this suspension combination");
     const int iVer = sus.getInt("HEADER", "VERSION");
     const float wheelBase = sus.getFloat("BASIC", "WHEELBASE");
     const float cg = sus.getFloat("BASIC", "CG_LOCATION");
@@ -305,13 +321,84 @@ void buildCarModel(const std::string& basePathIn, const std::string& modelName, 
         if (d.reboundFast == 0.0f) d.reboundFast = d.reboundSlow;
     };
 
+    // ---- double wishbone (SuspensionDW.cpp:17-207): hub body + 5 distance joints, front or rear ----
+    auto initDW = [&](int index) {
+        pdb_susp& S = P.susp[index];
+        memset(&S, 0, sizeof(S));
+        S.type = PDB_SUSP_DW;
+        const int hubB = hubOf[index];
+        S.hubBody = hubB; S.strutBody = -1;
+        const std::string id = (index < 2) ? "FRONT" : "REAR";
+        float ref[3];
+        if (index < 2) v3set(ref, (index == 0) ? frontTrack : -frontTrack, frontBaseY, (1.0f - cg) * wheelBase);
+        else v3set(ref, (index == 2) ? rearTrack : -rearTrack, rearBaseY, -(cg * wheelBase));
+        float carTopF[3], carTopR[3], carBotF[3], carBotR[3], tyreTop[3], tyreBot[3], tyreSteer[3], carSteer[3];
+        sus.getFloat3(id, "WBCAR_TOP_FRONT", carTopF); sus.getFloat3(id, "WBCAR_TOP_REAR", carTopR);
+        sus.getFloat3(id, "WBCAR_BOTTOM_FRONT", carBotF); sus.getFloat3(id, "WBCAR_BOTTOM_REAR", carBotR);
+        sus.getFloat3(id, "WBTYRE_TOP", tyreTop); sus.getFloat3(id, "WBTYRE_BOTTOM", tyreBot);
+        sus.getFloat3(id, "WBTYRE_STEER", tyreSteer); sus.getFloat3(id, "WBCAR_STEER", carSteer);
+        float* all[8] = {carTopF, carTopR, carBotF, carBotR, tyreTop, tyreBot, tyreSteer, carSteer};
+        if (iVer >= 2) {
+            const float rim = -sus.getFloat(id, "RIM_OFFSET");
+            if (rim != 0.0f) for (auto* p : all) p[0] += rim;
+        }
+        float hubMass = sus.getFloat(id, "HUB_MASS");
+        S.bumpStopUp = sus.getFloat(id, "BUMPSTOP_UP");
+        S.bumpStopDn = -sus.getFloat(id, "BUMPSTOP_DN");
+        S.rodLength = sus.getFloat(id, "ROD_LENGTH");
+        S.toeOutLinear = sus.getFloat(id, "TOE_OUT");
+        S.k = sus.getFloat(id, "SPRING_RATE");
+        S.progressiveK = sus.getFloat(id, "PROGRESSIVE_SPRING_RATE");
+        loadDamper(S.damper, id);
+        S.bumpStopRate = sus.getFloat(id, "BUMP_STOP_RATE");
+        if (S.bumpStopRate == 0.0f) S.bumpStopRate = 500000.0f;
+        if (sus.hasKey(id, "BUMP_STOP_PROGRESSIVE")) S.bumpStopProgressive = sus.getFloat(id, "BUMP_STOP_PROGRESSIVE");
+        S.staticCamber = -sus.getFloat(id, "STATIC_CAMBER") * 0.017453f;
+        if (index % 2) S.staticCamber *= -1.0f;
+        S.packerRange = sus.getFloat(id, "PACKER_RANGE");
+        if (ref[0] > 0.0f) for (auto* p : all) p[0] *= -1.0f;
+        if (hubMass <= 0.0f) hubMass = 20.0f;
+        B[hubB].mass = hubMass; hBoxInertia(hubMass, 0.2f, 0.6f, 0.6f, B[hubB].inertia);
+        S.mass = hubMass;
+        memcpy(S.basePosition, ref, sizeof(ref));
+        S.refPointY = ref[1];
+        S.refPointSignX = (ref[0] > 0.0f) ? 1.0f : ((ref[0] < 0.0f) ? -1.0f : 0.0f);
+        // attach(): hub at the reference point with the body's orientation; dataRelToBody.X = localToWorld(X + refPoint)
+        float Mb[9]; hWorldMatrix3(B[0], Mb);
+        hSetRotationM(B[hubB], Mb);
+        hLocalToWorld(B[0], S.basePosition, B[hubB].pos);
+        float t3[3], rbTopF[3], rbTopR[3], rbBotF[3], rbBotR[3], rbTyreTop[3], rbTyreBot[3], rbCarSteer[3], rbTyreSteer[3];
+        auto rel = [&](const float* p, float* o) { v3add(t3, p, ref); hLocalToWorld(B[0], t3, o); };
+        rel(carBotF, rbBotF); rel(carBotR, rbBotR); rel(carTopF, rbTopF); rel(carTopR, rbTopR);
+        rel(tyreBot, rbTyreBot); rel(tyreTop, rbTyreTop); rel(carSteer, rbCarSteer); rel(tyreSteer, rbTyreSteer);
+        mkDBall(J, B, PDB_BODY_CHASSIS, hubB, rbTopR, rbTyreTop, P.worldErp, P.worldCfm);
+        mkDBall(J, B, PDB_BODY_CHASSIS, hubB, rbTopF, rbTyreTop, P.worldErp, P.worldCfm);
+        mkDBall(J, B, PDB_BODY_CHASSIS, hubB, rbBotR, rbTyreBot, P.worldErp, P.worldCfm);
+        mkDBall(J, B, PDB_BODY_CHASSIS, hubB, rbBotF, rbTyreBot, P.worldErp, P.worldCfm);
+        mkDBall(J, B, PDB_BODY_CHASSIS, hubB, rbCarSteer, rbTyreSteer, P.worldErp, P.worldCfm);
+        memcpy(S.tyreSteer, tyreSteer, sizeof(float) * 3);
+        memcpy(S.baseCarSteer, rbCarSteer, sizeof(float) * 3);
+        // setSteerLengthOffset(0): the steering link reseated with the toe-out offset (front: every tick by SteeringSystem::step,
+        // rear: once, here) -- reseatDistanceJointLocal(carSteer + (sign(x) toe, 0, 0), tyreSteer)
+        {
+            RawJoint& sj = J.back();
+            const float offx = 0.0f + 0.0f + (S.refPointSignX * S.toeOutLinear);
+            float cs[3] = {rbCarSteer[0] + offx, rbCarSteer[1], rbCarSteer[2]}, w[3];
+            hLocalToWorld(B[0], cs, w); hWorldToLocal(B[0], w, sj.d.anchor1);
+            hLocalToWorld(B[hubB], tyreSteer, w); hWorldToLocal(B[hubB], w, sj.d.anchor2);
+            if (index < 2) sj.d.steerWheel = index;
+        }
+        for (size_t k = J.size() - 5; k < J.size(); ++k) { J[k].d.erp = 0.3f; J[k].d.cfm = 0.0000001f; }   // setERPCFM(0.3, baseCFM)
+    };
+
     // ---- front struts (SuspensionStrut.cpp:17-228) ----
     for (int index = 0; index < 2; ++index) {
+        if (typeF == "DWB") { initDW(index); continue; }
         pdb_susp& S = P.susp[index];
         memset(&S, 0, sizeof(S));
         S.type = PDB_SUSP_STRUT;
-        const int hubB = (index == 0) ? PDB_BODY_HUB0 : PDB_BODY_HUB1;
-        const int strB = (index == 0) ? PDB_BODY_STRUT0 : PDB_BODY_STRUT1;
+        const int hubB = hubOf[index];
+        const int strB = strutOf[index];
         S.hubBody = hubB; S.strutBody = strB;
         const std::string id = "FRONT";
         float ref[3];
@@ -403,9 +490,10 @@ void buildCarModel(const std::string& basePathIn, const std::string& modelName, 
 
     // ---- rear rigid axle (SuspensionAxle.cpp:15-118) ----
     for (int index = 2; index < 4; ++index) {
+        if (typeR == "DWB") { initDW(index); continue; }
         pdb_susp& S = P.susp[index];
         memset(&S, 0, sizeof(S));
-        S.type = PDB_SUSP_AXLE; S.hubBody = PDB_BODY_AXLE; S.strutBody = -1;
+        S.type = PDB_SUSP_AXLE; S.hubBody = axleB; S.strutBody = -1;
         S.sideSign = (index == 2) ? 1.0f : -1.0f;
         S.axleTrack = rearTrack; S.referenceY = rearBaseY;
         v3set(S.axleBasePos, 0.0f, rearBaseY, -(cg * wheelBase));
@@ -413,19 +501,19 @@ void buildCarModel(const std::string& basePathIn, const std::string& modelName, 
         if (iVer >= 4) S.attachRelativePos = sus.getFloat("AXLE", "ATTACH_REL_POS");
         if (index == 2) {
             const float m = sus.getFloat("REAR", "HUB_MASS");
-            B[PDB_BODY_AXLE].mass = m; hBoxInertia(m, S.axleTrack * 2.0f, 0.2f, 0.5f, B[PDB_BODY_AXLE].inertia);
+            B[axleB].mass = m; hBoxInertia(m, S.axleTrack * 2.0f, 0.2f, 0.5f, B[axleB].inertia);
             float Mb[9]; hWorldMatrix3(B[0], Mb);
-            hSetRotationM(B[PDB_BODY_AXLE], Mb);
-            hLocalToWorld(B[0], S.axleBasePos, B[PDB_BODY_AXLE].pos);
+            hSetRotationM(B[axleB], Mb);
+            hLocalToWorld(B[0], S.axleBasePos, B[axleB].pos);
             const int links = sus.getInt("AXLE", "LINK_COUNT");
             for (int i = 0; i < links; ++i) {
                 char kc[32], ka[32]; snprintf(kc, sizeof(kc), "J%d_CAR", i); snprintf(ka, sizeof(ka), "J%d_AXLE", i);
                 float bc[3], ba[3], w[3], relCar[3], relAxle[3], vJ0[3], vJ1[3];
                 sus.getFloat3("AXLE", kc, bc); sus.getFloat3("AXLE", ka, ba);
-                hLocalToWorld(B[PDB_BODY_AXLE], bc, w); hWorldToLocal(B[0], w, relCar);
-                hLocalToWorld(B[PDB_BODY_AXLE], ba, w); hWorldToLocal(B[0], w, relAxle);
+                hLocalToWorld(B[axleB], bc, w); hWorldToLocal(B[0], w, relCar);
+                hLocalToWorld(B[axleB], ba, w); hWorldToLocal(B[0], w, relAxle);
                 hLocalToWorld(B[0], relCar, vJ0); hLocalToWorld(B[0], relAxle, vJ1);
-                mkDBall(J, B, PDB_BODY_CHASSIS, PDB_BODY_AXLE, vJ0, vJ1, P.worldErp, P.worldCfm);
+                mkDBall(J, B, PDB_BODY_CHASSIS, axleB, vJ0, vJ1, P.worldErp, P.worldCfm);
             }
         }
         S.bumpStopUp = sus.getFloat("REAR", "BUMPSTOP_UP");
@@ -439,7 +527,7 @@ void buildCarModel(const std::string& basePathIn, const std::string& modelName, 
         if (S.bumpStopRate == 0.0f) S.bumpStopRate = 500000.0f;
         if (iVer >= 3) S.leafSpringKx = sus.getFloat("AXLE", "LEAF_SPRING_LAT_K");
         v3set(S.basePosition, S.sideSign * S.axleTrack, S.axleBasePos[1], S.axleBasePos[2]);   // getBasePosition()
-        S.mass = B[PDB_BODY_AXLE].mass * 0.5f;
+        S.mass = B[axleB].mass * 0.5f;
     }
 
     // ---- tyres ----
@@ -520,13 +608,44 @@ void buildCarModel(const std::string& basePathIn, const std::string& modelName, 
         int hz = eng.getInt("ENGINE_DATA", "LIMITER_HZ");
         P.engLimiterCycles = hz ? (1000 / hz / 3) : 50;
         if (eng.hasSection("COAST_SETTINGS")) throw std::runtime_error("pdb: [COAST_SETTINGS] unsupported this round");
-        if (eng.hasSection("TURBO_0")) throw std::runtime_error("pdb: turbo engines unsupported this round");
+        // turbos (Engine.cpp:69-94): TURBO_0.. until a section is missing; cockpit-adjustable ones take the default adjustment
+        bool adjustable = false;
+        for (int id = 0; ; ++id) {
+            char sec[32]; snprintf(sec, sizeof(sec), "TURBO_%d", id);
+            if (!eng.hasSection(sec)) break;
+            if (id >= PDB_MAX_TURBOS) throw std::runtime_error("pdb: more than 3 turbos");
+            pdb_turbo& tb = P.turbos[id];
+            tb.lagDN = (1.0f - eng.getFloat(sec, "LAG_DN")) * 1.333333f * 333.3333f;
+            tb.lagUP = (1.0f - eng.getFloat(sec, "LAG_UP")) * 1.333333f * 333.3333f;
+            tb.maxBoost = eng.getFloat(sec, "MAX_BOOST");
+            tb.wastegate = eng.getFloat(sec, "WASTEGATE");
+            tb.rpmRef = eng.getFloat(sec, "REFERENCE_RPM");
+            tb.gamma = eng.getFloat(sec, "GAMMA");
+            tb.isAdjustable = (eng.getInt(sec, "COCKPIT_ADJUSTABLE") != 0) ? 1 : 0;
+            tb.userSetting = 1.0f;   // Turbo.h default
+            if (tb.isAdjustable) adjustable = true;
+            P.numTurbos = id + 1;
+        }
+        if (adjustable) {   // setTurboBoostLevel (Turbo.cpp:46-52)
+            const float boost = eng.getFloat("ENGINE_DATA", "DEFAULT_TURBO_ADJUSTMENT");
+            for (int id = 0; id < P.numTurbos; ++id) P.turbos[id].userSetting = P.turbos[id].isAdjustable ? boost : 1.0f;
+        }
+        if (P.numTurbos > 0) {
+            for (int id = 0; id < P.numTurbos; ++id) {
+                char c1[64], c2[64]; snprintf(c1, sizeof(c1), "ctrl_turbo%d.ini", id); snprintf(c2, sizeof(c2), "ctrl_wastegate%d.ini", id);
+                if (fileExists(dataPath + c1) || fileExists(dataPath + c2)) throw std::runtime_error("pdb: turbo dynamic controllers are not implemented");
+            }
+        }
         if (eng.hasSection("OVERLAP") && eng.getFloat("OVERLAP", "GAIN") != 0.0f) throw std::runtime_error("pdb: [OVERLAP] unsupported this round");
         if (eng.hasSection("THROTTLE_RESPONSE")) throw std::runtime_error("pdb: [THROTTLE_RESPONSE] unsupported this round");
         curveLoad(P.throttleCurve, dataPath + "throttle.lut");
         if (eng.hasSection("DAMAGE")) {
             P.rpmDamageThreshold = eng.getFloat("DAMAGE", "RPM_THRESHOLD");
             P.rpmDamageK = eng.getFloat("DAMAGE", "RPM_DAMAGE_K");
+            if (P.numTurbos > 0) {
+                P.turboBoostDamageThreshold = eng.getFloat("DAMAGE", "TURBO_BOOST_THRESHOLD");
+                P.turboBoostDamageK = eng.getFloat("DAMAGE", "TURBO_DAMAGE_K");
+            }
         }
         P.bovThreshold = 0.2f;
         if (eng.hasSection("BOV")) P.bovThreshold = eng.getFloat("BOV", "PRESSURE_THRESHOLD");
@@ -635,7 +754,7 @@ void buildCarModel(const std::string& basePathIn, const std::string& modelName, 
         const float fuelMass = std::max(0.1f, P.fuelKG * (float)(double)P.fuel);
         B[1].mass = fuelMass; hBoxInertia(fuelMass, 0.5f, 0.5f, 0.5f, B[1].inertia);
     }
-    P.numBodies = 7;
+    P.numBodies = nextBody;
     for (int i = 0; i < P.numBodies; ++i) { P.bodies[i].mass = B[i].mass; memcpy(P.bodies[i].inertia, B[i].inertia, sizeof(float) * 3); }
 
     // ---- joints into solver order ----

@@ -5,7 +5,7 @@ import numpy as np
 PKG = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(PKG)
 
-MAX_CURVE, MAX_BODIES, MAX_JOINTS, MAX_WINGS, MAX_GEARS = 24, 8, 16, 4, 10
+MAX_CURVE, MAX_BODIES, MAX_JOINTS, MAX_WINGS, MAX_GEARS = 24, 8, 24, 4, 10
 
 class Curve(C.Structure):
     _fields_ = [('n', C.c_int32), ('x', C.c_float * MAX_CURVE), ('y', C.c_float * MAX_CURVE)]
@@ -39,7 +39,9 @@ class Susp(C.Structure):
         [('damper', Damper), ('basePosition', C.c_float * 3), ('carStrut', C.c_float * 3), ('tyreStrut', C.c_float * 3), ('tyreSteer', C.c_float * 3),
          ('baseCarSteer', C.c_float * 3), ('refPointY', C.c_float), ('refPointSignX', C.c_float), ('strutBaseLength', C.c_float), ('strutBodyLength', C.c_float),
          ('axleTrack', C.c_float), ('referenceY', C.c_float), ('attachRelativePos', C.c_float), ('leafSpringKx', C.c_float), ('axleBasePos', C.c_float * 3),
-         ('sideSign', C.c_float), ('mass', C.c_float)]
+         ('sideSign', C.c_float), ('mass', C.c_float), ('bumpStopProgressive', C.c_float)]
+class Turbo(C.Structure):
+    _fields_ = [(n, C.c_float) for n in ('lagDN', 'lagUP', 'maxBoost', 'wastegate', 'rpmRef', 'gamma', 'userSetting')] + [('isAdjustable', C.c_int32)]
 class Tyre(C.Structure):
     _fields_ = [(n, C.c_float) for n in ('radius', 'rimRadius', 'k', 'd', 'angularInertia', 'thermalFrictionK', 'thermalRollingK', 'thermalRollingSurfaceK',
                                          'radiusRaiseK', 'softnessIndex', 'Fz0', 'modelFz0', 'relaxationLength', 'rr0', 'rr1', 'rr_slip', 'pressureRef', 'pressureSpringGain',
@@ -71,8 +73,9 @@ class CarParams(C.Structure):
         [(n, C.c_double) for n in ('finalRatio', 'diffPowerRamp', 'diffCoastRamp', 'diffPreLoad', 'gearUpTime', 'gearDnTime', 'autoCutOffTime', 'controlsWindowGain',
                                    'validShiftRPMWindow', 'damageRpmWindow', 'clutchMaxTorque', 'clutchInertia', 'driveInertia', 'engineInertiaInit', 'outShaftInertiaL', 'outShaftInertiaR')] + \
         [('powerCurve', Curve), ('throttleCurve', Curve), ('engMinimum', C.c_int32), ('engLimiter', C.c_int32), ('engLimiterCycles', C.c_int32)] + \
-        [(n, C.c_float) for n in ('engCoast1', 'engCoast2', 'engInertia', 'limiterMultiplier', 'rpmDamageThreshold', 'rpmDamageK', 'bovThreshold', 'maxPowerRPM', 'maxTorqueRPM',
-                                  'acRpmMin', 'acRpmMax', 'acClutchSpeed')] + \
+        [(n, C.c_float) for n in ('engCoast1', 'engCoast2', 'engInertia', 'limiterMultiplier', 'rpmDamageThreshold', 'rpmDamageK', 'bovThreshold', 'maxPowerRPM', 'maxTorqueRPM')] + \
+        [('numTurbos', C.c_int32), ('turbos', Turbo * 3), ('turboBoostDamageThreshold', C.c_float), ('turboBoostDamageK', C.c_float), ('_padEngine', C.c_int32)] + \
+        [(n, C.c_float) for n in ('acRpmMin', 'acRpmMax', 'acClutchSpeed')] + \
         [(n, C.c_int32) for n in ('acUseOnChange', 'acUseOnStart', 'autoShiftActive', 'autoBlipActive', 'autoBlipElectronic')] + \
         [('upshiftProfile', Curve), ('downshiftProfile', Curve), ('blipProfile', Curve), ('blipPerformTime', C.c_double), ('asChangeUpRpm', C.c_int32), ('asChangeDnRpm', C.c_int32),
          ('asSlipThreshold', C.c_float), ('asGasCutoffTime', C.c_float), ('smoothSteer', C.c_int32), ('patchConnCount', C.c_int8 * 36), ('patchConn', (C.c_int8 * 4) * 36),
@@ -97,7 +100,7 @@ class DynState(C.Structure):
                                   'currentSpeedMultiplier', 'lastDriftDirection', 'driftStraightTimer', 'instantDriftDelta', 'instantDrift', 'driftPoints')] + \
         [(n, C.c_int32) for n in ('oldPointId', 'oldSplinePointId', 'drifting', 'driftExtreme', 'driftInvalid', 'driftComboCounter', 'collisionFlag', 'oldCollisionFlag',
                                   'outOfTrackFlag')] + \
-        [('gasUsage', C.c_float), ('locClutch', C.c_float), ('_pad', C.c_int32 * 1)]
+        [('gasUsage', C.c_float), ('locClutch', C.c_float), ('turboRotation', C.c_float * 3), ('_pad', C.c_int32 * 2)]
 assert C.sizeof(DynState) % 16 == 0
 class StepOut(C.Structure):
     _fields_ = [('obs', C.c_float * 24), ('reward', C.c_float), ('flags', C.c_int32)]

@@ -52,6 +52,15 @@ def env_params():
     return P
 
 
+def car_params(model):
+    """packed env-configured block of one of the supported cars (projectd-core_amd/data, tools/pack_cars.py)"""
+    P = pc.CarParams()
+    data = open(os.path.join(ROOT, 'projectd-core_amd', 'data', model + '.env.pdcar'), 'rb').read()
+    assert len(data) == C.sizeof(P)
+    C.memmove(C.byref(P), data, len(data))
+    return P
+
+
 @pytest.fixture(scope='session')
 def flat_track(hostlib, base_dir):
     return pc.build_track(hostlib, base_dir, 'flat')

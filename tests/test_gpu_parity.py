@@ -203,13 +203,22 @@ def test_full_controls_random(built):
         assert worst == 0.0
 
 
-def test_touge_closed_loop_feedback(built):
+@pytest.mark.parametrize('model', ['ks_mazda_rx7_tuned', 'ks_toyota_supra_mkiv_drift'])
+def test_double_wishbone_turbo_cars(built, model):
+    """the other shipped cars the loader supports: double wishbones on all four wheels (6 bodies, 21 joints, 26 rows -> the
+    row-guarded kernel instantiation), one / two turbos, 5 / 6 forward gears.  32 cars x 1200 ticks, random constant actions."""
+    worst = parity_util.run_parity(n_cars=32, ticks=1200, seed=21, resync=False, verbose=True, check_every=20, model=model)
+    assert worst == 0.0
+
+
+@pytest.mark.parametrize('model', ['ks_toyota_ae86_drift', 'ks_toyota_supra_mkiv_drift'])
+def test_touge_closed_loop_feedback(built, model):
     """BASELINE configs[2] shape: closed, hilly, banked mountain road (1782 triangles, 891 spline points, CLOSED_LOOP=1), 16 cars
     spread around the lap, each steered by the probe-feedback controller of oracle/scenarios.h from its own observations
     (the script whose reference-TU trajectory pins the oracle in tests/test_oracle_golden.py).  Bit-exact state parity."""
     import pdbatch, oracle_ctypes
     n, ticks = 16, 1500
-    P = pdbatch.packed_params(); trk = pdbatch.synthetic_track('touge')
+    P = pdbatch.packed_params(model + '.env'); trk = pdbatch.synthetic_track('touge')
     lib = pc.load_product(); orc = oracle_ctypes.load_oracle(portable_math=True)
     S0 = pc.DynState()
     assert lib.pdb_initial_state(C.byref(P), trk, C.byref(S0)) == 0

@@ -1,0 +1,20 @@
+#!/usr/bin/env python3
+"""Build container only: pack the reference's shipped cars that the loader supports into the product's own block format
+(projectd-core_amd/data/<model>.env.pdcar = configured like pyprojectd/projectd_env.py, .default.pdcar = as loaded).
+The blocks are what travels to machines without the reference's content/ directory."""
+import ctypes as C, os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, 'projectd-core_amd'))
+import pdb_ctypes as pc
+REF = '/root/reference'
+lib = pc.load_product(host_only=True)
+out = os.path.join(ROOT, 'projectd-core_amd', 'data')
+os.makedirs(out, exist_ok=True)
+for m in sorted(os.listdir(os.path.join(REF, 'content', 'cars'))):
+    P = pc.CarParams()
+    if lib.pdb_build_car_model(REF.encode(), m.encode(), C.byref(P)) != 0:
+        print('%-36s not supported: %s' % (m, lib.pdb_last_error().decode())); continue
+    open(os.path.join(out, m + '.default.pdcar'), 'wb').write(bytes(P))
+    E = pc.env_params(lib, REF, m)
+    open(os.path.join(out, m + '.env.pdcar'), 'wb').write(bytes(E))
+    print('%-36s bodies %d joints %d rows %d turbos %d gears %d' % (m, P.numBodies, P.numJoints, P.numRows, P.numTurbos, P.numGears))
