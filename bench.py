@@ -54,6 +54,7 @@ def main():
     ap.add_argument('--warmup', type=int, default=333)
     ap.add_argument('--cars', type=int, default=CARS_PER_GPU)
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--backend', default='nccl', help='torch.distributed backend for N > 1 (nccl = RCCL; gloo only to exercise the multi-rank path on a single-GPU box)')
     ap.add_argument('--workload', choices=['flat', 'touge'], default='flat',
                     help='flat = BASELINE configs[1] (the bench line); touge = configs[2] shape: closed hilly road, cars spread around the lap, probe-feedback steering computed on the GPU each tick')
     args = ap.parse_args()
@@ -69,11 +70,13 @@ def main():
         raise SystemExit('launch with torch.distributed.run --nproc-per-node %d' % args.gpus)
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs an MI355X: there is no CPU fallback for the product path')
-    torch.cuda.set_device(local_rank)
+    ndev = torch.cuda.device_count()
+    dev_index = local_rank % ndev          # one rank per GPU on the driver's node; ranks share devices only in the single-GPU gloo test
+    torch.cuda.set_device(dev_index)
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group('nccl', init_method='env://')
+        dist.init_process_group(args.backend, init_method='env://')
 
     n = args.cars
     P = pdbatch.packed_params()
@@ -84,7 +87,7 @@ def main():
     all_actions = sharding.global_actions(n * world, 1234)          # indexed by global car id => invariant to the sharding
     first, last = sharding.shard_bounds(n * world, world, rank)
     actions = all_actions[first:last]
-    b = pdbatch.Batch(n, P, trk, device=local_rank, action_mode=1)
+    b = pdbatch.Batch(n, P, trk, device=dev_index, action_mode=1)
     stream = torch.cuda.current_stream()
     b.set_stream(stream.cuda_stream)
     b.upload_actions(actions)
@@ -99,9 +102,9 @@ def main():
     class _Arr:   # zero-copy torch view of the library-owned output block
         def __init__(self, ptr, shape):
             self.__cuda_array_interface__ = {'shape': shape, 'typestr': '<f4', 'data': (ptr, False), 'version': 2}
-    out_t = torch.as_tensor(_Arr(b.out_device_ptr(), (n, 26)), device='cuda:%d' % local_rank)
-    gather = sharding.ObsGather(n, world, 'cuda:%d' % local_rank, dist)
-    act_t = torch.as_tensor(_Arr(b.actions_device_ptr(), (n, 2)), device='cuda:%d' % local_rank)
+    out_t = torch.as_tensor(_Arr(b.out_device_ptr(), (n, 26)), device='cuda:%d' % dev_index)
+    gather = sharding.ObsGather(n, world, 'cuda:%d' % dev_index, dist)
+    act_t = torch.as_tensor(_Arr(b.actions_device_ptr(), (n, 2)), device='cuda:%d' % dev_index)
 
     def tick():
         b.step_async()
@@ -129,7 +132,7 @@ def main():
     t1 = time.perf_counter()
     elapsed = t1 - t0
     region_ms = b.event_elapsed_ms()
-    elapsed = sharding.max_over_ranks(elapsed, 'cuda:%d' % local_rank, dist, world)
+    elapsed = sharding.max_over_ranks(elapsed, 'cuda:%d' % dev_index, dist, world)
 
     if rank == 0:
         traffic = None

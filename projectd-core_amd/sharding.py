@@ -42,6 +42,11 @@ class ObsGather:
     def __call__(self, out_block):
         if self.world == 1:
             return out_block
+        if out_block.is_cuda and self.dist.get_backend() == 'gloo':   # single-GPU test of the multi-rank path: stage through the host
+            host = self.gathered.cpu()
+            self.dist.all_gather_into_tensor(host, out_block.cpu())
+            self.gathered.copy_(host)
+            return self.gathered
         self.dist.all_gather_into_tensor(self.gathered, out_block)
         return self.gathered
 
@@ -63,6 +68,6 @@ def max_over_ranks(value, device, dist=None, world=1):
     if world == 1:
         return float(value)
     import torch
-    t = torch.tensor([value], dtype=torch.float64, device=device)
+    t = torch.tensor([value], dtype=torch.float64, device=('cpu' if dist.get_backend() == 'gloo' else device))
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())

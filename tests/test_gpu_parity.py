@@ -260,3 +260,21 @@ def test_touge_closed_loop_feedback(built, model):
         b.close()
         for h in hs:
             orc.cpuref_destroy(h)
+
+
+def test_bench_multi_rank_path_on_one_gpu(built):
+    """the driver launches bench.py with torch.distributed.run for N > 1; with one GPU in the box the same launch is exercised
+    with two ranks sharing the device over gloo (RCCL itself needs two GPUs): env parsing, sharding, barrier, gather,
+    max-over-ranks timing, one JSON line from rank 0"""
+    import json, subprocess, socket
+    s = socket.socket(); s.bind(('127.0.0.1', 0)); port = s.getsockname()[1]; s.close()
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1', '--master-port', str(port),
+           os.path.join(root, 'bench.py'), '--gpus', '2', '--steps', '40', '--warmup', '10', '--cars', '256', '--backend', 'gloo', '--no-cpu-baseline']
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith('{')]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d['n_gpus'] == 2 and d['steps'] == 40 and d['scaling'] == 'weak' and d['value'] > 0 and d['config']['cars_per_gpu'] == 256
+    assert 'all-gather' in d['config']['collective']
