@@ -492,7 +492,7 @@ void World::step(float h) {
     const int nb = (int)bodies.size();
     const float fps = 1.0f / h;
 
-    std::vector<float> invIw(nb * 9);
+    static thread_local std::vector<float> invIw; invIw.assign(nb * 9, float());
     for (int bi = 0; bi < nb; ++bi) {
         Body& b = bodies[bi];
         float tmp[9];
@@ -539,8 +539,8 @@ void World::step(float h) {
     int m = 0;
     for (int j : jointOrder) m += joints[j].rows();
     lastM = m;
-    std::vector<Row> rows(m > 0 ? m : 1);
-    std::vector<int> rb0(m), rb1(m), jofs(jointOrder.size() + 1);
+    static thread_local std::vector<Row> rows; rows.assign(m > 0 ? m : 1, Row());
+    static thread_local std::vector<int> rb0, rb1, jofs; rb0.assign(m, 0); rb1.assign(m, 0); jofs.assign(jointOrder.size() + 1, 0);
     {
         int o = 0;
         for (size_t t = 0; t < jointOrder.size(); ++t) {
@@ -553,10 +553,10 @@ void World::step(float h) {
         jofs[jointOrder.size()] = o;
     }
 
-    std::vector<float> lambda(m, 0.0f);
+    static thread_local std::vector<float> lambda; lambda.assign(m, 0.0f);
     if (m > 0) {
         // JinvM
-        std::vector<float> JinvM(m * 12);
+        static thread_local std::vector<float> JinvM; JinvM.assign(m * 12, float());
         for (int i = 0; i < m; ++i) {
             const float* J = rows[i].J;
             float* o = &JinvM[i * 12];
@@ -572,7 +572,7 @@ void World::step(float h) {
             }
         }
         // A = JinvM J^T (lower triangle), + cfm*fps on the diagonal
-        std::vector<float> Am(m * m, 0.0f);
+        static thread_local std::vector<float> Am; Am.assign(m * m, 0.0f);
         auto dot6 = [](const float* a, const float* b) {
             return a[0] * b[0] + a[1] * b[1] + a[2] * b[2] + a[3] * b[3] + a[4] * b[4] + a[5] * b[5];
         };
@@ -594,7 +594,7 @@ void World::step(float h) {
             Am[i * m + i] += rows[i].cfm * fps;
         }
         // rhs = c*fps - J (v*fps + invM fe)
-        std::vector<float> tmp1(nb * 6);
+        static thread_local std::vector<float> tmp1; tmp1.assign(nb * 6, float());
         for (int bi = 0; bi < nb; ++bi) {
             const Body& b = bodies[bi];
             float* t = &tmp1[bi * 6];
@@ -602,7 +602,7 @@ void World::step(float h) {
             mul0_331(t + 3, &invIw[bi * 9], b.tacc);
             for (int k = 0; k < 3; ++k) t[3 + k] += b.avel[k] * fps;
         }
-        std::vector<float> rhs(m);
+        static thread_local std::vector<float> rhs; rhs.assign(m, float());
         for (int i = 0; i < m; ++i) {
             float r = rows[i].c * fps;
             r -= dot6(&rows[i].J[0], &tmp1[rb0[i] * 6]);
@@ -612,7 +612,7 @@ void World::step(float h) {
         lastA = Am;
         lastRhs = rhs;
         // right-looking LDL^T, lower triangle, explicit fmaf
-        std::vector<float> dinv(m);
+        static thread_local std::vector<float> dinv; dinv.assign(m, float());
         for (int k = 0; k < m; ++k) {
             const float d = Am[k * m + k];
             const float id = 1.0f / d;
@@ -635,7 +635,7 @@ void World::step(float h) {
     lastLambda = lambda;
 
     // cforce = J^T lambda (per joint, per component: sum over the joint's rows, then accumulate)
-    std::vector<float> cf(nb * 6, 0.0f);
+    static thread_local std::vector<float> cf; cf.assign(nb * 6, 0.0f);
     for (size_t t = 0; t < jointOrder.size(); ++t) {
         const Joint& j = joints[jointOrder[t]];
         const int o = jofs[t], mm = jofs[t + 1] - jofs[t];

@@ -113,6 +113,7 @@ class ProjectDVecEnv:
             raise RuntimeError('createBatch failed (no GPU? there is no CPU fallback)')
         self.total_reward = np.zeros(self.num_envs, dtype=np.float64)
         self.step_id = np.zeros(self.num_envs, dtype=np.int64)
+        self.pending_reset = np.zeros(self.num_envs, dtype=bool)
         self.observation_bounds = obs_bounds(self.cfg)
         self.action_bounds = (np.array([-1.0, -1.0], np.float32), np.array([1.0, 1.0], np.float32))
 
@@ -129,8 +130,14 @@ class ProjectDVecEnv:
         return out[:, :OBS_DIM], out[:, 24].astype(np.float64), out[:, 25].view(np.int32)
 
     def step(self, actions):
+        """One tick of every lane.  A lane whose episode ended on the previous call was teleported to the start then; on
+        this call its action is replaced by the reference reset's zero action (projectd_env.py:216-227: teleport, one
+        step([0,0]), clear the episode sums), its reward is 0 and the observation returned is the new episode's first."""
         cfg = self.cfg
-        obs, reward, flags = self._raw_step(actions)
+        a = np.array(actions, dtype=np.float32).reshape(self.num_envs, 2)
+        fresh = self.pending_reset.copy()
+        a[fresh] = 0.0
+        obs, reward, flags = self._raw_step(a)
         terminated = np.zeros(self.num_envs, dtype=bool)
         if cfg.terminate_on_hit:
             hit = (flags & FLAG_COLLISION) != 0
@@ -144,34 +151,33 @@ class ProjectDVecEnv:
         self.total_reward += reward
         terminated |= self.total_reward < cfg.terminate_low_reward
         self.step_id += 1
+        # the reset tick itself: the reference discards its reward / termination and zeroes the sums afterwards
+        reward[fresh] = 0.0; terminated[fresh] = False
+        self.total_reward[fresh] = 0.0; self.step_id[fresh] = 0
+        self.pending_reset[:] = False
         truncated = np.zeros(self.num_envs, dtype=bool)
         info = {}
         if self.auto_reset and terminated.any():
-            info['terminal_observation'] = obs.copy()
             info['episode_reward'] = self.total_reward.copy()
-            obs = obs.copy()
-            obs[terminated] = self.reset(terminated)[terminated]
+            if cfg.teleport_on_reset:
+                pd.resetBatch(self.batch, terminated.astype(np.uint8))
+            self.pending_reset |= terminated
         return obs, reward.astype(np.float32), terminated, truncated, info
 
     def reset(self, mask=None):
-        """projectd_env.py:216-227 per lane: teleport to the start, one tick with zero action, clear the episode sums"""
-        m = np.ones(self.num_envs, dtype=np.uint8) if mask is None else np.ascontiguousarray(mask, dtype=np.uint8)
-        if self.cfg.teleport_on_reset:
-            pd.resetBatch(self.batch, m)
-        sel = m.astype(bool)
-        if sel.all():
+        """Reset every lane (mask None) -- teleport + one zero-action tick, returns the first observations -- or schedule
+        the masked lanes: they are teleported now and take their zero-action reset tick inside the next step()."""
+        if mask is None:
+            if self.cfg.teleport_on_reset:
+                pd.resetBatch(self.batch, None)
             obs, _, _ = self._raw_step(np.zeros((self.num_envs, 2), np.float32))
-        else:
-            # lanes that are not reset must not advance: handled by the caller stepping them again next tick; the
-            # reference resets one env at a time, so only the masked lanes' observations are meaningful here
-            obs = np.zeros((self.num_envs, OBS_DIM), np.float32)
-            cs = pd.CarState()
-            for i in np.where(sel)[0]:
-                pd.getBatchCarState(self.batch, int(i), cs)
-                obs[i] = obs_from_state(cs)
-        self.total_reward[sel] = 0.0
-        self.step_id[sel] = 0
-        return obs
+            self.total_reward[:] = 0.0; self.step_id[:] = 0; self.pending_reset[:] = False
+            return obs
+        m = np.ascontiguousarray(mask).astype(bool)
+        if self.cfg.teleport_on_reset:
+            pd.resetBatch(self.batch, m.astype(np.uint8))
+        self.pending_reset |= m
+        return None
 
 
 def obs_from_state(s):

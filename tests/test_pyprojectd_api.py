@@ -166,13 +166,67 @@ def test_vec_env_matches_oracle_and_resets(pd, base):
                 assert rew[i] == np.float32(np.float64(o.reward)), (t, i)
         if term.any():
             break
-    # masked reset: only the selected lanes return to the start line
+    # masked reset: only the selected lanes return to the start line; they take their zero-action tick in the next step
     m = np.zeros(n, np.uint8); m[[1, 5]] = 1
     cs = pd.CarState()
     pd.getBatchCarState(env.batch, 0, cs); z0 = cs.bodyPos.z
-    env.reset(m)
+    assert env.reset(m) is None
     pd.getBatchCarState(env.batch, 1, cs); assert abs(cs.bodyPos.z + 1500.0) < 1.0
     pd.getBatchCarState(env.batch, 0, cs); assert cs.bodyPos.z == z0
+    for h in hs:
+        orc.cpuref_destroy(h)
+    env.close()
+
+
+@pytest.mark.gpu
+def test_vec_env_episodes_with_auto_reset_match_oracle(pd, base):
+    """4000 ticks of 24 lanes on the mountain road under a deliberately poor policy (the feedback controller plus steering
+    noise), so that lanes leave the road, terminate and are reset at different times: every observation, reward and
+    termination of ProjectDVecEnv equals an oracle-side replay of the reference env logic (projectd_env.py:157-227)."""
+    import projectd_env as E, pdbatch, pdb_ctypes as pc, oracle_ctypes, synthetic_tracks
+    synthetic_tracks.make_base(base, tracks=('flat', 'touge'))
+    n = 24
+    env = E.ProjectDVecEnv(n, base, track_name='touge')
+    P = pdbatch.packed_params(); trk = pc.build_track(pc.load_product(host_only=True), base, 'touge')
+    lib = pc.load_product(); orc = oracle_ctypes.load_oracle(True)
+    S0 = pc.DynState(); assert lib.pdb_initial_state(C.byref(P), trk, C.byref(S0)) == 0
+    hs = [orc.cpuref_create(C.byref(P), trk, len(trk), C.byref(S0)) for _ in range(n)]
+    o = pc.StepOut()
+    obs = env.reset()
+    ref_obs = np.zeros((n, 24), np.float32)
+    for i in range(n):
+        orc.cpuref_step_env(hs[i], 0.0, 0.0); orc.cpuref_get_out(hs[i], C.byref(o)); ref_obs[i] = o.obs[:]
+    assert np.array_equal(obs, ref_obs)
+    total = np.zeros(n); pending = np.zeros(n, bool)
+    rng = np.random.RandomState(9)
+    noise = np.zeros(n, np.float32); episodes = 0
+    a = np.zeros((n, 2), np.float32)
+    for t in range(4000):
+        if t % 50 == 0:
+            noise = (rng.uniform(-1, 1, n) * (rng.uniform(0, 1, n) < 0.3) * 0.6).astype(np.float32)
+        for i in range(n):
+            orc.cpuref_scenario_feedback(6, t, obs[i].ctypes.data_as(C.c_void_p), a[i].ctypes.data_as(C.c_void_p))
+        a[:, 0] = np.clip(a[:, 0] + noise, -1, 1)
+        a[:8, 0] = np.where(np.arange(8) % 2 == 0, 0.8, -0.8); a[:8, 1] = 1.0      # eight lanes drive straight off the road, again and again
+        obs, rew, term, trunc, info = env.step(a)
+        for i in range(n):
+            ai = (0.0, 0.0) if pending[i] else (float(a[i, 0]), float(a[i, 1]))
+            orc.cpuref_step_env(hs[i], ai[0], ai[1]); orc.cpuref_get_out(hs[i], C.byref(o))
+            assert np.array_equal(obs[i], np.array(o.obs[:], np.float32)), (t, i)
+            r = float(np.float32(o.reward)); done = False
+            if o.flags & 1: r -= 50.0; done = True
+            if o.flags & 2: r -= 50.0; done = True
+            if o.flags & 4: r -= 50.0; done = True
+            total[i] += r
+            if total[i] < -200.0: done = True
+            if pending[i]:
+                r = 0.0; done = False; total[i] = 0.0; pending[i] = False
+            assert rew[i] == np.float32(r) and bool(term[i]) == done, (t, i, rew[i], r, term[i], done)
+            if done:   # reference reset: teleportCarByMode(Start) now, the zero-action tick on the next step
+                s = pc.DynState(); orc.cpuref_get_state(hs[i], C.byref(s))
+                assert lib.pdb_teleport_to_spline(C.byref(P), trk, C.c_float(0.0), C.byref(s)) == 0
+                orc.cpuref_set_state(hs[i], C.byref(s)); pending[i] = True; episodes += 1
+    assert episodes >= 5, episodes          # the noisy lanes really did crash out and restart
     for h in hs:
         orc.cpuref_destroy(h)
     env.close()
