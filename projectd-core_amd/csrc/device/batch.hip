@@ -122,7 +122,7 @@ pdb_batch* pdb_create(int device, int n_cars, const pdb_car_params* params, cons
     }
 #ifdef PDB_STAMPS
     if (ok) {
-        ok = ok && hipMalloc(&b->dStamps, sizeof(unsigned long long) * 16 * (size_t)n_cars) == hipSuccess;
+        ok = ok && hipMalloc(&b->dStamps, sizeof(unsigned long long) * 32 * (size_t)n_cars) == hipSuccess;
         b->K.stamps = b->dStamps;
         ok = ok && hipMemcpy(b->dK, &b->K, sizeof(DevConst), hipMemcpyHostToDevice) == hipSuccess;
     }
@@ -285,7 +285,7 @@ int pdb_get_car_state(pdb_batch* b, int first, int count, pdb_car_state* out) {
 #ifdef PDB_STAMPS
 int pdb_debug_stamps(pdb_batch* b, unsigned long long* out) {
     HIPCHK(hipStreamSynchronize(b->stream));
-    HIPCHK(hipMemcpy(out, b->dStamps, sizeof(unsigned long long) * 16 * (size_t)b->n, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(out, b->dStamps, sizeof(unsigned long long) * 32 * (size_t)b->n, hipMemcpyDeviceToHost));
     return PDB_OK;
 }
 #endif

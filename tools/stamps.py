@@ -33,7 +33,7 @@ pc.load_product = lp
 b = pdbatch.Batch(n, P, trk, 0, 1)
 a = pu.make_actions(n, 1234)
 for _ in range(400): b.step_host(a)
-st = np.zeros((n, 16), dtype=np.uint64)
+st = np.zeros((n, 32), dtype=np.uint64)
 lib.pdb_debug_stamps(b.h, st.ctypes.data_as(C.c_void_p))
 sti = st.astype(np.int64)
 CPB = 3
@@ -48,5 +48,6 @@ for nm, k in (('record loaded, ERP set', 1), ('world inertia + non-steer joint r
 print('pack wave (median, relative to the block\'s first car wave start):')
 for nm, k in (('pre-step + steering rods done', 4), ('suspensions + tyres done', 14), ('wings, drivetrain, ARB done', 15)):
     print('  %-58s %8.0f' % (nm, med(first[:, k] - first[:, 0])))
+print('pack internals (car 0 of the block, wheel 0): pre-step end -> hub matrix %d | ray cast %d | contact + SCTM + forces %d | torque/lock %d | thermal %d ;; drive: tyres end -> before drivetrainStep %d | drivetrainStep %d' % (med(first[:,16]-first[:,4]), med(first[:,17]-first[:,16]), med(first[:,18]-first[:,17]), med(first[:,19]-first[:,18]), med(first[:,20]-first[:,19]), med(first[:,22]-first[:,14]), med(first[:,23]-first[:,22])))
 print('wave lifetime median %.0f clocks' % med(sti[:, 13] - t0))
 b.close()
