@@ -20,8 +20,8 @@ extern "C" {
 #define PDB_MAX_CURVE 24
 #define PDB_MAX_BODIES 8
 #define PDB_MAX_JOINTS 24
-#define PDB_MAX_ROWS 33   /* strut-front / live-axle-rear topology: 2 x (3 dball + 5 slider + 3 ball) + 5 dball + 6 fixed */
-#define PDB_MAX_WINGS 4
+#define PDB_MAX_ROWS 40   /* 33: strut front / live axle rear; 26: double wishbones; 38: strut front / double wishbone rear */
+#define PDB_MAX_WINGS 6
 #define PDB_MAX_GEARS 10
 #define PDB_NUM_PROBES 7
 #define PDB_NUM_LOOKAHEAD 5
@@ -300,7 +300,7 @@ typedef struct pdb_track_header {
 }
 /* sizes are part of the ABI (tests/test_abi.py reads these numbers) */
 static_assert(sizeof(pdb_car_state) == 664, "pdb_car_state must equal the reference CarState (pack 4)");
-static_assert(sizeof(pdb_car_params) == 9248, "pdb_car_params layout");
+static_assert(sizeof(pdb_car_params) == 10104, "pdb_car_params layout");
 static_assert(sizeof(pdb_dyn_state) == 2224, "pdb_dyn_state layout (multiple of 16 bytes)");
 static_assert(sizeof(pdb_step_out) == 104, "pdb_step_out layout");
 #endif

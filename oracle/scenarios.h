@@ -23,8 +23,10 @@ static const Scenario kScenarios[] = {
     {"drive", 7000, 300, 10, 0, 1, 1, 1, "touge", 1, nullptr},   // closed hilly, banked mountain road driven by a probe-feedback controller (configs[2] shape)
     {"rx7", 2400, 300, 10, 0, 1, 1, 1, "flat", 0, "ks_mazda_rx7_tuned"},          // double wishbones all round, one turbo: the slalom script
     {"supra", 5000, 300, 10, 0, 1, 1, 1, "touge", 1, "ks_toyota_supra_mkiv_drift"},   // double wishbones, two turbos, 6 gears, on the mountain road
+    {"fc3s", 2400, 300, 10, 0, 1, 1, 1, "flat", 0, "dthwsh_mazda_rx7_fc3s_sr20"},      // strut front + double wishbone rear (38 rows), 3 wings + 2 fins, turbo
+    {"readie", 5000, 300, 10, 0, 1, 1, 1, "touge", 1, "gravygarage_street_ae86_readie"},   // strut front + double wishbone rear on the mountain road
 };
-static const int kNumScenarios = 9;
+static const int kNumScenarios = 11;
 #define PDORACLE_DEFAULT_CAR "ks_toyota_ae86_drift"
 
 // closed-loop action from the previous observation (projectd_env.py:239-273 slot order): centre between the side probes,
@@ -52,7 +54,7 @@ inline void scenarioAction(int sid, int tick, float& a0, float& a1) {
     case 0: a0 = 0.0f; a1 = -1.0f; break;
     case 1: a0 = 0.0f; a1 = 1.0f; break;
     case 2: a0 = 0.35f; a1 = 0.2f; break;
-    default:   // slalom (3) and the rx7 run (7)
+    default:   // slalom (3), the rx7 run (7), the fc3s run (9)
         a0 = (float)(0.4 * sin(6.283185307179586 * t / 2.0));
         a1 = (float)(0.6 * sin(6.283185307179586 * t / 5.0 + 1.0));
         break;
@@ -64,7 +66,7 @@ inline float envGas(float a1);
 inline void scenarioControls(int sid, int tick, Ctl& c) {
     c.steer = 0; c.clutch = 0; c.brake = 0; c.handBrake = 0; c.gas = 0; c.requestedGearIndex = -1; c.gearUp = 0; c.gearDn = 0;
     const double t = (double)tick * (1.0 / 333.0);
-    if (sid < 4 || sid == 7) { float a0, a1; scenarioAction(sid, tick, a0, a1); c.steer = a0; c.gas = envGas(a1); return; }
+    if (sid < 4 || sid == 7 || sid == 9) { float a0, a1; scenarioAction(sid, tick, a0, a1); c.steer = a0; c.gas = envGas(a1); return; }
     if (sid == 4) {
         if (t < 3.0) { c.gas = 1.0f; }
         else if (t < 5.0) { c.brake = 0.8f; }

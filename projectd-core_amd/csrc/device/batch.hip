@@ -8,7 +8,33 @@
 #include <string>
 #include <vector>
 
+#include "dev_const.hpp"
+
+// two LDS size classes of the same kernel source: 33 constraint rows (the strut / live-axle and the all-double-wishbone
+// cars; 8 KB of LDS per car, 6 workgroups per CU) and 40 rows (strut front + double wishbone rear: 38 rows; 5 per CU)
+#define PDB_KROWS 33
+#define PDB_KNS k33
+#define PDB_KMINWAVES 6
+#define PDB_KERNEL_EXACT pdb_step_kernel
+#define PDB_KERNEL_GUARDED pdb_step_kernel_generic
 #include "step_kernel.hip.inc"
+#undef PDB_KROWS
+#undef PDB_KNS
+#undef PDB_KMINWAVES
+#undef PDB_KERNEL_EXACT
+#undef PDB_KERNEL_GUARDED
+#define PDB_KROWS 40
+#define PDB_KNS k40
+#define PDB_KMINWAVES 5
+#define PDB_KERNEL_EXACT pdb_step_kernel_wide40
+#define PDB_KERNEL_GUARDED pdb_step_kernel_wide
+#include "step_kernel.hip.inc"
+#undef PDB_KROWS
+#undef PDB_KNS
+#undef PDB_KMINWAVES
+#undef PDB_KERNEL_EXACT
+#undef PDB_KERNEL_GUARDED
+
 
 namespace pdb { void setError(const std::string& s); }
 
@@ -70,7 +96,10 @@ static void fillConst(const pdb_car_params& P, DevConst& K, int actionMode) {
 }
 
 typedef void (*StepKernel)(pdb_dyn_state*, const float*, pdb_step_out*, pdb_car_state*, const pdb_car_params*, const DevConst*, const uint8_t*, int);
-static StepKernel stepKernelFor(const pdb_batch* b) { return (b->params.numRows == 33) ? pdb_step_kernel : pdb_step_kernel_generic; }
+static StepKernel stepKernelFor(const pdb_batch* b) {
+    const int m = b->params.numRows;
+    return (m == 33) ? k33::pdb_step_kernel : (m < 33) ? k33::pdb_step_kernel_generic : k40::pdb_step_kernel_wide;
+}
 
 static int launch(pdb_batch* b, float dt, bool wantCarState) {
     if (b->K.dt != dt || b->K.wantCarState != (wantCarState ? 1 : 0)) {

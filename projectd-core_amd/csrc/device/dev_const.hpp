@@ -1,0 +1,21 @@
+// pdbatch device side: constants block shared by the host launcher and every kernel instantiation.
+#pragma once
+#include "dev_math.hpp"
+#include "pmath.hpp"
+
+#define PDB_WAVE 64
+#define PDB_CH_SLOTS 44          // chassis contribution slots: 4x5 suspension, 4 tyre, 2x6 wings, 1 axle reaction, 4 ARB (+ spare)
+#define PDB_HUB_SLOTS 8
+#define PDB_AXLE_SLOTS 20
+
+struct DevConst {
+    float camC[4], camS[4], camM33[4];   // cos/sin of the static camber and ((1-c)+c) (mat44f::createFromAxisAngle about z)
+    float acos096;                        // pm::acosf_(0.96f)
+    int rowStart[PDB_MAX_JOINTS + 1];
+    float dt;
+    double dtD;
+    int actionMode;
+    int wantCarState;
+    unsigned long long* stamps;   // diagnostic build only (-DPDB_STAMPS): [car][16] shader-clock stamps
+};
+

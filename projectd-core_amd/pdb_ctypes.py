@@ -5,7 +5,7 @@ import numpy as np
 PKG = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(PKG)
 
-MAX_CURVE, MAX_BODIES, MAX_JOINTS, MAX_WINGS, MAX_GEARS = 24, 8, 24, 4, 10
+MAX_CURVE, MAX_BODIES, MAX_JOINTS, MAX_WINGS, MAX_GEARS = 24, 8, 24, 6, 10
 
 class Curve(C.Structure):
     _fields_ = [('n', C.c_int32), ('x', C.c_float * MAX_CURVE), ('y', C.c_float * MAX_CURVE)]
