@@ -12,9 +12,12 @@ import os, struct, sys, math
 
 MAGIC = 0xAABBCCDD
 
-def write_surface(f, verts, indices, sector=0, category=1, grip=1.0, valid=1):
+def write_surface(f, verts, indices, sector=0, category=1, grip=1.0, valid=1, damping=0.0, sin_height=0.0, sin_length=0.0,
+                  granularity=0.0, dirt=0.0):
+    # BlobSurface (Sim/Surface.h:25-45): gripMod, damping, sinHeight, sinLength, granularity, dirtAdditiveK, vibrationGain,
+    # vibrationLength, wavPitchSpeed, isValidTrack, isPitlane
     hdr = struct.pack('<5I9f2B', MAGIC, len(verts), len(indices), sector, category,
-                      grip, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, valid, 0)
+                      grip, damping, sin_height, sin_length, granularity, dirt, 0.0, 0.0, 0.0, valid, 0)
     assert len(hdr) == 58
     f.write(hdr)
     for v in verts:
@@ -65,10 +68,16 @@ def touge_centreline(step=5.0, radius=600.0):
     return out
 
 
-def gen_touge(out, step=5.0, side=5.0, margin=4.0, bank_gain=6.0, bank_max=0.08, points_per_surface=400):
+# surface kinds cycled along the road (values in the range of the reference's shipped surfaces.ini files): road, smooth,
+# rumble strip (sine-wave height), road, grass-like (low grip, damping, dirt), granular
+TOUGE_SURFACES = [dict(grip=0.97), dict(grip=0.98), dict(grip=0.95, sin_height=0.03, sin_length=0.5), dict(grip=0.97),
+                  dict(grip=0.8, damping=0.01, dirt=1.0, valid=0), dict(grip=0.9, granularity=1.0, dirt=0.1)]
+
+
+def gen_touge(out, step=5.0, side=5.0, margin=4.0, bank_gain=6.0, bank_max=0.08, points_per_surface=40):
     """Synthetic "Akina-like" closed mountain road (BASELINE configs[2] shape): curvy ring with hills and curvature-
-    proportional banking; ribbon mesh (two triangles per spline interval, TRACK surfaces of <= points_per_surface
-    intervals so that uint16 indices suffice), spline every `step` metres with symmetric sides, CLOSED_LOOP=1."""
+    proportional banking; ribbon mesh (two triangles per spline interval) cut into surfaces of points_per_surface intervals
+    that cycle through six kinds of surface properties, spline every `step` metres with symmetric sides, CLOSED_LOOP=1."""
     os.makedirs(out, exist_ok=True)
     c = touge_centreline(step)
     n = len(c)
@@ -103,7 +112,8 @@ def gen_touge(out, step=5.0, side=5.0, margin=4.0, bank_gain=6.0, bank_max=0.08,
                     v0, v1, v2 = verts[tri[0]], verts[tri[1]], verts[tri[2]]
                     ny = (v1[2] - v0[2]) * (v2[0] - v0[0]) - (v1[0] - v0[0]) * (v2[2] - v0[2])
                     idx.extend(tri if ny > 0 else (tri[0], tri[2], tri[1]))      # front face up
-            write_surface(f, [tuple(float(x) for x in v) for v in verts], idx)
+            write_surface(f, [tuple(float(x) for x in v) for v in verts], idx, sector=i0 // points_per_surface,
+                          **TOUGE_SURFACES[(i0 // points_per_surface) % len(TOUGE_SURFACES)])
             i0 += cnt
     with open(os.path.join(out, 'spline.bin'), 'wb') as f:
         for p in c:
