@@ -204,13 +204,22 @@ int pdb_get_state(pdb_batch* b, int first, int count, pdb_dyn_state* states) {
 int pdb_reset(pdb_batch* b, const uint8_t* mask) {
     if (!b) { pdb::setError("null argument"); return PDB_ERR_ARG; }
     // teleportCarByMode(Start): Car::teleportToSpline(0) edits applied to each masked car's current record
-    std::vector<pdb_dyn_state> st((size_t)b->n);
-    int rc = pdb_get_state(b, 0, b->n, st.data());
-    if (rc != PDB_OK) return rc;
+    // only the masked lanes cross PCIe, one contiguous run of lanes at a time (episode ends are sparse)
     pdb::TrackView tv(b->track.data());
-    for (int i = 0; i < b->n; ++i)
-        if (!mask || mask[i]) pdb::teleportToSpline(b->params, tv, 0.0f, st[i]);
-    return pdb_set_state(b, 0, b->n, st.data());
+    std::vector<pdb_dyn_state> st;
+    for (int i = 0; i < b->n;) {
+        if (mask && !mask[i]) { ++i; continue; }
+        int j = i;
+        while (j < b->n && (!mask || mask[j])) ++j;
+        st.resize((size_t)(j - i));
+        int rc = pdb_get_state(b, i, j - i, st.data());
+        if (rc != PDB_OK) return rc;
+        for (auto& s : st) pdb::teleportToSpline(b->params, tv, 0.0f, s);
+        rc = pdb_set_state(b, i, j - i, st.data());
+        if (rc != PDB_OK) return rc;
+        i = j;
+    }
+    return PDB_OK;
 }
 
 float* pdb_actions_device(pdb_batch* b) { return b ? b->dActions : nullptr; }

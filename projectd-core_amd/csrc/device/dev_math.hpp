@@ -42,12 +42,19 @@ PDB_DEV DV3 mulMT(const float* M, const DV3& v) {  // M^T v
     return mk3(M[0] * v.x + M[3] * v.y + M[6] * v.z, M[1] * v.x + M[4] * v.y + M[7] * v.z, M[2] * v.x + M[5] * v.y + M[8] * v.z);
 }
 
-// clamp-ended piecewise-linear LUT (reference Core/Curve.cpp:94-115)
+// clamp-ended piecewise-linear LUT (reference Core/Curve.cpp:94-115): value at the first knot i >= 1 with ref <= x[i].
+// The knots are non-decreasing (the loader refuses curves that are not), so that knot is found by counting the knots
+// below ref -- 24 independent compares instead of a data-dependent loop of dependent loads -- and one interpolation follows.
 PDB_DEV float lut(const pdb_curve& c, float ref) {
     const int n = c.n;
     if (n == 0) return 0.0f;
-    if (ref <= c.x[0]) return c.y[0];
-    for (int i = 1; i < n; ++i)
-        if (ref <= c.x[i]) return (((c.y[i] - c.y[i - 1]) * (ref - c.x[i - 1])) / (c.x[i] - c.x[i - 1])) + c.y[i - 1];
-    return c.y[n - 1];
+    if (!(ref == ref)) return c.y[n - 1];   // NaN compares false everywhere in the reference's scan
+    int below = 0;
+#pragma unroll
+    for (int i = 0; i < PDB_MAX_CURVE; ++i) below += (i < n && c.x[i] < ref) ? 1 : 0;
+    if (below == 0) return c.y[0];          // ref <= x[0]
+    if (below >= n) return c.y[n - 1];      // beyond the last knot
+    const int i = below;                    // first knot with ref <= x[i], i >= 1
+    const float x0 = c.x[i - 1], x1 = c.x[i], y0 = c.y[i - 1], y1 = c.y[i];
+    return (((y1 - y0) * (ref - x0)) / (x1 - x0)) + y0;
 }

@@ -776,6 +776,16 @@ void buildCarModel(const std::string& basePathIn, const std::string& modelName, 
         const float t2 = fabsf(P.susp[2].basePosition[1] - P.tyre[2].rimRadius);
         P.baseCarHeight = std::max(t0, t2);
     }
+    // the device evaluates LUTs by counting knots below the argument: every curve must be sorted
+    {
+        auto sorted = [](const pdb_curve& c, const char* what) {
+            for (int i = 1; i < c.n; ++i) if (c.x[i] < c.x[i - 1]) throw std::runtime_error(std::string("pdb: LUT with decreasing abscissae: ") + what);
+        };
+        sorted(P.powerCurve, "power"); sorted(P.throttleCurve, "throttle"); sorted(P.upshiftProfile, "upshift"); sorted(P.downshiftProfile, "downshift");
+        sorted(P.blipProfile, "blip");
+        for (int i = 0; i < 4; ++i) { sorted(P.tyre[i].performanceCurve, "tyre performance"); sorted(P.tyre[i].wearCurve, "tyre wear"); }
+        for (int i = 0; i < P.numWings; ++i) { sorted(P.wings[i].lutAOA_CL, "wing CL"); sorted(P.wings[i].lutAOA_CD, "wing CD"); }
+    }
     // ScoringConfig defaults (ScoringSystem.cpp:46-71)
     pdb_scoring& sc = P.scoring;
     memset(&sc, 0, sizeof(sc));
