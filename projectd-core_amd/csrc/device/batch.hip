@@ -118,6 +118,18 @@ extern "C" {
 
 pdb_batch* pdb_create(int device, int n_cars, const pdb_car_params* params, const void* track_blob, uint64_t track_bytes, int action_mode) {
     if (!params || !track_blob || n_cars <= 0) { pdb::setError("pdb_create: bad argument"); return nullptr; }
+    if (action_mode < PDB_ACTION_CONTROLS || action_mode > PDB_ACTION_FULL) { pdb::setError("pdb_create: unknown action mode"); return nullptr; }
+    if (params->magic != 0x50434450 || params->version != 1 || params->numBodies < 2 || params->numBodies > PDB_MAX_BODIES ||
+        params->numJoints < 1 || params->numJoints > PDB_MAX_JOINTS || params->numRows < 1 || params->numRows > PDB_MAX_ROWS ||
+        params->numWings < 0 || params->numWings > PDB_MAX_WINGS || params->numTurbos < 0 || params->numTurbos > PDB_MAX_TURBOS) {
+        pdb::setError("pdb_create: not a pdb_car_params block of this version (build it with pdb_build_car_model)"); return nullptr;
+    }
+    {
+        const pdb_track_header* th = static_cast<const pdb_track_header*>(track_blob);
+        if (track_bytes < sizeof(pdb_track_header) || th->magic != 0x4B544450 || th->version != 2 || th->totalBytes != track_bytes) {
+            pdb::setError("pdb_create: not a track blob of this version (build it with pdb_build_track)"); return nullptr;
+        }
+    }
     int count = 0;
     if (hipGetDeviceCount(&count) != hipSuccess || count <= 0 || device < 0 || device >= count) {
         pdb::setError("pdb_create: no usable HIP device (there is no CPU fallback)");
@@ -132,7 +144,6 @@ pdb_batch* pdb_create(int device, int n_cars, const pdb_car_params* params, cons
     bool ok = true;
     ok = ok && hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking) == hipSuccess;
     ok = ok && hipMalloc(&b->dStates, sizeof(pdb_dyn_state) * (size_t)n_cars) == hipSuccess;
-    if (action_mode < PDB_ACTION_CONTROLS || action_mode > PDB_ACTION_FULL) { pdb::setError("pdb_create: unknown action mode"); delete b; return nullptr; }
     b->actionStride = (action_mode == PDB_ACTION_FULL) ? 8 : 2;
     ok = ok && hipMalloc(&b->dActions, sizeof(float) * b->actionStride * (size_t)n_cars) == hipSuccess;
     ok = ok && hipMalloc(&b->dOut, sizeof(pdb_step_out) * (size_t)n_cars) == hipSuccess;

@@ -279,3 +279,21 @@ def test_bench_multi_rank_path_on_one_gpu(built):
     d = json.loads(lines[0])
     assert d['n_gpus'] == 2 and d['steps'] == 40 and d['scaling'] == 'weak' and d['value'] > 0 and d['config']['cars_per_gpu'] == 256
     assert 'all-gather' in d['config']['collective']
+
+
+def test_create_rejects_malformed_inputs(built):
+    import pdbatch
+    lib = pc.load_product()
+    P = pdbatch.packed_params(); trk = pdbatch.synthetic_track('flat')
+    assert not lib.pdb_create(0, 4, C.byref(P), trk, len(trk), 7) and b'action mode' in lib.pdb_last_error()
+    bad = pc.CarParams.from_buffer_copy(bytes(P)); bad.magic = 1
+    assert not lib.pdb_create(0, 4, C.byref(bad), trk, len(trk), 1) and b'pdb_car_params' in lib.pdb_last_error()
+    bad = pc.CarParams.from_buffer_copy(bytes(P)); bad.numRows = 99
+    assert not lib.pdb_create(0, 4, C.byref(bad), trk, len(trk), 1)
+    assert not lib.pdb_create(0, 4, C.byref(P), trk[:-16], len(trk) - 16, 1) and b'track blob' in lib.pdb_last_error()
+    assert not lib.pdb_create(0, 0, C.byref(P), trk, len(trk), 1)
+    assert not lib.pdb_create(99, 4, C.byref(P), trk, len(trk), 1) and b'no usable HIP device' in lib.pdb_last_error()
+    h = lib.pdb_create(0, 4, C.byref(P), trk, len(trk), 1)
+    assert h
+    assert lib.pdb_get_state(h, 3, 2, None) < 0 and lib.pdb_step_host(h, None, C.c_float(0.003), None) < 0
+    lib.pdb_destroy(h)
