@@ -7,6 +7,7 @@
 #include <vector>
 #include <string>
 #include <chrono>
+#include <algorithm>
 #ifdef _OPENMP
 #include <omp.h>
 #endif
@@ -77,6 +78,55 @@ int cpuref_math_eval(int fn, int glibc, const float* x, const float* y, float* o
                           case 4: out[i] = pmref::r_atan2f(a, b); break; case 5: out[i] = pmref::r_asinf(a); break; case 6: out[i] = pmref::r_acosf(a); break; default: out[i] = pmref::r_powf(a, b); break; }
         }
     }
+    return 0;
+}
+// Solver invariants (SURVEY.md 8c (ii),(iii)): the car's bodies and joints alone, no tyres / suspension forces, gravity off,
+// launched as one rigid motion (chassis velocity v, spin w).  out: [0..2] linear momentum before, [3..5] after, [6..8] angular
+// momentum about the origin before, [9..11] after, [12] kinetic energy before, [13] after, [14] worst distance-joint error (m),
+// [15] worst ball / fixed anchor separation (m)
+int cpuref_solver_freeflight(void* hh, int ticks, const float* v, const float* w, double* out) {
+    auto* h = (CpuRefHandle*)hh;
+    cpuref::Car car;
+    car.init(&h->P, &h->T, h->s0);
+    pdrb::World& W = car.w;
+    W.gravity[0] = 0; W.gravity[1] = 0; W.gravity[2] = 0;
+    const float* c = W.bodies[0].pos;
+    for (auto& b : W.bodies) {
+        const float r[3] = {b.pos[0] - c[0], b.pos[1] - c[1], b.pos[2] - c[2]};
+        float wr[3]; pdrb::cross3(wr, w, r);
+        for (int k = 0; k < 3; ++k) { b.lvel[k] = v[k] + wr[k]; b.avel[k] = w[k]; b.facc[k] = 0; b.tacc[k] = 0; }
+    }
+    auto measure = [&](double* P3, double* L3, double& E) {
+        for (int k = 0; k < 3; ++k) { P3[k] = 0; L3[k] = 0; }
+        E = 0;
+        for (auto& b : W.bodies) {
+            double Iw[9], t[9];
+            for (int r = 0; r < 3; ++r) for (int cc = 0; cc < 3; ++cc) { t[r * 3 + cc] = 0; for (int k = 0; k < 3; ++k) t[r * 3 + cc] += (double)b.I[r * 3 + k] * b.R[cc * 3 + k]; }
+            for (int r = 0; r < 3; ++r) for (int cc = 0; cc < 3; ++cc) { Iw[r * 3 + cc] = 0; for (int k = 0; k < 3; ++k) Iw[r * 3 + cc] += (double)b.R[r * 3 + k] * t[k * 3 + cc]; }
+            double Lw[3];
+            for (int r = 0; r < 3; ++r) Lw[r] = Iw[r * 3] * b.avel[0] + Iw[r * 3 + 1] * b.avel[1] + Iw[r * 3 + 2] * b.avel[2];
+            const double m = b.mass, p[3] = {b.pos[0], b.pos[1], b.pos[2]}, vv[3] = {b.lvel[0], b.lvel[1], b.lvel[2]};
+            for (int k = 0; k < 3; ++k) P3[k] += m * vv[k];
+            L3[0] += m * (p[1] * vv[2] - p[2] * vv[1]) + Lw[0];
+            L3[1] += m * (p[2] * vv[0] - p[0] * vv[2]) + Lw[1];
+            L3[2] += m * (p[0] * vv[1] - p[1] * vv[0]) + Lw[2];
+            E += 0.5 * m * (vv[0] * vv[0] + vv[1] * vv[1] + vv[2] * vv[2]) + 0.5 * (Lw[0] * b.avel[0] + Lw[1] * b.avel[1] + Lw[2] * b.avel[2]);
+        }
+    };
+    measure(out + 0, out + 6, out[12]);
+    double worstD = 0, worstA = 0;
+    for (int t = 0; t < ticks; ++t) {
+        W.step((float)(1.0 / 333.0));
+        for (auto& j : W.joints) {
+            float a1[3], a2[3];
+            W.bodies[j.b0].relPointPos(j.anchor1, a1); W.bodies[j.b1].relPointPos(j.anchor2, a2);
+            const double d = sqrt((double)(a1[0] - a2[0]) * (a1[0] - a2[0]) + (double)(a1[1] - a2[1]) * (a1[1] - a2[1]) + (double)(a1[2] - a2[2]) * (a1[2] - a2[2]));
+            if (j.type == pdrb::JT_DBALL) worstD = std::max(worstD, fabs(d - (double)j.targetDistance));
+            else if (j.type == pdrb::JT_BALL) worstA = std::max(worstA, d);
+        }
+    }
+    measure(out + 3, out + 9, out[13]);
+    out[14] = worstD; out[15] = worstA;
     return 0;
 }
 const char* cpuref_scenario_name(int sid) { return pdoracle::kScenarios[sid].name; }

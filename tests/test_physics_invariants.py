@@ -60,3 +60,27 @@ def test_straight_line_launch_is_straight_and_accelerates(oracle, env_params, fl
     assert s.speed > 20.0 and s.currentGear >= 3
     assert cs.collisionFlag == 0 and cs.outOfTrackFlag == 0
     assert cs.engineRPM > 1000.0
+
+
+import pytest
+from conftest import car_params
+
+
+@pytest.mark.parametrize('model', ['ks_toyota_ae86_drift', 'ks_mazda_rx7_tuned', 'gravygarage_street_ae86_readie'])
+def test_free_flight_conserves_momentum_and_holds_the_joints(oracle, hostlib, flat_track, model):
+    """(iii) bodies + joints only, gravity off, launched as one rigid tumbling motion: constraint forces are internal, so the
+    linear momentum must be conserved to rounding, the angular momentum and the energy to the integrator's first-order error,
+    and every joint must stay closed -- for the three joint topologies (33 / 26 / 38 rows)"""
+    import ctypes as C
+    P = car_params(model)
+    s0 = pc.DynState(); assert hostlib.pdb_initial_state(C.byref(P), flat_track, C.byref(s0)) == 0
+    h = oracle.cpuref_create(C.byref(P), flat_track, len(flat_track), C.byref(s0))
+    v = np.array([10.0, 2.0, 5.0], np.float32); w = np.array([0.5, 1.0, -0.3], np.float32)
+    out = np.zeros(16)
+    assert oracle.cpuref_solver_freeflight(h, 1000, v.ctypes.data_as(C.c_void_p), w.ctypes.data_as(C.c_void_p), out.ctypes.data_as(C.c_void_p)) == 0
+    oracle.cpuref_destroy(h)
+    p0, p1, l0, l1, e0, e1 = out[0:3], out[3:6], out[6:9], out[9:12], out[12], out[13]
+    assert np.linalg.norm(p1 - p0) / np.linalg.norm(p0) < 1e-5, (p0, p1)
+    assert np.linalg.norm(l1 - l0) / np.linalg.norm(l0) < 2e-2, (l0, l1)
+    assert abs(e1 - e0) / e0 < 2e-2, (e0, e1)
+    assert out[14] < 2e-3 and out[15] < 2e-3, (out[14], out[15])
