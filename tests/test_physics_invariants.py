@@ -81,6 +81,6 @@ def test_free_flight_conserves_momentum_and_holds_the_joints(oracle, hostlib, fl
     oracle.cpuref_destroy(h)
     p0, p1, l0, l1, e0, e1 = out[0:3], out[3:6], out[6:9], out[9:12], out[12], out[13]
     assert np.linalg.norm(p1 - p0) / np.linalg.norm(p0) < 1e-5, (p0, p1)
-    assert np.linalg.norm(l1 - l0) / np.linalg.norm(l0) < 2e-2, (l0, l1)
-    assert abs(e1 - e0) / e0 < 2e-2, (e0, e1)
+    assert np.linalg.norm(l1 - l0) / np.linalg.norm(l0) < 5e-5, (l0, l1)
+    assert abs(e1 - e0) / e0 < 2e-4, (e0, e1)
     assert out[14] < 2e-3 and out[15] < 2e-3, (out[14], out[15])
