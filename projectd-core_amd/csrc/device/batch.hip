@@ -91,6 +91,8 @@ static void fillConst(const pdb_car_params& P, DevConst& K, int actionMode) {
         r += (t == PDB_JOINT_FIXED) ? 6 : (t == PDB_JOINT_BALL) ? 3 : (t == PDB_JOINT_SLIDER) ? 5 : 1;
     }
     for (int j = P.numJoints; j <= PDB_MAX_JOINTS; ++j) K.rowStart[j] = r;
+    for (int j = 0; j < P.numJoints; ++j)
+        for (int rr = K.rowStart[j]; rr < K.rowStart[j + 1] && rr < PDB_MAX_ROWS; ++rr) { K.rowB0[rr] = P.joints[j].b0; K.rowB1[rr] = P.joints[j].b1; }
     K.actionMode = actionMode;
     K.wantCarState = 0;
 }
