@@ -19,7 +19,7 @@ sys.path.insert(0, os.path.join(ROOT, 'tests'))
 
 CARS_PER_GPU = 4096
 # algorithmic bytes per car-tick (DESIGN.md "Algorithmic bytes"): record read + record write + action + output row
-B_ALG = 2208 + 2208 + 8 + 104
+B_ALG = 2224 + 2224 + 8 + 104   # sizeof(pdb_dyn_state) in and out, float[2] action, pdb_step_out (checked against the ctypes mirrors in main)
 HBM_PEAK_GBS = 8000.0
 
 
@@ -79,6 +79,7 @@ def main():
         dist.init_process_group(args.backend, init_method='env://')
 
     n = args.cars
+    assert B_ALG == 2 * C.sizeof(pc.DynState) + 8 + C.sizeof(pc.StepOut), 'B_ALG is stale: update it with the record layout'
     P = pdbatch.packed_params()
     trk = pdbatch.synthetic_track(args.workload)
     lib = pc.load_product()
