@@ -54,6 +54,8 @@ def main():
     ap.add_argument('--warmup', type=int, default=333)
     ap.add_argument('--cars', type=int, default=CARS_PER_GPU)
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--gather-ticks', type=int, default=8, help='ticks per trajectory ring gathered to the learner (N > 1): 1 = plain per-tick gather')
+    ap.add_argument('--force-gather', action='store_true', help='run the observation all-gather even with one rank (exercises the RCCL + side-stream path on a single GPU)')
     ap.add_argument('--backend', default='nccl', help='torch.distributed backend for N > 1 (nccl = RCCL; gloo only to exercise the multi-rank path on a single-GPU box)')
     ap.add_argument('--workload', choices=['flat', 'touge'], default='flat',
                     help='flat = BASELINE configs[1] (the bench line); touge = configs[2] shape: closed hilly road, cars spread around the lap, probe-feedback steering computed on the GPU each tick')
@@ -74,7 +76,7 @@ def main():
     dev_index = local_rank % ndev          # one rank per GPU on the driver's node; ranks share devices only in the single-GPU gloo test
     torch.cuda.set_device(dev_index)
     dist = None
-    if world > 1:
+    if world > 1 or args.force_gather:
         import torch.distributed as dist
         dist.init_process_group(args.backend, init_method='env://')
 
@@ -104,16 +106,21 @@ def main():
         def __init__(self, ptr, shape):
             self.__cuda_array_interface__ = {'shape': shape, 'typestr': '<f4', 'data': (ptr, False), 'version': 2}
     out_t = torch.as_tensor(_Arr(b.out_device_ptr(), (n, 26)), device='cuda:%d' % dev_index)
-    gather = sharding.ObsGather(n, world, 'cuda:%d' % dev_index, dist)
+    gather = sharding.TrajectoryGather(n, world, 'cuda:%d' % dev_index, dist, k=args.gather_ticks, force=args.force_gather)
     act_t = torch.as_tensor(_Arr(b.actions_device_ptr(), (n, 2)), device='cuda:%d' % dev_index)
 
+    tick_id = [0]
+
     def tick():
+        t = tick_id[0]; tick_id[0] = t + 1
+        out_t = gather.slot(t)                  # the kernel writes tick t straight into its trajectory-ring slot
+        b.set_out_device_ptr(out_t.data_ptr())
         b.step_async()
         if args.workload == 'touge':   # the policy: oracle/scenarios.h scenarioFeedback as elementwise device ops on the observation block
             o = out_t
             act_t[:, 0] = torch.clamp(0.03 * (o[:, 21] - o[:, 20]) + 0.015 * (o[:, 19] - o[:, 18]) + 0.15 * o[:, 4], -1.0, 1.0)
             act_t[:, 1] = torch.clamp(0.3 * (12.0 - o[:, 2]), -1.0, 1.0)
-        gather(out_t)
+        gather.after_tick(t)
 
     for _ in range(args.warmup):
         tick()
@@ -126,6 +133,7 @@ def main():
     for _ in range(args.steps):
         tick()
     b.event_record(1)
+    gather.finish()                       # outstanding gathers belong to the timed region
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -155,7 +163,7 @@ def main():
             "dtype": "f32 (+f64 drivetrain)", "data": "synthetic",
             "config": {"workload": ("configs[1]: %d cars/GPU, AE86, flat-plane track, per-car constant random actions, dt=1/333 s" % n) if args.workload == 'flat' else
                                    ("configs[2] shape: %d cars/GPU, AE86, synthetic closed mountain road (1782 triangles, 891 spline points), probe-feedback steering on the GPU, dt=1/333 s" % n),
-                       "cars_per_gpu": n, "collective": "per-tick RCCL all-gather of [N,26] obs/reward/flags" if world > 1 else "none",
+                       "cars_per_gpu": n, "collective": ("RCCL all-gather of %d-tick trajectory rings [k,N,26] obs/reward/flags on a side stream, kernel writes the ring in place" % args.gather_ticks) if (world > 1 or args.force_gather) else "none",
                        "parity": "bit-exact vs CPU oracle (tests/test_gpu_parity.py)"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic, "traffic_source": ("profiles/r01_pmc.json: (2*FETCH_SIZE + WRITE_SIZE)*1024 per launch, rocprofv3 --pmc passes of this command" if traffic else None),
@@ -165,7 +173,7 @@ def main():
             res["cpu_baseline"] = cpu_baseline(P, trk, S0, all_actions)
         print(json.dumps(res))
     b.close()
-    if world > 1:
+    if world > 1 or args.force_gather:
         dist.destroy_process_group()
 
 

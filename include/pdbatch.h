@@ -78,6 +78,9 @@ int pdb_reset(pdb_batch* b, const uint8_t* mask);
 /* device pointers owned by the batch: float actions[N][2], pdb_step_out out[N] */
 float* pdb_actions_device(pdb_batch* b);
 pdb_step_out* pdb_out_device(pdb_batch* b);
+/* redirect the per-tick outputs into a caller-owned device block of n_cars pdb_step_out (e.g. one slot of a trajectory ring
+ * that is gathered to the learner every k ticks); NULL restores the library's own block */
+int pdb_set_out_device(pdb_batch* b, pdb_step_out* out);
 void* pdb_stream(pdb_batch* b);
 /* one tick of every car, reading pdb_actions_device and writing pdb_out_device; asynchronous on pdb_stream */
 int pdb_step(pdb_batch* b, float dt);

@@ -57,7 +57,8 @@ struct pdb_batch {
     pdb_dyn_state* dStates = nullptr;
     float* dActions = nullptr;
     int actionStride = 2;   // floats per car: 2 (CONTROLS / ENV) or 8 (FULL)
-    pdb_step_out* dOut = nullptr;
+    pdb_step_out* dOut = nullptr;        // library-owned output block
+    pdb_step_out* dOutActive = nullptr;  // where the next tick writes: dOut, or a caller-owned block (pdb_set_out_device)
     pdb_car_state* dCarStates = nullptr;
     pdb_car_params* dParams = nullptr;
     DevConst* dK = nullptr;
@@ -110,7 +111,7 @@ static int launch(pdb_batch* b, float dt, bool wantCarState) {
         b->K.wantCarState = wantCarState ? 1 : 0;
         HIPCHK(hipMemcpyAsync(b->dK, &b->K, sizeof(DevConst), hipMemcpyHostToDevice, b->stream));
     }
-    hipLaunchKernelGGL(stepKernelFor(b), dim3((b->n + PDB_CPB - 1) / PDB_CPB), dim3(PDB_BLOCK_THREADS), 0, b->stream, b->dStates, b->dActions, b->dOut, b->dCarStates, b->dParams, b->dK,
+    hipLaunchKernelGGL(stepKernelFor(b), dim3((b->n + PDB_CPB - 1) / PDB_CPB), dim3(PDB_BLOCK_THREADS), 0, b->stream, b->dStates, b->dActions, b->dOutActive, b->dCarStates, b->dParams, b->dK,
                        b->dTrack, b->n);
     HIPCHK(hipGetLastError());
     return PDB_OK;
@@ -161,6 +162,7 @@ pdb_batch* pdb_create(int device, int n_cars, const pdb_car_params* params, cons
         ok = ok && hipMemcpy(b->dTrack, b->track.data(), track_bytes, hipMemcpyHostToDevice) == hipSuccess;
         ok = ok && hipMemset(b->dActions, 0, sizeof(float) * b->actionStride * (size_t)n_cars) == hipSuccess;
         ok = ok && hipMemset(b->dOut, 0, sizeof(pdb_step_out) * (size_t)n_cars) == hipSuccess;
+        b->dOutActive = b->dOut;
     }
 #ifdef PDB_STAMPS
     if (ok) {
@@ -236,7 +238,14 @@ int pdb_reset(pdb_batch* b, const uint8_t* mask) {
 }
 
 float* pdb_actions_device(pdb_batch* b) { return b ? b->dActions : nullptr; }
-pdb_step_out* pdb_out_device(pdb_batch* b) { return b ? b->dOut : nullptr; }
+pdb_step_out* pdb_out_device(pdb_batch* b) { return b ? b->dOutActive : nullptr; }
+int pdb_set_out_device(pdb_batch* b, pdb_step_out* out) {
+    if (!b) { pdb::setError("null argument"); return PDB_ERR_ARG; }
+    pdb_step_out* p = out ? out : b->dOut;
+    if (p != b->dOutActive && b->graphExec) { (void)hipGraphExecDestroy(b->graphExec); b->graphExec = nullptr; }   // the captured launches carry the old pointer
+    b->dOutActive = p;
+    return PDB_OK;
+}
 void* pdb_stream(pdb_batch* b) { return b ? (void*)b->stream : nullptr; }
 
 int pdb_step(pdb_batch* b, float dt) {
@@ -266,7 +275,7 @@ int pdb_step_n(pdb_batch* b, float dt, int n) {
         hipGraph_t g = nullptr;
         HIPCHK(hipStreamBeginCapture(b->stream, hipStreamCaptureModeThreadLocal));
         for (int i = 0; i < n; ++i)
-            hipLaunchKernelGGL(stepKernelFor(b), dim3((b->n + PDB_CPB - 1) / PDB_CPB), dim3(PDB_BLOCK_THREADS), 0, b->stream, b->dStates, b->dActions, b->dOut, b->dCarStates, b->dParams,
+            hipLaunchKernelGGL(stepKernelFor(b), dim3((b->n + PDB_CPB - 1) / PDB_CPB), dim3(PDB_BLOCK_THREADS), 0, b->stream, b->dStates, b->dActions, b->dOutActive, b->dCarStates, b->dParams,
                                b->dK, b->dTrack, b->n);
         HIPCHK(hipStreamEndCapture(b->stream, &g));
         HIPCHK(hipGraphInstantiate(&b->graphExec, g, nullptr, nullptr, 0));
@@ -321,7 +330,7 @@ int pdb_step_host(pdb_batch* b, const float* actions, float dt, pdb_step_out* ou
     HIPCHK(hipMemcpyAsync(b->dActions, actions, sizeof(float) * b->actionStride * (size_t)b->n, hipMemcpyHostToDevice, b->stream));
     int rc = launch(b, dt, true);
     if (rc != PDB_OK) return rc;
-    if (out) HIPCHK(hipMemcpyAsync(out, b->dOut, sizeof(pdb_step_out) * (size_t)b->n, hipMemcpyDeviceToHost, b->stream));
+    if (out) HIPCHK(hipMemcpyAsync(out, b->dOutActive, sizeof(pdb_step_out) * (size_t)b->n, hipMemcpyDeviceToHost, b->stream));
     HIPCHK(hipStreamSynchronize(b->stream));
     return PDB_OK;
 }

@@ -131,6 +131,7 @@ def load_product(host_only=False):
         lib.pdb_reset.argtypes = [C.c_void_p, C.c_void_p]
         lib.pdb_actions_device.restype = C.c_void_p; lib.pdb_actions_device.argtypes = [C.c_void_p]
         lib.pdb_out_device.restype = C.c_void_p; lib.pdb_out_device.argtypes = [C.c_void_p]
+        lib.pdb_set_out_device.argtypes = [C.c_void_p, C.c_void_p]
         lib.pdb_stream.restype = C.c_void_p; lib.pdb_stream.argtypes = [C.c_void_p]
         lib.pdb_step.argtypes = [C.c_void_p, C.c_float]
         lib.pdb_step_n.argtypes = [C.c_void_p, C.c_float, C.c_int]

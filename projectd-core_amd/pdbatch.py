@@ -73,6 +73,9 @@ class Batch:
         if rc != 0:
             raise RuntimeError('hipMemcpy failed: %d' % rc)
 
+    def set_out_device_ptr(self, ptr):
+        self._chk(self.lib.pdb_set_out_device(self.h, C.c_void_p(ptr)))
+
     def out_device_ptr(self):
         return self.lib.pdb_out_device(self.h)
 

@@ -2,6 +2,7 @@
 N/P cars, one process per GPU, with no collective inside a tick.  The only exchange is the learner-side one the
 reference's RL loop implies: gather of the [N/P, 26] observation/reward/flag block and scatter of the [N/P, 2]
 actions (RCCL over xGMI on the GPU box; the same code runs on gloo/CPU tensors in tests/test_sharding.py).
+The output blocks are gathered as k-tick trajectory rings (TrajectoryGather) so that the collective overlaps compute.
 Per-car inputs are keyed by the GLOBAL car index so results do not depend on the number of ranks."""
 import numpy as np
 
@@ -27,28 +28,70 @@ def global_actions(n_global, seed, lo=-0.3, hi=0.3):
     return a
 
 
-class ObsGather:
-    """Per-tick all-gather of every rank's [n_local, 26] output block into one [world * n_local, 26] tensor
-    (equal block sizes: weak scaling).  Buffers are allocated once; the collective is enqueued on torch's current
-    stream, i.e. behind the step kernel when the batch was attached to that stream with pdb_set_stream."""
+class TrajectoryGather:
+    """Learner-side exchange of the per-tick output blocks ("per tick (or per k-tick macro-step)").
 
-    def __init__(self, n_local, world, device, dist=None):
+    The step kernel writes tick t's [n_local, 26] block straight into slot t % k of a trajectory ring that this object
+    owns (pdb_set_out_device: no staging copy); when a ring of k ticks is full it is all-gathered to every rank
+    ([world, k, n_local, 26]) while the kernel already fills the second ring.  On the GPU (RCCL) the collective runs on a
+    side stream, ordered after the ring's last kernel by an event, so its latency over xGMI overlaps compute; a ring is
+    not rewritten before its previous gather has completed.  k = 1 is the plain per-tick gather.  On CPU tensors (gloo,
+    tests) everything is synchronous and `write(t, block)` stands in for the kernel."""
+
+    def __init__(self, n_local, world, device, dist=None, k=8, force=False):
         import torch
-        self.dist = dist
-        self.world = world
-        self.n_local = n_local
-        self.gathered = torch.empty((world * n_local, OUT_COLS), dtype=torch.float32, device=device) if world > 1 else None
+        self.dist, self.world, self.n_local, self.k = dist, world, n_local, max(1, int(k))
+        self.active = (world > 1 or force) and dist is not None
+        self.cuda = str(device).startswith('cuda')
+        self.rings = [torch.zeros((self.k, n_local, OUT_COLS), dtype=torch.float32, device=device) for _ in range(2)]
+        self.gathered = [torch.empty((world, self.k, n_local, OUT_COLS), dtype=torch.float32, device=device) for _ in range(2)] if self.active else None
+        self.overlap = self.active and self.cuda and dist.get_backend() == 'nccl'
+        self.work = [None, None]
+        self.last = None
+        if self.overlap:
+            self.comm = torch.cuda.Stream(device=device)
+            self.e_full = torch.cuda.Event()
 
-    def __call__(self, out_block):
-        if self.world == 1:
-            return out_block
-        if out_block.is_cuda and self.dist.get_backend() == 'gloo':   # single-GPU test of the multi-rank path: stage through the host
-            host = self.gathered.cpu()
-            self.dist.all_gather_into_tensor(host, out_block.cpu())
-            self.gathered.copy_(host)
-            return self.gathered
-        self.dist.all_gather_into_tensor(self.gathered, out_block)
-        return self.gathered
+    def slot(self, t):
+        """tensor [n_local, 26] the kernel of tick t must write (its data_ptr() goes to pdb_set_out_device)"""
+        r = (t // self.k) & 1
+        if self.overlap and t % self.k == 0 and self.work[r] is not None:
+            self.work[r].wait()            # current stream waits: this ring's previous gather still reads it
+            self.work[r] = None
+        return self.rings[r][t % self.k]
+
+    def write(self, t, block):
+        self.slot(t).copy_(block)
+
+    def after_tick(self, t):
+        """call once tick t's kernel is enqueued; starts the gather when the ring is full.  Returns the gathered tensor
+        ([world, k, n_local, 26]) of that ring, else None."""
+        if not self.active or (t + 1) % self.k != 0:
+            return None
+        import torch
+        r = (t // self.k) & 1
+        flat_in = self.rings[r].view(-1, OUT_COLS)
+        flat_out = self.gathered[r].view(-1, OUT_COLS)
+        if self.overlap:
+            self.e_full.record(torch.cuda.current_stream())
+            with torch.cuda.stream(self.comm):
+                self.comm.wait_event(self.e_full)
+                self.work[r] = self.dist.all_gather_into_tensor(flat_out, flat_in, async_op=True)
+        elif self.cuda and self.dist.get_backend() == 'gloo':   # single-GPU test of the multi-rank path: through the host
+            host = flat_out.cpu()
+            self.dist.all_gather_into_tensor(host, flat_in.cpu())
+            flat_out.copy_(host)
+        else:
+            self.dist.all_gather_into_tensor(flat_out, flat_in)
+        self.last = r
+        return self.gathered[r]
+
+    def finish(self):
+        """make the caller's current stream wait for every outstanding gather"""
+        for r in (0, 1):
+            if self.work[r] is not None:
+                self.work[r].wait(); self.work[r] = None
+        return self.gathered[self.last] if (self.active and self.last is not None) else None
 
 
 def scatter_actions(all_actions, n_local, world, rank, device, dist=None):

@@ -36,11 +36,15 @@ def main(rank, world, port, n_global, ticks, out_path):
     all_a = torch.from_numpy(sharding.global_actions(n_global, 1234)) if rank == 0 else None
     mine = sharding.scatter_actions(all_a, n_local, world, rank, 'cpu', dist).numpy()
     hs = [orc.cpuref_create(C.byref(P), trk, len(trk), C.byref(S0)) for _ in range(n_local)]
-    gather = sharding.ObsGather(n_local, world, 'cpu', dist)
+    k = 8
+    gather = sharding.TrajectoryGather(n_local, world, 'cpu', dist, k=k)
     g = None
     for t in range(ticks):
-        block = torch.from_numpy(step_block(orc, hs, mine))
-        g = gather(block)
+        gather.write(t, torch.from_numpy(step_block(orc, hs, mine)))      # stands in for the kernel writing the ring slot
+        full = gather.after_tick(t)
+        if full is not None:
+            g = full.clone()                                                # [world, k, n_local, 26]
+    gather.finish()
     slow = sharding.max_over_ranks(1.0 + rank, 'cpu', dist, world)
     if rank == 0:
         np.save(out_path, np.concatenate([g.numpy().reshape(-1), [slow]]))

@@ -297,3 +297,17 @@ def test_create_rejects_malformed_inputs(built):
     assert h
     assert lib.pdb_get_state(h, 3, 2, None) < 0 and lib.pdb_step_host(h, None, C.c_float(0.003), None) < 0
     lib.pdb_destroy(h)
+
+
+def test_bench_rccl_gather_side_stream_on_one_gpu(built):
+    """the RCCL leg itself, as far as one GPU allows: one rank, nccl backend, --force-gather: process-group init, staging copy
+    and all-gather on the side stream, event ordering against the step kernel, teardown"""
+    import json, subprocess, socket
+    s = socket.socket(); s.bind(('127.0.0.1', 0)); port = s.getsockname()[1]; s.close()
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '1', '--master-addr', '127.0.0.1', '--master-port', str(port),
+           os.path.join(root, 'bench.py'), '--gpus', '1', '--steps', '200', '--warmup', '20', '--cars', '1024', '--force-gather', '--no-cpu-baseline']
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600, env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0'))
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = json.loads([l for l in r.stdout.splitlines() if l.startswith('{')][0])
+    assert d['n_gpus'] == 1 and 'side stream' in d['config']['collective'] and d['value'] > 1e6

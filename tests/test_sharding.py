@@ -1,5 +1,5 @@
 """The N > 1 path on CPU: two gloo ranks, each stepping its contiguous block of cars, action
-scatter from the learner rank, per-tick gather of the [n,26] output block -- must give exactly what one process gives
+scatter from the learner rank, gather of 8-tick trajectory rings of [n,26] output blocks -- must give exactly what one process gives
 for all cars (results keyed by global car id, invariant to the number of ranks)."""
 import ctypes as C, os, socket, subprocess, sys, tempfile
 import numpy as np
@@ -49,16 +49,18 @@ def test_two_rank_gather_equals_single_process(built, oracle):
         assert rcs == [0, 0]
         got = np.load(out)
     assert got[-1] == 2.0                                   # max over ranks of (1 + rank)
-    got = got[:-1].astype(np.float32).reshape(n_global, 26)
+    got = got[:-1].astype(np.float32).reshape(2, 8, n_global // 2, 26)    # [world, k, n_local, 26]: the last full 8-tick ring
     # single process, all cars
     P = pdbatch.packed_params(); trk = pdbatch.synthetic_track('flat')
     lib = pc.load_product(host_only=True); orc = oracle_ctypes.load_oracle(True)
     S0 = pc.DynState(); assert lib.pdb_initial_state(C.byref(P), trk, C.byref(S0)) == 0
     hs = [orc.cpuref_create(C.byref(P), trk, len(trk), C.byref(S0)) for _ in range(n_global)]
     a = sharding.global_actions(n_global, 1234)
+    ring = np.zeros((8, n_global, 26), np.float32)
     for t in range(ticks):
-        ref = w.step_block(orc, hs, a)
+        ring[t % 8] = w.step_block(orc, hs, a)
     for h in hs:
         orc.cpuref_destroy(h)
-    assert np.array_equal(got.view(np.int32), ref.view(np.int32))
-    assert np.any(ref[:, :24] != 0)
+    ref = ring.reshape(8, 2, n_global // 2, 26).transpose(1, 0, 2, 3)      # rank-major like the gathered tensor
+    assert np.array_equal(got.view(np.int32), np.ascontiguousarray(ref).view(np.int32))
+    assert np.any(ref[..., :24] != 0)
