@@ -311,3 +311,37 @@ def test_bench_rccl_gather_side_stream_on_one_gpu(built):
     assert r.returncode == 0, r.stderr[-2000:]
     d = json.loads([l for l in r.stdout.splitlines() if l.startswith('{')][0])
     assert d['n_gpus'] == 1 and 'side stream' in d['config']['collective'] and d['value'] > 1e6
+
+
+@pytest.mark.parametrize('n_cars,track', [(4099, 'flat'), (16384, 'touge')])
+def test_full_size_batches_by_replication(built, n_cars, track):
+    """BASELINE configs[1] / configs[2] sizes (and a car count that is not a multiple of the 3 cars per workgroup): 37 distinct
+    constant actions tiled over the whole batch.  Size-independent properties: (1) every replica of an action ends in the
+    byte-identical record wherever it sits in the batch (any workgroup, any pack-wave lane, the partial last workgroup);
+    (2) the 37 representatives equal the CPU oracle bit for bit."""
+    import pdbatch, oracle_ctypes, sharding
+    ticks, distinct = 300, 37
+    P = pdbatch.packed_params(); trk = pdbatch.synthetic_track(track)
+    lib = pc.load_product(); orc = oracle_ctypes.load_oracle(portable_math=True)
+    S0 = pc.DynState(); assert lib.pdb_initial_state(C.byref(P), trk, C.byref(S0)) == 0
+    base = sharding.global_actions(distinct, 5)
+    base[:, 1] = np.abs(base[:, 1])                  # enough throttle that every car gets going
+    acts = base[np.arange(n_cars) % distinct]
+    b = pdbatch.Batch(n_cars, P, trk, device=0, action_mode=1)
+    try:
+        b.step_host(acts)
+        b.step(ticks - 1)                            # graph replay of the remaining ticks
+        st = b.get_state()
+    finally:
+        b.close()
+    raw = np.frombuffer(bytes(st), dtype=np.uint8).reshape(n_cars, C.sizeof(pc.DynState))
+    for k in range(distinct):
+        reps = raw[k::distinct]
+        assert (reps == reps[0]).all(), 'action %d: replicas differ (first bad lane %d)' % (k, int(np.argmax((reps != reps[0]).any(axis=1))) * distinct + k)
+    for k in range(distinct):
+        h = orc.cpuref_create(C.byref(P), trk, len(trk), C.byref(S0))
+        for t in range(ticks):
+            orc.cpuref_step_env(h, float(base[k, 0]), float(base[k, 1]))
+        sc = pc.DynState(); orc.cpuref_get_state(h, C.byref(sc)); orc.cpuref_destroy(h)
+        rel, name, vg, vc, bad_int = parity_util.compare_states(st[k], sc)
+        assert not bad_int and rel == 0.0, (k, name, vg, vc, bad_int[:3])
