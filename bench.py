@@ -54,6 +54,9 @@ def main():
     ap.add_argument('--warmup', type=int, default=333)
     ap.add_argument('--cars', type=int, default=CARS_PER_GPU)
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--policy', choices=['constant', 'feedback', 'mlp'], default=None,
+                    help='where actions come from each tick: constant (configs[1]), feedback (probe controller on the GPU, default for touge), '
+                         'mlp (configs[4] shape: a SAC-sized 24-256-256-2 tanh MLP with fixed random weights, evaluated with torch on the GPU from the observation block)')
     ap.add_argument('--gather-ticks', type=int, default=8, help='ticks per trajectory ring gathered to the learner (N > 1): 1 = plain per-tick gather')
     ap.add_argument('--force-gather', action='store_true', help='run the observation all-gather even with one rank (exercises the RCCL + side-stream path on a single GPU)')
     ap.add_argument('--backend', default='nccl', help='torch.distributed backend for N > 1 (nccl = RCCL; gloo only to exercise the multi-rank path on a single-GPU box)')
@@ -81,6 +84,7 @@ def main():
         dist.init_process_group(args.backend, init_method='env://')
 
     n = args.cars
+    policy = args.policy or ('feedback' if args.workload == 'touge' else 'constant')
     assert B_ALG == 2 * C.sizeof(pc.DynState) + 8 + C.sizeof(pc.StepOut), 'B_ALG is stale: update it with the record layout'
     P = pdbatch.packed_params()
     trk = pdbatch.synthetic_track(args.workload)
@@ -109,6 +113,14 @@ def main():
     gather = sharding.TrajectoryGather(n, world, 'cuda:%d' % dev_index, dist, k=args.gather_ticks, force=args.force_gather)
     act_t = torch.as_tensor(_Arr(b.actions_device_ptr(), (n, 2)), device='cuda:%d' % dev_index)
 
+    if policy == 'mlp':
+        g = torch.Generator(device='cpu'); g.manual_seed(4567)
+        dev = 'cuda:%d' % dev_index
+        w1 = (torch.randn(24, 256, generator=g) / 24 ** 0.5).to(dev); b1 = torch.zeros(256, device=dev)
+        w2 = (torch.randn(256, 256, generator=g) / 16.0).to(dev); b2 = torch.zeros(256, device=dev)
+        w3 = (torch.randn(256, 2, generator=g) / 16.0).to(dev); b3 = torch.tensor([0.0, 0.5], device=dev)
+        import projectd_env
+        obs_scale = (1.0 / torch.from_numpy(projectd_env.obs_bounds(projectd_env.EnvConfig())[1])).to(dev)
     tick_id = [0]
 
     def tick():
@@ -116,10 +128,15 @@ def main():
         out_t = gather.slot(t)                  # the kernel writes tick t straight into its trajectory-ring slot
         b.set_out_device_ptr(out_t.data_ptr())
         b.step_async()
-        if args.workload == 'touge':   # the policy: oracle/scenarios.h scenarioFeedback as elementwise device ops on the observation block
+        if policy == 'feedback':   # oracle/scenarios.h scenarioFeedback as elementwise device ops on the observation block
             o = out_t
             act_t[:, 0] = torch.clamp(0.03 * (o[:, 21] - o[:, 20]) + 0.015 * (o[:, 19] - o[:, 18]) + 0.15 * o[:, 4], -1.0, 1.0)
             act_t[:, 1] = torch.clamp(0.3 * (12.0 - o[:, 2]), -1.0, 1.0)
+        elif policy == 'mlp':      # obs -> normalise -> 256 -> 256 -> 2, tanh-squashed like SAC's actor mean (hyperparams/sac.yml net_arch)
+            x = out_t[:, :24] * obs_scale
+            h1 = torch.relu(x @ w1 + b1)
+            h2 = torch.relu(h1 @ w2 + b2)
+            torch.tanh(h2 @ w3 + b3, out=act_t)
         gather.after_tick(t)
 
     for _ in range(args.warmup):
@@ -161,8 +178,8 @@ def main():
             "ms_per_step": elapsed * 1000.0 / args.steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32 (+f64 drivetrain)", "data": "synthetic",
-            "config": {"workload": ("configs[1]: %d cars/GPU, AE86, flat-plane track, per-car constant random actions, dt=1/333 s" % n) if args.workload == 'flat' else
-                                   ("configs[2] shape: %d cars/GPU, AE86, synthetic closed mountain road (1782 triangles, 891 spline points), probe-feedback steering on the GPU, dt=1/333 s" % n),
+            "config": {"workload": ("configs[1]: %d cars/GPU, AE86, flat-plane track, %s, dt=1/333 s" % (n, "per-car constant random actions" if policy == "constant" else "policy=" + policy)) if args.workload == 'flat' else
+                                   ("configs[2] shape: %d cars/GPU, AE86, synthetic closed mountain road (1782 triangles, 891 spline points), policy=%s on the GPU, dt=1/333 s" % (n, policy)),
                        "cars_per_gpu": n, "collective": ("RCCL all-gather of %d-tick trajectory rings [k,N,26] obs/reward/flags on a side stream, kernel writes the ring in place" % args.gather_ticks) if (world > 1 or args.force_gather) else "none",
                        "parity": "bit-exact vs CPU oracle (tests/test_gpu_parity.py)"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
