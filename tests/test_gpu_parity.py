@@ -345,3 +345,25 @@ def test_full_size_batches_by_replication(built, n_cars, track):
         sc = pc.DynState(); orc.cpuref_get_state(h, C.byref(sc)); orc.cpuref_destroy(h)
         rel, name, vg, vc, bad_int = parity_util.compare_states(st[k], sc)
         assert not bad_int and rel == 0.0, (k, name, vg, vc, bad_int[:3])
+
+
+def test_snapshot_restore_replays_identically(built):
+    """state snapshot / restore through pdb_get_state / pdb_set_state (episode resets from saved states): the
+    record is the whole per-car state, so restoring it and replaying the same actions reproduces the trajectory bit for bit"""
+    import pdbatch, sharding
+    n = 96
+    P = pdbatch.packed_params('ks_toyota_supra_mkiv_drift.env'); trk = pdbatch.synthetic_track('touge')
+    b = pdbatch.Batch(n, P, trk, device=0, action_mode=1)
+    try:
+        a = sharding.global_actions(n, 11); a[:, 1] = np.abs(a[:, 1])
+        for _ in range(400):
+            b.step_host(a)
+        snap = b.get_state()
+        outs1 = [b.step_host(a).copy() for _ in range(200)]
+        end1 = bytes(b.get_state())
+        b.set_state(snap)
+        outs2 = [b.step_host(a).copy() for _ in range(200)]
+        assert bytes(b.get_state()) == end1
+        assert all(o1.tobytes() == o2.tobytes() for o1, o2 in zip(outs1, outs2))
+    finally:
+        b.close()
