@@ -210,7 +210,7 @@ static float damperForce(const pdb_damper& d, float speed) {
 // ISuspension::getHubWorldMatrix (SuspensionStrut.cpp:367-373, SuspensionAxle.cpp:224-232)
 static M44 hubWorldMatrix(const pdb_car_params& P, const pdrb::World& w, int i) {
     const pdb_susp& su = P.susp[i];
-    if (su.type == PDB_SUSP_STRUT || su.type == PDB_SUSP_DW) {   // SuspensionDW.cpp:343-346: mat44f::rotate == the same product
+    if (su.type != PDB_SUSP_AXLE) {   // SuspensionDW.cpp:343-346, SuspensionML.cpp:198-201: mat44f::rotate == the same product
         const M44 m0 = worldMatrix(w.bodies[su.hubBody]);
         const M44 rot = axisAngle(V3(0, 0, 1), su.staticCamber);
         return mult44(rot, m0);
@@ -320,6 +320,36 @@ static void dwStep(const pdb_susp& su, pdrb::World& w, TyreScratch& sc) {
         const V3 lf(0, fForce, 0);
         body.addRelForceAtRelPos(&lf.x, &vHubLocalPos.x);
     }
+}
+
+// SuspensionML::step (SuspensionML.cpp:106-137): like the double wishbone's travel spring, but applied whatever its sign,
+// a plain packer term and no bump stops
+static void mlStep(const pdb_susp& su, pdrb::World& w, TyreScratch& sc) {
+    Body& body = w.bodies[PDB_BODY_CHASSIS];
+    Body& hub = w.bodies[su.hubBody];
+    const M44 mb = worldMatrix(body);
+    const V3 vM2(mb.m[4], mb.m[5], mb.m[6]);
+    const V3 vHubWorld = getPos(hub);
+    const V3 vHubLocal = w2l(body, vHubWorld);
+    const V3 basePos(su.basePosition);
+    const float fTravel = (vHubLocal.y - basePos.y) + su.rodLength;
+    sc.travel = fTravel;
+    float fForce = (fTravel * su.progressiveK + su.k) * fTravel;
+    if (su.packerRange != 0.0f && fTravel > su.packerRange && su.k != 0.0f) fForce += ((fTravel - su.packerRange) * su.bumpStopRate);
+    {
+        const V3 f = vM2 * -fForce;
+        hub.addForceAtPos(&f.x, &vHubWorld.x);
+        const V3 lf(0.0f, fForce, 0.0f);
+        body.addRelForceAtRelPos(&lf.x, &basePos.x);
+    }
+    const V3 vPointVel = localPointVel(body, basePos);
+    const V3 vDeltaVel = getVelocity(hub) - vPointVel;
+    const float fDamperSpeed = vDeltaVel * vM2;
+    sc.damperSpeedMS = fDamperSpeed;
+    const V3 vForce = vM2 * damperForce(su.damper, fDamperSpeed);
+    hub.addForceAtPos(&vForce.x, &vHubWorld.x);
+    const V3 neg = vForce * -1.0f;
+    body.addForceAtRelPos(&neg.x, &basePos.x);
 }
 
 // SuspensionAxle::step (SuspensionAxle.cpp:120-185)
@@ -1262,6 +1292,7 @@ void Car::carStep(float dt) {
     for (int i = 0; i < 4; ++i) {
         if (Pm.susp[i].type == PDB_SUSP_STRUT) strutStep(Pm.susp[i], w, ts[i]);
         else if (Pm.susp[i].type == PDB_SUSP_DW) dwStep(Pm.susp[i], w, ts[i]);
+        else if (Pm.susp[i].type == PDB_SUSP_ML) mlStep(Pm.susp[i], w, ts[i]);
         else axleStep(Pm.susp[i], w, ts[i]);
     }
     for (int i = 0; i < 4; ++i) tyreStep(*this, i, dt);

@@ -8,6 +8,36 @@ here = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.join(here, '..', 'projectd-core_amd'))
 import synthetic_tracks as gen_track
 REF = '/root/reference'
+def make_multilink_car(base, src='ks_toyota_supra_mkiv_drift', dst='pdb_ml_supra'):
+    """No shipped car uses the reference's multilink suspension (Car/SuspensionML.cpp), so there is nothing to run it on.  This
+    derives one: the Supra's data directory with suspensions.ini rewritten to TYPE=ML front and rear, the five links
+    (JOINTn_CAR / JOINTn_TYRE) taken from the double wishbone's pick-up points (top rear/front, bottom rear/front, steering
+    link).  The reference TUs load and run it like any other car, which pins the oracle's restatement of that class."""
+    import re
+    s = os.path.join(REF, 'content', 'cars', src, 'data'); d = os.path.join(base, 'content', 'cars', dst, 'data')
+    if os.path.isdir(d):
+        shutil.rmtree(d)
+    shutil.copytree(s, d)
+    os.system('chmod -R u+w "%s"' % d)
+    p = os.path.join(d, 'suspensions.ini')
+    raw = open(p, newline='').read()
+    eol = '\r\n' if '\r\n' in raw else '\n'          # keep the file's own line endings (the reference's reader does not strip CR)
+    text = raw.replace('\r\n', '\n')
+    out = []
+    for sec in re.split(r'(?m)^(?=\[)', text):
+        m = re.match(r'\[(FRONT|REAR)\]', sec)
+        if m:
+            kv = dict(l.split('=', 1) for l in sec.splitlines()[1:] if '=' in l)
+            links = [('WBCAR_TOP_REAR', 'WBTYRE_TOP'), ('WBCAR_TOP_FRONT', 'WBTYRE_TOP'), ('WBCAR_BOTTOM_REAR', 'WBTYRE_BOTTOM'),
+                     ('WBCAR_BOTTOM_FRONT', 'WBTYRE_BOTTOM'), ('WBCAR_STEER', 'WBTYRE_STEER')]
+            sec = sec.replace('TYPE=DWB', 'TYPE=ML').rstrip('\n') + '\n'
+            for i, (c, t) in enumerate(links):
+                sec += 'JOINT%d_CAR=%s\nJOINT%d_TYRE=%s\n' % (i, kv[c].strip(), i, kv[t].strip())
+            sec += '\n'
+        out.append(sec)
+    open(p, 'w', newline='').write(''.join(out).replace('\n', eol))
+
+
 def main():
     base = os.path.join(here, '_ref', 'base')
     os.makedirs(os.path.join(base, 'cfg'), exist_ok=True)
@@ -18,6 +48,7 @@ def main():
             shutil.rmtree(dst)
         shutil.copytree(os.path.join(REF, 'content', 'cars', model, 'data'), dst)
         os.system('chmod -R u+w "%s"' % dst)
+    make_multilink_car(base)
     gen_track.gen_flat(os.path.join(base, 'content', 'tracks', 'flat'))
     gen_track.gen_touge(os.path.join(base, 'content', 'tracks', 'touge'))
     for trk in ('driftplayground',):

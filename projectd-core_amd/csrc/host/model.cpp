@@ -283,11 +283,11 @@ void buildCarModel(const std::string& basePathIn, const std::string& modelName, 
     Ini sus(dataPath + "suspensions.ini");
     if (!sus.ready) throw std::runtime_error("pdb: suspensions.ini not found");
     const std::string typeF = sus.getString("FRONT", "TYPE"), typeR = sus.getString("REAR", "TYPE");
-    if ((typeF != "STRUT" && typeF != "DWB") || (typeR != "AXLE" && typeR != "DWB"))
-        throw std::runtime_error("pdb: suspension types " + typeF + "/" + typeR + " are not implemented (front STRUT|DWB, rear AXLE|DWB)");
+    if ((typeF != "STRUT" && typeF != "DWB" && typeF != "ML") || (typeR != "AXLE" && typeR != "DWB" && typeR != "ML"))
+        throw std::runtime_error("pdb: suspension types " + typeF + "/" + typeR + " are not implemented (front STRUT|DWB|ML, rear AXLE|DWB|ML)");
     if (sus.hasSection("HEAVE_FRONT") || sus.hasSection("HEAVE_REAR")) throw std::runtime_error("pdb: heave springs are not implemented");
-    P.suspTypeF = (typeF == "STRUT") ? PDB_SUSP_STRUT : PDB_SUSP_DW;
-    P.suspTypeR = (typeR == "AXLE") ? PDB_SUSP_AXLE : PDB_SUSP_DW;
+    P.suspTypeF = (typeF == "STRUT") ? PDB_SUSP_STRUT : (typeF == "ML") ? PDB_SUSP_ML : PDB_SUSP_DW;
+    P.suspTypeR = (typeR == "AXLE") ? PDB_SUSP_AXLE : (typeR == "ML") ? PDB_SUSP_ML : PDB_SUSP_DW;
     if (typeR == "AXLE") P.axleTorqueReaction = sus.getFloat("AXLE", "TORQUE_REACTION");
     // body slots in the reference's creation order (Car.cpp:38-39,63-107): chassis, tank, [rigid axle], then per wheel
     // hub (+ strut body for struts)
@@ -391,9 +391,59 @@ void buildCarModel(const std::string& basePathIn, const std::string& modelName, 
         for (size_t k = J.size() - 5; k < J.size(); ++k) { J[k].d.erp = 0.3f; J[k].d.cfm = 0.0000001f; }   // setERPCFM(0.3, baseCFM)
     };
 
+    // ---- multilink (SuspensionML.cpp:16-104): hub body + 5 distance joints given as (car, tyre) ball pairs relative to the wheel;
+    //      no bump stops, damper thresholds as written in the file, joints keep the world ERP/CFM (setERPCFM is empty) ----
+    auto initML = [&](int index) {
+        pdb_susp& S = P.susp[index];
+        memset(&S, 0, sizeof(S));
+        S.type = PDB_SUSP_ML;
+        const int hubB = hubOf[index];
+        S.hubBody = hubB; S.strutBody = -1;
+        const std::string id = (index < 2) ? "FRONT" : "REAR";
+        float ref[3];
+        if (index < 2) v3set(ref, (index == 0) ? frontTrack : -frontTrack, frontBaseY, (1.0f - cg) * wheelBase);
+        else v3set(ref, (index == 2) ? rearTrack : -rearTrack, rearBaseY, -(cg * wheelBase));
+        memcpy(S.basePosition, ref, sizeof(ref));
+        S.refPointY = ref[1];
+        S.refPointSignX = (ref[0] > 0.0f) ? 1.0f : ((ref[0] < 0.0f) ? -1.0f : 0.0f);
+        const float hubMass = sus.getFloat(id, "HUB_MASS");
+        B[hubB].mass = hubMass; hBoxInertia(hubMass, 0.2f, 0.6f, 0.6f, B[hubB].inertia);
+        S.mass = hubMass;
+        float Mb[9]; hWorldMatrix3(B[0], Mb);
+        hSetRotationM(B[hubB], Mb);
+        hLocalToWorld(B[0], S.basePosition, B[hubB].pos);
+        for (int i = 0; i < 5; ++i) {
+            char kc[32], kt[32]; snprintf(kc, sizeof(kc), "JOINT%d_CAR", i); snprintf(kt, sizeof(kt), "JOINT%d_TYRE", i);
+            float car[3], tyre[3], w[3], relCarC[3], relCarT[3], vC[3], vT[3];
+            sus.getFloat3(id, kc, car); sus.getFloat3(id, kt, tyre);
+            if (ref[0] > 0.0f) { car[0] *= -1.0f; tyre[0] *= -1.0f; }
+            hLocalToWorld(B[hubB], car, w); hWorldToLocal(B[0], w, relCarC);     // ballCar.relToCar
+            hLocalToWorld(B[hubB], tyre, w); hWorldToLocal(B[0], w, relCarT);    // ballTyre.relToCar
+            hLocalToWorld(B[0], relCarC, vC); hLocalToWorld(B[0], relCarT, vT);
+            mkDBall(J, B, PDB_BODY_CHASSIS, hubB, vC, vT, P.worldErp, P.worldCfm);
+            J.back().d.suspErp = 0;
+            if (i == 4) {
+                memcpy(S.baseCarSteer, relCarC, sizeof(float) * 3);   // baseCarSteerPosition = joints[4].ballCar.relToCar
+                memcpy(S.tyreSteer, tyre, sizeof(float) * 3);         // joints[4].ballTyre.relToTyre
+                if (index < 2) J.back().d.steerWheel = index;
+            }
+        }
+        S.rodLength = sus.getFloat(id, "ROD_LENGTH");
+        S.toeOutLinear = sus.getFloat(id, "TOE_OUT");
+        S.k = sus.getFloat(id, "SPRING_RATE");
+        S.progressiveK = sus.getFloat(id, "PROGRESSIVE_SPRING_RATE");
+        S.damper.bumpSlow = sus.getFloat(id, "DAMP_BUMP"); S.damper.reboundSlow = sus.getFloat(id, "DAMP_REBOUND");
+        S.damper.bumpFast = sus.getFloat(id, "DAMP_FAST_BUMP"); S.damper.reboundFast = sus.getFloat(id, "DAMP_FAST_REBOUND");
+        S.damper.fastThresholdBump = sus.getFloat(id, "DAMP_FAST_BUMPTHRESHOLD"); S.damper.fastThresholdRebound = sus.getFloat(id, "DAMP_FAST_REBOUNDTHRESHOLD");
+        S.staticCamber = -sus.getFloat(id, "STATIC_CAMBER") * 0.017453f;
+        if (index % 2) S.staticCamber *= -1.0f;
+        // packerRange / bumpStopRate / bump stops keep the SuspensionBase defaults (0): SuspensionML::init never reads them
+    };
+
     // ---- front struts (SuspensionStrut.cpp:17-228) ----
     for (int index = 0; index < 2; ++index) {
         if (typeF == "DWB") { initDW(index); continue; }
+        if (typeF == "ML") { initML(index); continue; }
         pdb_susp& S = P.susp[index];
         memset(&S, 0, sizeof(S));
         S.type = PDB_SUSP_STRUT;
@@ -491,6 +541,7 @@ void buildCarModel(const std::string& basePathIn, const std::string& modelName, 
     // ---- rear rigid axle (SuspensionAxle.cpp:15-118) ----
     for (int index = 2; index < 4; ++index) {
         if (typeR == "DWB") { initDW(index); continue; }
+        if (typeR == "ML") { initML(index); continue; }
         pdb_susp& S = P.susp[index];
         memset(&S, 0, sizeof(S));
         S.type = PDB_SUSP_AXLE; S.hubBody = axleB; S.strutBody = -1;

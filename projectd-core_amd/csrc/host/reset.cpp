@@ -50,7 +50,7 @@ static void attachAll(const pdb_car_params& P, pdb_dyn_state& S) {
             hSetRotationM(strut, Ms);
             for (int k = 0; k < 3; ++k) strut.pos[k] = (vNorm[k] * su.strutBodyLength) * 0.5f + vCarStrut[k];
             fromHBody(hub, S.body[su.hubBody]); fromHBody(strut, S.body[su.strutBody]);
-        } else if (su.type == PDB_SUSP_DW) {   // SuspensionDW::attach (SuspensionDW.cpp:156-162)
+        } else if (su.type == PDB_SUSP_DW || su.type == PDB_SUSP_ML) {   // SuspensionDW::attach (SuspensionDW.cpp:156-162), SuspensionML::attach (:95-99)
             HBody hub; toHBody(S.body[su.hubBody], hub);
             hSetRotationM(hub, Mb);
             hLocalToWorld(body, su.basePosition, hub.pos);

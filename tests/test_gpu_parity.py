@@ -203,16 +203,16 @@ def test_full_controls_random(built):
         assert worst == 0.0
 
 
-@pytest.mark.parametrize('model', ['ks_mazda_rx7_tuned', 'ks_toyota_supra_mkiv_drift', 'dthwsh_mazda_rx7_fc3s_sr20', 'gravygarage_street_ae86_readie'])
+@pytest.mark.parametrize('model', ['ks_mazda_rx7_tuned', 'ks_toyota_supra_mkiv_drift', 'dthwsh_mazda_rx7_fc3s_sr20', 'gravygarage_street_ae86_readie', 'pdb_ml_supra'])
 def test_double_wishbone_turbo_cars(built, model):
     """the other four cars the reference ships: double wishbones on all four wheels (6 bodies, 21 joints, 26 rows -> the
     row-guarded kernel), or struts in front and double wishbones behind (8 bodies, 38 rows -> the 40-row LDS size class);
-    one / two turbos, 5 / 6 forward gears, up to 5 wings.  32 cars x 1200 ticks, random constant actions."""
+    one / two turbos, 5 / 6 forward gears, up to 5 wings; and the derived multilink car (reference SuspensionML front and rear).  32 cars x 1200 ticks, random constant actions."""
     worst = parity_util.run_parity(n_cars=32, ticks=1200, seed=21, resync=False, verbose=True, check_every=20, model=model)
     assert worst == 0.0
 
 
-@pytest.mark.parametrize('model', ['ks_toyota_ae86_drift', 'ks_toyota_supra_mkiv_drift', 'gravygarage_street_ae86_readie'])
+@pytest.mark.parametrize('model', ['ks_toyota_ae86_drift', 'ks_toyota_supra_mkiv_drift', 'gravygarage_street_ae86_readie', 'pdb_ml_supra'])
 def test_touge_closed_loop_feedback(built, model):
     """BASELINE configs[2] shape: closed, hilly, banked mountain road (1782 triangles, 891 spline points, CLOSED_LOOP=1), 16 cars
     spread around the lap, each steered by the probe-feedback controller of oracle/scenarios.h from its own observations

@@ -10,11 +10,13 @@ REF = '/root/reference'
 lib = pc.load_product(host_only=True)
 out = os.path.join(ROOT, 'projectd-core_amd', 'data')
 os.makedirs(out, exist_ok=True)
-for m in sorted(os.listdir(os.path.join(REF, 'content', 'cars'))):
+DERIVED = os.path.join(ROOT, 'oracle', '_ref', 'base')   # cars derived for the fixtures (oracle/make_base.py): the multilink Supra
+models = [(REF, m) for m in sorted(os.listdir(os.path.join(REF, 'content', 'cars')))] + [(DERIVED, 'pdb_ml_supra')]
+for REFB, m in models:
     P = pc.CarParams()
-    if lib.pdb_build_car_model(REF.encode(), m.encode(), C.byref(P)) != 0:
+    if lib.pdb_build_car_model(REFB.encode(), m.encode(), C.byref(P)) != 0:
         print('%-36s not supported: %s' % (m, lib.pdb_last_error().decode())); continue
     open(os.path.join(out, m + '.default.pdcar'), 'wb').write(bytes(P))
-    E = pc.env_params(lib, REF, m)
+    E = pc.env_params(lib, REFB, m)
     open(os.path.join(out, m + '.env.pdcar'), 'wb').write(bytes(E))
     print('%-36s bodies %d joints %d rows %d turbos %d gears %d' % (m, P.numBodies, P.numJoints, P.numRows, P.numTurbos, P.numGears))
