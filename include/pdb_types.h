@@ -112,6 +112,12 @@ typedef struct pdb_susp {
     float bumpStopProgressive;
 } pdb_susp;
 
+typedef struct pdb_heave {               /* Car/HeaveSpring.h: third spring/damper across a double-wishbone axle; active when k != 0 */
+    float k, progressiveK, bumpStopUp, bumpStopDn, rodLength, bumpStopRate, packerRange;
+    pdb_damper damper;
+    int32_t _pad;
+} pdb_heave;
+
 #define PDB_MAX_TURBOS 3
 typedef struct pdb_turbo {               /* Car/Turbo.h TurboDef + Turbo::userSetting */
     float lagDN, lagUP, maxBoost, wastegate, rpmRef, gamma, userSetting;
@@ -191,6 +197,7 @@ typedef struct pdb_car_params {
     int32_t engMinimum, engLimiter, engLimiterCycles;
     float engCoast1, engCoast2, engInertia, limiterMultiplier, rpmDamageThreshold, rpmDamageK, bovThreshold;
     float maxPowerRPM, maxTorqueRPM;
+    pdb_heave heave[2];                  /* front, rear */
     int32_t numTurbos;
     pdb_turbo turbos[PDB_MAX_TURBOS];
     float turboBoostDamageThreshold, turboBoostDamageK;
@@ -300,7 +307,7 @@ typedef struct pdb_track_header {
 }
 /* sizes are part of the ABI (tests/test_abi.py reads these numbers) */
 static_assert(sizeof(pdb_car_state) == 664, "pdb_car_state must equal the reference CarState (pack 4)");
-static_assert(sizeof(pdb_car_params) == 10104, "pdb_car_params layout");
+static_assert(sizeof(pdb_car_params) == 10216, "pdb_car_params layout");
 static_assert(sizeof(pdb_dyn_state) == 2224, "pdb_dyn_state layout (multiple of 16 bytes)");
 static_assert(sizeof(pdb_step_out) == 104, "pdb_step_out layout");
 #endif

@@ -352,6 +352,42 @@ static void mlStep(const pdb_susp& su, pdrb::World& w, TyreScratch& sc) {
     body.addForceAtRelPos(&neg.x, &basePos.x);
 }
 
+// HeaveSpring::step (HeaveSpring.cpp:56-149) for the axle whose wheels are i0, i0 + 1 (both double wishbones)
+static void heaveStep(const pdb_car_params& P, const pdb_heave& H, pdrb::World& w, int i0) {
+    const pdb_susp& s0 = P.susp[i0];
+    const pdb_susp& s1 = P.susp[i0 + 1];
+    Body& body = w.bodies[PDB_BODY_CHASSIS];
+    Body& hub0 = w.bodies[s0.hubBody];
+    Body& hub1 = w.bodies[s1.hubBody];
+    const M44 mb = worldMatrix(body);
+    const V3 vM2(mb.m[4], mb.m[5], mb.m[6]);
+    const V3 ref0(s0.basePosition), ref1(s1.basePosition);
+    const V3 hubPos0 = getPos(hub0), hubPos1 = getPos(hub1);
+    const V3 hubLoc0 = w2l(body, hubPos0), hubLoc1 = w2l(body, hubPos1);
+    float rodLength = H.rodLength;
+    if (s0.k != 0.0f || s1.k != 0.0f) rodLength = (s1.rodLength + s0.rodLength) * 0.5f;
+    const float fAvgY = (hubLoc0.y + hubLoc1.y) * 0.5f;
+    const float fTravel = (fAvgY - ref0.y) + rodLength;
+    float v12 = ((fTravel * H.progressiveK) + H.k) * fTravel;
+    if (H.packerRange != 0.0f && fTravel > H.packerRange) v12 += ((fTravel - H.packerRange) * H.bumpStopRate);
+    auto pair = [&](const V3& hubForce, const V3& bodyLocalForce) {
+        hub0.addForceAtPos(&hubForce.x, &hubPos0.x);
+        hub1.addForceAtPos(&hubForce.x, &hubPos1.x);
+        body.addRelForceAtRelPos(&bodyLocalForce.x, &ref0.x);
+        body.addRelForceAtRelPos(&bodyLocalForce.x, &ref1.x);
+    };
+    pair(vM2 * -v12, V3(0, v12, 0));
+    const float fDeltaY0 = fAvgY - ref0.y;
+    if (H.bumpStopUp != 0.0f && fDeltaY0 > H.bumpStopUp) { const float f = (fDeltaY0 - H.bumpStopUp) * 500000.0f; pair(vM2 * -f, V3(0, f, 0)); }
+    if (H.bumpStopDn != 0.0f && fDeltaY0 < H.bumpStopDn) { const float f = (fDeltaY0 - H.bumpStopDn) * 500000.0f; pair(vM2 * -f, V3(0, f, 0)); }
+    const V3 vHubVel = (getVelocity(hub0) + getVelocity(hub1)) * 0.5f;
+    const V3 vLpv = (localPointVel(body, ref0) + localPointVel(body, ref1)) * 0.5f;
+    const V3 vDeltaVel = vHubVel - vLpv;
+    const float fDamperSpeed = vDeltaVel * vM2;
+    const V3 vForce = vM2 * damperForce(H.damper, fDamperSpeed);
+    pair(vForce, vForce * -1.0f);   // the reference hands the world-space vector to addLocalForceAtLocalPos (HeaveSpring.cpp:145-147)
+}
+
 // SuspensionAxle::step (SuspensionAxle.cpp:120-185)
 static void axleStep(const pdb_susp& su, pdrb::World& w, TyreScratch& sc) {
     Body& body = w.bodies[PDB_BODY_CHASSIS];
@@ -1296,6 +1332,7 @@ void Car::carStep(float dt) {
         else axleStep(Pm.susp[i], w, ts[i]);
     }
     for (int i = 0; i < 4; ++i) tyreStep(*this, i, dt);
+    for (int a = 0; a < 2; ++a) if (Pm.heave[a].k != 0.0f) heaveStep(Pm, Pm.heave[a], w, a * 2);   // Car.cpp:654-658
     for (int wi = 0; wi < Pm.numWings; ++wi) wingStep(*this, wi);
     {   // SteeringSystem::step (SteeringSystem.cpp:17-24) -> setSteerLengthOffset (SuspensionStrut.cpp:340-350)
         const float steer = -finalSteerAngleSignal * Pm.steerLinearRatio;

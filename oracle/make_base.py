@@ -38,6 +38,26 @@ def make_multilink_car(base, src='ks_toyota_supra_mkiv_drift', dst='pdb_ml_supra
     open(p, 'w', newline='').write(''.join(out).replace('\n', eol))
 
 
+def make_heave_car(base, src='ks_mazda_rx7_tuned', dst='pdb_heave_rx7'):
+    """No shipped car carries [HEAVE_FRONT] / [HEAVE_REAR] (Car/HeaveSpring.cpp stays idle with k = 0).  This derives one: the
+    tuned RX-7 (double wishbones all round) with a third spring/damper across each axle, stiff enough that its bump stops and
+    packer come into play on the mountain road."""
+    s = os.path.join(REF, 'content', 'cars', src, 'data'); d = os.path.join(base, 'content', 'cars', dst, 'data')
+    if os.path.isdir(d):
+        shutil.rmtree(d)
+    shutil.copytree(s, d)
+    os.system('chmod -R u+w "%s"' % d)
+    p = os.path.join(d, 'suspensions.ini')
+    raw = open(p, newline='').read()
+    eol = '\r\n' if '\r\n' in raw else '\n'
+    def section(name, k, rod, up, dn, packer, bump, rebound):
+        return ['', '[%s]' % name, 'SPRING_RATE=%d' % k, 'PROGRESSIVE_SPRING_RATE=15000', 'ROD_LENGTH=%.3f' % rod, 'BUMPSTOP_UP=%.3f' % up,
+                'BUMPSTOP_DN=%.3f' % dn, 'PACKER_RANGE=%.3f' % packer, 'BUMP_STOP_RATE=0', 'DAMP_BUMP=%d' % bump, 'DAMP_REBOUND=%d' % rebound,
+                'DAMP_FAST_BUMP=%d' % (bump // 2), 'DAMP_FAST_REBOUND=%d' % (rebound // 2), 'DAMP_FAST_BUMPTHRESHOLD=0.08', 'DAMP_FAST_REBOUNDTHRESHOLD=0']
+    extra = section('HEAVE_FRONT', 30000, 0.02, 0.012, 0.02, 0.03, 1800, 3500) + section('HEAVE_REAR', 22000, 0.015, 0.015, 0.025, 0.035, 1500, 3000) + ['']
+    open(p, 'w', newline='').write(raw.rstrip('\r\n') + eol + eol.join(extra))
+
+
 def main():
     base = os.path.join(here, '_ref', 'base')
     os.makedirs(os.path.join(base, 'cfg'), exist_ok=True)
@@ -49,6 +69,7 @@ def main():
         shutil.copytree(os.path.join(REF, 'content', 'cars', model, 'data'), dst)
         os.system('chmod -R u+w "%s"' % dst)
     make_multilink_car(base)
+    make_heave_car(base)
     gen_track.gen_flat(os.path.join(base, 'content', 'tracks', 'flat'))
     gen_track.gen_touge(os.path.join(base, 'content', 'tracks', 'touge'))
     for trk in ('driftplayground',):

@@ -27,8 +27,9 @@ static const Scenario kScenarios[] = {
     {"readie", 5000, 300, 10, 0, 1, 1, 1, "touge", 1, "gravygarage_street_ae86_readie"},   // strut front + double wishbone rear on the mountain road
     {"playground", 2500, 300, 10, 0, 1, 1, 1, "driftplayground", 1, nullptr},   // the env's default track as shipped (510 surfaces, 112 411 triangles, spline.cache)
     {"multilink", 4000, 300, 10, 0, 1, 1, 1, "touge", 1, "pdb_ml_supra"},   // reference SuspensionML on a derived car (oracle/make_base.py), front and rear
+    {"heave", 4000, 300, 10, 0, 1, 1, 1, "touge", 1, "pdb_heave_rx7"},       // reference HeaveSpring on a derived car (third spring across both axles)
 };
-static const int kNumScenarios = 13;
+static const int kNumScenarios = 14;
 #define PDORACLE_DEFAULT_CAR "ks_toyota_ae86_drift"
 
 // closed-loop action from the previous observation (projectd_env.py:239-273 slot order): centre between the side probes,

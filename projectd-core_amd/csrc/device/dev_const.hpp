@@ -4,8 +4,8 @@
 #include "pmath.hpp"
 
 #define PDB_WAVE 64
-#define PDB_CH_SLOTS 44          // chassis contribution slots: 4x5 suspension, 4 tyre, 2x6 wings, 1 axle reaction, 4 ARB (+ spare)
-#define PDB_HUB_SLOTS 8
+#define PDB_CH_SLOTS 60          // chassis contribution slots in the reference's call order: 4x5 suspension, 4 tyre, 2x8 heave, 6x2 wings, 1 axle reaction, 4 ARB (+ spare)
+#define PDB_HUB_SLOTS 12         // per hub: 4 suspension, 3 tyre, 4 heave, 1 ARB
 #define PDB_AXLE_SLOTS 20
 
 struct DevConst {

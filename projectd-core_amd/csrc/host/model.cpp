@@ -285,7 +285,6 @@ void buildCarModel(const std::string& basePathIn, const std::string& modelName, 
     const std::string typeF = sus.getString("FRONT", "TYPE"), typeR = sus.getString("REAR", "TYPE");
     if ((typeF != "STRUT" && typeF != "DWB" && typeF != "ML") || (typeR != "AXLE" && typeR != "DWB" && typeR != "ML"))
         throw std::runtime_error("pdb: suspension types " + typeF + "/" + typeR + " are not implemented (front STRUT|DWB|ML, rear AXLE|DWB|ML)");
-    if (sus.hasSection("HEAVE_FRONT") || sus.hasSection("HEAVE_REAR")) throw std::runtime_error("pdb: heave springs are not implemented");
     P.suspTypeF = (typeF == "STRUT") ? PDB_SUSP_STRUT : (typeF == "ML") ? PDB_SUSP_ML : PDB_SUSP_DW;
     P.suspTypeR = (typeR == "AXLE") ? PDB_SUSP_AXLE : (typeR == "ML") ? PDB_SUSP_ML : PDB_SUSP_DW;
     if (typeR == "AXLE") P.axleTorqueReaction = sus.getFloat("AXLE", "TORQUE_REACTION");
@@ -579,6 +578,23 @@ void buildCarModel(const std::string& basePathIn, const std::string& modelName, 
         if (iVer >= 3) S.leafSpringKx = sus.getFloat("AXLE", "LEAF_SPRING_LAT_K");
         v3set(S.basePosition, S.sideSign * S.axleTrack, S.axleBasePos[1], S.axleBasePos[2]);   // getBasePosition()
         S.mass = B[axleB].mass * 0.5f;
+    }
+
+    // ---- heave springs (Car.cpp:131-147, HeaveSpring.cpp:11-54): one per axle whose two wheels are double wishbones ----
+    for (int a = 0; a < 2; ++a) {
+        pdb_heave& H = P.heave[a];
+        memset(&H, 0, sizeof(H));
+        const std::string id = a ? "HEAVE_REAR" : "HEAVE_FRONT";
+        if (P.susp[a * 2].type != PDB_SUSP_DW || P.susp[a * 2 + 1].type != PDB_SUSP_DW || !sus.hasSection(id)) continue;
+        H.bumpStopUp = sus.getFloat(id, "BUMPSTOP_UP");
+        H.bumpStopDn = -sus.getFloat(id, "BUMPSTOP_DN");
+        H.rodLength = sus.getFloat(id, "ROD_LENGTH");
+        H.k = sus.getFloat(id, "SPRING_RATE");
+        H.progressiveK = sus.getFloat(id, "PROGRESSIVE_SPRING_RATE");
+        loadDamper(H.damper, id);
+        H.bumpStopRate = sus.getFloat(id, "BUMP_STOP_RATE");
+        if (H.bumpStopRate == 0.0f) H.bumpStopRate = 500000.0f;
+        H.packerRange = sus.getFloat(id, "PACKER_RANGE");
     }
 
     // ---- tyres ----

@@ -40,6 +40,8 @@ class Susp(C.Structure):
          ('baseCarSteer', C.c_float * 3), ('refPointY', C.c_float), ('refPointSignX', C.c_float), ('strutBaseLength', C.c_float), ('strutBodyLength', C.c_float),
          ('axleTrack', C.c_float), ('referenceY', C.c_float), ('attachRelativePos', C.c_float), ('leafSpringKx', C.c_float), ('axleBasePos', C.c_float * 3),
          ('sideSign', C.c_float), ('mass', C.c_float), ('bumpStopProgressive', C.c_float)]
+class Heave(C.Structure):
+    _fields_ = [(n, C.c_float) for n in ('k', 'progressiveK', 'bumpStopUp', 'bumpStopDn', 'rodLength', 'bumpStopRate', 'packerRange')] + [('damper', Damper), ('_pad', C.c_int32)]
 class Turbo(C.Structure):
     _fields_ = [(n, C.c_float) for n in ('lagDN', 'lagUP', 'maxBoost', 'wastegate', 'rpmRef', 'gamma', 'userSetting')] + [('isAdjustable', C.c_int32)]
 class Tyre(C.Structure):
@@ -74,7 +76,7 @@ class CarParams(C.Structure):
                                    'validShiftRPMWindow', 'damageRpmWindow', 'clutchMaxTorque', 'clutchInertia', 'driveInertia', 'engineInertiaInit', 'outShaftInertiaL', 'outShaftInertiaR')] + \
         [('powerCurve', Curve), ('throttleCurve', Curve), ('engMinimum', C.c_int32), ('engLimiter', C.c_int32), ('engLimiterCycles', C.c_int32)] + \
         [(n, C.c_float) for n in ('engCoast1', 'engCoast2', 'engInertia', 'limiterMultiplier', 'rpmDamageThreshold', 'rpmDamageK', 'bovThreshold', 'maxPowerRPM', 'maxTorqueRPM')] + \
-        [('numTurbos', C.c_int32), ('turbos', Turbo * 3), ('turboBoostDamageThreshold', C.c_float), ('turboBoostDamageK', C.c_float), ('_padEngine', C.c_int32)] + \
+        [('heave', Heave * 2), ('numTurbos', C.c_int32), ('turbos', Turbo * 3), ('turboBoostDamageThreshold', C.c_float), ('turboBoostDamageK', C.c_float), ('_padEngine', C.c_int32)] + \
         [(n, C.c_float) for n in ('acRpmMin', 'acRpmMax', 'acClutchSpeed')] + \
         [(n, C.c_int32) for n in ('acUseOnChange', 'acUseOnStart', 'autoShiftActive', 'autoBlipActive', 'autoBlipElectronic')] + \
         [('upshiftProfile', Curve), ('downshiftProfile', Curve), ('blipProfile', Curve), ('blipPerformTime', C.c_double), ('asChangeUpRpm', C.c_int32), ('asChangeDnRpm', C.c_int32),

@@ -212,7 +212,7 @@ def test_double_wishbone_turbo_cars(built, model):
     assert worst == 0.0
 
 
-@pytest.mark.parametrize('model', ['ks_toyota_ae86_drift', 'ks_toyota_supra_mkiv_drift', 'gravygarage_street_ae86_readie', 'pdb_ml_supra'])
+@pytest.mark.parametrize('model', ['ks_toyota_ae86_drift', 'ks_toyota_supra_mkiv_drift', 'gravygarage_street_ae86_readie', 'pdb_ml_supra', 'pdb_heave_rx7'])
 def test_touge_closed_loop_feedback(built, model):
     """BASELINE configs[2] shape: closed, hilly, banked mountain road (1782 triangles, 891 spline points, CLOSED_LOOP=1), 16 cars
     spread around the lap, each steered by the probe-feedback controller of oracle/scenarios.h from its own observations
