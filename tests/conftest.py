@@ -8,6 +8,15 @@ sys.path.insert(0, HERE)
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, 'projectd-core_amd'))
 
+# PyTorch bundles its own HIP runtime: when both live in one process, torch.cuda has to come up before libpdbatch.so pulls in
+# the system's libamdhip64 (the other order leaves torch without a device).  Harmless on a box without a GPU.
+try:
+    import torch as _torch
+    if _torch.cuda.is_available():
+        _torch.cuda.init()
+except Exception:   # pragma: no cover
+    pass
+
 import pdb_ctypes as pc  # noqa: E402
 import oracle_ctypes  # noqa: E402
 

@@ -230,3 +230,27 @@ def test_vec_env_episodes_with_auto_reset_match_oracle(pd, base):
     for h in hs:
         orc.cpuref_destroy(h)
     env.close()
+
+
+@pytest.mark.gpu
+def test_torch_env_equals_numpy_env(pd, base):
+    """the device-resident env (zero-copy tensors, bookkeeping in torch ops) and ProjectDVecEnv (host arrays through the
+    PyProjectD-compatible module) produce the same observations, rewards and terminations, episode ends and resets included"""
+    import torch, projectd_env as E, projectd_torch_env as TE, pdbatch, pdb_ctypes as pc, synthetic_tracks
+    synthetic_tracks.make_base(base, tracks=('flat', 'touge'))
+    n = 24
+    envA = E.ProjectDVecEnv(n, base, track_name='touge')
+    P = pdbatch.packed_params(); trk = pc.build_track(pc.load_product(host_only=True), base, 'touge')
+    envB = TE.ProjectDTorchVecEnv(n, P, trk, device=0)
+    obsA = envA.reset(); obsB = envB.reset()
+    assert np.array_equal(obsA, obsB.cpu().numpy())
+    a = np.zeros((n, 2), np.float32); ends = 0
+    for t in range(2500):
+        a[:, 0] = np.where(np.arange(n) % 3 == 0, 0.7, 0.02 * np.sin(0.01 * t + np.arange(n))); a[:, 1] = np.where(np.arange(n) % 3 == 0, 1.0, 0.2)
+        oA, rA, tA, _, _ = envA.step(a)
+        oB, rB, tB, _ = envB.step(torch.from_numpy(a).to('cuda:0'))
+        assert np.array_equal(oA, oB.cpu().numpy()), t
+        assert np.array_equal(rA, rB.cpu().numpy()) and np.array_equal(tA, tB.cpu().numpy()), t
+        ends += int(tA.sum())
+    assert ends >= 3
+    envA.close(); envB.close()

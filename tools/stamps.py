@@ -43,7 +43,7 @@ t0 = sti[:, 0]
 print('cars %d (car wave, median shader clocks since wave start):' % n)
 for nm, k in (('record loaded, ERP set', 1), ('world inertia + non-steer joint rows done (barrier 1)', 2), ('steer rows done, A assembly starts', 7),
               ('A assembled', 8), ('LDL^T done', 3), ('barrier 2 passed (forces ready)', 5), ('late bodies done, rhs starts', 6), ('lambda solved', 9),
-              ('integration done', 11), ('post scans + pack scoring done', 12), ('record stored', 13)):
+              ('integration done', 11), ('post scans done', 14), ('pack scoring done (barrier)', 12), ('record stored', 13)):
     print('  %-58s %8.0f' % (nm, med(sti[:, k] - t0)))
 print('pack wave (median, relative to the block\'s first car wave start):')
 for nm, k in (('pre-step + steering rods done', 4), ('suspensions + tyres done', 14), ('wings, drivetrain, ARB done', 15)):
