@@ -186,7 +186,7 @@ def main():
                          "traffic": traffic, "traffic_source": ("profiles/r01_pmc.json: (2*FETCH_SIZE + WRITE_SIZE)*1024 per launch, rocprofv3 --pmc passes of this command" if traffic else None),
                          "kernel": "pdb_step_kernel", "kernel_avg_us": kernel_us, "alg_bytes_per_car_tick": B_ALG},
         }
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:   # the CPU leg is timed at N = 1 only
             res["cpu_baseline"] = cpu_baseline(P, trk, S0, all_actions)
         print(json.dumps(res))
     b.close()
