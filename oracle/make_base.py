@@ -58,6 +58,19 @@ def make_heave_car(base, src='ks_mazda_rx7_tuned', dst='pdb_heave_rx7'):
     open(p, 'w', newline='').write(raw.rstrip('\r\n') + eol + eol.join(extra))
 
 
+def make_fwd_car(base, src='ks_toyota_ae86_drift', dst='pdb_fwd_ae86'):
+    """No shipped car is front-wheel drive; Drivetrain::step2WD serves both.  The AE86 with [TRACTION] TYPE=FWD pins that branch."""
+    s = os.path.join(REF, 'content', 'cars', src, 'data'); d = os.path.join(base, 'content', 'cars', dst, 'data')
+    if os.path.isdir(d):
+        shutil.rmtree(d)
+    shutil.copytree(s, d)
+    os.system('chmod -R u+w "%s"' % d)
+    p = os.path.join(d, 'drivetrain.ini')
+    raw = open(p, newline='').read()
+    assert 'TYPE=RWD' in raw
+    open(p, 'w', newline='').write(raw.replace('TYPE=RWD', 'TYPE=FWD'))
+
+
 def main():
     base = os.path.join(here, '_ref', 'base')
     os.makedirs(os.path.join(base, 'cfg'), exist_ok=True)
@@ -70,6 +83,7 @@ def main():
         os.system('chmod -R u+w "%s"' % dst)
     make_multilink_car(base)
     make_heave_car(base)
+    make_fwd_car(base)
     gen_track.gen_flat(os.path.join(base, 'content', 'tracks', 'flat'))
     gen_track.gen_touge(os.path.join(base, 'content', 'tracks', 'touge'))
     for trk in ('driftplayground',):

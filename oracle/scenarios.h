@@ -28,8 +28,9 @@ static const Scenario kScenarios[] = {
     {"playground", 2500, 300, 10, 0, 1, 1, 1, "driftplayground", 1, nullptr},   // the env's default track as shipped (510 surfaces, 112 411 triangles, spline.cache)
     {"multilink", 4000, 300, 10, 0, 1, 1, 1, "touge", 1, "pdb_ml_supra"},   // reference SuspensionML on a derived car (oracle/make_base.py), front and rear
     {"heave", 4000, 300, 10, 0, 1, 1, 1, "touge", 1, "pdb_heave_rx7"},       // reference HeaveSpring on a derived car (third spring across both axles)
+    {"fwd", 2400, 300, 10, 0, 1, 1, 1, "flat", 0, "pdb_fwd_ae86"},            // front-wheel drive through the same 2WD drivetrain (derived car), slalom script
 };
-static const int kNumScenarios = 14;
+static const int kNumScenarios = 15;
 #define PDORACLE_DEFAULT_CAR "ks_toyota_ae86_drift"
 
 // closed-loop action from the previous observation (projectd_env.py:239-273 slot order): centre between the side probes,
@@ -69,7 +70,7 @@ inline float envGas(float a1);
 inline void scenarioControls(int sid, int tick, Ctl& c) {
     c.steer = 0; c.clutch = 0; c.brake = 0; c.handBrake = 0; c.gas = 0; c.requestedGearIndex = -1; c.gearUp = 0; c.gearDn = 0;
     const double t = (double)tick * (1.0 / 333.0);
-    if (sid < 4 || sid == 7 || sid == 9) { float a0, a1; scenarioAction(sid, tick, a0, a1); c.steer = a0; c.gas = envGas(a1); return; }
+    if (sid < 4 || sid == 7 || sid == 9 || sid == 14) { float a0, a1; scenarioAction(sid, tick, a0, a1); c.steer = a0; c.gas = envGas(a1); return; }
     if (sid == 4) {
         if (t < 3.0) { c.gas = 1.0f; }
         else if (t < 5.0) { c.brake = 0.8f; }

@@ -203,7 +203,7 @@ def test_full_controls_random(built):
         assert worst == 0.0
 
 
-@pytest.mark.parametrize('model', ['ks_mazda_rx7_tuned', 'ks_toyota_supra_mkiv_drift', 'dthwsh_mazda_rx7_fc3s_sr20', 'gravygarage_street_ae86_readie', 'pdb_ml_supra'])
+@pytest.mark.parametrize('model', ['ks_mazda_rx7_tuned', 'ks_toyota_supra_mkiv_drift', 'dthwsh_mazda_rx7_fc3s_sr20', 'gravygarage_street_ae86_readie', 'pdb_ml_supra', 'pdb_fwd_ae86'])
 def test_double_wishbone_turbo_cars(built, model):
     """the other four cars the reference ships: double wishbones on all four wheels (6 bodies, 21 joints, 26 rows -> the
     row-guarded kernel), or struts in front and double wishbones behind (8 bodies, 38 rows -> the 40-row LDS size class);
