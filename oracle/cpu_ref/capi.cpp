@@ -57,10 +57,10 @@ void cpuref_scenario_controls(int sid, int tick, float* a) {
     pdoracle::Ctl c; pdoracle::scenarioControls(sid, tick, c);
     a[0] = c.steer; a[1] = c.clutch; a[2] = c.brake; a[3] = c.handBrake; a[4] = c.gas; a[5] = (float)c.requestedGearIndex; a[6] = (float)c.gearUp; a[7] = (float)c.gearDn;
 }
-int cpuref_scenario_info(int sid, int* ticks, int* full, int* assists3) {
+int cpuref_scenario_info(int sid, int* ticks, int* full, int* assists3) {   // assists3[0..2] clutch/shift/blip, [3] smooth steering
     if (sid < 0 || sid >= pdoracle::kNumScenarios) return -1;
     const auto& sc = pdoracle::kScenarios[sid];
-    *ticks = sc.ticks; *full = sc.full; assists3[0] = sc.autoClutch; assists3[1] = sc.autoShift; assists3[2] = sc.autoBlip;
+    *ticks = sc.ticks; *full = sc.full; assists3[0] = sc.autoClutch; assists3[1] = sc.autoShift; assists3[2] = sc.autoBlip; assists3[3] = sc.rawSteer ? 0 : 1;
     return 0;
 }
 void cpuref_get_out(void* hh, pdb_step_out* o) { ((CpuRefHandle*)hh)->car.fillStepOut(*o); }
@@ -141,6 +141,7 @@ int cpuref_run_scenario(void* hh, int sid, const char* outPath) {
     const auto& sc = pdoracle::kScenarios[sid];
     // setCarAssists (PyProjectD.cpp:307-317) per scenario; smooth steering stays on like the env
     h->P.acUseOnStart = sc.autoClutch; h->P.acUseOnChange = sc.autoClutch; h->P.autoShiftActive = sc.autoShift; h->P.autoBlipActive = sc.autoBlip;
+    h->P.smoothSteer = sc.rawSteer ? 0 : 1;
     h->car = cpuref::Car();
     h->car.init(&h->P, &h->T, h->s0);
     pdoracle::ProbeFile pf;

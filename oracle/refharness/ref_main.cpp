@@ -155,6 +155,7 @@ struct Env {
     Car* car = nullptr;
     double dt = 1.0 / 333.0;  // projectd_env.py:19
     CarControls dcontrols;    // persistent python-side object (projectd_env.py:135)
+    bool smooth = true;       // setCarControls(sim, car, smooth, controls)
 
     void init(const std::string& base, const std::string& track, const std::string& model, bool autoClutch = true, bool autoShift = true, bool autoBlip = true) {
         // projectd_env.py:118-136, PyProjectD.cpp:111-137
@@ -184,7 +185,7 @@ struct Env {
         dcontrols.steer = a0;
         dcontrols.gas = pdoracle::envGas(a1);
         car->controls = dcontrols;
-        car->smoothSteer = true;
+        car->smoothSteer = smooth;
         sim->step((float)dt, sim->physicsTime, sim->gameTime);
         sim->physicsTime += dt;
         sim->gameTime += dt;
@@ -194,7 +195,7 @@ struct Env {
         dcontrols.steer = c.steer; dcontrols.clutch = c.clutch; dcontrols.brake = c.brake; dcontrols.handBrake = c.handBrake; dcontrols.gas = c.gas;
         dcontrols.requestedGearIndex = (int8_t)c.requestedGearIndex; dcontrols.gearUp = c.gearUp != 0; dcontrols.gearDn = c.gearDn != 0;
         car->controls = dcontrols;
-        car->smoothSteer = true;
+        car->smoothSteer = smooth;
         sim->step((float)dt, sim->physicsTime, sim->gameTime);
         sim->physicsTime += dt;
         sim->gameTime += dt;
@@ -219,6 +220,7 @@ int main(int argc, char** argv) {
             const std::string track = sc.track;
             if (!only.empty() && only != track) continue;
             env.init(base, track, sc.car ? std::string(sc.car) : model, sc.autoClutch != 0, sc.autoShift != 0, sc.autoBlip != 0);
+            env.smooth = sc.rawSteer == 0;
             pdoracle::ProbeFile pf;
             env.reset();
             {

@@ -10,25 +10,25 @@ namespace pdoracle {
 // (PyProjectD.cpp:297-305 setCarControls) with the scenario's own assist switches (setCarAssists :307-317)
 // track: synthetic track the scenario runs on (projectd-core_amd/synthetic_tracks.py); feedback: 1 = the action is a function of the
 // previous tick's 24-slot observation (scenarioFeedback), i.e. a closed loop like an RL policy
-// car: model directory under content/cars (nullptr = the env default, ks_toyota_ae86_drift)
-struct Scenario { const char* name; int ticks; int denseTicks; int stride; int full; int autoClutch, autoShift, autoBlip; const char* track; int feedback; const char* car; };
+// car: model directory under content/cars (nullptr = the env default, ks_toyota_ae86_drift); rawSteer: 1 = setCarControls(smooth = false)
+struct Scenario { const char* name; int ticks; int denseTicks; int stride; int full; int autoClutch, autoShift, autoBlip; const char* track; int feedback; const char* car; int rawSteer; };
 
 static const Scenario kScenarios[] = {
-    {"idle", 600, 200, 10, 0, 1, 1, 1, "flat", 0, nullptr},
-    {"launch", 2000, 450, 10, 0, 1, 1, 1, "flat", 0, nullptr},
-    {"circle", 1600, 300, 10, 0, 1, 1, 1, "flat", 0, nullptr},
-    {"slalom", 2400, 300, 10, 0, 1, 1, 1, "flat", 0, nullptr},
-    {"brake", 2400, 200, 10, 1, 1, 1, 1, "flat", 0, nullptr},    // pedal brake to a stop, handbrake turn (BrakeSystem, tyre lock)
-    {"manual", 2600, 300, 10, 1, 0, 0, 0, "flat", 0, nullptr},   // no assists: manual clutch, gearUp/gearDn pulses, H-shifter gear select, grinding
-    {"drive", 7000, 300, 10, 0, 1, 1, 1, "touge", 1, nullptr},   // closed hilly, banked mountain road driven by a probe-feedback controller (configs[2] shape)
-    {"rx7", 2400, 300, 10, 0, 1, 1, 1, "flat", 0, "ks_mazda_rx7_tuned"},          // double wishbones all round, one turbo: the slalom script
-    {"supra", 5000, 300, 10, 0, 1, 1, 1, "touge", 1, "ks_toyota_supra_mkiv_drift"},   // double wishbones, two turbos, 6 gears, on the mountain road
-    {"fc3s", 2400, 300, 10, 0, 1, 1, 1, "flat", 0, "dthwsh_mazda_rx7_fc3s_sr20"},      // strut front + double wishbone rear (38 rows), 3 wings + 2 fins, turbo
-    {"readie", 5000, 300, 10, 0, 1, 1, 1, "touge", 1, "gravygarage_street_ae86_readie"},   // strut front + double wishbone rear on the mountain road
-    {"playground", 2500, 300, 10, 0, 1, 1, 1, "driftplayground", 1, nullptr},   // the env's default track as shipped (510 surfaces, 112 411 triangles, spline.cache)
-    {"multilink", 4000, 300, 10, 0, 1, 1, 1, "touge", 1, "pdb_ml_supra"},   // reference SuspensionML on a derived car (oracle/make_base.py), front and rear
-    {"heave", 4000, 300, 10, 0, 1, 1, 1, "touge", 1, "pdb_heave_rx7"},       // reference HeaveSpring on a derived car (third spring across both axles)
-    {"fwd", 2400, 300, 10, 0, 1, 1, 1, "flat", 0, "pdb_fwd_ae86"},            // front-wheel drive through the same 2WD drivetrain (derived car), slalom script
+    {"idle", 600, 200, 10, 0, 1, 1, 1, "flat", 0, nullptr, 0},
+    {"launch", 2000, 450, 10, 0, 1, 1, 1, "flat", 0, nullptr, 0},
+    {"circle", 1600, 300, 10, 0, 1, 1, 1, "flat", 0, nullptr, 0},
+    {"slalom", 2400, 300, 10, 0, 1, 1, 1, "flat", 0, nullptr, 0},
+    {"brake", 2400, 200, 10, 1, 1, 1, 1, "flat", 0, nullptr, 0},    // pedal brake to a stop, handbrake turn (BrakeSystem, tyre lock)
+    {"manual", 2600, 300, 10, 1, 0, 0, 0, "flat", 0, nullptr, 1},   // no assists: manual clutch, gearUp/gearDn pulses, H-shifter gear select, grinding
+    {"drive", 7000, 300, 10, 0, 1, 1, 1, "touge", 1, nullptr, 0},   // closed hilly, banked mountain road driven by a probe-feedback controller (configs[2] shape)
+    {"rx7", 2400, 300, 10, 0, 1, 1, 1, "flat", 0, "ks_mazda_rx7_tuned", 0},          // double wishbones all round, one turbo: the slalom script
+    {"supra", 5000, 300, 10, 0, 1, 1, 1, "touge", 1, "ks_toyota_supra_mkiv_drift", 0},   // double wishbones, two turbos, 6 gears, on the mountain road
+    {"fc3s", 2400, 300, 10, 0, 1, 1, 1, "flat", 0, "dthwsh_mazda_rx7_fc3s_sr20", 0},      // strut front + double wishbone rear (38 rows), 3 wings + 2 fins, turbo
+    {"readie", 5000, 300, 10, 0, 1, 1, 1, "touge", 1, "gravygarage_street_ae86_readie", 0},   // strut front + double wishbone rear on the mountain road
+    {"playground", 2500, 300, 10, 0, 1, 1, 1, "driftplayground", 1, nullptr, 0},   // the env's default track as shipped (510 surfaces, 112 411 triangles, spline.cache)
+    {"multilink", 4000, 300, 10, 0, 1, 1, 1, "touge", 1, "pdb_ml_supra", 0},   // reference SuspensionML on a derived car (oracle/make_base.py), front and rear
+    {"heave", 4000, 300, 10, 0, 1, 1, 1, "touge", 1, "pdb_heave_rx7", 0},       // reference HeaveSpring on a derived car (third spring across both axles)
+    {"fwd", 2400, 300, 10, 0, 1, 1, 1, "flat", 0, "pdb_fwd_ae86", 0},            // front-wheel drive through the same 2WD drivetrain (derived car), slalom script
 };
 static const int kNumScenarios = 15;
 #define PDORACLE_DEFAULT_CAR "ks_toyota_ae86_drift"

@@ -164,11 +164,11 @@ def test_full_controls_scenarios(built, sid):
     reference-TU trajectories pin the oracle in tests/test_oracle_golden.py"""
     import pdbatch, oracle_ctypes
     orc = oracle_ctypes.load_oracle(portable_math=True)
-    ticks, full, assists = C.c_int(), C.c_int(), (C.c_int * 3)()
+    ticks, full, assists = C.c_int(), C.c_int(), (C.c_int * 4)()
     assert orc.cpuref_scenario_info(sid, C.byref(ticks), C.byref(full), assists) == 0 and full.value == 1
     P = pc.CarParams.from_buffer_copy(bytes(pdbatch.packed_params()))
     lib = pc.load_product()
-    lib.pdb_set_assists(C.byref(P), assists[0], assists[1], assists[2], 1)
+    lib.pdb_set_assists(C.byref(P), assists[0], assists[1], assists[2], assists[3])   # the manual script also steers raw (smooth = false)
     n = 4
 
     def controls(t):
