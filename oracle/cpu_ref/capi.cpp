@@ -129,6 +129,16 @@ int cpuref_solver_freeflight(void* hh, int ticks, const float* v, const float* w
     out[14] = worstD; out[15] = worstA;
     return 0;
 }
+// the linear system of the last tick's rigid-body solve: A (m x m row-major, lower triangle meaningful), rhs and the fp32 solution
+int cpuref_last_system(void* hh, float* A, float* rhs, float* lambda, int cap) {
+    const pdrb::World& W = ((CpuRefHandle*)hh)->car.w;
+    const int m = W.lastM;
+    if (m > cap) return -1;
+    if (A) memcpy(A, W.lastA.data(), sizeof(float) * m * m);
+    if (rhs) memcpy(rhs, W.lastRhs.data(), sizeof(float) * m);
+    if (lambda) memcpy(lambda, W.lastLambda.data(), sizeof(float) * m);
+    return m;
+}
 const char* cpuref_scenario_name(int sid) { return pdoracle::kScenarios[sid].name; }
 const char* cpuref_scenario_track(int sid) { return pdoracle::kScenarios[sid].track; }
 const char* cpuref_scenario_car(int sid) { return pdoracle::kScenarios[sid].car ? pdoracle::kScenarios[sid].car : PDORACLE_DEFAULT_CAR; }

@@ -25,6 +25,7 @@ def load_oracle(portable_math=False):
     lib.cpuref_scenario_controls.argtypes = [C.c_int, C.c_int, C.c_void_p]
     lib.cpuref_scenario_info.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
     lib.cpuref_solver_freeflight.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.cpuref_last_system.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
     lib.cpuref_get_out.argtypes = [C.c_void_p, C.c_void_p]
     lib.cpuref_get_car_state.argtypes = [C.c_void_p, C.c_void_p]
     lib.cpuref_env_gas.restype = C.c_float; lib.cpuref_env_gas.argtypes = [C.c_float]
