@@ -60,6 +60,11 @@ int pdb_set_assists(pdb_car_params* params, int auto_clutch, int auto_shift, int
  * 4 atan2(x,y), 5 asin, 6 acos, 7 pow(x,y); y may be NULL for the one-argument functions */
 int pdb_math_eval(int fn, const float* x, const float* y, float* out, int n);
 int pdb_build_track(const char* base_path, const char* track_name, void** blob, uint64_t* bytes);
+/* Track::init with options.  PDB_TRACK_RECOMPUTE_FAT_POINTS ignores spline.cache and runs Track::computeFatPoints
+ * (Sim/Track.cpp:366-467, incl. the ray-traced sides of TRACE_SIDES=1 tracks) the way the reference does when the cache
+ * is missing or stale (Track.cpp:209-218); nothing is written back to the content directory. */
+#define PDB_TRACK_RECOMPUTE_FAT_POINTS 1
+int pdb_build_track_opts(const char* base_path, const char* track_name, int flags, void** blob, uint64_t* bytes);
 void pdb_free(void* p);
 int pdb_initial_state(const pdb_car_params* params, const void* track_blob, pdb_dyn_state* out);
 int pdb_teleport_to_spline(const pdb_car_params* params, const void* track_blob, float distance_norm, pdb_dyn_state* inout);

@@ -53,9 +53,13 @@ int pdb_set_assists(pdb_car_params* params, int auto_clutch, int auto_shift, int
     return PDB_OK;
 }
 int pdb_build_track(const char* base_path, const char* track_name, void** blob, uint64_t* bytes) {
+    return pdb_build_track_opts(base_path, track_name, 0, blob, bytes);
+}
+int pdb_build_track_opts(const char* base_path, const char* track_name, int flags, void** blob, uint64_t* bytes) {
     if (!base_path || !track_name || !blob || !bytes) { pdb::setError("null argument"); return PDB_ERR_ARG; }
+    if (flags & ~PDB_TRACK_RECOMPUTE_FAT_POINTS) { pdb::setError("unknown track build flag"); return PDB_ERR_ARG; }
     PDB_TRY
-    std::vector<uint8_t> v = pdb::buildTrack(base_path, track_name);
+    std::vector<uint8_t> v = pdb::buildTrack(base_path, track_name, (flags & PDB_TRACK_RECOMPUTE_FAT_POINTS) != 0);
     void* p = malloc(v.size());
     if (!p) { pdb::setError("out of memory"); return PDB_ERR_ARG; }
     memcpy(p, v.data(), v.size());

@@ -13,7 +13,7 @@ bool setScoringVar(pdb_car_params& P, const std::string& name, float w);
 bool getScoringVar(const pdb_car_params& P, const std::string& name, float& w);
 
 // track blob (pdb_track_header + arrays)
-std::vector<uint8_t> buildTrack(const std::string& basePath, const std::string& trackName);
+std::vector<uint8_t> buildTrack(const std::string& basePath, const std::string& trackName, bool recomputeFatPoints = false);
 
 struct TrackView {
     const pdb_track_header* h = nullptr;

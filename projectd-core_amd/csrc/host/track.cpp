@@ -4,8 +4,8 @@
 //   spline.bin    Sim/Track.cpp:274-293 (SlimTrackPoint, Sim/Track.h:12-17)
 //   spline.cache  Sim/Track.cpp:294-311 (FatTrackPoint, Sim/Track.h:18-25)
 //   spline.ini    Sim/Track.cpp:158-186
-// and restates the load-time geometry: computeFatPoints (Track.cpp:366-434, untraced sides),
-// initTrackPoints (Track.cpp:188-272) and BSpline3d::init_from_array (Core/Spline3d.cpp:79-162).
+// and restates the load-time geometry: computeFatPoints / computeSideLocation (Track.cpp:366-467, both the
+// TRACE_SIDES=0 and the ray-traced sides; pinned by the spline.cache files the reference ships), initTrackPoints (Track.cpp:188-272) and BSpline3d::init_from_array (Core/Spline3d.cpp:79-162).
 #include "model.hpp"
 #include "ini.hpp"
 #include <cstdio>
@@ -108,7 +108,58 @@ static V3 bsInterp(float u, V3 P0, V3 P1, V3 P2, V3 P3) {
     return p;
 }
 
-std::vector<uint8_t> buildTrack(const std::string& basePathIn, const std::string& trackName) {
+// Rays of one side trace share their origin and lie in one vertical plane, so their xz footprint is a segment: the
+// triangles whose xz box meets that segment (slab test) are a superset of everything any of the rays can hit.  The ids
+// stay in ascending order, so the per-mesh "nearest, first on ties" rule sees the candidates in the order of a full scan.
+static void trisNearSegment(const std::vector<float>& tris, float ax, float az, float bx, float bz, std::vector<int32_t>& out) {
+    out.clear();
+    const float dx = bx - ax, dz = bz - az;
+    const float eps = 1.0e-3f;
+    const size_t nt = tris.size() / 9;
+    for (size_t t = 0; t < nt; ++t) {
+        const float* p = tris.data() + 9 * t;
+        const float x0 = std::min(p[0], std::min(p[3], p[6])) - eps, x1 = std::max(p[0], std::max(p[3], p[6])) + eps;
+        const float z0 = std::min(p[2], std::min(p[5], p[8])) - eps, z1 = std::max(p[2], std::max(p[5], p[8])) + eps;
+        float t0 = 0.0f, t1 = 1.0f;
+        bool ok = true;
+        if (dx != 0.0f) { float u0 = (x0 - ax) / dx, u1 = (x1 - ax) / dx; if (u0 > u1) std::swap(u0, u1); t0 = std::max(t0, u0); t1 = std::min(t1, u1); }
+        else if (ax < x0 || ax > x1) ok = false;
+        if (dz != 0.0f) { float u0 = (z0 - az) / dz, u1 = (z1 - az) / dz; if (u0 > u1) std::swap(u0, u1); t0 = std::max(t0, u0); t1 = std::min(t1, u1); }
+        else if (az < z0 || az > z1) ok = false;
+        if (ok && t0 <= t1) out.push_back((int32_t)t);
+    }
+}
+
+// rayCastRaw restricted to a candidate list (ascending triangle ids; triSurf maps triangle -> surface)
+static RayHitH rayCastSubset(const std::vector<int32_t>& cand, const std::vector<int32_t>& triSurf, const float* tris, const float* o, const float* d, float maxDist) {
+    RayHitH best;
+    size_t i = 0;
+    while (i < cand.size()) {
+        const int32_t s = triSurf[(size_t)cand[i]];
+        float bt = -1.0f; int btri = -1;
+        for (; i < cand.size() && triSurf[(size_t)cand[i]] == s; ++i) {
+            const int t = cand[i];
+            float tt;
+            if (rayTri(o, d, maxDist, tris + 9 * t, tris + 9 * t + 3, tris + 9 * t + 6, tt))
+                if (bt < 0.0f || tt < bt) { bt = tt; btri = t; }
+        }
+        if (btri >= 0 && (best.depth < 0.0f || best.depth > bt)) {
+            const float* v0 = tris + 9 * btri; const float* v1 = v0 + 3; const float* v2 = v0 + 6;
+            const float vu[3] = {v1[0] - v0[0], v1[1] - v0[1], v1[2] - v0[2]};
+            const float vv[3] = {v2[0] - v0[0], v2[1] - v0[1], v2[2] - v0[2]};
+            const float n[3] = {vu[1] * vv[2] - vu[2] * vv[1], vu[2] * vv[0] - vu[0] * vv[2], vu[0] * vv[1] - vu[1] * vv[0]};
+            const float l = n[0] * n[0] + n[1] * n[1] + n[2] * n[2];
+            if (l > 0.0f) {
+                const float sc = 1.0f / sqrtf(l);
+                best.has = true; best.depth = bt; best.surface = s;
+                for (int k = 0; k < 3; ++k) { best.pos[k] = o[k] + d[k] * bt; best.normal[k] = n[k] * sc; }
+            }
+        }
+    }
+    return best;
+}
+
+std::vector<uint8_t> buildTrack(const std::string& basePathIn, const std::string& trackName, bool recomputeFatPoints) {
     std::string base = basePathIn;
     std::replace(base.begin(), base.end(), '\\', '/');
     if (!base.empty() && base.back() != '/') base += '/';
@@ -154,13 +205,28 @@ std::vector<uint8_t> buildTrack(const std::string& basePathIn, const std::string
 
     // ---- spline ----
     bool closedLoop = false, traceSides = false;
-    float traceRayOffsetY = 20.0f, traceRayLength = 100.0f;
+    float traceRayOffsetY = 20.0f, traceRayLength = 100.0f, traceSideMax = 10.0f, traceDiffHeightMax = 0.01f, traceDiffGripMax = 0.1f, traceStep = 0.01f;   // Sim/Track.h:83-89
+    std::vector<int> traceBadSectors;
     Ini spl(dir + "spline.ini");
     if (spl.ready) {
         closedLoop = spl.getInt("SPLINE", "CLOSED_LOOP") != 0;
         traceSides = spl.getInt("SPLINE", "TRACE_SIDES") != 0;
         spl.tryGetFloat("SPLINE", "TRACE_RAY_OFFSET_Y", traceRayOffsetY);
         spl.tryGetFloat("SPLINE", "TRACE_RAY_LENGTH", traceRayLength);
+        spl.tryGetFloat("SPLINE", "TRACE_SIDE_MAX", traceSideMax);
+        spl.tryGetFloat("SPLINE", "TRACE_DIFF_HEIGHT_MAX", traceDiffHeightMax);
+        spl.tryGetFloat("SPLINE", "TRACE_DIFF_GRIP_MAX", traceDiffGripMax);
+        spl.tryGetFloat("SPLINE", "TRACE_STEP", traceStep);
+        if (spl.hasKey("SPLINE", "TRACE_BAD_SECTORS")) {   // "2|4" (Track.cpp:194-203)
+            const std::string list = spl.getString("SPLINE", "TRACE_BAD_SECTORS");
+            size_t a = 0;
+            while (a <= list.size()) {
+                size_t b = list.find('|', a);
+                if (b == std::string::npos) b = list.size();
+                if (b > a) traceBadSectors.push_back(atoi(list.substr(a, b - a).c_str()));
+                a = b + 1;
+            }
+        }
     }
     struct Slim { float best[3]; float sides[2]; };
     struct Fat { V3 best, left, right, center, forwardDir; };
@@ -175,10 +241,42 @@ std::vector<uint8_t> buildTrack(const std::string& basePathIn, const std::string
         const std::vector<uint8_t> d = readFile(dir + "spline.cache");
         fat.resize(d.size() / sizeof(Fat));
         if (!fat.empty()) memcpy(fat.data(), d.data(), fat.size() * sizeof(Fat));
-        if (fat.size() != slim.size()) fat.clear();
+        if (fat.size() != slim.size() || recomputeFatPoints) fat.clear();
     }
     if (fat.empty() && !slim.empty()) {
-        if (traceSides) throw std::runtime_error("pdb: TRACE_SIDES=1 tracks need their spline.cache (side tracing not implemented)");
+        std::vector<int32_t> triSurfL, cand;
+        if (traceSides) {
+            triSurfL.assign(tris.size() / 9, 0);
+            for (size_t s = 0; s < surfaces.size(); ++s)
+                for (int t = surfaces[s].triStart; t < surfaces[s].triStart + surfaces[s].triCount; ++t) triSurfL[(size_t)t] = (int32_t)s;
+        }
+        const int numTraceSteps = (int)(traceSideMax / traceStep);
+        // Track::computeSideLocation (Track.cpp:435-467): fan of rays from the point's ray origin towards origHit + dir*k*step;
+        // the side moves outwards while the hit stays on valid track of the same category, within the height / grip steps
+        // and outside the bad sectors; a miss is skipped, the first disqualified hit ends the trace.
+        auto sideLocation = [&](const RayHitH& orig, const V3& rayStart, const V3& traceDir) {
+            const V3 origPos = {orig.pos[0], orig.pos[1], orig.pos[2]};
+            V3 result = origPos, prevHit = origPos;
+            float prevGrip = surfaces[(size_t)orig.surface].gripMod;
+            // horizontal reach of the longest ray: direction (k*step along traceDir, down to the hit), length traceRayLength
+            const V3 far = norm(origPos + traceDir * ((float)numTraceSteps * traceStep) - rayStart) * traceRayLength;
+            trisNearSegment(tris, rayStart.x, rayStart.z, rayStart.x + far.x * 1.01f, rayStart.z + far.z * 1.01f, cand);
+            for (int k = 1; k < numTraceSteps; ++k) {
+                const V3 rayEnd = origPos + traceDir * ((float)k * traceStep);
+                const V3 rayN = norm(rayEnd - rayStart);
+                const RayHitH h = rayCastSubset(cand, triSurfL, tris.data(), &rayStart.x, &rayN.x, traceRayLength);
+                if (!h.has) continue;
+                const pdb_surface& sf = surfaces[(size_t)h.surface];
+                if (sf.isValidTrack && sf.collisionCategory == surfaces[(size_t)orig.surface].collisionCategory &&
+                    fabsf(h.pos[1] - prevHit.y) < traceDiffHeightMax && fabsf(sf.gripMod - prevGrip) < traceDiffGripMax &&
+                    std::find(traceBadSectors.begin(), traceBadSectors.end(), sf.sectorID) == traceBadSectors.end()) {
+                    result = {h.pos[0], h.pos[1], h.pos[2]};
+                    prevHit = result;
+                    prevGrip = sf.gripMod;
+                } else break;
+            }
+            return result;
+        };
         fat.resize(slim.size());
         memset(fat.data(), 0, fat.size() * sizeof(Fat));
         const float down[3] = {0, -1, 0};
@@ -193,6 +291,12 @@ std::vector<uint8_t> buildTrack(const std::string& basePathIn, const std::string
             else if (i > 0) f.forwardDir = norm(sb - V3{slim[i - 1].best[0], slim[i - 1].best[1], slim[i - 1].best[2]});
             const V3 leftDir = norm(cross(f.forwardDir, V3{0, -1, 0}));
             const V3 rightDir = leftDir * -1.0f;
+            if (traceSides) {
+                f.left = sideLocation(h, rs, leftDir);
+                f.right = sideLocation(h, rs, rightDir);
+                f.center = (f.left + f.right) * 0.5f;
+                continue;
+            }
             f.left = f.best + leftDir * slim[i].sides[0];
             f.right = f.best + rightDir * slim[i].sides[1];
             V3 o = f.left + V3{0, traceRayOffsetY, 0};

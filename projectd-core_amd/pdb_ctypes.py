@@ -168,9 +168,9 @@ def env_params(lib, base, model='ks_toyota_ae86_drift'):
         assert lib.pdb_set_scoring_var(C.byref(P), k.encode(), v) == 0
     return P
 
-def build_track(lib, base, name):
+def build_track(lib, base, name, recompute_fat_points=False):
     blob = C.c_void_p(); n = C.c_uint64()
-    rc = lib.pdb_build_track(base.encode(), name.encode(), C.byref(blob), C.byref(n))
+    rc = lib.pdb_build_track_opts(base.encode(), name.encode(), 1 if recompute_fat_points else 0, C.byref(blob), C.byref(n))
     if rc != 0:
         raise RuntimeError(lib.pdb_last_error().decode())
     data = C.string_at(blob, n.value)

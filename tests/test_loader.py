@@ -156,3 +156,63 @@ def test_initial_state_and_spline_teleport(hostlib, env_params, flat_track, stat
     for b in range(env_params.numBodies):
         assert abs((t.body[b].pos[2] - s.body[b].pos[2]) - dz) < 1e-2
         assert abs(t.body[b].pos[1] - s.body[b].pos[1]) < 1e-3
+
+
+def _fat_points(blob):
+    nfat = struct.unpack_from('<8i', blob, 0)[4]
+    off = struct.unpack_from('<7Q', blob, 48)[2]
+    return np.frombuffer(blob, dtype='<f4', count=nfat * 15, offset=off).reshape(nfat, 15)
+
+
+@needs_ref
+@pytest.mark.parametrize('track', ['ebisu_touge', 'driftplayground', 'yamanashi_short', 'euphoria_hillside_park'])
+def test_traced_sides_reproduce_the_shipped_spline_cache(hostlib, track):
+    """Track::computeFatPoints + computeSideLocation (Sim/Track.cpp:366-467) recomputed from surfaces.bin + spline.bin
+    against the spline.cache the reference saved from the same routine (Track.cpp:214-218) -- a reference-held golden for
+    the track build step and, through the 2 x 1000 oblique rays per point, for the ray-vs-mesh query (ODE's collider in the
+    reference).  The racing-line hits are identical; a side is the last accepted hit of a 1 cm fan, so a last-ulp
+    difference at an acceptance threshold moves that side by a few steps -- seen at <= 2 % of the points of a track, <= 0.2 m."""
+    blob = pc.build_track(hostlib, REF, track, recompute_fat_points=True)
+    fat = _fat_points(blob)
+    cache = np.fromfile(os.path.join(REF, 'content', 'tracks', track, 'spline.cache'), dtype='<f4').reshape(-1, 15)
+    assert fat.shape == cache.shape
+    assert np.array_equal(fat[:, 0:3], cache[:, 0:3])                       # best: vertical ray hits, bit for bit
+    side_err = np.abs(fat[:, 3:9] - cache[:, 3:9]).max(axis=1)
+    assert np.mean(side_err < 1e-4) > 0.98, np.mean(side_err < 1e-4)
+    assert side_err.max() < 0.25, side_err.max()
+    assert np.abs(fat[:, 12:15] - cache[:, 12:15]).max() < 1e-2
+    # the default build (cache present) still takes the cached points verbatim, like Track::init
+    assert np.array_equal(_fat_points(pc.build_track(hostlib, REF, track)), cache)
+
+
+def test_traced_sides_on_a_synthetic_road(hostlib, tmp_path):
+    """TRACE_SIDES=1 without any cache: the sides run out to the ribbon's edge (9 m, rays beyond it miss and are skipped),
+    stay at the racing line where the road surface is not valid track, and stop at a bad sector's border."""
+    import shutil, synthetic_tracks
+    base = str(tmp_path)
+    synthetic_tracks.make_base(base, tracks=('touge',))
+    tdir = os.path.join(base, 'content', 'tracks', 'touge')
+
+    def build(extra):
+        with open(os.path.join(tdir, 'spline.ini'), 'w') as f:
+            f.write('[SPLINE]\nCLOSED_LOOP=1\nTRACE_SIDES=1\n' + extra)
+        return _fat_points(pc.build_track(hostlib, base, 'touge'))
+    fat = build('TRACE_SIDE_MAX=12.0\n')
+    w_l = np.linalg.norm(fat[:, 3:6] - fat[:, 0:3], axis=1); w_r = np.linalg.norm(fat[:, 6:9] - fat[:, 0:3], axis=1)
+    kind = (np.arange(len(fat)) // 40) % len(synthetic_tracks.TOUGE_SURFACES)
+    invalid = kind == 4                                                      # TOUGE_SURFACES[4]: valid=0
+    inner = (np.arange(len(fat)) % 40 > 2) & (np.arange(len(fat)) % 40 < 38)  # away from the seams between surface kinds
+    assert np.all(w_l[invalid & inner] == 0) and np.all(w_r[invalid & inner] == 0)
+    hit = np.any(fat[:, 0:3] != 0, axis=1)                                  # a racing-line ray that slips through a mesh seam leaves the zeroed point (Track.cpp:389)
+    ok = ~invalid & inner & hit
+    assert ok.sum() > 400
+    assert np.all((w_l[ok] > 8.7) & (w_l[ok] < 9.06)) and np.all((w_r[ok] > 8.7) & (w_r[ok] < 9.06)), (w_l[ok].min(), w_l[ok].max())
+    assert np.allclose(fat[:, 9:12], 0.5 * (fat[:, 3:6] + fat[:, 6:9]), atol=1e-5)
+    short = build('TRACE_SIDE_MAX=3.0\n')
+    w = np.linalg.norm(short[:, 3:6] - short[:, 0:3], axis=1)
+    assert np.all((w[ok] > 2.95) & (w[ok] < 3.03))                           # last step is (numSteps-1) * 1 cm
+    bad = build('TRACE_SIDE_MAX=12.0\nTRACE_BAD_SECTORS=1|3\n')              # sector = surface index: points whose ray starts there stop at once
+    wb = np.linalg.norm(bad[:, 3:6] - bad[:, 0:3], axis=1)
+    sector = np.arange(len(fat)) // 40
+    assert np.all(wb[inner & ((sector == 1) | (sector == 3))] == 0)
+    assert np.all(wb[inner & (sector == 0)] > 8.7)
