@@ -19,7 +19,7 @@ sys.path.insert(0, os.path.join(ROOT, 'tests'))
 
 CARS_PER_GPU = 4096
 # algorithmic bytes per car-tick (DESIGN.md "Algorithmic bytes"): record read + record write + action + output row
-B_ALG = 2224 + 2224 + 8 + 104   # sizeof(pdb_dyn_state) in and out, float[2] action, pdb_step_out (checked against the ctypes mirrors in main)
+B_ALG = 2256 + 2256 + 8 + 104   # sizeof(pdb_dyn_state) in and out, float[2] action, pdb_step_out (checked against the ctypes mirrors in main)
 HBM_PEAK_GBS = 8000.0
 
 

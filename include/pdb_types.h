@@ -156,6 +156,21 @@ typedef struct pdb_scoring {
         GearGrindPenalty, StallPenalty;
 } pdb_scoring;
 
+/* Body colliders of the chassis (Car/CarColliderManager.cpp:12-37 boxes from colliders.ini; Car.cpp:318-377 collider.bin
+ * hull).  Vertices are in the chassis body frame (the graphics-offset transform of Car::getGraphicsOffsetMatrix is applied at
+ * load time, like addMeshCollider's geom offset).  The box meets TRACK surfaces (C_MASK_CAR_BOX = 1), the hull meets what
+ * C_MASK_CAR_MESH = 30 selects (WALL) -- Sim/SimulatorCommon.h:7-13. */
+#define PDB_MAX_COLL_VERTS 128
+#define PDB_MAX_COLL_TRIS 192
+typedef struct pdb_collider {
+    int32_t enabled;          /* evaluate body contacts (the loader sets 1 when colliders.ini / collider.bin were read) */
+    int32_t hasBox, numVerts, numTris;
+    float boxCentre[3], boxHalf[3];
+    float boundsLo[3], boundsHi[3];   /* body-frame box around hull and belly box: the broad phase works on its world AABB */
+    float verts[PDB_MAX_COLL_VERTS][3];
+    uint8_t tris[PDB_MAX_COLL_TRIS][3];
+} pdb_collider;
+
 typedef struct pdb_car_params {
     int32_t magic;            /* 'PDCP' */
     int32_t version;
@@ -214,6 +229,7 @@ typedef struct pdb_car_params {
     int8_t patchConnCount[36];
     int8_t patchConn[36][4];
     pdb_scoring scoring;
+    pdb_collider collider;
 } pdb_car_params;
 
 /* ---------------------------------------------------------------------------------------------
@@ -262,7 +278,11 @@ typedef struct pdb_dyn_state {
     float gasUsage;          /* Engine::gasUsage of the previous tick (fuel burn input, Car.cpp:478) */
     float locClutch;         /* Drivetrain::locClutch of the previous tick (read by the H-shifter gear select, Drivetrain.cpp:189) */
     float turboRotation[PDB_MAX_TURBOS];   /* Turbo::rotation */
-    int32_t _pad[2];         /* record size is a multiple of 16 bytes (coalesced 16-byte-per-lane copies) */
+    /* body contacts (PhysicsEngineODE::collisionStep, Car::onCollisionCallback) */
+    int32_t simFrame;        /* PhysicsEngineODE::currentFrame: dynamic-vs-static pairs are collided on odd frames only (:230-241) */
+    int32_t damageChanged;   /* some damageZoneLevel moved by more than 0.001 this tick (ScoringSystem::validateDrift, :360-368) */
+    float damageZoneLevel[5];   /* Car.h:204 */
+    int32_t _pad[3];         /* record size is a multiple of 16 bytes (coalesced 16-byte-per-lane copies) */
 } pdb_dyn_state;
 
 /* per-tick outputs (compact) */
@@ -307,8 +327,8 @@ typedef struct pdb_track_header {
 }
 /* sizes are part of the ABI (tests/test_abi.py reads these numbers) */
 static_assert(sizeof(pdb_car_state) == 664, "pdb_car_state must equal the reference CarState (pack 4)");
-static_assert(sizeof(pdb_car_params) == 10216, "pdb_car_params layout");
-static_assert(sizeof(pdb_dyn_state) == 2224, "pdb_dyn_state layout (multiple of 16 bytes)");
+static_assert(sizeof(pdb_car_params) == 12392, "pdb_car_params layout");
+static_assert(sizeof(pdb_dyn_state) == 2256, "pdb_dyn_state layout (multiple of 16 bytes)");
 static_assert(sizeof(pdb_step_out) == 104, "pdb_step_out layout");
 #endif
 #endif

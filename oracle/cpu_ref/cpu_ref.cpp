@@ -1245,6 +1245,132 @@ static void drivetrainStep(Car& c, float dt) {
 
 // ------------------------------------------------------------------------------------------------
 // Car::step (Car.cpp:421-553) + stepComponents (:638-681)
+
+// ------------------------------------------------------------------------------------------------
+// Body contacts: PhysicsEngineODE::collisionStep / collisionNearCallback / onCollision (PhysicsEngineODE.cpp:228-341) and
+// Car::onCollisionCallback (Car.cpp:921-1044).  PARITY UNPINNED: contact generation is ODE's (dCollide box-trimesh and
+// trimesh-trimesh), which is not in the reference tree; what follows is this project's own definition of the same
+// quantities, chosen so that every result is an OR or a maximum over contacts (independent of any traversal order):
+//   * pairs: the chassis' belly box against surfaces whose category meets C_MASK_CAR_BOX (1: TRACK), its hull mesh against
+//     surfaces whose category meets C_MASK_CAR_MESH (30: WALL); dynamic-vs-static pairs are collided on odd frames only;
+//   * box vs triangle: separating-axis test in the box frame; the contact normal is the triangle's, turned towards the
+//     box centre, and contacts whose body-local normal.y < 0.9 are dropped (PhysicsEngineODE.cpp:303-312);
+//   * hull vs triangle: every edge of one triangle that pierces the other is a contact at the piercing point, with the
+//     wall triangle's normal turned towards the chassis origin;
+//   * each contact raises collisionFlag; hull contacts feed relative speed -> damage zones / engine blow-up.
+// What is NOT built: the contact joints themselves (no collision response in the solve).
+// ------------------------------------------------------------------------------------------------
+static bool segTri(const V3& a, const V3& b, const V3& p0, const V3& p1, const V3& p2, V3& hit) {
+    const V3 e1 = p1 - p0, e2 = p2 - p0, d = b - a;
+    const V3 pv = d.cross(e2);
+    float det = e1 * pv;
+    const V3 tv = a - p0;
+    float u = tv * pv;
+    const V3 qv = tv.cross(e1);
+    float v = d * qv;
+    float t = e2 * qv;
+    if (det < 0.0f) { det = -det; u = -u; v = -v; t = -t; }
+    if (!(det > 0.0f)) return false;
+    if (u < 0.0f || v < 0.0f || u + v > det || t < 0.0f || t > det) return false;
+    const float sc = t / det;
+    hit = V3(a.x + d.x * sc, a.y + d.y * sc, a.z + d.z * sc);
+    return true;
+}
+// box (half extents h, centred at the origin, axis-aligned in its own frame) against triangle q0 q1 q2 given in that frame
+static bool boxTri(const V3& h, const V3& q0, const V3& q1, const V3& q2, float& normalY) {
+    const V3 f0 = q1 - q0, f1 = q2 - q1, f2 = q0 - q2;
+    const V3 n = f0.cross(q2 - q0);
+    const float d = n * q0;
+    if (fabsf(d) > h.x * fabsf(n.x) + h.y * fabsf(n.y) + h.z * fabsf(n.z)) return false;
+    if (tmin(q0.x, tmin(q1.x, q2.x)) > h.x || tmax(q0.x, tmax(q1.x, q2.x)) < -h.x) return false;
+    if (tmin(q0.y, tmin(q1.y, q2.y)) > h.y || tmax(q0.y, tmax(q1.y, q2.y)) < -h.y) return false;
+    if (tmin(q0.z, tmin(q1.z, q2.z)) > h.z || tmax(q0.z, tmax(q1.z, q2.z)) < -h.z) return false;
+    const V3 f[3] = {f0, f1, f2};
+    for (int j = 0; j < 3; ++j)
+        for (int k = 0; k < 3; ++k) {
+            const V3 a = (k == 0) ? V3(0.0f, -f[j].z, f[j].y) : (k == 1) ? V3(f[j].z, 0.0f, -f[j].x) : V3(-f[j].y, f[j].x, 0.0f);   // e_k x f_j
+            const float p0 = a * q0, p1 = a * q1, p2 = a * q2;
+            const float r = h.x * fabsf(a.x) + h.y * fabsf(a.y) + h.z * fabsf(a.z);
+            if (tmin(p0, tmin(p1, p2)) > r || tmax(p0, tmax(p1, p2)) < -r) return false;
+        }
+    const float l = n.len();
+    float ny = (l != 0.0f) ? n.y / l : 0.0f;
+    if (d > 0.0f) ny = -ny;      // turned towards the box centre
+    normalY = ny;
+    return true;
+}
+void Car::collisionStep() {
+    const pdb_collider& C = P->collider;
+    const int frame = S.simFrame;
+    S.simFrame = frame + 1;
+    S.damageChanged = 0;
+    if (!C.enabled || !(frame & 1)) return;
+    const Body& body = w.bodies[PDB_BODY_CHASSIS];
+    const V3 lo(C.boundsLo), hi(C.boundsHi);
+    const V3 cb = (lo + hi) * 0.5f, hb = (hi - lo) * 0.5f;
+    const V3 cw = l2w(body, cb);
+    const float* R = body.R;
+    const V3 ext(fabsf(R[0]) * hb.x + fabsf(R[1]) * hb.y + fabsf(R[2]) * hb.z, fabsf(R[3]) * hb.x + fabsf(R[4]) * hb.y + fabsf(R[5]) * hb.z,
+                 fabsf(R[6]) * hb.x + fabsf(R[7]) * hb.y + fabsf(R[8]) * hb.z);
+    const V3 aLo = cw - ext, aHi = cw + ext;
+    const TrackData& Tk = *T;
+    bool flag = false, blow = false;
+    float dmg[5] = {0, 0, 0, 0, 0};
+    for (int s = 0; s < Tk.h->numSurfaces; ++s) {
+        const int cat = Tk.surfaces[s].collisionCategory;
+        const bool meshPair = (cat & 30) != 0 && C.numTris > 0, boxPair = (cat & 1) != 0 && C.hasBox;
+        if (!meshPair && !boxPair) continue;
+        const bool noDamage = (cat == 1 || cat == 16);
+        for (int t = Tk.surfaces[s].triStart; t < Tk.surfaces[s].triStart + Tk.surfaces[s].triCount; ++t) {
+            const V3 p0(Tk.tris + 9 * t), p1(Tk.tris + 9 * t + 3), p2(Tk.tris + 9 * t + 6);
+            if (tmin(p0.x, tmin(p1.x, p2.x)) > aHi.x || tmax(p0.x, tmax(p1.x, p2.x)) < aLo.x) continue;
+            if (tmin(p0.y, tmin(p1.y, p2.y)) > aHi.y || tmax(p0.y, tmax(p1.y, p2.y)) < aLo.y) continue;
+            if (tmin(p0.z, tmin(p1.z, p2.z)) > aHi.z || tmax(p0.z, tmax(p1.z, p2.z)) < aLo.z) continue;
+            if (boxPair) {
+                const V3 bc(C.boxCentre);
+                float ny;
+                if (boxTri(V3(C.boxHalf), w2l(body, p0) - bc, w2l(body, p1) - bc, w2l(body, p2) - bc, ny) && ny >= 0.9f) flag = true;
+            }
+            if (meshPair) {
+                const V3 nw = (p1 - p0).cross(p2 - p0).get_norm();
+                for (int ct = 0; ct < C.numTris; ++ct) {
+                    const V3 c0 = l2w(body, V3(C.verts[C.tris[ct][0]])), c1 = l2w(body, V3(C.verts[C.tris[ct][1]])), c2 = l2w(body, V3(C.verts[C.tris[ct][2]]));
+                    for (int e = 0; e < 6; ++e) {
+                        V3 hit;
+                        bool got;
+                        if (e == 0) got = segTri(c0, c1, p0, p1, p2, hit); else if (e == 1) got = segTri(c1, c2, p0, p1, p2, hit); else if (e == 2) got = segTri(c2, c0, p0, p1, p2, hit);
+                        else if (e == 3) got = segTri(p0, p1, c0, c1, c2, hit); else if (e == 4) got = segTri(p1, p2, c0, c1, c2, hit); else got = segTri(p2, p0, c0, c1, c2, hit);
+                        if (!got) continue;
+                        flag = true;
+                        // Car::onCollisionCallback (Car.cpp:964-1003)
+                        V3 n = nw;
+                        if (n * (getPos(body) - hit) < 0.0f) n = n * -1.0f;
+                        const V3 posLocal = w2l(body, hit);
+                        const V3 vel = pointVel(body, hit);
+                        const float relSpeed = -((vel * n) * 3.6f);
+                        const float fDamage = relSpeed * P->mechanicalDamageRate;
+                        if (relSpeed > 0.0f && !noDamage) {
+                            if (relSpeed * P->mechanicalDamageRate > 150.0f) blow = true;
+                            const V3 vn = posLocal.get_norm();
+                            int zone;
+                            if (fabsf(vn.z) <= 0.70700002f) zone = (posLocal.x >= 0.0f) ? 2 : 3; else zone = (posLocal.z <= 0.0f) ? 1 : 0;
+                            dmg[zone] = tmax(dmg[zone], fDamage);
+                            dmg[4] = tmax(dmg[4], fDamage);
+                        }
+                    }
+                }
+            }
+        }
+    }
+    if (flag) S.collisionFlag = 1;
+    if (blow) S.lifeLeft = -100.0f;   // Engine::blowUp (Engine.cpp:406-409)
+    for (int i = 0; i < 5; ++i) {
+        const float nv = tmax(S.damageZoneLevel[i], dmg[i]);
+        if (fabsf(nv - S.damageZoneLevel[i]) > 0.001f) S.damageChanged = 1;
+        S.damageZoneLevel[i] = nv;
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 void Car::carStep(float dt) {
     const pdb_car_params& Pm = *P;
@@ -1586,7 +1712,7 @@ void Car::postStep(float dt) {
         bool bInvalid = true;
         int nDirty = 0;
         for (int i = 0; i < 4; ++i) nDirty += (ts[i].surface >= 0 && Tk.surfaces[ts[i].surface].dirtAdditiveK > 0.001f) ? 1 : 0;
-        if (nDirty <= 2) { if (kmh(S.speed) >= 20.0f) { if (S.currentGear) bInvalid = false; } }
+        if (nDirty <= 2) { if (kmh(S.speed) >= 20.0f) { if (!S.damageChanged && S.currentGear) bInvalid = false; } }
         if (bInvalid) S.driftInvalid = 1;
         // getBetaRad (Car.cpp:1472-1484)
         const V3 lvel = w2lN(body, getVelocity(body));
@@ -1680,6 +1806,7 @@ void Car::stepControls(const pdb_controls& c, float dt, double dtD) {
     stepTime = S.physicsTime;
     S.speed = getVelocity(w.bodies[PDB_BODY_CHASSIS]).len();   // Car::stepPreCacheValues (Car.cpp:414-417)
     carStep(dt);
+    collisionStep();   // PhysicsEngineODE::step: collisionStep, then dWorldStep (PhysicsEngineODE.cpp:216-224)
     w.step(dt);
     postStep(dt);
     storeState();

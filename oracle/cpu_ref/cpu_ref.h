@@ -73,6 +73,7 @@ struct Car {
 
    private:
     void carStep(float dt);
+    void collisionStep();
     void postStep(float dt);
 };
 

@@ -20,6 +20,7 @@
 #include <cstdio>
 #include <cstring>
 #include <cmath>
+#include <cfloat>
 #include <algorithm>
 #include <sys/stat.h>
 
@@ -852,6 +853,58 @@ void buildCarModel(const std::string& basePathIn, const std::string& modelName, 
         sorted(P.blipProfile, "blip");
         for (int i = 0; i < 4; ++i) { sorted(P.tyre[i].performanceCurve, "tyre performance"); sorted(P.tyre[i].wearCurve, "tyre wear"); }
         for (int i = 0; i < P.numWings; ++i) { sorted(P.wings[i].lutAOA_CL, "wing CL"); sorted(P.wings[i].lutAOA_CD, "wing CD"); }
+    }
+    // ---- body colliders: CarColliderManager::init (CarColliderManager.cpp:12-37), Car::loadColliderBlob / initColliderMesh
+    //      (Car.cpp:318-377).  Both files are optional here (the reference insists on them); without them the car has no
+    //      body contacts.  The hull's vertices go through the geom offset addMeshCollider installs (RigidBodyODE.cpp:294-317):
+    //      getGraphicsOffsetMatrix() of the freshly created body = pitch rotation about x, then the graphics offset. ----
+    {
+        pdb_collider& C = P.collider;
+        memset(&C, 0, sizeof(C));
+        float lo[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, hi[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
+        auto grow = [&](const float* v) { for (int k = 0; k < 3; ++k) { lo[k] = std::min(lo[k], v[k]); hi[k] = std::max(hi[k], v[k]); } };
+        Ini col(dataPath + "colliders.ini");
+        if (col.ready && col.hasSection("COLLIDER_0")) {
+            if (col.hasSection("COLLIDER_1")) throw std::runtime_error("pdb: more than one box collider unsupported");
+            float size[3];
+            col.getFloat3("COLLIDER_0", "CENTRE", C.boxCentre);
+            col.getFloat3("COLLIDER_0", "SIZE", size);
+            for (int k = 0; k < 3; ++k) C.boxHalf[k] = size[k] * 0.5f;
+            C.hasBox = 1;
+            for (int c = 0; c < 8; ++c) {
+                const float v[3] = {C.boxCentre[0] + ((c & 1) ? C.boxHalf[0] : -C.boxHalf[0]), C.boxCentre[1] + ((c & 2) ? C.boxHalf[1] : -C.boxHalf[1]),
+                                    C.boxCentre[2] + ((c & 4) ? C.boxHalf[2] : -C.boxHalf[2])};
+                grow(v);
+            }
+        }
+        if (FILE* f = fopen((dataPath + "collider.bin").c_str(), "rb")) {
+            uint32_t hdr[3] = {0, 0, 0};   // magic, numVertices, numIndices (Car.cpp:320-327)
+            const bool okH = fread(hdr, sizeof(hdr), 1, f) == 1;
+            std::vector<float> vb; std::vector<uint16_t> ib;
+            bool ok = okH && hdr[1] > 0 && hdr[2] > 0 && hdr[1] <= 65536 && hdr[2] <= 1000000;
+            if (ok) { vb.resize((size_t)hdr[1] * 3); ib.resize(hdr[2]); ok = fread(vb.data(), vb.size() * 4, 1, f) == 1 && fread(ib.data(), ib.size() * 2, 1, f) == 1; }
+            fclose(f);
+            if (!ok) throw std::runtime_error("pdb: malformed collider.bin for " + modelName);
+            if (hdr[1] > PDB_MAX_COLL_VERTS || hdr[2] / 3 > PDB_MAX_COLL_TRIS) throw std::runtime_error("pdb: collider.bin too large (max 128 vertices, 192 triangles)");
+            float off[3] = {0, 0, 0};
+            if (car.hasKey("BASIC", "GRAPHICS_OFFSET")) car.getFloat3("BASIC", "GRAPHICS_OFFSET", off);
+            const float pitch = (float)((double)(car.hasKey("BASIC", "GRAPHICS_PITCH_ROTATION") ? car.getFloat("BASIC", "GRAPHICS_PITCH_ROTATION") : 0.0f) * (3.14159265358979323846 / (double)180.0f));
+            float M[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+            const float ax[3] = {1, 0, 0};
+            if (pitch != 0.0f) hAxisAngle(ax, pitch, M);
+            C.numVerts = (int32_t)hdr[1]; C.numTris = (int32_t)(hdr[2] / 3);
+            for (int i = 0; i < C.numVerts; ++i) {
+                const float* v = vb.data() + 3 * (size_t)i;
+                for (int c = 0; c < 3; ++c) C.verts[i][c] = off[c] + (v[0] * M[c] + v[1] * M[3 + c] + v[2] * M[6 + c]);   // v * gm (row vector)
+                grow(C.verts[i]);
+            }
+            for (int t = 0; t < C.numTris; ++t)
+                for (int k = 0; k < 3; ++k) {
+                    if (ib[3 * (size_t)t + k] >= hdr[1]) throw std::runtime_error("pdb: collider.bin index out of range");
+                    C.tris[t][k] = (uint8_t)ib[3 * (size_t)t + k];
+                }
+        }
+        if (C.hasBox || C.numTris) { for (int k = 0; k < 3; ++k) { C.boundsLo[k] = lo[k]; C.boundsHi[k] = hi[k]; } C.enabled = 1; }
     }
     // ScoringConfig defaults (ScoringSystem.cpp:46-71)
     pdb_scoring& sc = P.scoring;

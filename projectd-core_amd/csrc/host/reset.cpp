@@ -114,6 +114,8 @@ void teleportToSpline(const pdb_car_params& P, const TrackView& tv, float distan
         S.lastTrackPointTimestamp = (float)S.physicsTime;
         S.nearestTrackPointId = 0; S.oldTrackPointId = 0; S.splinePointId = 0;
         S.trackLocation = 0; S.oldTrackLocation = 0;
+        for (int i = 0; i < 5; ++i) S.damageZoneLevel[i] = 0;   // Car.cpp:403-407 (the simulator's collision frame counter runs on)
+        S.damageChanged = 0;
         S.totalReward = 0; S.stepReward = 0; S.oldPointId = 0; S.oldSplinePointId = 0;   // ScoringSystem::reset
         stopBody(S.body[PDB_BODY_CHASSIS]);
         memcpy(S.body[PDB_BODY_CHASSIS].pos, bodyPos, 12);

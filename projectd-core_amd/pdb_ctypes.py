@@ -44,6 +44,10 @@ class Heave(C.Structure):
     _fields_ = [(n, C.c_float) for n in ('k', 'progressiveK', 'bumpStopUp', 'bumpStopDn', 'rodLength', 'bumpStopRate', 'packerRange')] + [('damper', Damper), ('_pad', C.c_int32)]
 class Turbo(C.Structure):
     _fields_ = [(n, C.c_float) for n in ('lagDN', 'lagUP', 'maxBoost', 'wastegate', 'rpmRef', 'gamma', 'userSetting')] + [('isAdjustable', C.c_int32)]
+class Collider(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ('enabled', 'hasBox', 'numVerts', 'numTris')] + \
+        [('boxCentre', C.c_float * 3), ('boxHalf', C.c_float * 3), ('boundsLo', C.c_float * 3), ('boundsHi', C.c_float * 3),
+         ('verts', (C.c_float * 3) * 128), ('tris', (C.c_uint8 * 3) * 192)]
 class Tyre(C.Structure):
     _fields_ = [(n, C.c_float) for n in ('radius', 'rimRadius', 'k', 'd', 'angularInertia', 'thermalFrictionK', 'thermalRollingK', 'thermalRollingSurfaceK',
                                          'radiusRaiseK', 'softnessIndex', 'Fz0', 'modelFz0', 'relaxationLength', 'rr0', 'rr1', 'rr_slip', 'pressureRef', 'pressureSpringGain',
@@ -81,7 +85,7 @@ class CarParams(C.Structure):
         [(n, C.c_int32) for n in ('acUseOnChange', 'acUseOnStart', 'autoShiftActive', 'autoBlipActive', 'autoBlipElectronic')] + \
         [('upshiftProfile', Curve), ('downshiftProfile', Curve), ('blipProfile', Curve), ('blipPerformTime', C.c_double), ('asChangeUpRpm', C.c_int32), ('asChangeDnRpm', C.c_int32),
          ('asSlipThreshold', C.c_float), ('asGasCutoffTime', C.c_float), ('smoothSteer', C.c_int32), ('patchConnCount', C.c_int8 * 36), ('patchConn', (C.c_int8 * 4) * 36),
-         ('scoring', Scoring)]
+         ('scoring', Scoring), ('collider', Collider)]
 class BodyState(C.Structure):
     _fields_ = [('pos', C.c_float * 3), ('q', C.c_float * 4), ('R', C.c_float * 9), ('lvel', C.c_float * 3), ('avel', C.c_float * 3)]
 class TyreState(C.Structure):
@@ -102,7 +106,8 @@ class DynState(C.Structure):
                                   'currentSpeedMultiplier', 'lastDriftDirection', 'driftStraightTimer', 'instantDriftDelta', 'instantDrift', 'driftPoints')] + \
         [(n, C.c_int32) for n in ('oldPointId', 'oldSplinePointId', 'drifting', 'driftExtreme', 'driftInvalid', 'driftComboCounter', 'collisionFlag', 'oldCollisionFlag',
                                   'outOfTrackFlag')] + \
-        [('gasUsage', C.c_float), ('locClutch', C.c_float), ('turboRotation', C.c_float * 3), ('_pad', C.c_int32 * 2)]
+        [('gasUsage', C.c_float), ('locClutch', C.c_float), ('turboRotation', C.c_float * 3), ('simFrame', C.c_int32), ('damageChanged', C.c_int32),
+         ('damageZoneLevel', C.c_float * 5), ('_pad', C.c_int32 * 3)]
 assert C.sizeof(DynState) % 16 == 0
 class StepOut(C.Structure):
     _fields_ = [('obs', C.c_float * 24), ('reward', C.c_float), ('flags', C.c_int32)]

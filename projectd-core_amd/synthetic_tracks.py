@@ -41,6 +41,44 @@ def gen_flat(out, half=2000.0, z0=-1500.0, z1=1500.0, step=10.0, side=6.0):
     if os.path.exists(c):
         os.remove(c)
 
+def gen_walled(out, z0=-200.0, z1=200.0, step=10.0, side=6.0, half_width=8.0, wall_z=-120.0, bump_z=-170.0, bump_h=0.22):
+    """Walled test strip (BASELINE configs[4] shape in miniature: a collision mesh next to the road): the flat plane, WALL
+    surfaces (category 2) on both sides at x = +-half_width and across the road at wall_z, and a 0.22 m ridge of TRACK
+    surface across the road at bump_z that the wheels climb and the belly box scrapes.  The car starts at z0 heading +z."""
+    os.makedirs(out, exist_ok=True)
+    with open(os.path.join(out, 'surfaces.bin'), 'wb') as f:
+        half = 1000.0
+        write_surface(f, [(-half, 0.0, -half), (-half, 0.0, half), (half, 0.0, half), (half, 0.0, -half)], [0, 1, 2, 0, 2, 3])
+        # ridge: two slopes meeting at height bump_h, 0.6 m run each (normal.y = 0.94), front faces up
+        x = half_width + 2.0
+        rv = [(-x, 0.0, bump_z - 0.6), (x, 0.0, bump_z - 0.6), (-x, bump_h, bump_z), (x, bump_h, bump_z), (-x, 0.0, bump_z + 0.6), (x, 0.0, bump_z + 0.6)]
+        write_surface(f, rv, [0, 2, 1, 1, 2, 3, 2, 4, 3, 3, 4, 5], sector=1, grip=0.95)
+        for sgn in (-1.0, 1.0):     # side walls in 10 m panels
+            verts, idx = [], []
+            z = z0 - 10.0
+            while z < wall_z + 10.0:
+                b = len(verts)
+                verts += [(sgn * half_width, -0.5, z), (sgn * half_width, 2.0, z), (sgn * half_width, 2.0, z + 10.0), (sgn * half_width, -0.5, z + 10.0)]
+                idx += [b, b + 1, b + 2, b, b + 2, b + 3]
+                z += 10.0
+            write_surface(f, verts, idx, sector=2, category=2, valid=0)
+        verts, idx = [], []
+        for k in range(4):          # the wall across the road, four panels
+            xa = -half_width + k * (half_width / 2.0); xb = xa + half_width / 2.0
+            b = len(verts)
+            verts += [(xa, -0.5, wall_z), (xa, 2.0, wall_z), (xb, 2.0, wall_z), (xb, -0.5, wall_z)]
+            idx += [b, b + 1, b + 2, b, b + 2, b + 3]
+        write_surface(f, verts, idx, sector=3, category=2, valid=0)
+    n = int(round((z1 - z0) / step)) + 1
+    with open(os.path.join(out, 'spline.bin'), 'wb') as f:
+        for i in range(n):
+            f.write(struct.pack('<5f', 0.0, 0.0, z0 + step * i, side, side))
+    with open(os.path.join(out, 'spline.ini'), 'w') as f:
+        f.write('[SPLINE]\nCLOSED_LOOP=0\nTRACE_SIDES=0\n')
+    c = os.path.join(out, 'spline.cache')
+    if os.path.exists(c):
+        os.remove(c)
+
 def touge_centreline(step=5.0, radius=600.0):
     """Closed mountain-road centreline: a wobbly ring (3- and 5-lobed) with +-40 m of elevation, resampled at `step` metres.
     Pure float64 math with fixed constants => the same bytes on every machine."""
@@ -189,9 +227,9 @@ def make_base(base, tracks=('flat',)):
     with open(os.path.join(base, 'cfg', 'sim.ini'), 'w') as f:
         f.write(SIM_INI)
     for t in tracks:
-        {'flat': gen_flat, 'touge': gen_touge}[t](os.path.join(base, 'content', 'tracks', t))
+        {'flat': gen_flat, 'touge': gen_touge, 'walled': gen_walled}[t](os.path.join(base, 'content', 'tracks', t))
     return base
 
 if __name__ == '__main__':
     kind, out = sys.argv[1], sys.argv[2]
-    {'flat': gen_flat, 'touge': gen_touge}[kind](out)
+    {'flat': gen_flat, 'touge': gen_touge, 'walled': gen_walled}[kind](out)

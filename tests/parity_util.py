@@ -103,13 +103,14 @@ def make_actions(n, seed, lo=-0.3, hi=0.3):
     return sharding.global_actions(n, seed, lo, hi)
 
 
-def run_parity(n_cars=8, ticks=200, seed=1234, resync=False, verbose=False, check_every=1, actions_fn=None, model='ks_toyota_ae86_drift'):
+def run_parity(n_cars=8, ticks=200, seed=1234, resync=False, verbose=False, check_every=1, actions_fn=None, model='ks_toyota_ae86_drift', track='flat',
+               on_tick=None):
     """Step `n_cars` cars for `ticks` ticks on the GPU (through the C ABI) and in the CPU oracle, from the same
     initial state.  resync=True re-injects the oracle state into the GPU before every tick (single-tick parity).
     Returns the worst relative deviation over all cars, ticks and float fields; raises on integer mismatches."""
     import pdbatch
     P = pdbatch.packed_params(model + '.env')
-    trk = pdbatch.synthetic_track('flat')
+    trk = pdbatch.synthetic_track(track)
     lib = pc.load_product(); orc = oracle_ctypes.load_oracle(portable_math=True)
     S0 = pc.DynState()
     assert lib.pdb_initial_state(C.byref(P), trk, C.byref(S0)) == 0
@@ -138,6 +139,8 @@ def run_parity(n_cars=8, ticks=200, seed=1234, resync=False, verbose=False, chec
                         raise AssertionError('integer state mismatch car %d tick %d: %s' % (i, t, bad_int[:5]))
                     if rel > worst:
                         worst = rel; worst_info = (t, i, name, vg, vc)
+                    if on_tick is not None:
+                        on_tick(t, i, sg[i], sc)
     finally:
         b.close()
         for h in hs:

@@ -1,0 +1,124 @@
+"""Body contacts: PhysicsEngineODE::collisionStep + Car::onCollisionCallback -- detection and its
+consequences (collisionFlag, damage zones, drift validity, engine blow-up).  PARITY UNPINNED: ODE's colliders are not in the
+reference tree, so contact generation follows this project's own definition; these tests check that
+definition's behaviour on a walled strip (CPU oracle) and, under -m gpu, that the HIP path reproduces the oracle bit for bit."""
+import ctypes as C, os
+import numpy as np
+import pytest
+import pdb_ctypes as pc
+import oracle_ctypes
+from conftest import car_params
+
+AE86 = 'ks_toyota_ae86_drift'
+
+
+@pytest.fixture(scope='module')
+def walled(hostlib):
+    import synthetic_tracks, tempfile
+    d = tempfile.mkdtemp(prefix='pdb_walled_')
+    synthetic_tracks.make_base(d, tracks=('walled',))
+    return pc.build_track(hostlib, d, 'walled')
+
+
+def test_packed_cars_carry_their_colliders():
+    """colliders.ini box + collider.bin hull of the shipped cars, in the chassis frame (graphics offset applied)"""
+    for model, nv, nt in ((AE86, 50, 96), ('ks_mazda_rx7_tuned', 113, 178), ('ks_toyota_supra_mkiv_drift', 69, 102),
+                          ('dthwsh_mazda_rx7_fc3s_sr20', 107, 170), ('gravygarage_street_ae86_readie', 50, 96)):
+        c = car_params(model).collider
+        assert (c.enabled, c.hasBox, c.numVerts, c.numTris) == (1, 1, nv, nt)
+        v = np.array([list(c.verts[i]) for i in range(nv)])
+        t = np.array([list(c.tris[i]) for i in range(nt)])
+        assert t.max() < nv
+        assert np.allclose(v.min(0), list(c.boundsLo)[:3], atol=0.2) or c.boundsLo[1] < v[:, 1].min()    # the belly box hangs below the hull
+        assert np.all(np.array(list(c.boundsLo)) <= np.minimum(v.min(0), np.array(list(c.boxCentre)) - np.array(list(c.boxHalf))) + 1e-6)
+        assert abs(v[:, 0].min() + v[:, 0].max()) < 1e-3 and 3.5 < v[:, 2].max() - v[:, 2].min() < 5.0     # symmetric, car-sized
+        assert -0.45 < v[:, 1].min() < -0.15 and 0.6 < v[:, 1].max() < 1.0                               # sill .. roof around the CoG
+    assert list(car_params(AE86).collider.boxHalf) == pytest.approx([0.74, 0.05, 1.95])
+
+
+def _drive(orc, hostlib, blob, P, ticks, shift_z=0.0, speed=0.0, frame0=0):
+    """full throttle, steering centred; optionally start further down the strip, already rolling"""
+    s0 = pc.DynState()
+    assert hostlib.pdb_initial_state(C.byref(P), blob, C.byref(s0)) == 0
+    for b in range(P.numBodies):
+        s0.body[b].pos[2] += shift_z
+        s0.body[b].lvel[2] = speed
+    s0.simFrame = frame0
+    h = orc.cpuref_create(C.byref(P), blob, len(blob), C.byref(s0))
+    S = pc.DynState()
+    rows = []
+    for t in range(ticks):
+        orc.cpuref_step_env(h, 0.0, 1.0)
+        orc.cpuref_get_state(h, C.byref(S))
+        rows.append((t, S.simFrame, S.collisionFlag, S.damageChanged, S.driftInvalid, S.body[0].pos[0], S.body[0].pos[2], S.speed * 3.6, S.lifeLeft) +
+                    tuple(S.damageZoneLevel))
+    orc.cpuref_destroy(h)
+    return np.array(rows, dtype=np.float64)
+
+
+def test_belly_box_scrapes_the_ridge(oracle, hostlib, walled):
+    """the belly box (colliders.ini) meets TRACK surfaces only: over the 22 cm ridge the flag rises, on odd engine frames only
+    (PhysicsEngineODE.cpp:230-241), and nothing is damaged (TRACK contacts carry no damage, Car.cpp:948-958)"""
+    r = _drive(oracle, hostlib, walled, car_params(AE86), 1700)
+    t, frame, flag, changed, invalid, x, z, kmh, life = r[:, :9].T
+    assert np.all(frame == t + 1)
+    hit = flag != 0
+    assert hit.sum() >= 10
+    assert np.all(frame[hit] % 2 == 0)                                   # the counter has already advanced: the collided frame was odd
+    assert np.all(np.abs(z[hit] + 170.0) < 3.0)                          # only while the ridge is under the floor
+    assert np.all(r[:, 9:] == 0) and np.all(changed == 0)
+
+
+def test_nose_into_the_wall(oracle, hostlib, walled):
+    """the hull (collider.bin) meets WALL surfaces: rolling at 54 km/h from 15 m out, the first contact comes when the nose
+    (about 2 m ahead of the CoG) reaches the wall plane; front damage zone = closing speed in km/h (Car.cpp:964-1003), the
+    drift is invalidated on the ticks the damage moves (ScoringSystem.cpp:360-368), the flanks follow as the car
+    crosses the plane -- there are no contact joints, so it does cross (documented gap)"""
+    r = _drive(oracle, hostlib, walled, car_params(AE86), 700, shift_z=65.0, speed=15.0)
+    t, frame, flag, changed, invalid, x, z, kmh, life = r[:, :9].T
+    dmg = r[:, 9:]
+    hit = flag != 0
+    assert np.all(frame[hit] % 2 == 0)
+    first = int(np.argmax(hit))
+    assert abs(z[first] + 2.0 + 120.0) < 0.5, z[first]
+    assert np.all(dmg[:first] == 0)
+    assert abs(dmg[first, 0] - kmh[first]) < 0.05 * kmh[first] and dmg[first, 4] == dmg[first, 0] and np.all(dmg[first, 1:4] == 0)
+    assert changed[first] == 1 and invalid[first] == 1
+    assert np.all(np.diff(dmg, axis=0) >= 0)                             # zones only ever grow (tmax)
+    assert dmg[-1, 0] > 0 and dmg[-1, 2] > 0 and dmg[-1, 3] > 0 and dmg[-1, 4] == dmg[-1, :4].max()   # nose and both flanks, closing
+    assert dmg[-1, 1] == 0                                               # the tail crosses once the CoG is past the plane: receding, no damage
+    assert np.all(life == life[0])                                       # < 150 km/h: the engine survives (Car.cpp:979-980)
+    assert z[-1] > -117.0 and not hit[-1]                                # through and clear
+
+
+def test_collisions_can_be_switched_off_and_do_not_steer_the_car(oracle, hostlib, walled):
+    """without the response rows the trajectory is the same with and without the collision pass, except for what the flag
+    and the damage feed: drift validity and (when set) the penalty"""
+    P = car_params(AE86)
+    on = _drive(oracle, hostlib, walled, P, 2300)
+    P.collider.enabled = 0
+    off = _drive(oracle, hostlib, walled, P, 2300)
+    assert on[:, 2].sum() > 50 and off[:, 2].sum() == 0
+    assert np.array_equal(on[:, 5:8], off[:, 5:8])                       # x, z, speed
+    assert np.all(off[:, 9:] == 0)
+
+
+def test_blow_up_above_150_kmh(oracle, hostlib, walled):
+    r = _drive(oracle, hostlib, walled, car_params(AE86), 60, shift_z=75.0, speed=47.2, frame0=1)
+    assert r[-1, 8] == -100.0 and r[-1, 9] > 150.0                       # Engine::blowUp (Engine.cpp:406-409)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('model', [AE86, 'ks_toyota_supra_mkiv_drift', 'dthwsh_mazda_rx7_fc3s_sr20'])
+def test_gpu_matches_oracle_on_the_walled_strip(built, model):
+    """48 cars with their own constant steering fan out over ridge, side walls and cross wall: every state scalar incl. frame
+    counter, flags and damage zones, every tick, bit for bit"""
+    import parity_util
+    seen = {'flag': 0, 'dmg': 0}
+
+    def on_tick(t, i, sg, sc):
+        seen['flag'] += int(sg.collisionFlag != 0)
+        seen['dmg'] += int(sg.damageZoneLevel[4] > 0)
+    worst = parity_util.run_parity(n_cars=48, ticks=2600, seed=99, track='walled', model=model, check_every=7, on_tick=on_tick)
+    assert worst == 0.0, worst
+    assert seen['flag'] > 100 and seen['dmg'] > 100, seen
