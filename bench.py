@@ -34,16 +34,17 @@ def cpu_baseline(P, trk, S0, actions, seconds_target=15.0):
     t = orc.cpuref_bench(h, n, ticks, a.ctypes.data_as(C.c_void_p), 1, None)
     rate1 = n * ticks / t
     # size the sample for ~seconds_target of CPU work
-    n2 = int(max(16, min(512, rate1 * seconds_target / 333)))
+    ticks2 = 3330   # configs[1] runs 3330 ticks per car
+    n2 = int(max(16, min(len(actions), rate1 * seconds_target / ticks2)))
     a2 = np.ascontiguousarray(actions[:n2], dtype=np.float32)
-    t2 = orc.cpuref_bench(h, n2, 333, a2.ctypes.data_as(C.c_void_p), 1, None)
+    t2 = orc.cpuref_bench(h, n2, ticks2, a2.ctypes.data_as(C.c_void_p), 1, None)
     ncores = os.cpu_count() or 1
     n3 = min(len(actions), max(ncores * 4, 64))
     a3 = np.ascontiguousarray(actions[:n3], dtype=np.float32)
     t3 = orc.cpuref_bench(h, n3, 333, a3.ctypes.data_as(C.c_void_p), ncores, None)
     orc.cpuref_destroy(h)
-    return {"value": n2 * 333 / t2, "unit": "env-steps/s", "cores": 1, "kind": "port",
-            "sample": "%d cars x 333 ticks of the bench workload (first %d cars), CPU restatement of Car::step + ODE-equivalent solve, single thread" % (n2, n2),
+    return {"value": n2 * ticks2 / t2, "unit": "env-steps/s", "cores": 1, "kind": "port",
+            "sample": "%d cars x %d ticks of the bench workload (its first %d cars, %.0f s of CPU work), CPU restatement of Car::step + ODE-equivalent solve, single thread" % (n2, ticks2, n2, t2),
             "all_cores_value": n3 * 333 / t3, "all_cores": ncores}
 
 
@@ -54,6 +55,7 @@ def main():
     ap.add_argument('--warmup', type=int, default=333)
     ap.add_argument('--cars', type=int, default=CARS_PER_GPU)
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-body-contacts', action='store_true', help='diagnostic A/B: switch the collision pass off in the car block (never the bench line)')
     ap.add_argument('--policy', choices=['constant', 'feedback', 'mlp'], default=None,
                     help='where actions come from each tick: constant (configs[1]), feedback (probe controller on the GPU, default for touge), '
                          'mlp (configs[4] shape: a SAC-sized 24-256-256-2 tanh MLP with fixed random weights, evaluated with torch on the GPU from the observation block)')
@@ -87,6 +89,8 @@ def main():
     policy = args.policy or ('feedback' if args.workload == 'touge' else 'constant')
     assert B_ALG == 2 * C.sizeof(pc.DynState) + 8 + C.sizeof(pc.StepOut), 'B_ALG is stale: update it with the record layout'
     P = pdbatch.packed_params()
+    if args.no_body_contacts:
+        P.collider.enabled = 0
     trk = pdbatch.synthetic_track(args.workload)
     lib = pc.load_product()
     S0 = pc.DynState()

@@ -254,3 +254,49 @@ def test_torch_env_equals_numpy_env(pd, base):
         ends += int(tA.sum())
     assert ends >= 3
     envA.close(); envB.close()
+
+
+@pytest.mark.gpu
+def test_vec_env_terminates_on_hit(pd, base):
+    """walled strip, env defaults (terminate_on_hit, projectd_env.py:38,186-189): lanes end their episodes on the ridge (belly
+    box) or at a wall (hull) with the hit penalty, are teleported back and start over -- every observation, reward and
+    termination equal to an oracle-side replay, and collisions are what ended the episodes"""
+    import projectd_env as E, pdbatch, pdb_ctypes as pc, oracle_ctypes, synthetic_tracks
+    synthetic_tracks.make_base(base, tracks=('flat', 'walled'))
+    n = 12
+    env = E.ProjectDVecEnv(n, base, track_name='walled', terminate_off_track=False)
+    P = pdbatch.packed_params(); trk = pc.build_track(pc.load_product(host_only=True), base, 'walled')
+    lib = pc.load_product(); orc = oracle_ctypes.load_oracle(True)
+    S0 = pc.DynState(); assert lib.pdb_initial_state(C.byref(P), trk, C.byref(S0)) == 0
+    hs = [orc.cpuref_create(C.byref(P), trk, len(trk), C.byref(S0)) for _ in range(n)]
+    o = pc.StepOut()
+    obs = env.reset()
+    for i in range(n):
+        orc.cpuref_step_env(hs[i], 0.0, 0.0)
+    total = np.zeros(n); pending = np.zeros(n, bool); hits = 0; other = 0
+    a = np.zeros((n, 2), np.float32)
+    a[:, 0] = np.linspace(-0.25, 0.25, n); a[:, 1] = 1.0
+    for t in range(2200):
+        obs, rew, term, trunc, info = env.step(a)
+        for i in range(n):
+            ai = (0.0, 0.0) if pending[i] else (float(a[i, 0]), float(a[i, 1]))
+            orc.cpuref_step_env(hs[i], ai[0], ai[1]); orc.cpuref_get_out(hs[i], C.byref(o))
+            assert np.array_equal(obs[i], np.array(o.obs[:], np.float32)), (t, i)
+            r = float(np.float32(o.reward)); done = False
+            if o.flags & 1: r -= 50.0; done = True
+            if o.flags & 4: r -= 50.0; done = True
+            total[i] += r
+            if total[i] < -200.0: done = True
+            if pending[i]:
+                r = 0.0; done = False; total[i] = 0.0; pending[i] = False
+            assert rew[i] == np.float32(r) and bool(term[i]) == done, (t, i, rew[i], r, term[i], done)
+            if done:
+                hits += int(o.flags & 1 != 0); other += int(o.flags & 1 == 0)
+                s = pc.DynState(); orc.cpuref_get_state(hs[i], C.byref(s))
+                assert lib.pdb_teleport_to_spline(C.byref(P), trk, C.c_float(0.0), C.byref(s)) == 0
+                assert all(s.damageZoneLevel[k] == 0 for k in range(5))      # Car::reset clears the damage (Car.cpp:403-407)
+                orc.cpuref_set_state(hs[i], C.byref(s)); pending[i] = True
+    assert hits >= n, (hits, other)          # every lane reaches the ridge or a wall at least once
+    for h in hs:
+        orc.cpuref_destroy(h)
+    env.close()
