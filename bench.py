@@ -55,6 +55,7 @@ def main():
     ap.add_argument('--warmup', type=int, default=333)
     ap.add_argument('--cars', type=int, default=CARS_PER_GPU)
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--spline-step', type=float, default=0.0, help='touge workload: metres between spline points (default 5 m = 891 points; 0.9 = 4.9 k points, the density of the reference tracks)')
     ap.add_argument('--no-body-contacts', action='store_true', help='diagnostic A/B: switch the collision pass off in the car block (never the bench line)')
     ap.add_argument('--policy', choices=['constant', 'feedback', 'mlp'], default=None,
                     help='where actions come from each tick: constant (configs[1]), feedback (probe controller on the GPU, default for touge), '
@@ -91,7 +92,7 @@ def main():
     P = pdbatch.packed_params()
     if args.no_body_contacts:
         P.collider.enabled = 0
-    trk = pdbatch.synthetic_track(args.workload)
+    trk = pdbatch.synthetic_track(args.workload, **({'step': args.spline_step} if args.spline_step else {}))
     lib = pc.load_product()
     S0 = pc.DynState()
     assert lib.pdb_initial_state(C.byref(P), trk, C.byref(S0)) == 0

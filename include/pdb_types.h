@@ -321,6 +321,13 @@ typedef struct pdb_track_header {
     uint64_t offGridStart;  /* int32[gridNx*gridNz + 1] */
     uint64_t offGridTris;   /* int32[...]  triangle ids */
     uint64_t offTriSurf;    /* int32[numTris] surface of each triangle */
+    /* version >= 3: uniform xz grid over the fat points (cell edge = hashCellSize, the reference's VertexHash cell,
+     * Core/VertexHash.h:45-104) for Track::nearbyPoints: cell (ix, iz) lists its points in ascending id; cells are
+     * stored row by row, so the lists of the cells ix0..ix1 of one row are one contiguous run of ids. */
+    int32_t fatGridNx, fatGridNz;
+    float fatGridMinX, fatGridMinZ, fatGridCell, _fatGridPad;
+    uint64_t offFatGridStart;   /* int32[fatGridNx*fatGridNz + 1] */
+    uint64_t offFatGridIds;     /* int32[numFat] */
 } pdb_track_header;
 
 #ifdef __cplusplus

@@ -363,7 +363,7 @@ std::vector<uint8_t> buildTrack(const std::string& basePathIn, const std::string
     // ---- pack ----
     pdb_track_header h;
     memset(&h, 0, sizeof(h));
-    h.magic = 0x4B544450; h.version = 2;
+    h.magic = 0x4B544450; h.version = 3;
     h.numSurfaces = (int32_t)surfaces.size(); h.numTris = (int32_t)(tris.size() / 9);
     h.numFat = (int32_t)fat.size(); h.numNodes = (int32_t)nodes.size();
     h.interpolateStep = steps; h.closedLoop = closedLoop ? 1 : 0;
@@ -407,6 +407,26 @@ std::vector<uint8_t> buildTrack(const std::string& basePathIn, const std::string
     h.offGridStart = off; off = align(off + gridStart.size() * 4);
     h.offGridTris = off; off = align(off + gridTris.size() * 4);
     h.offTriSurf = off; off = align(off + triSurf.size() * 4);
+    // ---- xz grid over the fat points (see pdb_track_header) ----
+    std::vector<int32_t> fgStart, fgIds;
+    if (!fat.empty()) {
+        float mnx = fat[0].best.x, mxx = mnx, mnz = fat[0].best.z, mxz = mnz;
+        for (const Fat& f : fat) { mnx = std::min(mnx, f.best.x); mxx = std::max(mxx, f.best.x); mnz = std::min(mnz, f.best.z); mxz = std::max(mxz, f.best.z); }
+        float cell = cellSize > 1.0f ? cellSize : 50.0f;
+        while ((double)((mxx - mnx) / cell + 1.0f) * (double)((mxz - mnz) / cell + 1.0f) > 1048576.0) cell *= 2.0f;
+        h.fatGridMinX = mnx; h.fatGridMinZ = mnz; h.fatGridCell = cell;
+        auto cellOf = [&](float x, float mn) { return (int)floorf((x - mn) / cell); };   // the kernel uses the same expression
+        h.fatGridNx = cellOf(mxx, mnx) + 1; h.fatGridNz = cellOf(mxz, mnz) + 1;
+        const size_t nc = (size_t)h.fatGridNx * (size_t)h.fatGridNz;
+        fgStart.assign(nc + 1, 0);
+        for (const Fat& f : fat) fgStart[(size_t)cellOf(f.best.z, mnz) * h.fatGridNx + cellOf(f.best.x, mnx) + 1]++;
+        for (size_t c = 0; c < nc; ++c) fgStart[c + 1] += fgStart[c];
+        fgIds.assign(fat.size(), 0);
+        std::vector<int32_t> fill(fgStart.begin(), fgStart.end() - 1);
+        for (size_t i = 0; i < fat.size(); ++i) fgIds[(size_t)fill[(size_t)cellOf(fat[i].best.z, mnz) * h.fatGridNx + cellOf(fat[i].best.x, mnx)]++] = (int32_t)i;   // ascending id per cell
+    }
+    h.offFatGridStart = off; off = align(off + fgStart.size() * 4);
+    h.offFatGridIds = off; off = align(off + fgIds.size() * 4);
     h.totalBytes = off;
     std::vector<uint8_t> blob(off, 0);
     memcpy(blob.data(), &h, sizeof(h));
@@ -419,6 +439,8 @@ std::vector<uint8_t> buildTrack(const std::string& basePathIn, const std::string
     if (!gridStart.empty()) memcpy(blob.data() + h.offGridStart, gridStart.data(), gridStart.size() * 4);
     if (!gridTris.empty()) memcpy(blob.data() + h.offGridTris, gridTris.data(), gridTris.size() * 4);
     if (!triSurf.empty()) memcpy(blob.data() + h.offTriSurf, triSurf.data(), triSurf.size() * 4);
+    if (!fgStart.empty()) memcpy(blob.data() + h.offFatGridStart, fgStart.data(), fgStart.size() * 4);
+    if (!fgIds.empty()) memcpy(blob.data() + h.offFatGridIds, fgIds.data(), fgIds.size() * 4);
     return blob;
 }
 

@@ -121,9 +121,13 @@ def packed_params(name='ks_toyota_ae86_drift.env'):
     return P
 
 
-def synthetic_track(kind='flat'):
+def synthetic_track(kind='flat', **gen_args):
+    """blob of one of the synthetic tracks; gen_args go to its generator (e.g. step=0.9 for a dense mountain-road spline)"""
     import synthetic_tracks
     lib = pc.load_product()
     d = tempfile.mkdtemp(prefix='pdb_base_')
-    synthetic_tracks.make_base(d, tracks=(kind,))
+    synthetic_tracks.make_base(d, tracks=() if gen_args else (kind,))
+    if gen_args:
+        {'flat': synthetic_tracks.gen_flat, 'touge': synthetic_tracks.gen_touge, 'walled': synthetic_tracks.gen_walled}[kind](
+            os.path.join(d, 'content', 'tracks', kind), **gen_args)
     return pc.build_track(lib, d, kind)

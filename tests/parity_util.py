@@ -110,7 +110,7 @@ def run_parity(n_cars=8, ticks=200, seed=1234, resync=False, verbose=False, chec
     Returns the worst relative deviation over all cars, ticks and float fields; raises on integer mismatches."""
     import pdbatch
     P = pdbatch.packed_params(model + '.env')
-    trk = pdbatch.synthetic_track(track)
+    trk = track if isinstance(track, (bytes, bytearray)) else pdbatch.synthetic_track(track)
     lib = pc.load_product(); orc = oracle_ctypes.load_oracle(portable_math=True)
     S0 = pc.DynState()
     assert lib.pdb_initial_state(C.byref(P), trk, C.byref(S0)) == 0

@@ -367,3 +367,18 @@ def test_snapshot_restore_replays_identically(built):
         assert all(o1.tobytes() == o2.tobytes() for o1, o2 in zip(outs1, outs2))
     finally:
         b.close()
+
+
+@pytest.mark.gpu
+def test_fat_point_grid_on_a_long_dense_spline(built):
+    """Track::nearbyPoints through the blob's fat-point grid: a 4.4 km road with a spline point every 0.9 m (4900 points, the
+    scale of the reference's ek_akina spline) -- probes, nearest point, spline location and rewards equal the oracle's, which
+    scans every point"""
+    import synthetic_tracks, tempfile, parity_util, pdb_ctypes as pc
+    d = tempfile.mkdtemp(prefix='pdb_dense_')
+    synthetic_tracks.make_base(d, tracks=())
+    n = synthetic_tracks.gen_touge(os.path.join(d, 'content', 'tracks', 'dense'), step=0.9)
+    assert n > 4500
+    blob = pc.build_track(pc.load_product(host_only=True), d, 'dense')
+    worst = parity_util.run_parity(n_cars=24, ticks=1500, seed=5, track=blob, check_every=5)
+    assert worst == 0.0, worst
