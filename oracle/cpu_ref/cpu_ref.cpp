@@ -1253,7 +1253,7 @@ static void drivetrainStep(Car& c, float dt) {
 // quantities, chosen so that every result is an OR or a maximum over contacts (independent of any traversal order):
 //   * pairs: the chassis' belly box against surfaces whose category meets C_MASK_CAR_BOX (1: TRACK), its hull mesh against
 //     surfaces whose category meets C_MASK_CAR_MESH (30: WALL); dynamic-vs-static pairs are collided on odd frames only;
-//   * box vs triangle: separating-axis test in the box frame; the contact normal is the triangle's, turned towards the
+//   * box vs triangle: plane reach test in world space, then the separating-axis test in the box frame; the contact normal is the triangle's, turned towards the
 //     box centre, and contacts whose body-local normal.y < 0.9 are dropped (PhysicsEngineODE.cpp:303-312);
 //   * hull vs triangle: every edge of one triangle that pierces the other is a contact at the piercing point, with the
 //     wall triangle's normal turned towards the chassis origin;
@@ -1327,9 +1327,14 @@ void Car::collisionStep() {
             if (tmin(p0.y, tmin(p1.y, p2.y)) > aHi.y || tmax(p0.y, tmax(p1.y, p2.y)) < aLo.y) continue;
             if (tmin(p0.z, tmin(p1.z, p2.z)) > aHi.z || tmax(p0.z, tmax(p1.z, p2.z)) < aLo.z) continue;
             if (boxPair) {
-                const V3 bc(C.boxCentre);
+                const V3 bc(C.boxCentre), bh(C.boxHalf);
+                // does the box reach the triangle's plane at all?  world-space evaluation first, then the full test in the box frame
+                const V3 nW = (p1 - p0).cross(p2 - p0);
+                const float dW = nW * (l2w(body, bc) - p0);
+                const float* Rm = body.R;
+                const float rW = bh.x * fabsf(nW * V3(Rm[0], Rm[3], Rm[6])) + bh.y * fabsf(nW * V3(Rm[1], Rm[4], Rm[7])) + bh.z * fabsf(nW * V3(Rm[2], Rm[5], Rm[8]));
                 float ny;
-                if (boxTri(V3(C.boxHalf), w2l(body, p0) - bc, w2l(body, p1) - bc, w2l(body, p2) - bc, ny) && ny >= 0.9f) flag = true;
+                if (!(fabsf(dW) > rW) && boxTri(bh, w2l(body, p0) - bc, w2l(body, p1) - bc, w2l(body, p2) - bc, ny) && ny >= 0.9f) flag = true;
             }
             if (meshPair) {
                 const V3 nw = (p1 - p0).cross(p2 - p0).get_norm();

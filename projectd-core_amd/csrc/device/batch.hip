@@ -106,7 +106,7 @@ static StepKernel stepKernelFor(const pdb_batch* b) {
 
 static int launch(pdb_batch* b, float dt, bool wantCarState) {
     if (b->K.dt != dt || b->K.wantCarState != (wantCarState ? 1 : 0)) {
-        b->K.dt = dt;
+        b->K.dt = dt; b->K.fps = 1.0f / dt;
         b->K.dtD = (dt == (float)(1.0 / 333.0)) ? (1.0 / 333.0) : (double)dt;   // PyProjectD.cpp:160-173: double dt, float step
         b->K.wantCarState = wantCarState ? 1 : 0;
         HIPCHK(hipMemcpyAsync(b->dK, &b->K, sizeof(DevConst), hipMemcpyHostToDevice, b->stream));
@@ -143,7 +143,7 @@ pdb_batch* pdb_create(int device, int n_cars, const pdb_car_params* params, cons
     b->device = device; b->n = n_cars; b->params = *params;
     b->track.assign((const uint8_t*)track_blob, (const uint8_t*)track_blob + track_bytes);
     fillConst(b->params, b->K, action_mode);
-    b->K.dt = (float)(1.0 / 333.0); b->K.dtD = 1.0 / 333.0;
+    b->K.dt = (float)(1.0 / 333.0); b->K.fps = 1.0f / b->K.dt; b->K.dtD = 1.0 / 333.0;
     bool ok = true;
     ok = ok && hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking) == hipSuccess;
     ok = ok && hipMalloc(&b->dStates, sizeof(pdb_dyn_state) * (size_t)n_cars) == hipSuccess;
@@ -268,7 +268,7 @@ int pdb_step_n(pdb_batch* b, float dt, int n) {
         if (b->graphExec) { (void)hipGraphExecDestroy(b->graphExec); b->graphExec = nullptr; }
         // make sure the constants are current before capture (the capture must not contain the H2D copy)
         if (b->K.dt != dt || b->K.wantCarState != 0) {
-            b->K.dt = dt; b->K.dtD = (dt == (float)(1.0 / 333.0)) ? (1.0 / 333.0) : (double)dt; b->K.wantCarState = 0;
+            b->K.dt = dt; b->K.fps = 1.0f / dt; b->K.dtD = (dt == (float)(1.0 / 333.0)) ? (1.0 / 333.0) : (double)dt; b->K.wantCarState = 0;
             HIPCHK(hipMemcpyAsync(b->dK, &b->K, sizeof(DevConst), hipMemcpyHostToDevice, b->stream));
             HIPCHK(hipStreamSynchronize(b->stream));
         }

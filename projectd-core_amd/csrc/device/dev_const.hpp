@@ -14,6 +14,7 @@ struct DevConst {
     int rowStart[PDB_MAX_JOINTS + 1];
     int rowB0[PDB_MAX_ROWS], rowB1[PDB_MAX_ROWS];   // bodies of each constraint row (static per model: scalar loads in the A assembly)
     float dt;
+    float fps;   // 1.0f / dt
     double dtD;
     int actionMode;
     int wantCarState;
