@@ -143,6 +143,7 @@ const char* cpuref_scenario_name(int sid) { return pdoracle::kScenarios[sid].nam
 const char* cpuref_scenario_track(int sid) { return pdoracle::kScenarios[sid].track; }
 const char* cpuref_scenario_car(int sid) { return pdoracle::kScenarios[sid].car ? pdoracle::kScenarios[sid].car : PDORACLE_DEFAULT_CAR; }
 int cpuref_num_scenarios(void) { return pdoracle::kNumScenarios; }
+int cpuref_scenario_collide(int sid) { return pdoracle::kScenarios[sid].collide; }
 void cpuref_scenario_feedback(int sid, int tick, const float* obs, float* a) { pdoracle::scenarioFeedback(sid, tick, obs, a[0], a[1]); }
 
 // run one scripted scenario exactly like oracle/refharness/ref_main.cpp and write the probe file

@@ -1,6 +1,7 @@
 // ORACLE / TEST INFRASTRUCTURE -- see cpu_ref.h.  Citations are relative to
 // /root/reference/src/ProjectD unless stated otherwise.
 #include "cpu_ref.h"
+#include "../rb/pdcollide.h"
 #include "mathsel.h"
 #include "../rb/pdray.h"
 #include <cmath>
@@ -1260,45 +1261,6 @@ static void drivetrainStep(Car& c, float dt) {
 //   * each contact raises collisionFlag; hull contacts feed relative speed -> damage zones / engine blow-up.
 // What is NOT built: the contact joints themselves (no collision response in the solve).
 // ------------------------------------------------------------------------------------------------
-static bool segTri(const V3& a, const V3& b, const V3& p0, const V3& p1, const V3& p2, V3& hit) {
-    const V3 e1 = p1 - p0, e2 = p2 - p0, d = b - a;
-    const V3 pv = d.cross(e2);
-    float det = e1 * pv;
-    const V3 tv = a - p0;
-    float u = tv * pv;
-    const V3 qv = tv.cross(e1);
-    float v = d * qv;
-    float t = e2 * qv;
-    if (det < 0.0f) { det = -det; u = -u; v = -v; t = -t; }
-    if (!(det > 0.0f)) return false;
-    if (u < 0.0f || v < 0.0f || u + v > det || t < 0.0f || t > det) return false;
-    const float sc = t / det;
-    hit = V3(a.x + d.x * sc, a.y + d.y * sc, a.z + d.z * sc);
-    return true;
-}
-// box (half extents h, centred at the origin, axis-aligned in its own frame) against triangle q0 q1 q2 given in that frame
-static bool boxTri(const V3& h, const V3& q0, const V3& q1, const V3& q2, float& normalY) {
-    const V3 f0 = q1 - q0, f1 = q2 - q1, f2 = q0 - q2;
-    const V3 n = f0.cross(q2 - q0);
-    const float d = n * q0;
-    if (fabsf(d) > h.x * fabsf(n.x) + h.y * fabsf(n.y) + h.z * fabsf(n.z)) return false;
-    if (tmin(q0.x, tmin(q1.x, q2.x)) > h.x || tmax(q0.x, tmax(q1.x, q2.x)) < -h.x) return false;
-    if (tmin(q0.y, tmin(q1.y, q2.y)) > h.y || tmax(q0.y, tmax(q1.y, q2.y)) < -h.y) return false;
-    if (tmin(q0.z, tmin(q1.z, q2.z)) > h.z || tmax(q0.z, tmax(q1.z, q2.z)) < -h.z) return false;
-    const V3 f[3] = {f0, f1, f2};
-    for (int j = 0; j < 3; ++j)
-        for (int k = 0; k < 3; ++k) {
-            const V3 a = (k == 0) ? V3(0.0f, -f[j].z, f[j].y) : (k == 1) ? V3(f[j].z, 0.0f, -f[j].x) : V3(-f[j].y, f[j].x, 0.0f);   // e_k x f_j
-            const float p0 = a * q0, p1 = a * q1, p2 = a * q2;
-            const float r = h.x * fabsf(a.x) + h.y * fabsf(a.y) + h.z * fabsf(a.z);
-            if (tmin(p0, tmin(p1, p2)) > r || tmax(p0, tmax(p1, p2)) < -r) return false;
-        }
-    const float l = n.len();
-    float ny = (l != 0.0f) ? n.y / l : 0.0f;
-    if (d > 0.0f) ny = -ny;      // turned towards the box centre
-    normalY = ny;
-    return true;
-}
 void Car::collisionStep() {
     const pdb_collider& C = P->collider;
     const int frame = S.simFrame;
@@ -1306,65 +1268,45 @@ void Car::collisionStep() {
     S.damageChanged = 0;
     if (!C.enabled || !(frame & 1)) return;
     const Body& body = w.bodies[PDB_BODY_CHASSIS];
-    const V3 lo(C.boundsLo), hi(C.boundsHi);
-    const V3 cb = (lo + hi) * 0.5f, hb = (hi - lo) * 0.5f;
-    const V3 cw = l2w(body, cb);
-    const float* R = body.R;
-    const V3 ext(fabsf(R[0]) * hb.x + fabsf(R[1]) * hb.y + fabsf(R[2]) * hb.z, fabsf(R[3]) * hb.x + fabsf(R[4]) * hb.y + fabsf(R[5]) * hb.z,
-                 fabsf(R[6]) * hb.x + fabsf(R[7]) * hb.y + fabsf(R[8]) * hb.z);
-    const V3 aLo = cw - ext, aHi = cw + ext;
+    pdcol::Pose pose;
+    memcpy(pose.pos, body.pos, 12); memcpy(pose.R, body.R, 36);
+    pdcol::V aLo, aHi;
+    pdcol::worldAabb(pose, C.boundsLo, C.boundsHi, aLo, aHi);
     const TrackData& Tk = *T;
     bool flag = false, blow = false;
     float dmg[5] = {0, 0, 0, 0, 0};
     for (int s = 0; s < Tk.h->numSurfaces; ++s) {
         const int cat = Tk.surfaces[s].collisionCategory;
+        // collisionNearCallback (PhysicsEngineODE.cpp:258-264): (cat1 & mask2) && (cat2 & mask1), car geoms are category 4,
+        // surfaces collide with mask 20, the box with mask 1, the hull with mask 30 (Sim/SimulatorCommon.h:7-13)
         const bool meshPair = (cat & 30) != 0 && C.numTris > 0, boxPair = (cat & 1) != 0 && C.hasBox;
         if (!meshPair && !boxPair) continue;
-        const bool noDamage = (cat == 1 || cat == 16);
+        const bool noDamage = (cat == 1 || cat == 16);   // Car.cpp:948-958: bFlag for groups 1 and 16
         for (int t = Tk.surfaces[s].triStart; t < Tk.surfaces[s].triStart + Tk.surfaces[s].triCount; ++t) {
-            const V3 p0(Tk.tris + 9 * t), p1(Tk.tris + 9 * t + 3), p2(Tk.tris + 9 * t + 6);
-            if (tmin(p0.x, tmin(p1.x, p2.x)) > aHi.x || tmax(p0.x, tmax(p1.x, p2.x)) < aLo.x) continue;
-            if (tmin(p0.y, tmin(p1.y, p2.y)) > aHi.y || tmax(p0.y, tmax(p1.y, p2.y)) < aLo.y) continue;
-            if (tmin(p0.z, tmin(p1.z, p2.z)) > aHi.z || tmax(p0.z, tmax(p1.z, p2.z)) < aLo.z) continue;
+            const pdcol::V p0 = pdcol::ld(Tk.tris + 9 * t), p1 = pdcol::ld(Tk.tris + 9 * t + 3), p2 = pdcol::ld(Tk.tris + 9 * t + 6);
+            if (!pdcol::triMeetsAabb(p0, p1, p2, aLo, aHi)) continue;
             if (boxPair) {
-                const V3 bc(C.boxCentre), bh(C.boxHalf);
-                // does the box reach the triangle's plane at all?  world-space evaluation first, then the full test in the box frame
-                const V3 nW = (p1 - p0).cross(p2 - p0);
-                const float dW = nW * (l2w(body, bc) - p0);
-                const float* Rm = body.R;
-                const float rW = bh.x * fabsf(nW * V3(Rm[0], Rm[3], Rm[6])) + bh.y * fabsf(nW * V3(Rm[1], Rm[4], Rm[7])) + bh.z * fabsf(nW * V3(Rm[2], Rm[5], Rm[8]));
                 float ny;
-                if (!(fabsf(dW) > rW) && boxTri(bh, w2l(body, p0) - bc, w2l(body, p1) - bc, w2l(body, p2) - bc, ny) && ny >= 0.9f) flag = true;
+                if (pdcol::boxContact(pose, C.boxCentre, C.boxHalf, p0, p1, p2, ny) && ny >= 0.9f) flag = true;   // PhysicsEngineODE.cpp:303-312
             }
-            if (meshPair) {
-                const V3 nw = (p1 - p0).cross(p2 - p0).get_norm();
-                for (int ct = 0; ct < C.numTris; ++ct) {
-                    const V3 c0 = l2w(body, V3(C.verts[C.tris[ct][0]])), c1 = l2w(body, V3(C.verts[C.tris[ct][1]])), c2 = l2w(body, V3(C.verts[C.tris[ct][2]]));
-                    for (int e = 0; e < 6; ++e) {
-                        V3 hit;
-                        bool got;
-                        if (e == 0) got = segTri(c0, c1, p0, p1, p2, hit); else if (e == 1) got = segTri(c1, c2, p0, p1, p2, hit); else if (e == 2) got = segTri(c2, c0, p0, p1, p2, hit);
-                        else if (e == 3) got = segTri(p0, p1, c0, c1, c2, hit); else if (e == 4) got = segTri(p1, p2, c0, c1, c2, hit); else got = segTri(p2, p0, c0, c1, c2, hit);
-                        if (!got) continue;
-                        flag = true;
-                        // Car::onCollisionCallback (Car.cpp:964-1003)
-                        V3 n = nw;
-                        if (n * (getPos(body) - hit) < 0.0f) n = n * -1.0f;
-                        const V3 posLocal = w2l(body, hit);
-                        const V3 vel = pointVel(body, hit);
-                        const float relSpeed = -((vel * n) * 3.6f);
-                        const float fDamage = relSpeed * P->mechanicalDamageRate;
-                        if (relSpeed > 0.0f && !noDamage) {
-                            if (relSpeed * P->mechanicalDamageRate > 150.0f) blow = true;
-                            const V3 vn = posLocal.get_norm();
-                            int zone;
-                            if (fabsf(vn.z) <= 0.70700002f) zone = (posLocal.x >= 0.0f) ? 2 : 3; else zone = (posLocal.z <= 0.0f) ? 1 : 0;
-                            dmg[zone] = tmax(dmg[zone], fDamage);
-                            dmg[4] = tmax(dmg[4], fDamage);
-                        }
+            if (meshPair)
+                pdcol::hullContacts(pose, C.verts, C.tris, C.numTris, p0, p1, p2, [&](const pdcol::V& nrm, const pdcol::V& hitp) {
+                    // Car::onCollisionCallback (Car.cpp:960-1003)
+                    flag = true;
+                    const V3 n(nrm.x, nrm.y, nrm.z), hit(hitp.x, hitp.y, hitp.z);
+                    const V3 posLocal = w2l(body, hit);
+                    const V3 vel = pointVel(body, hit);
+                    const float relSpeed = -((vel * n) * 3.6f);
+                    const float fDamage = relSpeed * P->mechanicalDamageRate;
+                    if (relSpeed > 0.0f && !noDamage) {
+                        if (relSpeed * P->mechanicalDamageRate > 150.0f) blow = true;
+                        const V3 vn = posLocal.get_norm();
+                        int zone;
+                        if (fabsf(vn.z) <= 0.70700002f) zone = (posLocal.x >= 0.0f) ? 2 : 3; else zone = (posLocal.z <= 0.0f) ? 1 : 0;
+                        dmg[zone] = tmax(dmg[zone], fDamage);
+                        dmg[4] = tmax(dmg[4], fDamage);
                     }
-                }
-            }
+                });
         }
     }
     if (flag) S.collisionFlag = 1;
@@ -1967,6 +1909,7 @@ void Car::fillProbe(pdoracle::Probe& Pr) const {
     Pr.p("sc.instantDrift", S.instantDrift); Pr.p("sc.driftPoints", S.driftPoints);
     Pr.p("sc.driftComboCounter", S.driftComboCounter);
     Pr.p("car.collisionFlag", S.collisionFlag ? 1 : 0); Pr.p("car.outOfTrackFlag", S.outOfTrackFlag ? 1 : 0);
+    for (int i = 0; i < 5; ++i) { char nm[40]; snprintf(nm, sizeof(nm), "car.damageZoneLevel%d", i); Pr.p(nm, S.damageZoneLevel[i]); }
     pdb_car_state cs;
     fillCarState(cs);
     Pr.p("cs.timestamp", cs.timestamp); Pr.p("cs.engineRPM", cs.engineRPM); Pr.p("cs.speedMS", cs.speedMS);

@@ -86,6 +86,7 @@ def main():
     make_fwd_car(base)
     gen_track.gen_flat(os.path.join(base, 'content', 'tracks', 'flat'))
     gen_track.gen_touge(os.path.join(base, 'content', 'tracks', 'touge'))
+    gen_track.gen_walled(os.path.join(base, 'content', 'tracks', 'walled'))
     for trk in ('driftplayground',):
         dst = os.path.join(base, 'content', 'tracks', trk)
         if os.path.isdir(dst):

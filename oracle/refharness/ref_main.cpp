@@ -123,6 +123,7 @@ static void fillProbe(Probe& P, Simulator* sim, Car* car) {
     P.p("sc.instantDrift", sc->instantDrift); P.p("sc.driftPoints", sc->driftPoints);
     P.p("sc.driftComboCounter", sc->driftComboCounter);
     P.p("car.collisionFlag", car->collisionFlag ? 1 : 0); P.p("car.outOfTrackFlag", car->outOfTrackFlag ? 1 : 0);
+    for (int i = 0; i < 5; ++i) { char nm[40]; snprintf(nm, sizeof(nm), "car.damageZoneLevel%d", i); P.p(nm, car->damageZoneLevel[i]); }
     // CarState (what getCarState hands to python)
     const CarState& cs = *car->state;
     P.p("cs.timestamp", cs.timestamp); P.p("cs.engineRPM", cs.engineRPM); P.p("cs.speedMS", cs.speedMS);
@@ -221,6 +222,7 @@ int main(int argc, char** argv) {
             if (!only.empty() && only != track) continue;
             env.init(base, track, sc.car ? std::string(sc.car) : model, sc.autoClutch != 0, sc.autoShift != 0, sc.autoBlip != 0);
             env.smooth = sc.rawSteer == 0;
+            ref_set_collide(env.sim->physics.get(), sc.collide != 0);
             pdoracle::ProbeFile pf;
             env.reset();
             {

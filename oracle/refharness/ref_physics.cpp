@@ -4,15 +4,22 @@
 // PhysicsFactory::createPhysicsEngine, Physics/PhysicsFactory.cpp:6-9) on top of this project's
 // rigid-body restatement oracle/rb (pdrb).  It plays the role of Physics/ODE/*.cpp, which cannot
 // be built here because libode is absent.  Method-by-method it follows RigidBodyODE.cpp:9-319,
-// JointODE.cpp:21-89, PhysicsEngineODE.cpp:111-224.  Body-vs-track collision (collisionStep,
-// PhysicsEngineODE.cpp:228-341) is NOT implemented: colliders are recorded and ignored.
+// JointODE.cpp:21-89, PhysicsEngineODE.cpp:111-341.  Body-vs-track collision (collisionStep / collisionNearCallback /
+// onCollision, PhysicsEngineODE.cpp:228-341) is optional (ref_set_collide): the frame parity, the category / mask pairing, the
+// body-local normal.y filter of box contacts and the callback into the reference's Simulator / Car::onCollisionCallback follow
+// the reference; the contacts themselves come from this project's own generator (oracle/rb/pdcollide.h -- ODE's dCollide is
+// not available), and no contact joints are created (no collision response).
 #include "Physics/PhysicsFactory.h"
 #include "Physics/IPhysicsEngine.h"
 #include "Core/Diag.h"
 #include "../rb/pdrb.h"
 #include "../rb/pdray.h"
+#include "../rb/pdcollide.h"
+#include <cfloat>
 #include "ref_physics.h"
 #include <vector>
+#include <algorithm>
+#include <cstring>
 #include <memory>
 
 namespace D {
@@ -88,9 +95,12 @@ struct BodyPD : public IRigidBody {
     void addLocalForceAtLocalPos(const vec3f& f, const vec3f& p) override { b().addRelForceAtRelPos(&f.x, &p.x); }
     void addTorque(const vec3f& t) override { b().addTorque(&t.x); }
     void addLocalTorque(const vec3f& t) override { b().addRelTorque(&t.x); }
-    void addBoxCollider(const vec3f&, const vec3f&, unsigned int, unsigned int, unsigned long) override {}
-    void addMeshCollider(ITriMeshPtr, const mat44f&, unsigned int, unsigned long, unsigned long) override {}
+    void addBoxCollider(const vec3f& pos, const vec3f& size, unsigned int, unsigned int category, unsigned long mask) override;
+    void addMeshCollider(ITriMeshPtr tm, const mat44f& offset, unsigned int, unsigned long category, unsigned long mask) override;
 };
+// geoms attached to a body (RigidBodyODE::addBoxCollider / addMeshCollider, RigidBodyODE.cpp:274-317), in the body frame
+struct DynBox { BodyPD* body; float centre[3], half[3]; unsigned long cat, mask; };
+struct DynMesh { BodyPD* body; std::vector<float> verts; std::vector<unsigned char> tris; std::shared_ptr<ColliderPD> shape; };
 
 struct JointPD : public IJoint {
     EnginePD* e;
@@ -114,6 +124,11 @@ struct EnginePD : public IPhysicsEngine {
     std::vector<pdrb::StaticMesh> statics;
     std::vector<std::shared_ptr<ColliderPD>> staticColliders;
     ICollisionCallback* cb = nullptr;
+    std::vector<DynBox> boxes;
+    std::vector<DynMesh> meshes;
+    bool collide = false;
+    int currentFrame = 0;
+    void collisionStep();
 
     IRigidBodyPtr createRigidBody() override { return std::make_shared<BodyPD>(this, world.createBody()); }
     static int bid(const IRigidBodyPtr& p) { return std::dynamic_pointer_cast<BodyPD>(p)->id; }
@@ -165,10 +180,77 @@ struct EnginePD : public IPhysicsEngine {
     RayCastHit rayCast(const vec3f& pos, const vec3f& dir, IRayCasterPtr ray) override {
         return rayImpl(pos, dir, std::dynamic_pointer_cast<RayCasterPD>(ray)->length);
     }
-    void step(float dt) override { world.step(dt); }  // PhysicsEngineODE.cpp:216-224 without collisionStep
+    void step(float dt) override { if (collide) collisionStep(); else currentFrame++; world.step(dt); }  // PhysicsEngineODE.cpp:216-224
 };
 
 pdrb::Body& BodyPD::b() { return e->world.bodies[id]; }
+void BodyPD::addBoxCollider(const vec3f& pos, const vec3f& size, unsigned int, unsigned int category, unsigned long mask) {
+    DynBox bx; bx.body = this; bx.cat = category; bx.mask = mask;
+    bx.centre[0] = pos.x; bx.centre[1] = pos.y; bx.centre[2] = pos.z;
+    bx.half[0] = size.x * 0.5f; bx.half[1] = size.y * 0.5f; bx.half[2] = size.z * 0.5f;
+    e->boxes.push_back(bx);
+}
+void BodyPD::addMeshCollider(ITriMeshPtr tm, const mat44f& o, unsigned int, unsigned long category, unsigned long mask) {
+    // geom offset: rotation = transposed 3x3 of `offset`, position = its fourth row (RigidBodyODE.cpp:300-314): a mesh
+    // vertex v sits at v * offset (row vector) in the body frame
+    auto t = std::dynamic_pointer_cast<TriMeshPD>(tm);
+    DynMesh m; m.body = this;
+    m.shape = std::make_shared<ColliderPD>(); m.shape->cat = category; m.shape->mask = mask;
+    const float M[9] = {o.M11, o.M12, o.M13, o.M21, o.M22, o.M23, o.M31, o.M32, o.M33};
+    const float off[3] = {o.M41, o.M42, o.M43};
+    for (size_t i = 0; i < t->vb.size(); ++i) {
+        const float v[3] = {t->vb[i].x, t->vb[i].y, t->vb[i].z};
+        for (int c = 0; c < 3; ++c) m.verts.push_back(off[c] + (v[0] * M[c] + v[1] * M[3 + c] + v[2] * M[6 + c]));
+    }
+    for (size_t i = 0; i < t->ib.size(); ++i) m.tris.push_back((unsigned char)t->ib[i]);
+    if (t->vb.size() > 256) SHOULD_NOT_REACH_FATAL;
+    e->meshes.push_back(std::move(m));
+}
+void EnginePD::collisionStep() {
+    const int frame = currentFrame++;
+    if (!(frame & 1)) return;   // even frames collide dynamic geoms with each other (one car: nothing), odd ones dynamic vs static
+    // one broad-phase box per body: around all of its geoms, in the body frame
+    std::vector<BodyPD*> bodies;
+    for (auto& b : boxes) if (std::find(bodies.begin(), bodies.end(), b.body) == bodies.end()) bodies.push_back(b.body);
+    for (auto& m : meshes) if (std::find(bodies.begin(), bodies.end(), m.body) == bodies.end()) bodies.push_back(m.body);
+    for (BodyPD* body : bodies) {
+        float lo[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, hi[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
+        auto grow = [&](const float* v) { for (int k = 0; k < 3; ++k) { lo[k] = std::min(lo[k], v[k]); hi[k] = std::max(hi[k], v[k]); } };
+        for (auto& b : boxes) if (b.body == body)
+            for (int c = 0; c < 8; ++c) {
+                const float v[3] = {b.centre[0] + ((c & 1) ? b.half[0] : -b.half[0]), b.centre[1] + ((c & 2) ? b.half[1] : -b.half[1]), b.centre[2] + ((c & 4) ? b.half[2] : -b.half[2])};
+                grow(v);
+            }
+        for (auto& m : meshes) if (m.body == body) for (size_t i = 0; i + 2 < m.verts.size(); i += 3) grow(&m.verts[i]);
+        pdcol::Pose pose;
+        memcpy(pose.pos, body->b().pos, 12); memcpy(pose.R, body->b().R, 36);
+        pdcol::V aLo, aHi;
+        pdcol::worldAabb(pose, lo, hi, aLo, aHi);
+        for (size_t si = 0; si < statics.size(); ++si) {
+            const pdrb::StaticMesh& sm = statics[si];
+            for (size_t ti = 0; ti + 2 < sm.indices.size(); ti += 3) {
+                const pdcol::V p0 = pdcol::ld(&sm.verts[3 * sm.indices[ti]]), p1 = pdcol::ld(&sm.verts[3 * sm.indices[ti + 1]]), p2 = pdcol::ld(&sm.verts[3 * sm.indices[ti + 2]]);
+                if (!pdcol::triMeetsAabb(p0, p1, p2, aLo, aHi)) continue;
+                for (auto& b : boxes) {
+                    if (b.body != body || !((b.cat & sm.mask) && (sm.category & b.mask))) continue;   // collisionNearCallback, :258-264
+                    float ny;
+                    if (!pdcol::boxContact(pose, b.centre, b.half, p0, p1, p2, ny) || ny < 0.9f) continue;   // onCollision, :303-312
+                    pdcol::V n = pdcol::norm(pdcol::cross(p1 - p0, p2 - p0));
+                    const pdcol::V cw = pdcol::toWorld(pose, pdcol::ld(b.centre));
+                    if (pdcol::dot(n, cw - p0) < 0.0f) n = n * -1.0f;
+                    if (cb) cb->onCollisionCallback(body, nullptr, nullptr, staticColliders[si].get(), vec3f(n.x, n.y, n.z), vec3f(cw.x, cw.y, cw.z), 0.0f);   // a box geom carries no shape data
+                }
+                for (auto& m : meshes) {
+                    if (m.body != body || !((m.shape->cat & sm.mask) && (sm.category & m.shape->mask))) continue;
+                    pdcol::hullContacts(pose, reinterpret_cast<const float (*)[3]>(m.verts.data()), reinterpret_cast<const unsigned char (*)[3]>(m.tris.data()), (int)(m.tris.size() / 3),
+                                        p0, p1, p2, [&](const pdcol::V& n, const pdcol::V& hit) {
+                        if (cb) cb->onCollisionCallback(body, m.shape.get(), nullptr, staticColliders[si].get(), vec3f(n.x, n.y, n.z), vec3f(hit.x, hit.y, hit.z), 0.0f);
+                    });
+                }
+            }
+        }
+    }
+}
 
 void JointPD::setERPCFM(float erp, float cfm) {
     // Only SliderJointODE / DistanceJointODE override setERPCFM (JointODE.h:17-44).  The slider's
@@ -194,6 +276,7 @@ RayCastHit RayCasterPD::rayCast(const vec3f& pos, const vec3f& dir) { return e->
 std::shared_ptr<IPhysicsEngine> PhysicsFactory::createPhysicsEngine() { return std::make_shared<EnginePD>(); }
 
 pdrb::World* ref_get_world(IPhysicsEngine* p) { return &static_cast<EnginePD*>(p)->world; }
+void ref_set_collide(IPhysicsEngine* p, bool on) { static_cast<EnginePD*>(p)->collide = on; }
 int ref_body_id(IRigidBody* b) { return static_cast<BodyPD*>(b)->id; }
 
 }  // namespace D
