@@ -7,8 +7,10 @@
 One "step" = one physics tick (dt = 1/333 s) of every car resident on the GPU = one launch of the HIP step kernel.
 Workload = BASELINE.json configs[1]: 4096 AE86 cars per GPU on the synthetic flat-plane track, per-car constant random
 actions (steer ~ U(-0.3,0.3), a1 ~ U(-1,1), numpy RandomState(1234) indexed by GLOBAL car id).  State, actions and
-outputs are resident in HBM before the timed region.  Multi-GPU: cars are sharded contiguously (weak scaling, 4096 per
-GPU); the only collective is the per-tick RCCL all-gather of the [N,26] observation/reward/flag block to the learner.
+outputs are resident in HBM before the timed region.  On each GPU the cars step as --partitions free-running ranges (one HIP
+stream each: cars are independent, the ranges' kernels overlap).  Multi-GPU: cars are sharded contiguously (weak scaling,
+4096 per GPU); the only collective is the RCCL all-gather of k-tick trajectory rings of the [N,26] observation/reward/flag
+block to the learner, on a side stream.
 Prints ONE JSON line on rank 0.
 """
 import argparse, ctypes as C, json, os, sys, time
@@ -55,6 +57,8 @@ def main():
     ap.add_argument('--warmup', type=int, default=333)
     ap.add_argument('--cars', type=int, default=CARS_PER_GPU)
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--partitions', type=int, default=2,
+                    help='free-running car ranges per GPU, one HIP stream each (pdb_set_partitions / pdb_step_ring; constant policy only -- a per-tick policy joins the ranges every tick); 1 = one launch per tick')
     ap.add_argument('--spline-step', type=float, default=0.0, help='touge workload: metres between spline points (default 5 m = 891 points; 0.9 = 4.9 k points, the density of the reference tracks)')
     ap.add_argument('--no-body-contacts', action='store_true', help='diagnostic A/B: switch the collision pass off in the car block (never the bench line)')
     ap.add_argument('--policy', choices=['constant', 'feedback', 'mlp'], default=None,
@@ -115,7 +119,7 @@ def main():
         def __init__(self, ptr, shape):
             self.__cuda_array_interface__ = {'shape': shape, 'typestr': '<f4', 'data': (ptr, False), 'version': 2}
     out_t = torch.as_tensor(_Arr(b.out_device_ptr(), (n, 26)), device='cuda:%d' % dev_index)
-    gather = sharding.TrajectoryGather(n, world, 'cuda:%d' % dev_index, dist, k=args.gather_ticks, force=args.force_gather)
+    gather = sharding.TrajectoryGather(n, world, 'cuda:%d' % dev_index, dist, k=args.gather_ticks, force=args.force_gather, producer_wait=b.wait_partitions)
     act_t = torch.as_tensor(_Arr(b.actions_device_ptr(), (n, 2)), device='cuda:%d' % dev_index)
 
     if policy == 'mlp':
@@ -144,16 +148,38 @@ def main():
             torch.tanh(h2 @ w3 + b3, out=act_t)
         gather.after_tick(t)
 
-    for _ in range(args.warmup):
-        tick()
+    use_ring = policy == 'constant' and args.partitions > 1
+    if use_ring:
+        b.set_partitions(args.partitions)
+
+    def run(nsteps):
+        """enqueue nsteps ticks: one by one, or (free-running partitions) a trajectory ring at a time"""
+        if not use_ring:
+            for _ in range(nsteps):
+                tick()
+            return
+        k = gather.k
+        t = tick_id[0]; end = t + nsteps
+        while t < end:
+            m = min(k - t % k, end - t)
+            b.step_ring(m, gather.ring(t).data_ptr(), k, t % k, join=False)   # every partition's kernels of these m ticks, written straight into the ring;
+                                                                              # the partitions are never joined inside the loop: only the gather waits for a ring
+            t += m
+            gather.after_tick(t - 1)                              # a full ring starts its all-gather (N > 1)
+        tick_id[0] = end
+
+    run(args.warmup)
+    b.wait_partitions()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     b.event_record(0)
+    if use_ring:
+        b.partition_mark()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        tick()
+    run(args.steps)
+    b.wait_partitions()                   # the batch's stream (= torch's current one) waits for every partition's last kernel
     b.event_record(1)
     gather.finish()                       # outstanding gathers belong to the timed region
     torch.cuda.synchronize()
@@ -169,12 +195,18 @@ def main():
         traffic = None
         try:   # memory-side bytes per launch from the committed PMC passes of this same command (profiles/, tools/profile_round.sh)
             pm = json.load(open(os.path.join(ROOT, 'profiles', 'r01_pmc.json')))
-            if args.workload == 'flat' and n == CARS_PER_GPU and pm.get('bench', {}).get('config', {}).get('cars_per_gpu') == n:
+            pc_cfg = pm.get('bench', {}).get('config', {})
+            if args.workload == 'flat' and n == CARS_PER_GPU and pc_cfg.get('cars_per_gpu') == n and pc_cfg.get('partitions', 1) == (args.partitions if use_ring else 1):
                 traffic = pm.get('traffic_bytes_per_launch')
         except Exception:
             traffic = None
+        launch_cars, conc = n, 1
         kernel_us = region_ms * 1000.0 / args.steps          # HIP events on the kernel's stream around the timed region
-        achieved = B_ALG * n / (kernel_us * 1e-6) / 1e9
+        if use_ring:   # one launch = one partition's cars; HIP events on that partition's own stream, whose kernels run back to back
+            part_ms, launch_cars = b.partition_elapsed_ms(0)
+            kernel_us = part_ms * 1000.0 / args.steps
+            conc = args.partitions
+        achieved = B_ALG * launch_cars / (kernel_us * 1e-6) / 1e9
         res = {
             "metric": "env-steps/sec (333 Hz tick, 4-wheel car)",
             "value": n * world * args.steps / elapsed,
@@ -185,11 +217,13 @@ def main():
             "dtype": "f32 (+f64 drivetrain)", "data": "synthetic",
             "config": {"workload": ("configs[1]: %d cars/GPU, AE86, flat-plane track, %s, dt=1/333 s" % (n, "per-car constant random actions" if policy == "constant" else "policy=" + policy)) if args.workload == 'flat' else
                                    ("configs[2] shape: %d cars/GPU, AE86, synthetic closed mountain road (1782 triangles, 891 spline points), policy=%s on the GPU, dt=1/333 s" % (n, policy)),
-                       "cars_per_gpu": n, "collective": ("RCCL all-gather of %d-tick trajectory rings [k,N,26] obs/reward/flags on a side stream, kernel writes the ring in place" % args.gather_ticks) if (world > 1 or args.force_gather) else "none",
+                       "cars_per_gpu": n, "partitions": (args.partitions if use_ring else 1), "collective": ("RCCL all-gather of %d-tick trajectory rings [k,N,26] obs/reward/flags on a side stream, kernel writes the ring in place" % args.gather_ticks) if (world > 1 or args.force_gather) else "none",
                        "parity": "bit-exact vs CPU oracle (tests/test_gpu_parity.py)"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic, "traffic_source": ("profiles/r01_pmc.json: (2*FETCH_SIZE + WRITE_SIZE)*1024 per launch, rocprofv3 --pmc passes of this command" if traffic else None),
-                         "kernel": "pdb_step_kernel", "kernel_avg_us": kernel_us, "alg_bytes_per_car_tick": B_ALG},
+                         "kernel": "pdb_step_kernel", "kernel_avg_us": kernel_us, "alg_bytes_per_car_tick": B_ALG, "cars_per_launch": launch_cars,
+                         "concurrent_launches": conc, "device_achieved": achieved * conc, "device_frac": achieved * conc / HBM_PEAK_GBS,
+                         "note": ("one launch = one partition (%d cars); %d partitions step concurrently on their own streams, so the device moves concurrent_launches x achieved" % (launch_cars, conc)) if conc > 1 else None},
         }
         if not args.no_cpu_baseline and world == 1:   # the CPU leg is timed at N = 1 only
             res["cpu_baseline"] = cpu_baseline(P, trk, S0, all_actions)

@@ -86,6 +86,22 @@ pdb_step_out* pdb_out_device(pdb_batch* b);
 /* redirect the per-tick outputs into a caller-owned device block of n_cars pdb_step_out (e.g. one slot of a trajectory ring
  * that is gathered to the learner every k ticks); NULL restores the library's own block */
 int pdb_set_out_device(pdb_batch* b, pdb_step_out* out);
+/* Free-running partitions.  Cars are independent (one car per simulator in the reference): nothing orders one car's tick
+ * against another's.  pdb_set_partitions cuts the batch into 1..4 contiguous parts, each with its own HIP stream;
+ * pdb_step_ring enqueues n_ticks ticks of every car, part by part, and the parts' kernels run concurrently and drift against
+ * each other -- one part's ramp-up / drain and inter-kernel gap is filled by the other's work.  Ordering: every part starts
+ * after the work enqueued on the batch's stream so far; with join != 0 the batch's stream continues only after all parts have
+ * done their n_ticks, with join == 0 it is not held back (the parts keep drifting across calls) and whoever consumes the
+ * results orders itself with pdb_wait_partitions(b, stream): that stream then waits for every part's last enqueued kernel
+ * (stream == NULL: the batch's stream).  Tick i writes its outputs to ring + ((first_slot + i) % ring_slots) * n_cars; ring == NULL: the active
+ * output block, every tick.  With one part this is n_ticks plain launches on the batch's stream.  Results do not depend on
+ * the partitioning.  pdb_partition_mark / pdb_partition_elapsed_ms: HIP-event time of one part's kernels between the mark
+ * and the last pdb_step_ring (synchronises on that part), and the number of cars in the part. */
+int pdb_set_partitions(pdb_batch* b, int parts);
+int pdb_step_ring(pdb_batch* b, float dt, int n_ticks, pdb_step_out* ring, int ring_slots, int first_slot, int join);
+int pdb_wait_partitions(pdb_batch* b, void* hip_stream);
+int pdb_partition_mark(pdb_batch* b);
+int pdb_partition_elapsed_ms(pdb_batch* b, int part, float* ms, int* cars);
 void* pdb_stream(pdb_batch* b);
 /* one tick of every car, reading pdb_actions_device and writing pdb_out_device; asynchronous on pdb_stream */
 int pdb_step(pdb_batch* b, float dt);

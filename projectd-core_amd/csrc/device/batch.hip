@@ -47,6 +47,7 @@ namespace pdb { void setError(const std::string& s); }
         }                                                                                            \
     } while (0)
 
+#define PDB_MAX_PARTS 4
 struct pdb_batch {
     int device = 0;
     int n = 0;
@@ -73,7 +74,17 @@ struct pdb_batch {
     float graphDt = 0;
     pdb_dyn_state resetTemplate;   // state of a fresh car teleported to the spline start
     unsigned long long* dStamps = nullptr;
+    // free-running partitions (pdb_set_partitions / pdb_step_ring): contiguous car ranges, one stream each
+    int parts = 1;
+    hipStream_t partStream[PDB_MAX_PARTS] = {nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t partFork = nullptr, partEnd[PDB_MAX_PARTS] = {nullptr, nullptr, nullptr, nullptr}, partStart[PDB_MAX_PARTS] = {nullptr, nullptr, nullptr, nullptr};
+    bool partMark = false;
 };
+static int partFirst(const pdb_batch* b, int p) {   // boundaries on whole workgroups
+    if (p >= b->parts) return b->n;
+    const long long raw = (long long)b->n * p / b->parts;
+    return (int)(raw / PDB_CPB * PDB_CPB);
+}
 
 static void fillConst(const pdb_car_params& P, DevConst& K, int actionMode) {
     memset(&K, 0, sizeof(K));
@@ -190,6 +201,12 @@ void pdb_destroy(pdb_batch* b) {
     if (b->ev1) (void)hipEventDestroy(b->ev1);
     if (b->tev0) (void)hipEventDestroy(b->tev0);
     if (b->tev1) (void)hipEventDestroy(b->tev1);
+    for (int p = 0; p < PDB_MAX_PARTS; ++p) {
+        if (b->partStream[p]) { (void)hipStreamSynchronize(b->partStream[p]); (void)hipStreamDestroy(b->partStream[p]); }
+        if (b->partEnd[p]) (void)hipEventDestroy(b->partEnd[p]);
+        if (b->partStart[p]) (void)hipEventDestroy(b->partStart[p]);
+    }
+    if (b->partFork) (void)hipEventDestroy(b->partFork);
     if (b->stream && b->ownStream) (void)hipStreamDestroy(b->stream);
     delete b;
 }
@@ -303,6 +320,65 @@ int pdb_set_stream(pdb_batch* b, void* hip_stream) {
     if (b->graphExec) { (void)hipGraphExecDestroy(b->graphExec); b->graphExec = nullptr; b->graphTicks = 0; }
     if (b->ownStream) { (void)hipStreamDestroy(b->stream); b->ownStream = false; }
     b->stream = (hipStream_t)hip_stream;
+    return PDB_OK;
+}
+
+int pdb_set_partitions(pdb_batch* b, int parts) {
+    if (!b || parts < 1 || parts > PDB_MAX_PARTS) { pdb::setError("pdb_set_partitions: 1..4 parts"); return PDB_ERR_ARG; }
+    HIPCHK(hipSetDevice(b->device));
+    HIPCHK(hipStreamSynchronize(b->stream));
+    for (int p = 0; p < parts; ++p) {
+        if (!b->partStream[p]) HIPCHK(hipStreamCreateWithFlags(&b->partStream[p], hipStreamNonBlocking));
+        if (!b->partEnd[p]) HIPCHK(hipEventCreate(&b->partEnd[p]));
+        if (!b->partStart[p]) HIPCHK(hipEventCreate(&b->partStart[p]));
+    }
+    if (!b->partFork) HIPCHK(hipEventCreateWithFlags(&b->partFork, hipEventDisableTiming));
+    b->parts = parts;
+    return PDB_OK;
+}
+
+int pdb_step_ring(pdb_batch* b, float dt, int n_ticks, pdb_step_out* ring, int ring_slots, int first_slot, int join) {
+    if (!b || n_ticks <= 0 || (ring && (ring_slots <= 0 || first_slot < 0))) { pdb::setError("pdb_step_ring: bad argument"); return PDB_ERR_ARG; }
+    if (b->K.dt != dt || b->K.wantCarState != 0) {
+        b->K.dt = dt; b->K.fps = 1.0f / dt; b->K.dtD = (dt == (float)(1.0 / 333.0)) ? (1.0 / 333.0) : (double)dt; b->K.wantCarState = 0;
+        HIPCHK(hipMemcpyAsync(b->dK, &b->K, sizeof(DevConst), hipMemcpyHostToDevice, b->stream));
+    }
+    const bool forked = b->parts > 1 && b->partStream[0];
+    if (forked) HIPCHK(hipEventRecord(b->partFork, b->stream));
+    for (int p = 0; p < (forked ? b->parts : 1); ++p) {
+        const int c0 = forked ? partFirst(b, p) : 0, c1 = forked ? partFirst(b, p + 1) : b->n;
+        if (c1 <= c0) continue;
+        hipStream_t st = forked ? b->partStream[p] : b->stream;
+        if (forked) HIPCHK(hipStreamWaitEvent(st, b->partFork, 0));
+        if (forked && b->partMark) HIPCHK(hipEventRecord(b->partStart[p], st));
+        for (int i = 0; i < n_ticks; ++i) {
+            pdb_step_out* out = ring ? ring + (size_t)((first_slot + i) % ring_slots) * (size_t)b->n : b->dOutActive;
+            hipLaunchKernelGGL(stepKernelFor(b), dim3((c1 - c0 + PDB_CPB - 1) / PDB_CPB), dim3(PDB_BLOCK_THREADS), 0, st, b->dStates + c0, b->dActions + (size_t)c0 * b->actionStride,
+                               out + c0, b->dCarStates ? b->dCarStates + c0 : nullptr, b->dParams, b->dK, b->dTrack, c1 - c0);
+        }
+        HIPCHK(hipGetLastError());
+        if (forked) { HIPCHK(hipEventRecord(b->partEnd[p], st)); if (join) HIPCHK(hipStreamWaitEvent(b->stream, b->partEnd[p], 0)); }
+    }
+    if (forked) b->partMark = false;
+    return PDB_OK;
+}
+int pdb_wait_partitions(pdb_batch* b, void* hip_stream) {
+    if (!b) { pdb::setError("null argument"); return PDB_ERR_ARG; }
+    hipStream_t s = hip_stream ? (hipStream_t)hip_stream : b->stream;
+    if (b->parts > 1)
+        for (int p = 0; p < b->parts; ++p) if (b->partEnd[p] && partFirst(b, p + 1) > partFirst(b, p)) HIPCHK(hipStreamWaitEvent(s, b->partEnd[p], 0));
+    return PDB_OK;
+}
+int pdb_partition_mark(pdb_batch* b) {
+    if (!b) { pdb::setError("null argument"); return PDB_ERR_ARG; }
+    b->partMark = true;
+    return PDB_OK;
+}
+int pdb_partition_elapsed_ms(pdb_batch* b, int part, float* ms, int* cars) {
+    if (!b || !ms || part < 0 || part >= b->parts || b->parts < 2 || !b->partEnd[part]) { pdb::setError("pdb_partition_elapsed_ms: no such partition"); return PDB_ERR_ARG; }
+    HIPCHK(hipEventSynchronize(b->partEnd[part]));
+    HIPCHK(hipEventElapsedTime(ms, b->partStart[part], b->partEnd[part]));
+    if (cars) *cars = partFirst(b, part + 1) - partFirst(b, part);
     return PDB_OK;
 }
 

@@ -53,6 +53,27 @@ class Batch:
     def sync(self):
         self._chk(self.lib.pdb_sync(self.h))
 
+    def set_partitions(self, parts):
+        """cut the batch into `parts` free-running car ranges, one HIP stream each (pdb_step_ring)"""
+        self._chk(self.lib.pdb_set_partitions(self.h, parts))
+
+    def step_ring(self, n_ticks, ring_ptr=None, ring_slots=1, first_slot=0, join=True):
+        """enqueue n_ticks ticks of every car, partition by partition; tick i writes outputs to ring slot (first_slot + i) % ring_slots.
+        join=False: the batch's stream is not held back; order consumers with wait_partitions()"""
+        self._chk(self.lib.pdb_step_ring(self.h, C.c_float(SIM_DT), n_ticks, C.c_void_p(ring_ptr) if ring_ptr else None, ring_slots, first_slot, 1 if join else 0))
+
+    def wait_partitions(self, stream_ptr=None):
+        """make a stream (default: the batch's) wait for every partition's last enqueued kernel"""
+        self._chk(self.lib.pdb_wait_partitions(self.h, C.c_void_p(stream_ptr) if stream_ptr else None))
+
+    def partition_mark(self):
+        self._chk(self.lib.pdb_partition_mark(self.h))
+
+    def partition_elapsed_ms(self, part):
+        ms = C.c_float(); cars = C.c_int()
+        self._chk(self.lib.pdb_partition_elapsed_ms(self.h, part, C.byref(ms), C.byref(cars)))
+        return ms.value, cars.value
+
     def set_stream(self, stream_ptr):
         self._chk(self.lib.pdb_set_stream(self.h, C.c_void_p(stream_ptr)))
 

@@ -38,7 +38,7 @@ class TrajectoryGather:
     not rewritten before its previous gather has completed.  k = 1 is the plain per-tick gather.  On CPU tensors (gloo,
     tests) everything is synchronous and `write(t, block)` stands in for the kernel."""
 
-    def __init__(self, n_local, world, device, dist=None, k=8, force=False):
+    def __init__(self, n_local, world, device, dist=None, k=8, force=False, producer_wait=None):
         import torch
         self.dist, self.world, self.n_local, self.k = dist, world, n_local, max(1, int(k))
         self.active = (world > 1 or force) and dist is not None
@@ -48,6 +48,8 @@ class TrajectoryGather:
         self.overlap = self.active and self.cuda and dist.get_backend() == 'nccl'
         self.work = [None, None]
         self.last = None
+        self.producer_wait = producer_wait   # callable(stream_ptr): make that stream wait for the kernels that fill the rings when they
+                                             # do not run on the current stream (free-running partitions: pdbatch.Batch.wait_partitions)
         if self.overlap:
             self.comm = torch.cuda.Stream(device=device)
             self.e_full = torch.cuda.Event()
@@ -59,6 +61,11 @@ class TrajectoryGather:
             self.work[r].wait()            # current stream waits: this ring's previous gather still reads it
             self.work[r] = None
         return self.rings[r][t % self.k]
+
+    def ring(self, t):
+        """the whole ring [k, n_local, 26] tick t belongs to (for pdb_step_ring: the kernels of up to k ticks are enqueued at once)"""
+        self.slot(t - t % self.k)          # same guard as slot(): a ring is not rewritten before its previous gather is done
+        return self.rings[(t // self.k) & 1]
 
     def write(self, t, block):
         self.slot(t).copy_(block)
@@ -76,8 +83,12 @@ class TrajectoryGather:
             self.e_full.record(torch.cuda.current_stream())
             with torch.cuda.stream(self.comm):
                 self.comm.wait_event(self.e_full)
+                if self.producer_wait is not None:
+                    self.producer_wait(self.comm.cuda_stream)
                 self.work[r] = self.dist.all_gather_into_tensor(flat_out, flat_in, async_op=True)
         elif self.cuda and self.dist.get_backend() == 'gloo':   # single-GPU test of the multi-rank path: through the host
+            if self.producer_wait is not None:
+                self.producer_wait(None)   # the batch's (= current) stream waits for the ring's kernels before the copy to the host
             host = flat_out.cpu()
             self.dist.all_gather_into_tensor(host, flat_in.cpu())
             flat_out.copy_(host)

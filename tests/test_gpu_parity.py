@@ -382,3 +382,43 @@ def test_fat_point_grid_on_a_long_dense_spline(built):
     blob = pc.build_track(pc.load_product(host_only=True), d, 'dense')
     worst = parity_util.run_parity(n_cars=24, ticks=1500, seed=5, track=blob, check_every=5)
     assert worst == 0.0, worst
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('parts', [2, 3])
+def test_free_running_partitions_equal_plain_stepping(built, parts):
+    """pdb_set_partitions + pdb_step_ring: the batch cut into car ranges that step on their own streams, concurrently and
+    without inter-range ordering -- every car's state and every tick's output block equal those of plain single launches"""
+    import torch, pdbatch, sharding
+    n, ticks, k = 1000, 203, 8          # neither a multiple of the part count nor of the ring
+    P = pdbatch.packed_params(); trk = pdbatch.synthetic_track('touge')
+    acts = sharding.global_actions(n, 31)
+    a = pdbatch.Batch(n, P, trk, device=0, action_mode=1); a.upload_actions(acts)
+    b = pdbatch.Batch(n, P, trk, device=0, action_mode=1); b.upload_actions(acts)
+    b.set_stream(torch.cuda.current_stream().cuda_stream)
+    b.set_partitions(parts)
+    ring = torch.zeros((k, n, 26), dtype=torch.float32, device='cuda:0')
+    a.set_stream(torch.cuda.current_stream().cuda_stream)
+    ref_t = torch.zeros((ticks, n, 26), dtype=torch.float32, device='cuda:0')
+    for t in range(ticks):
+        a.set_out_device_ptr(ref_t[t].data_ptr())
+        a.step_async()
+    torch.cuda.synchronize()
+    ref = ref_t.cpu().numpy()
+    done = 0
+    got = np.zeros_like(ref)
+    while done < ticks:
+        m = min(k - done % k, ticks - done, 5)          # chunks that stay inside the ring, of uneven length
+        b.step_ring(m, ring.data_ptr(), k, done % k, join=(done % 2 == 0))
+        b.wait_partitions()
+        torch.cuda.synchronize()
+        r = ring.cpu().numpy()
+        for i in range(m):
+            got[done + i] = r[(done + i) % k]
+        done += m
+    assert np.array_equal(got.view(np.uint32), ref.view(np.uint32))
+    sa, sb = a.get_state(), b.get_state()
+    assert bytes(sa) == bytes(sb)
+    ms, cars = (b.partition_mark(), b.step_ring(4), b.partition_elapsed_ms(parts - 1))[2]
+    assert cars > 0 and ms > 0
+    a.close(); b.close()
