@@ -64,7 +64,7 @@ def main():
     ap.add_argument('--policy', choices=['constant', 'feedback', 'mlp'], default=None,
                     help='where actions come from each tick: constant (configs[1]), feedback (probe controller on the GPU, default for touge), '
                          'mlp (configs[4] shape: a SAC-sized 24-256-256-2 tanh MLP with fixed random weights, evaluated with torch on the GPU from the observation block)')
-    ap.add_argument('--gather-ticks', type=int, default=8, help='ticks per trajectory ring gathered to the learner (N > 1): 1 = plain per-tick gather')
+    ap.add_argument('--gather-ticks', type=int, default=32, help='ticks per trajectory ring gathered to the learner (N > 1): 1 = plain per-tick gather')
     ap.add_argument('--force-gather', action='store_true', help='run the observation all-gather even with one rank (exercises the RCCL + side-stream path on a single GPU)')
     ap.add_argument('--backend', default='nccl', help='torch.distributed backend for N > 1 (nccl = RCCL; gloo only to exercise the multi-rank path on a single-GPU box)')
     ap.add_argument('--workload', choices=['flat', 'touge'], default='flat',
@@ -192,12 +192,13 @@ def main():
     elapsed = sharding.max_over_ranks(elapsed, 'cuda:%d' % dev_index, dist, world)
 
     if rank == 0:
-        traffic = None
+        traffic = None; valu_busy = None
         try:   # memory-side bytes per launch from the committed PMC passes of this same command (profiles/, tools/profile_round.sh)
             pm = json.load(open(os.path.join(ROOT, 'profiles', 'r01_pmc.json')))
             pc_cfg = pm.get('bench', {}).get('config', {})
             if args.workload == 'flat' and n == CARS_PER_GPU and pc_cfg.get('cars_per_gpu') == n and pc_cfg.get('partitions', 1) == (args.partitions if use_ring else 1):
                 traffic = pm.get('traffic_bytes_per_launch')
+                valu_busy = pm.get('valu_busy_frac_approx')
         except Exception:
             traffic = None
         launch_cars, conc = n, 1
@@ -223,6 +224,7 @@ def main():
                          "traffic": traffic, "traffic_source": ("profiles/r01_pmc.json: (2*FETCH_SIZE + WRITE_SIZE)*1024 per launch, rocprofv3 --pmc passes of this command" if traffic else None),
                          "kernel": "pdb_step_kernel", "kernel_avg_us": kernel_us, "alg_bytes_per_car_tick": B_ALG, "cars_per_launch": launch_cars,
                          "concurrent_launches": conc, "device_achieved": achieved * conc, "device_frac": achieved * conc / HBM_PEAK_GBS,
+                         "valu_issue_busy_frac": valu_busy,   # the resource that actually bounds the kernel (profiles/r01_pmc.json, SQ_ACTIVE_INST_VALU over all SIMD cycles)
                          "note": ("one launch = one partition (%d cars); %d partitions step concurrently on their own streams, so the device moves concurrent_launches x achieved" % (launch_cars, conc)) if conc > 1 else None},
         }
         if not args.no_cpu_baseline and world == 1:   # the CPU leg is timed at N = 1 only

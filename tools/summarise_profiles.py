@@ -44,9 +44,6 @@ waves = cnt.get('SQ_WAVES')
 if waves:
     summary['per_wave'] = {k: v / waves for k, v in cnt.items() if k.startswith('SQ_') and k != 'SQ_WAVES'}
     pw = summary['per_wave']
-    if 'SQ_ACTIVE_INST_VALU' in cnt and 'rocprof_avg_us' in summary:
-        # SQ_ACTIVE_INST_VALU counts quad-cycles summed over waves; 1024 SIMDs; 2.4 GHz nominal shader clock (approximate)
-        summary['valu_busy_frac_approx'] = 4.0 * cnt['SQ_ACTIVE_INST_VALU'] / (summary['rocprof_avg_us'] * 1e-6 * 2.4e9 * 1024)
 if 'FETCH_SIZE' in cnt and 'WRITE_SIZE' in cnt:
     # units: KiB (guide: hbm_bytes = (FETCH_SIZE + WRITE_SIZE) * 1024); gfx950: FETCH_SIZE reads 1/2 of wide coalesced
     # streaming reads (MI355X_MICROARCH.md, HBM section) -> doubled.  Memory-side (fabric) requests incl. Infinity-Cache hits.
@@ -58,5 +55,13 @@ if os.path.exists(b):
     if line:
         bj = json.loads(line[-1]); summary['bench'] = bj
         json.dump(bj, open(os.path.join(dst, tag + '_bench.json'), 'w'), indent=1)
+        conc = bj.get('roofline', {}).get('concurrent_launches', 1) or 1
+        if 'SQ_ACTIVE_INST_VALU' in cnt and 'rocprof_avg_us' in summary:
+            # VALU issue roofline.  SQ_ACTIVE_INST_VALU = quad-cycles a SIMD spends issuing VALU work, summed over the launch's waves
+            # (the counter passes serialise the launches, so this is per launch); `conc` launches share the 1024 SIMDs in the
+            # timed run, each taking rocprof_avg_us; 2.4 GHz nominal shader clock.
+            summary['concurrent_launches'] = conc
+            summary['valu_busy_frac_approx'] = conc * 4.0 * cnt['SQ_ACTIVE_INST_VALU'] / (summary['rocprof_avg_us'] * 1e-6 * 2.4e9 * 1024)
+            summary['valu_note'] = 'fraction of all SIMD issue cycles spent on VALU instructions with %d launch(es) in flight: the resource that bounds this kernel' % conc
 json.dump(summary, open(os.path.join(dst, tag + '_pmc.json'), 'w'), indent=1)
 print(json.dumps({k: v for k, v in summary.items() if k != 'bench'}, indent=1))
