@@ -93,7 +93,8 @@ int pdb_set_out_device(pdb_batch* b, pdb_step_out* out);
  * after the work enqueued on the batch's stream so far; with join != 0 the batch's stream continues only after all parts have
  * done their n_ticks, with join == 0 it is not held back (the parts keep drifting across calls) and whoever consumes the
  * results orders itself with pdb_wait_partitions(b, stream): that stream then waits for every part's last enqueued kernel
- * (stream == NULL: the batch's stream).  Tick i writes its outputs to ring + ((first_slot + i) % ring_slots) * n_cars; ring == NULL: the active
+ * (stream == NULL: the batch's stream).  The library's own entry points that work through the batch's stream (state reads and
+ * writes, resets, plain steps, pdb_sync) order themselves after the parts' kernels in flight.  Tick i writes its outputs to ring + ((first_slot + i) % ring_slots) * n_cars; ring == NULL: the active
  * output block, every tick.  With one part this is n_ticks plain launches on the batch's stream.  Results do not depend on
  * the partitioning.  pdb_partition_mark / pdb_partition_elapsed_ms: HIP-event time of one part's kernels between the mark
  * and the last pdb_step_ring (synchronises on that part), and the number of cars in the part. */

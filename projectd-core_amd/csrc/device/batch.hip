@@ -79,7 +79,19 @@ struct pdb_batch {
     hipStream_t partStream[PDB_MAX_PARTS] = {nullptr, nullptr, nullptr, nullptr};
     hipEvent_t partFork = nullptr, partEnd[PDB_MAX_PARTS] = {nullptr, nullptr, nullptr, nullptr}, partStart[PDB_MAX_PARTS] = {nullptr, nullptr, nullptr, nullptr};
     bool partMark = false;
+    bool partDirty = false;   // partition kernels enqueued that the batch's stream has not been ordered after
 };
+static int partFirst(const pdb_batch* b, int p);
+// Every entry point that works through the batch's stream first lets that stream wait for the partitions' kernels still in
+// flight (pdb_step_ring with join == 0): state reads, resets and plain launches are always ordered after them.
+static int joinParts(pdb_batch* b) {
+    if (b->parts > 1 && b->partDirty) {
+        for (int p = 0; p < b->parts; ++p)
+            if (b->partEnd[p] && partFirst(b, p + 1) > partFirst(b, p)) HIPCHK(hipStreamWaitEvent(b->stream, b->partEnd[p], 0));
+        b->partDirty = false;
+    }
+    return PDB_OK;
+}
 static int partFirst(const pdb_batch* b, int p) {   // boundaries on whole workgroups
     if (p >= b->parts) return b->n;
     const long long raw = (long long)b->n * p / b->parts;
@@ -116,6 +128,7 @@ static StepKernel stepKernelFor(const pdb_batch* b) {
 }
 
 static int launch(pdb_batch* b, float dt, bool wantCarState) {
+    if (int rcj = joinParts(b)) return rcj;
     if (b->K.dt != dt || b->K.wantCarState != (wantCarState ? 1 : 0)) {
         b->K.dt = dt; b->K.fps = 1.0f / dt;
         b->K.dtD = (dt == (float)(1.0 / 333.0)) ? (1.0 / 333.0) : (double)dt;   // PyProjectD.cpp:160-173: double dt, float step
@@ -215,6 +228,7 @@ int pdb_num_cars(const pdb_batch* b) { return b ? b->n : 0; }
 
 int pdb_set_state_all(pdb_batch* b, const pdb_dyn_state* state) {
     if (!b || !state) { pdb::setError("null argument"); return PDB_ERR_ARG; }
+    if (int rcj = joinParts(b)) return rcj;
     std::vector<pdb_dyn_state> tmp((size_t)b->n, *state);
     HIPCHK(hipMemcpyAsync(b->dStates, tmp.data(), sizeof(pdb_dyn_state) * (size_t)b->n, hipMemcpyHostToDevice, b->stream));
     HIPCHK(hipStreamSynchronize(b->stream));
@@ -222,12 +236,14 @@ int pdb_set_state_all(pdb_batch* b, const pdb_dyn_state* state) {
 }
 int pdb_set_state(pdb_batch* b, int first, int count, const pdb_dyn_state* states) {
     if (!b || !states || first < 0 || count < 0 || first + count > b->n) { pdb::setError("bad range"); return PDB_ERR_ARG; }
+    if (int rcj = joinParts(b)) return rcj;
     HIPCHK(hipMemcpyAsync(b->dStates + first, states, sizeof(pdb_dyn_state) * (size_t)count, hipMemcpyHostToDevice, b->stream));
     HIPCHK(hipStreamSynchronize(b->stream));
     return PDB_OK;
 }
 int pdb_get_state(pdb_batch* b, int first, int count, pdb_dyn_state* states) {
     if (!b || !states || first < 0 || count < 0 || first + count > b->n) { pdb::setError("bad range"); return PDB_ERR_ARG; }
+    if (int rcj = joinParts(b)) return rcj;
     HIPCHK(hipMemcpyAsync(states, b->dStates + first, sizeof(pdb_dyn_state) * (size_t)count, hipMemcpyDeviceToHost, b->stream));
     HIPCHK(hipStreamSynchronize(b->stream));
     return PDB_OK;
@@ -280,6 +296,7 @@ int pdb_step(pdb_batch* b, float dt) {
 
 int pdb_step_n(pdb_batch* b, float dt, int n) {
     if (!b || n <= 0) { pdb::setError("bad argument"); return PDB_ERR_ARG; }
+    if (int rcj = joinParts(b)) return rcj;
     if (n == 1) return pdb_step(b, dt);
     if (!b->graphExec || b->graphTicks != n || b->graphDt != dt) {
         if (b->graphExec) { (void)hipGraphExecDestroy(b->graphExec); b->graphExec = nullptr; }
@@ -316,6 +333,7 @@ int pdb_step_async(pdb_batch* b, float dt) {
 
 int pdb_set_stream(pdb_batch* b, void* hip_stream) {
     if (!b) { pdb::setError("null argument"); return PDB_ERR_ARG; }
+    if (int rcj = joinParts(b)) return rcj;
     HIPCHK(hipStreamSynchronize(b->stream));
     if (b->graphExec) { (void)hipGraphExecDestroy(b->graphExec); b->graphExec = nullptr; b->graphTicks = 0; }
     if (b->ownStream) { (void)hipStreamDestroy(b->stream); b->ownStream = false; }
@@ -359,12 +377,13 @@ int pdb_step_ring(pdb_batch* b, float dt, int n_ticks, pdb_step_out* ring, int r
         HIPCHK(hipGetLastError());
         if (forked) { HIPCHK(hipEventRecord(b->partEnd[p], st)); if (join) HIPCHK(hipStreamWaitEvent(b->stream, b->partEnd[p], 0)); }
     }
-    if (forked) b->partMark = false;
+    if (forked) { b->partMark = false; if (!join) b->partDirty = true; }
     return PDB_OK;
 }
 int pdb_wait_partitions(pdb_batch* b, void* hip_stream) {
     if (!b) { pdb::setError("null argument"); return PDB_ERR_ARG; }
     hipStream_t s = hip_stream ? (hipStream_t)hip_stream : b->stream;
+    if (s == b->stream) return joinParts(b);
     if (b->parts > 1)
         for (int p = 0; p < b->parts; ++p) if (b->partEnd[p] && partFirst(b, p + 1) > partFirst(b, p)) HIPCHK(hipStreamWaitEvent(s, b->partEnd[p], 0));
     return PDB_OK;
@@ -384,6 +403,7 @@ int pdb_partition_elapsed_ms(pdb_batch* b, int part, float* ms, int* cars) {
 
 int pdb_event_record(pdb_batch* b, int which) {
     if (!b) { pdb::setError("null argument"); return PDB_ERR_ARG; }
+    if (int rcj = joinParts(b)) return rcj;
     HIPCHK(hipEventRecord(which ? b->tev1 : b->tev0, b->stream));
     return PDB_OK;
 }
@@ -397,6 +417,7 @@ int pdb_event_elapsed_ms(pdb_batch* b, float* ms) {
 
 int pdb_sync(pdb_batch* b) {
     if (!b) { pdb::setError("null argument"); return PDB_ERR_ARG; }
+    if (int rcj = joinParts(b)) return rcj;
     HIPCHK(hipStreamSynchronize(b->stream));
     return PDB_OK;
 }
@@ -413,6 +434,7 @@ int pdb_step_host(pdb_batch* b, const float* actions, float dt, pdb_step_out* ou
 
 int pdb_get_car_state(pdb_batch* b, int first, int count, pdb_car_state* out) {
     if (!b || !out || first < 0 || count < 0 || first + count > b->n) { pdb::setError("bad range"); return PDB_ERR_ARG; }
+    if (int rcj = joinParts(b)) return rcj;
     HIPCHK(hipMemcpyAsync(out, b->dCarStates + first, sizeof(pdb_car_state) * (size_t)count, hipMemcpyDeviceToHost, b->stream));
     HIPCHK(hipStreamSynchronize(b->stream));
     return PDB_OK;

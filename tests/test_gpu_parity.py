@@ -419,6 +419,12 @@ def test_free_running_partitions_equal_plain_stepping(built, parts):
     assert np.array_equal(got.view(np.uint32), ref.view(np.uint32))
     sa, sb = a.get_state(), b.get_state()
     assert bytes(sa) == bytes(sb)
+    # un-joined partitions and an immediate state read: the library orders its own stream after the kernels in flight
+    b.step_ring(3, join=False)
+    sb = b.get_state()
+    for _ in range(3):
+        a.step_async()
+    assert bytes(a.get_state()) == bytes(sb)
     ms, cars = (b.partition_mark(), b.step_ring(4), b.partition_elapsed_ms(parts - 1))[2]
     assert cars > 0 and ms > 0
     a.close(); b.close()
