@@ -168,6 +168,7 @@ def main():
             gather.after_tick(t - 1)                              # a full ring starts its all-gather (N > 1)
         tick_id[0] = end
 
+    gather.warm()
     run(args.warmup)
     b.wait_partitions()
     torch.cuda.synchronize()

@@ -62,6 +62,17 @@ class TrajectoryGather:
             self.work[r] = None
         return self.rings[r][t % self.k]
 
+    def warm(self):
+        """one throw-away collective on the gather buffers (communicator set-up happens on first use: keep it out of a timed loop
+        whose warm-up is shorter than a ring)"""
+        if not self.active:
+            return
+        flat_in = self.rings[1].view(-1, OUT_COLS); flat_out = self.gathered[1].view(-1, OUT_COLS)
+        if self.cuda and self.dist.get_backend() == 'gloo':
+            host = flat_out.cpu(); self.dist.all_gather_into_tensor(host, flat_in.cpu())
+        else:
+            self.dist.all_gather_into_tensor(flat_out, flat_in)
+
     def ring(self, t):
         """the whole ring [k, n_local, 26] tick t belongs to (for pdb_step_ring: the kernels of up to k ticks are enqueued at once)"""
         self.slot(t - t % self.k)          # same guard as slot(): a ring is not rewritten before its previous gather is done
