@@ -135,22 +135,37 @@ def main():
     def tick():
         t = tick_id[0]; tick_id[0] = t + 1
         out_t = gather.slot(t)                  # the kernel writes tick t straight into its trajectory-ring slot
+        if part_loops:     # every partition runs its own closed loop (kernel, then the policy on its rows) on its own stream
+            for p in range(args.partitions):
+                f, c = part_rng[p]
+                with torch.cuda.stream(part_st[p]):
+                    b.step_partition(p, out_t.data_ptr())
+                    policy_step(out_t[f:f + c], act_t[f:f + c])
+            return
         b.set_out_device_ptr(out_t.data_ptr())
         b.step_async()
-        if policy == 'feedback':   # oracle/scenarios.h scenarioFeedback as elementwise device ops on the observation block
-            o = out_t
-            act_t[:, 0] = torch.clamp(0.03 * (o[:, 21] - o[:, 20]) + 0.015 * (o[:, 19] - o[:, 18]) + 0.15 * o[:, 4], -1.0, 1.0)
-            act_t[:, 1] = torch.clamp(0.3 * (12.0 - o[:, 2]), -1.0, 1.0)
-        elif policy == 'mlp':      # obs -> normalise -> 256 -> 256 -> 2, tanh-squashed like SAC's actor mean (hyperparams/sac.yml net_arch)
-            x = out_t[:, :24] * obs_scale
-            h1 = torch.relu(x @ w1 + b1)
-            h2 = torch.relu(h1 @ w2 + b2)
-            torch.tanh(h2 @ w3 + b3, out=act_t)
+        policy_step(out_t, act_t)
         gather.after_tick(t)
 
+    def policy_step(o, a):
+        if policy == 'feedback':   # oracle/scenarios.h scenarioFeedback as elementwise device ops on the observation block
+            a[:, 0] = torch.clamp(0.03 * (o[:, 21] - o[:, 20]) + 0.015 * (o[:, 19] - o[:, 18]) + 0.15 * o[:, 4], -1.0, 1.0)
+            a[:, 1] = torch.clamp(0.3 * (12.0 - o[:, 2]), -1.0, 1.0)
+        elif policy == 'mlp':      # obs -> normalise -> 256 -> 256 -> 2, tanh-squashed like SAC's actor mean (hyperparams/sac.yml net_arch)
+            x = o[:, :24] * obs_scale
+            h1 = torch.relu(x @ w1 + b1)
+            h2 = torch.relu(h1 @ w2 + b2)
+            torch.tanh(h2 @ w3 + b3, out=a)
+
     use_ring = policy == 'constant' and args.partitions > 1
-    if use_ring:
+    # a per-tick policy: per-partition closed loops, unless a gather has to see whole ticks (N > 1)
+    # and only where a tick is long enough to hide the doubled number of (small) policy launches: the host enqueues ~10 per partition and tick
+    part_loops = policy != 'constant' and args.partitions > 1 and not gather.active and n >= 8192
+    if use_ring or part_loops:
         b.set_partitions(args.partitions)
+    if part_loops:
+        part_st = [torch.cuda.ExternalStream(b.partition_stream(p), device='cuda:%d' % dev_index) for p in range(args.partitions)]
+        part_rng = [b.partition_range(p) for p in range(args.partitions)]
 
     def run(nsteps):
         """enqueue nsteps ticks: one by one, or (free-running partitions) a trajectory ring at a time"""
@@ -168,6 +183,7 @@ def main():
             gather.after_tick(t - 1)                              # a full ring starts its all-gather (N > 1)
         tick_id[0] = end
 
+    torch.cuda.synchronize()              # set-up done before any partition stream starts
     gather.warm()
     run(args.warmup)
     b.wait_partitions()
@@ -176,7 +192,7 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     b.event_record(0)
-    if use_ring:
+    if use_ring or part_loops:
         b.partition_mark()
     t0 = time.perf_counter()
     run(args.steps)
@@ -197,14 +213,14 @@ def main():
         try:   # memory-side bytes per launch from the committed PMC passes of this same command (profiles/, tools/profile_round.sh)
             pm = json.load(open(os.path.join(ROOT, 'profiles', 'r01_pmc.json')))
             pc_cfg = pm.get('bench', {}).get('config', {})
-            if args.workload == 'flat' and n == CARS_PER_GPU and pc_cfg.get('cars_per_gpu') == n and pc_cfg.get('partitions', 1) == (args.partitions if use_ring else 1):
+            if args.workload == 'flat' and n == CARS_PER_GPU and pc_cfg.get('cars_per_gpu') == n and pc_cfg.get('partitions', 1) == (args.partitions if (use_ring or part_loops) else 1):
                 traffic = pm.get('traffic_bytes_per_launch')
                 valu_busy = pm.get('valu_busy_frac_approx')
         except Exception:
             traffic = None
         launch_cars, conc = n, 1
         kernel_us = region_ms * 1000.0 / args.steps          # HIP events on the kernel's stream around the timed region
-        if use_ring:   # one launch = one partition's cars; HIP events on that partition's own stream, whose kernels run back to back
+        if use_ring or part_loops:   # one launch = one partition's cars; HIP events on that partition's own stream
             part_ms, launch_cars = b.partition_elapsed_ms(0)
             kernel_us = part_ms * 1000.0 / args.steps
             conc = args.partitions
@@ -219,7 +235,7 @@ def main():
             "dtype": "f32 (+f64 drivetrain)", "data": "synthetic",
             "config": {"workload": ("configs[1]: %d cars/GPU, AE86, flat-plane track, %s, dt=1/333 s" % (n, "per-car constant random actions" if policy == "constant" else "policy=" + policy)) if args.workload == 'flat' else
                                    ("configs[2] shape: %d cars/GPU, AE86, synthetic closed mountain road (1782 triangles, 891 spline points), policy=%s on the GPU, dt=1/333 s" % (n, policy)),
-                       "cars_per_gpu": n, "partitions": (args.partitions if use_ring else 1), "collective": ("RCCL all-gather of %d-tick trajectory rings [k,N,26] obs/reward/flags on a side stream, kernel writes the ring in place" % args.gather_ticks) if (world > 1 or args.force_gather) else "none",
+                       "cars_per_gpu": n, "partitions": (args.partitions if (use_ring or part_loops) else 1), "collective": ("RCCL all-gather of %d-tick trajectory rings [k,N,26] obs/reward/flags on a side stream, kernel writes the ring in place" % args.gather_ticks) if (world > 1 or args.force_gather) else "none",
                        "parity": "bit-exact vs CPU oracle (tests/test_gpu_parity.py)"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic, "traffic_source": ("profiles/r01_pmc.json: (2*FETCH_SIZE + WRITE_SIZE)*1024 per launch, rocprofv3 --pmc passes of this command" if traffic else None),

@@ -101,6 +101,12 @@ int pdb_set_out_device(pdb_batch* b, pdb_step_out* out);
 int pdb_set_partitions(pdb_batch* b, int parts);
 int pdb_step_ring(pdb_batch* b, float dt, int n_ticks, pdb_step_out* ring, int ring_slots, int first_slot, int join);
 int pdb_wait_partitions(pdb_batch* b, void* hip_stream);
+/* Per-partition loops: pdb_step_partition enqueues one tick of one part on that part's stream (pdb_partition_stream), nothing
+ * forked or joined; a caller that also puts its own per-tick work for the part's cars (pdb_partition_range) on that stream --
+ * a policy evaluated from the part's observation rows -- keeps each part's whole closed loop independent of the others. */
+int pdb_step_partition(pdb_batch* b, float dt, int part, pdb_step_out* out);
+void* pdb_partition_stream(pdb_batch* b, int part);
+int pdb_partition_range(pdb_batch* b, int part, int* first, int* count);
 int pdb_partition_mark(pdb_batch* b);
 int pdb_partition_elapsed_ms(pdb_batch* b, int part, float* ms, int* cars);
 void* pdb_stream(pdb_batch* b);

@@ -380,6 +380,34 @@ int pdb_step_ring(pdb_batch* b, float dt, int n_ticks, pdb_step_out* ring, int r
     if (forked) { b->partMark = false; if (!join) b->partDirty = true; }
     return PDB_OK;
 }
+// one tick of one partition on its own stream, nothing forked or joined: for callers that keep a whole per-partition loop
+// (kernel + their own work on pdb_partition_stream) running independently of the other partitions
+int pdb_step_partition(pdb_batch* b, float dt, int part, pdb_step_out* out) {
+    if (!b || part < 0 || part >= b->parts || b->parts < 2 || !b->partStream[part]) { pdb::setError("pdb_step_partition: no such partition"); return PDB_ERR_ARG; }
+    if (b->K.dt != dt || b->K.wantCarState != 0) {   // constants change: everything in flight first
+        if (int rcj = joinParts(b)) return rcj;
+        b->K.dt = dt; b->K.fps = 1.0f / dt; b->K.dtD = (dt == (float)(1.0 / 333.0)) ? (1.0 / 333.0) : (double)dt; b->K.wantCarState = 0;
+        HIPCHK(hipMemcpyAsync(b->dK, &b->K, sizeof(DevConst), hipMemcpyHostToDevice, b->stream));
+        HIPCHK(hipStreamSynchronize(b->stream));
+    }
+    const int c0 = partFirst(b, part), c1 = partFirst(b, part + 1);
+    if (c1 <= c0) return PDB_OK;
+    hipStream_t st = b->partStream[part];
+    if (b->partMark) { for (int p = 0; p < b->parts; ++p) HIPCHK(hipEventRecord(b->partStart[p], b->partStream[p])); b->partMark = false; }
+    pdb_step_out* o = out ? out : b->dOutActive;
+    hipLaunchKernelGGL(stepKernelFor(b), dim3((c1 - c0 + PDB_CPB - 1) / PDB_CPB), dim3(PDB_BLOCK_THREADS), 0, st, b->dStates + c0, b->dActions + (size_t)c0 * b->actionStride,
+                       o + c0, b->dCarStates ? b->dCarStates + c0 : nullptr, b->dParams, b->dK, b->dTrack, c1 - c0);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipEventRecord(b->partEnd[part], st));
+    b->partDirty = true;
+    return PDB_OK;
+}
+void* pdb_partition_stream(pdb_batch* b, int part) { return (b && part >= 0 && part < b->parts && b->parts > 1) ? (void*)b->partStream[part] : nullptr; }
+int pdb_partition_range(pdb_batch* b, int part, int* first, int* count) {
+    if (!b || part < 0 || part >= b->parts || !first || !count) { pdb::setError("pdb_partition_range: bad argument"); return PDB_ERR_ARG; }
+    *first = partFirst(b, part); *count = partFirst(b, part + 1) - partFirst(b, part);
+    return PDB_OK;
+}
 int pdb_wait_partitions(pdb_batch* b, void* hip_stream) {
     if (!b) { pdb::setError("null argument"); return PDB_ERR_ARG; }
     hipStream_t s = hip_stream ? (hipStream_t)hip_stream : b->stream;

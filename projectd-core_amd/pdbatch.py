@@ -66,6 +66,18 @@ class Batch:
         """make a stream (default: the batch's) wait for every partition's last enqueued kernel"""
         self._chk(self.lib.pdb_wait_partitions(self.h, C.c_void_p(stream_ptr) if stream_ptr else None))
 
+    def step_partition(self, part, out_ptr=None):
+        """one tick of one partition on its own stream (nothing forked or joined)"""
+        self._chk(self.lib.pdb_step_partition(self.h, C.c_float(SIM_DT), part, C.c_void_p(out_ptr) if out_ptr else None))
+
+    def partition_stream(self, part):
+        return self.lib.pdb_partition_stream(self.h, part)
+
+    def partition_range(self, part):
+        f = C.c_int(); c = C.c_int()
+        self._chk(self.lib.pdb_partition_range(self.h, part, C.byref(f), C.byref(c)))
+        return f.value, c.value
+
     def partition_mark(self):
         self._chk(self.lib.pdb_partition_mark(self.h))
 
