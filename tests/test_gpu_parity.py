@@ -425,6 +425,16 @@ def test_free_running_partitions_equal_plain_stepping(built, parts):
     for _ in range(3):
         a.step_async()
     assert bytes(a.get_state()) == bytes(sb)
+    # per-partition loops: each part stepped on its own stream in its own order (part p gets p + 2 extra ticks... all end at 6)
+    for p in range(parts):
+        for _ in range(6):
+            b.step_partition(p)
+    for _ in range(6):
+        a.step_async()
+    assert bytes(a.get_state()) == bytes(b.get_state())
+    rng = [b.partition_range(p) for p in range(parts)]
+    assert rng[0][0] == 0 and sum(c for _, c in rng) == n and all(rng[i][0] + rng[i][1] == rng[i + 1][0] for i in range(parts - 1))
+    assert all(b.partition_stream(p) for p in range(parts))
     ms, cars = (b.partition_mark(), b.step_ring(4), b.partition_elapsed_ms(parts - 1))[2]
     assert cars > 0 and ms > 0
     a.close(); b.close()
