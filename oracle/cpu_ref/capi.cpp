@@ -144,10 +144,15 @@ const char* cpuref_scenario_track(int sid) { return pdoracle::kScenarios[sid].tr
 const char* cpuref_scenario_car(int sid) { return pdoracle::kScenarios[sid].car ? pdoracle::kScenarios[sid].car : PDORACLE_DEFAULT_CAR; }
 int cpuref_num_scenarios(void) { return pdoracle::kNumScenarios; }
 int cpuref_scenario_collide(int sid) { return pdoracle::kScenarios[sid].collide; }
+int cpuref_scenario_resets(int sid) { return pdoracle::kScenarios[sid].resetEvery; }
 void cpuref_scenario_feedback(int sid, int tick, const float* obs, float* a) { pdoracle::scenarioFeedback(sid, tick, obs, a[0], a[1]); }
 
 // run one scripted scenario exactly like oracle/refharness/ref_main.cpp and write the probe file
-int cpuref_run_scenario(void* hh, int sid, const char* outPath) {
+int cpuref_run_scenario_cb(void* hh, int sid, const char* outPath, void (*teleportToStart)(pdb_dyn_state*));
+int cpuref_run_scenario(void* hh, int sid, const char* outPath) { return cpuref_run_scenario_cb(hh, sid, outPath, nullptr); }
+// teleportToStart: Car::teleportByMode(Start) on a state record -- the PRODUCT's host function (pdb_teleport_to_spline), handed in by
+// the test, so that the scenarios with mid-run resets pin it against the reference's own Car::teleportByMode
+int cpuref_run_scenario_cb(void* hh, int sid, const char* outPath, void (*teleportToStart)(pdb_dyn_state*)) {
     auto* h = (CpuRefHandle*)hh;
     const auto& sc = pdoracle::kScenarios[sid];
     // setCarAssists (PyProjectD.cpp:307-317) per scenario; smooth steering stays on like the env
@@ -159,6 +164,13 @@ int cpuref_run_scenario(void* hh, int sid, const char* outPath) {
     h->car.step(0.0f, pdoracle::envGas(0.0f), (float)(1.0 / 333.0), 1.0 / 333.0);   // env.reset(): teleport (already in s0) + step([0,0])
     { pdoracle::Probe P; P.names = &pf.names; h->car.fillProbe(P); pf.add(-1, 0.0f, 0.0f, P); }
     for (int t = 0; t < sc.ticks; ++t) {
+        if (sc.resetEvery && t > 0 && t % sc.resetEvery == 0) {   // env.reset(): teleportCarByMode(Start) + step([0,0])
+            if (!teleportToStart) return -2;
+            pdb_dyn_state st = h->car.S;
+            teleportToStart(&st);
+            h->car.loadState(st);
+            h->car.step(0.0f, pdoracle::envGas(0.0f), (float)(1.0 / 333.0), 1.0 / 333.0);
+        }
         float a0, a1;
         if (sc.feedback) {
             pdb_step_out o; h->car.fillStepOut(o);

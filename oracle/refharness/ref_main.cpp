@@ -231,6 +231,7 @@ int main(int argc, char** argv) {
                 pf.add(-1, 0.0f, 0.0f, P);
             }
             for (int t = 0; t < sc.ticks; ++t) {
+                if (sc.resetEvery && t > 0 && t % sc.resetEvery == 0) env.reset();
                 float a0, a1;
                 if (sc.feedback) {
                     float obs[24]; obsOf(*env.car->state, obs);

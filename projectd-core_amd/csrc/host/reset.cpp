@@ -126,6 +126,7 @@ void teleportToSpline(const pdb_car_params& P, const TrackView& tv, float distan
         // Drivetrain::reset + Engine::reset
         S.clutchOpenState = 1; S.rootVelocity = 0; S.engineVel = 0; S.outShaftLVel = 0; S.outShaftRVel = 0; S.driveVel = 0;
         S.gearReqRequest = 0; S.validShiftRPMWindow = P.validShiftRPMWindow; S.lifeLeft = 1000.0f;
+        for (int i = 0; i < PDB_MAX_TURBOS; ++i) S.turboRotation[i] = 0.0f;   // Engine::reset -> Turbo::reset (Engine.cpp:160-166, Turbo.cpp:42-45)
         for (int i = 0; i < 4; ++i) tyreReset(P, S.tyre[i]);
         S.isGearGrinding = 0; S.currentGear = 1;   // setCurrentGear(1, true)
         stopBody(S.body[PDB_BODY_CHASSIS]); stopBody(S.body[PDB_BODY_TANK]);

@@ -34,6 +34,7 @@ def load_oracle(portable_math=False):
     lib.cpuref_scenario_car.restype = C.c_char_p
     lib.cpuref_scenario_feedback.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_void_p]
     lib.cpuref_run_scenario.argtypes = [C.c_void_p, C.c_int, C.c_char_p]
+    lib.cpuref_run_scenario_cb.argtypes = [C.c_void_p, C.c_int, C.c_char_p, C.c_void_p]
     lib.cpuref_bench.restype = C.c_double
     lib.cpuref_bench.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p]
     return lib
