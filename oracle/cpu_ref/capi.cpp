@@ -145,6 +145,12 @@ const char* cpuref_scenario_car(int sid) { return pdoracle::kScenarios[sid].car 
 int cpuref_num_scenarios(void) { return pdoracle::kNumScenarios; }
 int cpuref_scenario_collide(int sid) { return pdoracle::kScenarios[sid].collide; }
 int cpuref_scenario_resets(int sid) { return pdoracle::kScenarios[sid].resetEvery; }
+// i-th setCarTune call of the scenario's tune set: returns 0 past the end
+int cpuref_scenario_tune(int sid, int i, const char** name, float* value) {
+    if (!pdoracle::kScenarios[sid].tuneSet || i < 0 || i >= pdoracle::kNumTuneSetA) return 0;
+    *name = pdoracle::kTuneSetA[i].name; *value = pdoracle::kTuneSetA[i].value;
+    return 1;
+}
 void cpuref_scenario_feedback(int sid, int tick, const float* obs, float* a) { pdoracle::scenarioFeedback(sid, tick, obs, a[0], a[1]); }
 
 // run one scripted scenario exactly like oracle/refharness/ref_main.cpp and write the probe file

@@ -223,6 +223,7 @@ int main(int argc, char** argv) {
             env.init(base, track, sc.car ? std::string(sc.car) : model, sc.autoClutch != 0, sc.autoShift != 0, sc.autoBlip != 0);
             env.smooth = sc.rawSteer == 0;
             ref_set_collide(env.sim->physics.get(), sc.collide != 0);
+            if (sc.tuneSet) for (int i = 0; i < pdoracle::kNumTuneSetA; ++i) env.car->setup->setTune(pdoracle::kTuneSetA[i].name, pdoracle::kTuneSetA[i].value);   // PyProjectD.cpp:328-335
             pdoracle::ProbeFile pf;
             env.reset();
             {

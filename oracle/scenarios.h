@@ -13,36 +13,54 @@ namespace pdoracle {
 // car: model directory under content/cars (nullptr = the env default, ks_toyota_ae86_drift); rawSteer: 1 = setCarControls(smooth = false)
 struct Scenario { const char* name; int ticks; int denseTicks; int stride; int full; int autoClutch, autoShift, autoBlip; const char* track; int feedback; const char* car; int rawSteer;
                   int collide; /* run the engine's collision pass (the other fixtures predate it and keep it off) */
-                  int resetEvery; /* env.reset() (teleportByMode(Start) + one zero-action tick, projectd_env.py:216-227) every so many ticks */ };
+                  int resetEvery; /* env.reset() (teleportByMode(Start) + one zero-action tick, projectd_env.py:216-227) every so many ticks */
+                  int tuneSet; /* apply kTuneSetA through setCarTune after the env's own tunes */ };
 
 static const Scenario kScenarios[] = {
-    {"idle", 600, 200, 10, 0, 1, 1, 1, "flat", 0, nullptr, 0, 0, 0},
-    {"launch", 2000, 450, 10, 0, 1, 1, 1, "flat", 0, nullptr, 0, 0, 0},
-    {"circle", 1600, 300, 10, 0, 1, 1, 1, "flat", 0, nullptr, 0, 0, 0},
-    {"slalom", 2400, 300, 10, 0, 1, 1, 1, "flat", 0, nullptr, 0, 0, 0},
-    {"brake", 2400, 200, 10, 1, 1, 1, 1, "flat", 0, nullptr, 0, 0, 0},    // pedal brake to a stop, handbrake turn (BrakeSystem, tyre lock)
-    {"manual", 2600, 300, 10, 1, 0, 0, 0, "flat", 0, nullptr, 1, 0, 0},   // no assists: manual clutch, gearUp/gearDn pulses, H-shifter gear select, grinding
-    {"drive", 7000, 300, 10, 0, 1, 1, 1, "touge", 1, nullptr, 0, 0, 0},   // closed hilly, banked mountain road driven by a probe-feedback controller (configs[2] shape)
-    {"rx7", 2400, 300, 10, 0, 1, 1, 1, "flat", 0, "ks_mazda_rx7_tuned", 0, 0, 0},          // double wishbones all round, one turbo: the slalom script
-    {"supra", 5000, 300, 10, 0, 1, 1, 1, "touge", 1, "ks_toyota_supra_mkiv_drift", 0, 0, 0},   // double wishbones, two turbos, 6 gears, on the mountain road
-    {"fc3s", 2400, 300, 10, 0, 1, 1, 1, "flat", 0, "dthwsh_mazda_rx7_fc3s_sr20", 0, 0, 0},      // strut front + double wishbone rear (38 rows), 3 wings + 2 fins, turbo
-    {"readie", 5000, 300, 10, 0, 1, 1, 1, "touge", 1, "gravygarage_street_ae86_readie", 0, 0, 0},   // strut front + double wishbone rear on the mountain road
-    {"playground", 2500, 300, 10, 0, 1, 1, 1, "driftplayground", 1, nullptr, 0, 0, 0},   // the env's default track as shipped (510 surfaces, 112 411 triangles, spline.cache)
-    {"multilink", 4000, 300, 10, 0, 1, 1, 1, "touge", 1, "pdb_ml_supra", 0, 0, 0},   // reference SuspensionML on a derived car (oracle/make_base.py), front and rear
-    {"heave", 4000, 300, 10, 0, 1, 1, 1, "touge", 1, "pdb_heave_rx7", 0, 0, 0},       // reference HeaveSpring on a derived car (third spring across both axles)
-    {"fwd", 2400, 300, 10, 0, 1, 1, 1, "flat", 0, "pdb_fwd_ae86", 0, 0, 0},            // front-wheel drive through the same 2WD drivetrain (derived car), slalom script
+    {"idle", 600, 200, 10, 0, 1, 1, 1, "flat", 0, nullptr, 0, 0, 0, 0},
+    {"launch", 2000, 450, 10, 0, 1, 1, 1, "flat", 0, nullptr, 0, 0, 0, 0},
+    {"circle", 1600, 300, 10, 0, 1, 1, 1, "flat", 0, nullptr, 0, 0, 0, 0},
+    {"slalom", 2400, 300, 10, 0, 1, 1, 1, "flat", 0, nullptr, 0, 0, 0, 0},
+    {"brake", 2400, 200, 10, 1, 1, 1, 1, "flat", 0, nullptr, 0, 0, 0, 0},    // pedal brake to a stop, handbrake turn (BrakeSystem, tyre lock)
+    {"manual", 2600, 300, 10, 1, 0, 0, 0, "flat", 0, nullptr, 1, 0, 0, 0},   // no assists: manual clutch, gearUp/gearDn pulses, H-shifter gear select, grinding
+    {"drive", 7000, 300, 10, 0, 1, 1, 1, "touge", 1, nullptr, 0, 0, 0, 0},   // closed hilly, banked mountain road driven by a probe-feedback controller (configs[2] shape)
+    {"rx7", 2400, 300, 10, 0, 1, 1, 1, "flat", 0, "ks_mazda_rx7_tuned", 0, 0, 0, 0},          // double wishbones all round, one turbo: the slalom script
+    {"supra", 5000, 300, 10, 0, 1, 1, 1, "touge", 1, "ks_toyota_supra_mkiv_drift", 0, 0, 0, 0},   // double wishbones, two turbos, 6 gears, on the mountain road
+    {"fc3s", 2400, 300, 10, 0, 1, 1, 1, "flat", 0, "dthwsh_mazda_rx7_fc3s_sr20", 0, 0, 0, 0},      // strut front + double wishbone rear (38 rows), 3 wings + 2 fins, turbo
+    {"readie", 5000, 300, 10, 0, 1, 1, 1, "touge", 1, "gravygarage_street_ae86_readie", 0, 0, 0, 0},   // strut front + double wishbone rear on the mountain road
+    {"playground", 2500, 300, 10, 0, 1, 1, 1, "driftplayground", 1, nullptr, 0, 0, 0, 0},   // the env's default track as shipped (510 surfaces, 112 411 triangles, spline.cache)
+    {"multilink", 4000, 300, 10, 0, 1, 1, 1, "touge", 1, "pdb_ml_supra", 0, 0, 0, 0},   // reference SuspensionML on a derived car (oracle/make_base.py), front and rear
+    {"heave", 4000, 300, 10, 0, 1, 1, 1, "touge", 1, "pdb_heave_rx7", 0, 0, 0, 0},       // reference HeaveSpring on a derived car (third spring across both axles)
+    {"fwd", 2400, 300, 10, 0, 1, 1, 1, "flat", 0, "pdb_fwd_ae86", 0, 0, 0, 0},            // front-wheel drive through the same 2WD drivetrain (derived car), slalom script
     // body contacts: full throttle down the walled strip -- the belly box scrapes the ridge, then the car drifts into the side wall
     // (hull).  Pins what the reference does with a contact (Simulator / Car::onCollisionCallback, the scoring that reads the flag
     // and the damage); the contacts themselves are this project's (oracle/rb/pdcollide.h).  Stride 3: odd and even frames alternate.
-    {"walled", 2150, 0, 3, 0, 1, 1, 1, "walled", 0, nullptr, 0, 1, 0},
+    {"walled", 2150, 0, 3, 0, 1, 1, 1, "walled", 0, nullptr, 0, 1, 0, 0},
     // episode resets in mid-flight (Car::teleportByMode(Start) -> teleportToSpline -> forceRotation / forcePosition -> Car::reset,
     // Tyre::reset, Drivetrain::reset, suspension attach: Car.cpp:385-410,1240-1358): the car is driven on the mountain road and
     // reset every 700 ticks from whatever state it is in (rolling, warm tyres, a gear engaged, turbos spun up)
-    {"resets", 3000, 300, 10, 0, 1, 1, 1, "touge", 1, nullptr, 0, 0, 700},
-    {"resets_supra", 3000, 300, 10, 0, 1, 1, 1, "touge", 1, "ks_toyota_supra_mkiv_drift", 0, 0, 700},
-    {"resets_fc3s", 3000, 300, 10, 0, 1, 1, 1, "touge", 1, "dthwsh_mazda_rx7_fc3s_sr20", 0, 0, 650},
+    {"resets", 3000, 300, 10, 0, 1, 1, 1, "touge", 1, nullptr, 0, 0, 700, 0},
+    {"resets_supra", 3000, 300, 10, 0, 1, 1, 1, "touge", 1, "ks_toyota_supra_mkiv_drift", 0, 0, 700, 0},
+    {"resets_fc3s", 3000, 300, 10, 0, 1, 1, 1, "touge", 1, "dthwsh_mazda_rx7_fc3s_sr20", 0, 0, 650, 0},
+    // SetupManager (Car/SetupManager.cpp:10-330): a broad set of setCarTune calls -- in and out of range, on and off the step
+    // grid, names a car's setup.ini does not list -- on a strut / live-axle car and on a strut / double-wishbone car with wings
+    {"tunes", 2400, 300, 10, 0, 1, 1, 1, "touge", 1, nullptr, 0, 0, 0, 1},
+    {"tunes_fc3s", 2400, 300, 10, 0, 1, 1, 1, "touge", 1, "dthwsh_mazda_rx7_fc3s_sr20", 0, 0, 0, 1},
 };
-static const int kNumScenarios = 19;
+static const int kNumScenarios = 21;
+struct Tune { const char* name; float value; };
+static const Tune kTuneSetA[] = {
+    {"ARB_FRONT", 22000.0f}, {"ARB_REAR", 5000.0f}, {"BRAKE_POWER_MULT", 93.0f}, {"CAMBER_LF", -2.0f}, {"CAMBER_RF", -3.5f}, {"CAMBER_LR", -1.5f},
+    {"CAMBER_RR", -1.0f}, {"DAMP_BUMP_LF", 5100.0f}, {"DAMP_BUMP_RF", 9000.0f}, {"DAMP_BUMP_LR", 6000.0f}, {"DAMP_BUMP_RR", 6500.0f},
+    {"DAMP_FAST_BUMP_LF", 8000.0f}, {"DAMP_FAST_BUMP_RR", 3000.0f}, {"DAMP_REBOUND_LF", 9300.0f}, {"DAMP_REBOUND_RR", 8800.0f},
+    {"DAMP_FAST_REBOUND_LF", 13000.0f}, {"DAMP_FAST_REBOUND_LR", 9000.0f}, {"DIFF_PRELOAD", 55.0f}, {"DIFF_POWER", 65.0f}, {"DIFF_COAST", 45.0f},
+    {"FRONT_BIAS", 61.0f}, {"PRESSURE_LF", 24.0f}, {"PRESSURE_RR", 33.0f}, {"ROD_LENGTH_LF", -120.0f}, {"ROD_LENGTH_RF", -95.0f},
+    {"ROD_LENGTH_LR", -330.0f}, {"ROD_LENGTH_RR", -310.0f}, {"SPRING_RATE_LF", 82.0f}, {"SPRING_RATE_RR", 71.0f}, {"TOE_OUT_LF", 20.0f},
+    {"TOE_OUT_RF", -35.0f}, {"TOE_OUT_LR", 15.0f}, {"FINAL_RATIO", 4.5f}, {"ENGINE_LIMITER", 95.0f}, {"WING_0", 5.0f}, {"WING_3", 12.0f},
+    {"INTERNAL_GEAR_2", 2.0f}, {"BUMP_STOP_RATE_LF", 80.0f}, {"PACKER_RANGE_LF", 60.0f}, {"PROGRESSIVE_SPRING_RATE_LF", 10.0f}, {"FUEL", 20.0f},
+    {"NO_SUCH_TUNE", 1.0f},
+};
+static const int kNumTuneSetA = (int)(sizeof(kTuneSetA) / sizeof(kTuneSetA[0]));
 #define PDORACLE_DEFAULT_CAR "ks_toyota_ae86_drift"
 
 // closed-loop action from the previous observation (projectd_env.py:239-273 slot order): centre between the side probes,

@@ -937,8 +937,12 @@ static bool findTune(pdb_car_params& P, const std::string& name, TuneVar& v) {
         if (name == b) { v.d = &P.gearRatio[g]; return true; }
     }
     for (int w = 0; w < P.numWings; ++w) {
+        // WING_n of a wing without a dynamic controller (the only kind the loader accepts) is bound to Wing::status.angle
+        // (SetupManager.cpp:112-125), which Wing::stepDynamicControllers overwrites with status.inputAngle -- the aero.ini
+        // angle -- on every tick (Wing.cpp:73-74,105-123): the tune is accepted and has no effect.  Pinned by the `tunes` goldens.
+        static float overwrittenEveryTick;
         char b[32]; snprintf(b, sizeof(b), "WING_%d", w);
-        if (name == b) { v.f = &P.wings[w].angle; return true; }
+        if (name == b) { v.f = &overwrittenEveryTick; return true; }
     }
     for (int i = 0; i < 4; ++i) {
         const std::string t = types[i];
