@@ -145,6 +145,11 @@ const char* cpuref_scenario_car(int sid) { return pdoracle::kScenarios[sid].car 
 int cpuref_num_scenarios(void) { return pdoracle::kNumScenarios; }
 int cpuref_scenario_collide(int sid) { return pdoracle::kScenarios[sid].collide; }
 int cpuref_scenario_resets(int sid) { return pdoracle::kScenarios[sid].resetEvery; }
+int cpuref_scenario_scoring(int sid, int i, const char** name, float* value) {
+    if (!pdoracle::kScenarios[sid].scoringSet || i < 0 || i >= pdoracle::kNumScoringSetA) return 0;
+    *name = pdoracle::kScoringSetA[i].name; *value = pdoracle::kScoringSetA[i].value;
+    return 1;
+}
 // i-th setCarTune call of the scenario's tune set: returns 0 past the end
 int cpuref_scenario_tune(int sid, int i, const char** name, float* value) {
     if (!pdoracle::kScenarios[sid].tuneSet || i < 0 || i >= pdoracle::kNumTuneSetA) return 0;
@@ -154,11 +159,11 @@ int cpuref_scenario_tune(int sid, int i, const char** name, float* value) {
 void cpuref_scenario_feedback(int sid, int tick, const float* obs, float* a) { pdoracle::scenarioFeedback(sid, tick, obs, a[0], a[1]); }
 
 // run one scripted scenario exactly like oracle/refharness/ref_main.cpp and write the probe file
-int cpuref_run_scenario_cb(void* hh, int sid, const char* outPath, void (*teleportToStart)(pdb_dyn_state*));
+int cpuref_run_scenario_cb(void* hh, int sid, const char* outPath, void (*teleportToStart)(pdb_dyn_state*, float));
 int cpuref_run_scenario(void* hh, int sid, const char* outPath) { return cpuref_run_scenario_cb(hh, sid, outPath, nullptr); }
 // teleportToStart: Car::teleportByMode(Start) on a state record -- the PRODUCT's host function (pdb_teleport_to_spline), handed in by
 // the test, so that the scenarios with mid-run resets pin it against the reference's own Car::teleportByMode
-int cpuref_run_scenario_cb(void* hh, int sid, const char* outPath, void (*teleportToStart)(pdb_dyn_state*)) {
+int cpuref_run_scenario_cb(void* hh, int sid, const char* outPath, void (*teleportToStart)(pdb_dyn_state*, float)) {
     auto* h = (CpuRefHandle*)hh;
     const auto& sc = pdoracle::kScenarios[sid];
     // setCarAssists (PyProjectD.cpp:307-317) per scenario; smooth steering stays on like the env
@@ -173,7 +178,7 @@ int cpuref_run_scenario_cb(void* hh, int sid, const char* outPath, void (*telepo
         if (sc.resetEvery && t > 0 && t % sc.resetEvery == 0) {   // env.reset(): teleportCarByMode(Start) + step([0,0])
             if (!teleportToStart) return -2;
             pdb_dyn_state st = h->car.S;
-            teleportToStart(&st);
+            teleportToStart(&st, sc.teleDist ? pdoracle::kTeleDist[(t / sc.resetEvery - 1) % 4] : 0.0f);
             h->car.loadState(st);
             h->car.step(0.0f, pdoracle::envGas(0.0f), (float)(1.0 / 333.0), 1.0 / 333.0);
         }

@@ -223,6 +223,7 @@ int main(int argc, char** argv) {
             env.init(base, track, sc.car ? std::string(sc.car) : model, sc.autoClutch != 0, sc.autoShift != 0, sc.autoBlip != 0);
             env.smooth = sc.rawSteer == 0;
             ref_set_collide(env.sim->physics.get(), sc.collide != 0);
+            if (sc.scoringSet) for (int i = 0; i < pdoracle::kNumScoringSetA; ++i) env.car->scoring->config->setVar(pdoracle::kScoringSetA[i].name, pdoracle::kScoringSetA[i].value);   // PyProjectD.cpp:347-355
             if (sc.tuneSet) for (int i = 0; i < pdoracle::kNumTuneSetA; ++i) env.car->setup->setTune(pdoracle::kTuneSetA[i].name, pdoracle::kTuneSetA[i].value);   // PyProjectD.cpp:328-335
             pdoracle::ProbeFile pf;
             env.reset();
@@ -232,7 +233,10 @@ int main(int argc, char** argv) {
                 pf.add(-1, 0.0f, 0.0f, P);
             }
             for (int t = 0; t < sc.ticks; ++t) {
-                if (sc.resetEvery && t > 0 && t % sc.resetEvery == 0) env.reset();
+                if (sc.resetEvery && t > 0 && t % sc.resetEvery == 0) {
+                    if (sc.teleDist) { env.car->teleportToSpline(pdoracle::kTeleDist[(t / sc.resetEvery - 1) % 4]); env.step(0.0f, 0.0f); }   // teleportCarToSpline + a zero-action tick
+                    else env.reset();
+                }
                 float a0, a1;
                 if (sc.feedback) {
                     float obs[24]; obsOf(*env.car->state, obs);

@@ -14,40 +14,59 @@ namespace pdoracle {
 struct Scenario { const char* name; int ticks; int denseTicks; int stride; int full; int autoClutch, autoShift, autoBlip; const char* track; int feedback; const char* car; int rawSteer;
                   int collide; /* run the engine's collision pass (the other fixtures predate it and keep it off) */
                   int resetEvery; /* env.reset() (teleportByMode(Start) + one zero-action tick, projectd_env.py:216-227) every so many ticks */
-                  int tuneSet; /* apply kTuneSetA through setCarTune after the env's own tunes */ };
+                  int tuneSet; /* apply kTuneSetA through setCarTune after the env's own tunes */
+                  int teleDist; /* the resets teleport to kTeleDist[k % 4] along the spline (teleportCarToSpline) instead of to the start */
+                  int scoringSet; /* kScoringSetA through setScoringVar: every reward weight and threshold non-default and non-zero */ };
 
 static const Scenario kScenarios[] = {
-    {"idle", 600, 200, 10, 0, 1, 1, 1, "flat", 0, nullptr, 0, 0, 0, 0},
-    {"launch", 2000, 450, 10, 0, 1, 1, 1, "flat", 0, nullptr, 0, 0, 0, 0},
-    {"circle", 1600, 300, 10, 0, 1, 1, 1, "flat", 0, nullptr, 0, 0, 0, 0},
-    {"slalom", 2400, 300, 10, 0, 1, 1, 1, "flat", 0, nullptr, 0, 0, 0, 0},
-    {"brake", 2400, 200, 10, 1, 1, 1, 1, "flat", 0, nullptr, 0, 0, 0, 0},    // pedal brake to a stop, handbrake turn (BrakeSystem, tyre lock)
-    {"manual", 2600, 300, 10, 1, 0, 0, 0, "flat", 0, nullptr, 1, 0, 0, 0},   // no assists: manual clutch, gearUp/gearDn pulses, H-shifter gear select, grinding
-    {"drive", 7000, 300, 10, 0, 1, 1, 1, "touge", 1, nullptr, 0, 0, 0, 0},   // closed hilly, banked mountain road driven by a probe-feedback controller (configs[2] shape)
-    {"rx7", 2400, 300, 10, 0, 1, 1, 1, "flat", 0, "ks_mazda_rx7_tuned", 0, 0, 0, 0},          // double wishbones all round, one turbo: the slalom script
-    {"supra", 5000, 300, 10, 0, 1, 1, 1, "touge", 1, "ks_toyota_supra_mkiv_drift", 0, 0, 0, 0},   // double wishbones, two turbos, 6 gears, on the mountain road
-    {"fc3s", 2400, 300, 10, 0, 1, 1, 1, "flat", 0, "dthwsh_mazda_rx7_fc3s_sr20", 0, 0, 0, 0},      // strut front + double wishbone rear (38 rows), 3 wings + 2 fins, turbo
-    {"readie", 5000, 300, 10, 0, 1, 1, 1, "touge", 1, "gravygarage_street_ae86_readie", 0, 0, 0, 0},   // strut front + double wishbone rear on the mountain road
-    {"playground", 2500, 300, 10, 0, 1, 1, 1, "driftplayground", 1, nullptr, 0, 0, 0, 0},   // the env's default track as shipped (510 surfaces, 112 411 triangles, spline.cache)
-    {"multilink", 4000, 300, 10, 0, 1, 1, 1, "touge", 1, "pdb_ml_supra", 0, 0, 0, 0},   // reference SuspensionML on a derived car (oracle/make_base.py), front and rear
-    {"heave", 4000, 300, 10, 0, 1, 1, 1, "touge", 1, "pdb_heave_rx7", 0, 0, 0, 0},       // reference HeaveSpring on a derived car (third spring across both axles)
-    {"fwd", 2400, 300, 10, 0, 1, 1, 1, "flat", 0, "pdb_fwd_ae86", 0, 0, 0, 0},            // front-wheel drive through the same 2WD drivetrain (derived car), slalom script
+    {"idle", 600, 200, 10, 0, 1, 1, 1, "flat", 0, nullptr, 0, 0, 0, 0, 0, 0},
+    {"launch", 2000, 450, 10, 0, 1, 1, 1, "flat", 0, nullptr, 0, 0, 0, 0, 0, 0},
+    {"circle", 1600, 300, 10, 0, 1, 1, 1, "flat", 0, nullptr, 0, 0, 0, 0, 0, 0},
+    {"slalom", 2400, 300, 10, 0, 1, 1, 1, "flat", 0, nullptr, 0, 0, 0, 0, 0, 0},
+    {"brake", 2400, 200, 10, 1, 1, 1, 1, "flat", 0, nullptr, 0, 0, 0, 0, 0, 0},    // pedal brake to a stop, handbrake turn (BrakeSystem, tyre lock)
+    {"manual", 2600, 300, 10, 1, 0, 0, 0, "flat", 0, nullptr, 1, 0, 0, 0, 0, 0},   // no assists: manual clutch, gearUp/gearDn pulses, H-shifter gear select, grinding
+    {"drive", 7000, 300, 10, 0, 1, 1, 1, "touge", 1, nullptr, 0, 0, 0, 0, 0, 0},   // closed hilly, banked mountain road driven by a probe-feedback controller (configs[2] shape)
+    {"rx7", 2400, 300, 10, 0, 1, 1, 1, "flat", 0, "ks_mazda_rx7_tuned", 0, 0, 0, 0, 0, 0},          // double wishbones all round, one turbo: the slalom script
+    {"supra", 5000, 300, 10, 0, 1, 1, 1, "touge", 1, "ks_toyota_supra_mkiv_drift", 0, 0, 0, 0, 0, 0},   // double wishbones, two turbos, 6 gears, on the mountain road
+    {"fc3s", 2400, 300, 10, 0, 1, 1, 1, "flat", 0, "dthwsh_mazda_rx7_fc3s_sr20", 0, 0, 0, 0, 0, 0},      // strut front + double wishbone rear (38 rows), 3 wings + 2 fins, turbo
+    {"readie", 5000, 300, 10, 0, 1, 1, 1, "touge", 1, "gravygarage_street_ae86_readie", 0, 0, 0, 0, 0, 0},   // strut front + double wishbone rear on the mountain road
+    {"playground", 2500, 300, 10, 0, 1, 1, 1, "driftplayground", 1, nullptr, 0, 0, 0, 0, 0, 0},   // the env's default track as shipped (510 surfaces, 112 411 triangles, spline.cache)
+    {"multilink", 4000, 300, 10, 0, 1, 1, 1, "touge", 1, "pdb_ml_supra", 0, 0, 0, 0, 0, 0},   // reference SuspensionML on a derived car (oracle/make_base.py), front and rear
+    {"heave", 4000, 300, 10, 0, 1, 1, 1, "touge", 1, "pdb_heave_rx7", 0, 0, 0, 0, 0, 0},       // reference HeaveSpring on a derived car (third spring across both axles)
+    {"fwd", 2400, 300, 10, 0, 1, 1, 1, "flat", 0, "pdb_fwd_ae86", 0, 0, 0, 0, 0, 0},            // front-wheel drive through the same 2WD drivetrain (derived car), slalom script
     // body contacts: full throttle down the walled strip -- the belly box scrapes the ridge, then the car drifts into the side wall
     // (hull).  Pins what the reference does with a contact (Simulator / Car::onCollisionCallback, the scoring that reads the flag
     // and the damage); the contacts themselves are this project's (oracle/rb/pdcollide.h).  Stride 3: odd and even frames alternate.
-    {"walled", 2150, 0, 3, 0, 1, 1, 1, "walled", 0, nullptr, 0, 1, 0, 0},
+    {"walled", 2150, 0, 3, 0, 1, 1, 1, "walled", 0, nullptr, 0, 1, 0, 0, 0, 0},
     // episode resets in mid-flight (Car::teleportByMode(Start) -> teleportToSpline -> forceRotation / forcePosition -> Car::reset,
     // Tyre::reset, Drivetrain::reset, suspension attach: Car.cpp:385-410,1240-1358): the car is driven on the mountain road and
     // reset every 700 ticks from whatever state it is in (rolling, warm tyres, a gear engaged, turbos spun up)
-    {"resets", 3000, 300, 10, 0, 1, 1, 1, "touge", 1, nullptr, 0, 0, 700, 0},
-    {"resets_supra", 3000, 300, 10, 0, 1, 1, 1, "touge", 1, "ks_toyota_supra_mkiv_drift", 0, 0, 700, 0},
-    {"resets_fc3s", 3000, 300, 10, 0, 1, 1, 1, "touge", 1, "dthwsh_mazda_rx7_fc3s_sr20", 0, 0, 650, 0},
+    {"resets", 3000, 300, 10, 0, 1, 1, 1, "touge", 1, nullptr, 0, 0, 700, 0, 0, 0},
+    {"resets_supra", 3000, 300, 10, 0, 1, 1, 1, "touge", 1, "ks_toyota_supra_mkiv_drift", 0, 0, 700, 0, 0, 0},
+    {"resets_fc3s", 3000, 300, 10, 0, 1, 1, 1, "touge", 1, "dthwsh_mazda_rx7_fc3s_sr20", 0, 0, 650, 0, 0, 0},
     // SetupManager (Car/SetupManager.cpp:10-330): a broad set of setCarTune calls -- in and out of range, on and off the step
     // grid, names a car's setup.ini does not list -- on a strut / live-axle car and on a strut / double-wishbone car with wings
-    {"tunes", 2400, 300, 10, 0, 1, 1, 1, "touge", 1, nullptr, 0, 0, 0, 1},
-    {"tunes_fc3s", 2400, 300, 10, 0, 1, 1, 1, "touge", 1, "dthwsh_mazda_rx7_fc3s_sr20", 0, 0, 0, 1},
+    {"tunes", 2400, 300, 10, 0, 1, 1, 1, "touge", 1, nullptr, 0, 0, 0, 1, 0, 0},
+    {"tunes_fc3s", 2400, 300, 10, 0, 1, 1, 1, "touge", 1, "dthwsh_mazda_rx7_fc3s_sr20", 0, 0, 0, 1, 0, 0},
+    // Car::teleportToSpline at arbitrary distances, in mid-flight (teleportCarToSpline, PyProjectD.cpp:274-281)
+    {"teleports", 2600, 300, 10, 0, 1, 1, 1, "touge", 1, nullptr, 0, 0, 500, 0, 1, 0},
+    // ScoringSystem::computeAgentReward with every weight in play (the env zeroes most of them): on the road and then off it,
+    // through the manual-gearbox script (grinding, stalling), and down the walled strip (collision penalty)
+    {"rewards", 3000, 300, 10, 0, 1, 1, 1, "touge", 1, nullptr, 0, 0, 0, 0, 0, 1},
+    {"rewards_manual", 2600, 300, 10, 1, 0, 0, 0, "flat", 0, nullptr, 1, 0, 0, 0, 0, 1},
+    {"rewards_walled", 2150, 0, 3, 0, 1, 1, 1, "walled", 0, nullptr, 0, 1, 0, 0, 0, 1},
 };
-static const int kNumScenarios = 21;
+static const int kNumScenarios = 25;
+static const float kTeleDist[4] = {0.13f, 0.41f, 0.77f, 0.95f};
+struct ScoreVar { const char* name; float value; };
+static const ScoreVar kScoringSetA[] = {
+    {"SmoothSteerSpeed", 7.0f}, {"MinBonusSpeed", 8.0f}, {"MaxBonusSpeed", 150.0f}, {"StallRpm", 900.0f}, {"DirectionThreshold", 0.6f},
+    {"OutOfTrackThreshold", 0.45f}, {"ApproachDistance", 6.0f}, {"CriticalDistance", 1.5f}, {"TravelBonus", 0.3f}, {"TravelSplineBonus", 0.02f},
+    {"DriftBonus", 0.07f}, {"SpeedBonus", 0.5f}, {"ThrottleBonus", 0.11f}, {"EngineRpmBonus", 0.13f}, {"DirectionBonus", 0.21f},
+    {"DirectionPenalty", 0.17f}, {"ObstApproachPenalty", 0.9f}, {"CollisionPenalty", 3.0f}, {"OffTrackPenalty", 2.0f}, {"GearGrindPenalty", 0.7f},
+    {"StallPenalty", 0.4f},
+};
+static const int kNumScoringSetA = (int)(sizeof(kScoringSetA) / sizeof(kScoringSetA[0]));
 struct Tune { const char* name; float value; };
 static const Tune kTuneSetA[] = {
     {"ARB_FRONT", 22000.0f}, {"ARB_REAR", 5000.0f}, {"BRAKE_POWER_MULT", 93.0f}, {"CAMBER_LF", -2.0f}, {"CAMBER_RF", -3.5f}, {"CAMBER_LR", -1.5f},
@@ -66,7 +85,6 @@ static const int kNumTuneSetA = (int)(sizeof(kTuneSetA) / sizeof(kTuneSetA[0]));
 // closed-loop action from the previous observation (projectd_env.py:239-273 slot order): centre between the side probes,
 // align with the +-25 degree probes, damp with the yaw rate, hold ~12 m/s.  Plain float arithmetic, fixed order.
 inline void scenarioFeedback(int sid, int tick, const float* obs, float& a0, float& a1) {
-    (void)sid; (void)tick;
     const float lat = obs[21] - obs[20];      // probes[4] - probes[3]  (-90 / +90 degrees, 10 m)
     const float head = obs[19] - obs[18];     // probes[2] - probes[1]  (-25 / +25 degrees, 50 m)
     const float yaw = obs[4];                 // localAngularVelocity.y
@@ -77,6 +95,7 @@ inline void scenarioFeedback(int sid, int tick, const float* obs, float& a0, flo
     float g = 0.3f * (12.0f - v);
     if (g < -1.0f) g = -1.0f;
     if (g > 1.0f) g = 1.0f;
+    if (sid == 22 && tick > 1500) s = 0.45f;   // `rewards`: then a fixed lock takes the car off the road, to meet the off-track / direction terms
     a0 = s; a1 = g;
 }
 
@@ -86,7 +105,7 @@ inline void scenarioAction(int sid, int tick, float& a0, float& a1) {
     const double t = (double)tick * (1.0 / 333.0);
     switch (sid) {
     case 0: a0 = 0.0f; a1 = -1.0f; break;
-    case 1: case 15: a0 = 0.0f; a1 = 1.0f; break;
+    case 1: case 15: case 24: a0 = 0.0f; a1 = 1.0f; break;
     case 2: a0 = 0.35f; a1 = 0.2f; break;
     default:   // slalom (3), the rx7 run (7), the fc3s run (9)
         a0 = (float)(0.4 * sin(6.283185307179586 * t / 2.0));
