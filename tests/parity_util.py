@@ -104,12 +104,14 @@ def make_actions(n, seed, lo=-0.3, hi=0.3):
 
 
 def run_parity(n_cars=8, ticks=200, seed=1234, resync=False, verbose=False, check_every=1, actions_fn=None, model='ks_toyota_ae86_drift', track='flat',
-               on_tick=None):
+               on_tick=None, params_fn=None):
     """Step `n_cars` cars for `ticks` ticks on the GPU (through the C ABI) and in the CPU oracle, from the same
     initial state.  resync=True re-injects the oracle state into the GPU before every tick (single-tick parity).
     Returns the worst relative deviation over all cars, ticks and float fields; raises on integer mismatches."""
     import pdbatch
     P = pdbatch.packed_params(model + '.env')
+    if params_fn is not None:
+        params_fn(P)
     trk = track if isinstance(track, (bytes, bytearray)) else pdbatch.synthetic_track(track)
     lib = pc.load_product(); orc = oracle_ctypes.load_oracle(portable_math=True)
     S0 = pc.DynState()

@@ -438,3 +438,24 @@ def test_free_running_partitions_equal_plain_stepping(built, parts):
     ms, cars = (b.partition_mark(), b.step_ring(4), b.partition_elapsed_ms(parts - 1))[2]
     assert cars > 0 and ms > 0
     a.close(); b.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('track', ['walled', 'touge'])
+def test_every_reward_weight_in_play(built, track):
+    """the env zeroes most ScoringConfig weights; here all 21 are non-default and non-zero (the set the `rewards*` goldens pin
+    against the reference): rewards, drift state and flags of 32 cars equal the oracle's, bit for bit"""
+    import parity_util, oracle_ctypes
+    orc = oracle_ctypes.load_oracle(True)
+    host = pc.load_product(host_only=True)
+    nm = C.c_char_p(); val = C.c_float()
+    sid = [i for i in range(orc.cpuref_num_scenarios()) if orc.cpuref_scenario_name(i) == b'rewards'][0]
+
+    def weights(P):
+        i = 0
+        while orc.cpuref_scenario_scoring(sid, i, C.byref(nm), C.byref(val)):
+            assert host.pdb_set_scoring_var(C.byref(P), nm.value, val.value) == 0
+            i += 1
+        assert i == 21
+    worst = parity_util.run_parity(n_cars=32, ticks=2300 if track == 'walled' else 1200, seed=11, track=track, check_every=9, params_fn=weights)
+    assert worst == 0.0, worst
