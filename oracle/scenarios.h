@@ -48,6 +48,7 @@ static const Scenario kScenarios[] = {
     // grid, names a car's setup.ini does not list -- on a strut / live-axle car and on a strut / double-wishbone car with wings
     {"tunes", 2400, 300, 10, 0, 1, 1, 1, "touge", 1, nullptr, 0, 0, 0, 1, 0, 0},
     {"tunes_fc3s", 2400, 300, 10, 0, 1, 1, 1, "touge", 1, "dthwsh_mazda_rx7_fc3s_sr20", 0, 0, 0, 1, 0, 0},
+    {"tunes_supra", 2400, 300, 10, 0, 1, 1, 1, "touge", 1, "ks_toyota_supra_mkiv_drift", 0, 0, 0, 1, 0, 0},   // two adjustable turbos: TURBO_n
     // Car::teleportToSpline at arbitrary distances, in mid-flight (teleportCarToSpline, PyProjectD.cpp:274-281)
     {"teleports", 2600, 300, 10, 0, 1, 1, 1, "touge", 1, nullptr, 0, 0, 500, 0, 1, 0},
     // ScoringSystem::computeAgentReward with every weight in play (the env zeroes most of them): on the road and then off it,
@@ -56,7 +57,7 @@ static const Scenario kScenarios[] = {
     {"rewards_manual", 2600, 300, 10, 1, 0, 0, 0, "flat", 0, nullptr, 1, 0, 0, 0, 0, 1},
     {"rewards_walled", 2150, 0, 3, 0, 1, 1, 1, "walled", 0, nullptr, 0, 1, 0, 0, 0, 1},
 };
-static const int kNumScenarios = 25;
+static const int kNumScenarios = 26;
 static const float kTeleDist[4] = {0.13f, 0.41f, 0.77f, 0.95f};
 struct ScoreVar { const char* name; float value; };
 static const ScoreVar kScoringSetA[] = {
@@ -77,7 +78,7 @@ static const Tune kTuneSetA[] = {
     {"ROD_LENGTH_LR", -330.0f}, {"ROD_LENGTH_RR", -310.0f}, {"SPRING_RATE_LF", 82.0f}, {"SPRING_RATE_RR", 71.0f}, {"TOE_OUT_LF", 20.0f},
     {"TOE_OUT_RF", -35.0f}, {"TOE_OUT_LR", 15.0f}, {"FINAL_RATIO", 4.5f}, {"ENGINE_LIMITER", 95.0f}, {"WING_0", 5.0f}, {"WING_3", 12.0f},
     {"INTERNAL_GEAR_2", 2.0f}, {"BUMP_STOP_RATE_LF", 80.0f}, {"PACKER_RANGE_LF", 60.0f}, {"PROGRESSIVE_SPRING_RATE_LF", 10.0f}, {"FUEL", 20.0f},
-    {"NO_SUCH_TUNE", 1.0f},
+    {"TURBO_0", 0.35f}, {"TURBO_1", 0.8f}, {"TURBO_2", 0.5f}, {"NO_SUCH_TUNE", 1.0f},
 };
 static const int kNumTuneSetA = (int)(sizeof(kTuneSetA) / sizeof(kTuneSetA[0]));
 #define PDORACLE_DEFAULT_CAR "ks_toyota_ae86_drift"
@@ -95,7 +96,7 @@ inline void scenarioFeedback(int sid, int tick, const float* obs, float& a0, flo
     float g = 0.3f * (12.0f - v);
     if (g < -1.0f) g = -1.0f;
     if (g > 1.0f) g = 1.0f;
-    if (sid == 22 && tick > 1500) s = 0.45f;   // `rewards`: then a fixed lock takes the car off the road, to meet the off-track / direction terms
+    if (sid == 23 && tick > 1500) s = 0.45f;   // `rewards`: then a fixed lock takes the car off the road, to meet the off-track / direction terms
     a0 = s; a1 = g;
 }
 
@@ -105,7 +106,7 @@ inline void scenarioAction(int sid, int tick, float& a0, float& a1) {
     const double t = (double)tick * (1.0 / 333.0);
     switch (sid) {
     case 0: a0 = 0.0f; a1 = -1.0f; break;
-    case 1: case 15: case 24: a0 = 0.0f; a1 = 1.0f; break;
+    case 1: case 15: case 25: a0 = 0.0f; a1 = 1.0f; break;
     case 2: a0 = 0.35f; a1 = 0.2f; break;
     default:   // slalom (3), the rx7 run (7), the fc3s run (9)
         a0 = (float)(0.4 * sin(6.283185307179586 * t / 2.0));

@@ -918,9 +918,9 @@ void buildCarModel(const std::string& basePathIn, const std::string& modelName, 
 // variables; spinner semantics from setup.ini (SHOW_CLICKS, MIN, MAX, STEP) and final.rto.
 // -------------------------------------------------------------------------------------------------
 namespace {
-struct TuneVar { float* f; double* d; float mult; };
+struct TuneVar { float* f; double* d; float mult; bool preset; /* tunable with a built-in range, setup.ini or not */ };
 static bool findTune(pdb_car_params& P, const std::string& name, TuneVar& v) {
-    v.f = nullptr; v.d = nullptr; v.mult = 1.0f;
+    v.f = nullptr; v.d = nullptr; v.mult = 1.0f; v.preset = false;
     static const char* types[] = {"LF", "RF", "LR", "RR"};
     static const double sides[] = {-1, 1, -1, 1};
     if (name == "FRONT_BIAS") { v.f = &P.frontBias; v.mult = (float)0.01; return true; }
@@ -935,6 +935,10 @@ static bool findTune(pdb_car_params& P, const std::string& name, TuneVar& v) {
     for (int g = 0; g < P.numGears; ++g) {
         char b[32]; snprintf(b, sizeof(b), "INTERNAL_GEAR_%d", g);
         if (name == b) { v.d = &P.gearRatio[g]; return true; }
+    }
+    for (int t = 0; t < P.numTurbos; ++t) {   // SetupManager.cpp:93-106: userSetting, tunable on its own (0..1 in steps of 0.1), no setup.ini needed
+        char b[32]; snprintf(b, sizeof(b), "TURBO_%d", t);
+        if (name == b) { v.f = &P.turbos[t].userSetting; v.mult = (float)0.01; v.preset = true; return true; }
     }
     for (int w = 0; w < P.numWings; ++w) {
         // WING_n of a wing without a dynamic controller (the only kind the loader accepts) is bound to Wing::status.angle
@@ -978,6 +982,7 @@ bool setCarTune(pdb_car_params& P, const std::string& basePathIn, const std::str
     float minV = -3.402823466e+38f, maxV = 3.402823466e+38f, step = 0.01f;
     int spinner = 3;  // RawFloat
     bool tunable = false;
+    if (v.preset) { minV = 0.0f; maxV = 1.0f; step = 0.1f; tunable = true; }
     std::vector<float> predefined;
     Ini ini(dataPath + "setup.ini");
     if (!ini.ready) {
