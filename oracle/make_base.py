@@ -87,7 +87,7 @@ def main():
     gen_track.gen_flat(os.path.join(base, 'content', 'tracks', 'flat'))
     gen_track.gen_touge(os.path.join(base, 'content', 'tracks', 'touge'))
     gen_track.gen_walled(os.path.join(base, 'content', 'tracks', 'walled'))
-    for trk in ('driftplayground',):
+    for trk in ('driftplayground', 'ebisu_touge', 'yamanashi_short', 'euphoria_hillside_park'):   # the shipped tracks that have both surfaces.bin and spline.bin
         dst = os.path.join(base, 'content', 'tracks', trk)
         if os.path.isdir(dst):
             shutil.rmtree(dst)

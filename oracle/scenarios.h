@@ -56,8 +56,12 @@ static const Scenario kScenarios[] = {
     {"rewards", 3000, 300, 10, 0, 1, 1, 1, "touge", 1, nullptr, 0, 0, 0, 0, 0, 1},
     {"rewards_manual", 2600, 300, 10, 1, 0, 0, 0, "flat", 0, nullptr, 1, 0, 0, 0, 0, 1},
     {"rewards_walled", 2150, 0, 3, 0, 1, 1, 1, "walled", 0, nullptr, 0, 1, 0, 0, 0, 1},
+    // the other shipped tracks that come with their mesh (build container only): real surface kinds, sectors, pit lanes, traced sides
+    {"ebisu", 3000, 300, 10, 0, 1, 1, 1, "ebisu_touge", 1, nullptr, 0, 0, 0, 0, 0, 0},
+    {"yamanashi", 3000, 300, 10, 0, 1, 1, 1, "yamanashi_short", 1, "ks_mazda_rx7_tuned", 0, 0, 0, 0, 0, 0},
+    {"euphoria", 3000, 300, 10, 0, 1, 1, 1, "euphoria_hillside_park", 1, "gravygarage_street_ae86_readie", 0, 0, 0, 0, 0, 0},
 };
-static const int kNumScenarios = 26;
+static const int kNumScenarios = 29;
 static const float kTeleDist[4] = {0.13f, 0.41f, 0.77f, 0.95f};
 struct ScoreVar { const char* name; float value; };
 static const ScoreVar kScoringSetA[] = {
