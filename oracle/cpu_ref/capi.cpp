@@ -182,6 +182,11 @@ int cpuref_run_scenario_cb(void* hh, int sid, const char* outPath, void (*telepo
             h->car.loadState(st);
             h->car.step(0.0f, pdoracle::envGas(0.0f), (float)(1.0 / 333.0), 1.0 / 333.0);
         }
+        if (sc.boostAt && t == sc.boostAt) {
+            pdb_dyn_state st = h->car.S;
+            for (int b = 0; b < h->P.numBodies; ++b) st.body[b].lvel[2] = 50.0f;
+            h->car.loadState(st);
+        }
         float a0, a1;
         if (sc.feedback) {
             pdb_step_out o; h->car.fillStepOut(o);

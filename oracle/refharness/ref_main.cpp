@@ -237,6 +237,10 @@ int main(int argc, char** argv) {
                     if (sc.teleDist) { env.car->teleportToSpline(pdoracle::kTeleDist[(t / sc.resetEvery - 1) % 4]); env.step(0.0f, 0.0f); }   // teleportCarToSpline + a zero-action tick
                     else env.reset();
                 }
+                if (sc.boostAt && t == sc.boostAt) {   // through the engine seam: every body, as the oracle edits the state record
+                    pdrb::World* w = ref_get_world(env.sim->physics.get());
+                    for (auto& b : w->bodies) b.lvel[2] = 50.0f;
+                }
                 float a0, a1;
                 if (sc.feedback) {
                     float obs[24]; obsOf(*env.car->state, obs);

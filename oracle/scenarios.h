@@ -16,52 +16,55 @@ struct Scenario { const char* name; int ticks; int denseTicks; int stride; int f
                   int resetEvery; /* env.reset() (teleportByMode(Start) + one zero-action tick, projectd_env.py:216-227) every so many ticks */
                   int tuneSet; /* apply kTuneSetA through setCarTune after the env's own tunes */
                   int teleDist; /* the resets teleport to kTeleDist[k % 4] along the spline (teleportCarToSpline) instead of to the start */
-                  int scoringSet; /* kScoringSetA through setScoringVar: every reward weight and threshold non-default and non-zero */ };
+                  int scoringSet; /* kScoringSetA through setScoringVar: every reward weight and threshold non-default and non-zero */
+                  int boostAt; /* before this tick every body's linear velocity z is set to 50 m/s (180 km/h); 0 = never */ };
 
 static const Scenario kScenarios[] = {
-    {"idle", 600, 200, 10, 0, 1, 1, 1, "flat", 0, nullptr, 0, 0, 0, 0, 0, 0},
-    {"launch", 2000, 450, 10, 0, 1, 1, 1, "flat", 0, nullptr, 0, 0, 0, 0, 0, 0},
-    {"circle", 1600, 300, 10, 0, 1, 1, 1, "flat", 0, nullptr, 0, 0, 0, 0, 0, 0},
-    {"slalom", 2400, 300, 10, 0, 1, 1, 1, "flat", 0, nullptr, 0, 0, 0, 0, 0, 0},
-    {"brake", 2400, 200, 10, 1, 1, 1, 1, "flat", 0, nullptr, 0, 0, 0, 0, 0, 0},    // pedal brake to a stop, handbrake turn (BrakeSystem, tyre lock)
-    {"manual", 2600, 300, 10, 1, 0, 0, 0, "flat", 0, nullptr, 1, 0, 0, 0, 0, 0},   // no assists: manual clutch, gearUp/gearDn pulses, H-shifter gear select, grinding
-    {"drive", 7000, 300, 10, 0, 1, 1, 1, "touge", 1, nullptr, 0, 0, 0, 0, 0, 0},   // closed hilly, banked mountain road driven by a probe-feedback controller (configs[2] shape)
-    {"rx7", 2400, 300, 10, 0, 1, 1, 1, "flat", 0, "ks_mazda_rx7_tuned", 0, 0, 0, 0, 0, 0},          // double wishbones all round, one turbo: the slalom script
-    {"supra", 5000, 300, 10, 0, 1, 1, 1, "touge", 1, "ks_toyota_supra_mkiv_drift", 0, 0, 0, 0, 0, 0},   // double wishbones, two turbos, 6 gears, on the mountain road
-    {"fc3s", 2400, 300, 10, 0, 1, 1, 1, "flat", 0, "dthwsh_mazda_rx7_fc3s_sr20", 0, 0, 0, 0, 0, 0},      // strut front + double wishbone rear (38 rows), 3 wings + 2 fins, turbo
-    {"readie", 5000, 300, 10, 0, 1, 1, 1, "touge", 1, "gravygarage_street_ae86_readie", 0, 0, 0, 0, 0, 0},   // strut front + double wishbone rear on the mountain road
-    {"playground", 2500, 300, 10, 0, 1, 1, 1, "driftplayground", 1, nullptr, 0, 0, 0, 0, 0, 0},   // the env's default track as shipped (510 surfaces, 112 411 triangles, spline.cache)
-    {"multilink", 4000, 300, 10, 0, 1, 1, 1, "touge", 1, "pdb_ml_supra", 0, 0, 0, 0, 0, 0},   // reference SuspensionML on a derived car (oracle/make_base.py), front and rear
-    {"heave", 4000, 300, 10, 0, 1, 1, 1, "touge", 1, "pdb_heave_rx7", 0, 0, 0, 0, 0, 0},       // reference HeaveSpring on a derived car (third spring across both axles)
-    {"fwd", 2400, 300, 10, 0, 1, 1, 1, "flat", 0, "pdb_fwd_ae86", 0, 0, 0, 0, 0, 0},            // front-wheel drive through the same 2WD drivetrain (derived car), slalom script
+    {"idle", 600, 200, 10, 0, 1, 1, 1, "flat", 0, nullptr, 0, 0, 0, 0, 0, 0, 0},
+    {"launch", 2000, 450, 10, 0, 1, 1, 1, "flat", 0, nullptr, 0, 0, 0, 0, 0, 0, 0},
+    {"circle", 1600, 300, 10, 0, 1, 1, 1, "flat", 0, nullptr, 0, 0, 0, 0, 0, 0, 0},
+    {"slalom", 2400, 300, 10, 0, 1, 1, 1, "flat", 0, nullptr, 0, 0, 0, 0, 0, 0, 0},
+    {"brake", 2400, 200, 10, 1, 1, 1, 1, "flat", 0, nullptr, 0, 0, 0, 0, 0, 0, 0},    // pedal brake to a stop, handbrake turn (BrakeSystem, tyre lock)
+    {"manual", 2600, 300, 10, 1, 0, 0, 0, "flat", 0, nullptr, 1, 0, 0, 0, 0, 0, 0},   // no assists: manual clutch, gearUp/gearDn pulses, H-shifter gear select, grinding
+    {"drive", 7000, 300, 10, 0, 1, 1, 1, "touge", 1, nullptr, 0, 0, 0, 0, 0, 0, 0},   // closed hilly, banked mountain road driven by a probe-feedback controller (configs[2] shape)
+    {"rx7", 2400, 300, 10, 0, 1, 1, 1, "flat", 0, "ks_mazda_rx7_tuned", 0, 0, 0, 0, 0, 0, 0},          // double wishbones all round, one turbo: the slalom script
+    {"supra", 5000, 300, 10, 0, 1, 1, 1, "touge", 1, "ks_toyota_supra_mkiv_drift", 0, 0, 0, 0, 0, 0, 0},   // double wishbones, two turbos, 6 gears, on the mountain road
+    {"fc3s", 2400, 300, 10, 0, 1, 1, 1, "flat", 0, "dthwsh_mazda_rx7_fc3s_sr20", 0, 0, 0, 0, 0, 0, 0},      // strut front + double wishbone rear (38 rows), 3 wings + 2 fins, turbo
+    {"readie", 5000, 300, 10, 0, 1, 1, 1, "touge", 1, "gravygarage_street_ae86_readie", 0, 0, 0, 0, 0, 0, 0},   // strut front + double wishbone rear on the mountain road
+    {"playground", 2500, 300, 10, 0, 1, 1, 1, "driftplayground", 1, nullptr, 0, 0, 0, 0, 0, 0, 0},   // the env's default track as shipped (510 surfaces, 112 411 triangles, spline.cache)
+    {"multilink", 4000, 300, 10, 0, 1, 1, 1, "touge", 1, "pdb_ml_supra", 0, 0, 0, 0, 0, 0, 0},   // reference SuspensionML on a derived car (oracle/make_base.py), front and rear
+    {"heave", 4000, 300, 10, 0, 1, 1, 1, "touge", 1, "pdb_heave_rx7", 0, 0, 0, 0, 0, 0, 0},       // reference HeaveSpring on a derived car (third spring across both axles)
+    {"fwd", 2400, 300, 10, 0, 1, 1, 1, "flat", 0, "pdb_fwd_ae86", 0, 0, 0, 0, 0, 0, 0},            // front-wheel drive through the same 2WD drivetrain (derived car), slalom script
     // body contacts: full throttle down the walled strip -- the belly box scrapes the ridge, then the car drifts into the side wall
     // (hull).  Pins what the reference does with a contact (Simulator / Car::onCollisionCallback, the scoring that reads the flag
     // and the damage); the contacts themselves are this project's (oracle/rb/pdcollide.h).  Stride 3: odd and even frames alternate.
-    {"walled", 2150, 0, 3, 0, 1, 1, 1, "walled", 0, nullptr, 0, 1, 0, 0, 0, 0},
+    {"walled", 2150, 0, 3, 0, 1, 1, 1, "walled", 0, nullptr, 0, 1, 0, 0, 0, 0, 0},
     // episode resets in mid-flight (Car::teleportByMode(Start) -> teleportToSpline -> forceRotation / forcePosition -> Car::reset,
     // Tyre::reset, Drivetrain::reset, suspension attach: Car.cpp:385-410,1240-1358): the car is driven on the mountain road and
     // reset every 700 ticks from whatever state it is in (rolling, warm tyres, a gear engaged, turbos spun up)
-    {"resets", 3000, 300, 10, 0, 1, 1, 1, "touge", 1, nullptr, 0, 0, 700, 0, 0, 0},
-    {"resets_supra", 3000, 300, 10, 0, 1, 1, 1, "touge", 1, "ks_toyota_supra_mkiv_drift", 0, 0, 700, 0, 0, 0},
-    {"resets_fc3s", 3000, 300, 10, 0, 1, 1, 1, "touge", 1, "dthwsh_mazda_rx7_fc3s_sr20", 0, 0, 650, 0, 0, 0},
+    {"resets", 3000, 300, 10, 0, 1, 1, 1, "touge", 1, nullptr, 0, 0, 700, 0, 0, 0, 0},
+    {"resets_supra", 3000, 300, 10, 0, 1, 1, 1, "touge", 1, "ks_toyota_supra_mkiv_drift", 0, 0, 700, 0, 0, 0, 0},
+    {"resets_fc3s", 3000, 300, 10, 0, 1, 1, 1, "touge", 1, "dthwsh_mazda_rx7_fc3s_sr20", 0, 0, 650, 0, 0, 0, 0},
     // SetupManager (Car/SetupManager.cpp:10-330): a broad set of setCarTune calls -- in and out of range, on and off the step
     // grid, names a car's setup.ini does not list -- on a strut / live-axle car and on a strut / double-wishbone car with wings
-    {"tunes", 2400, 300, 10, 0, 1, 1, 1, "touge", 1, nullptr, 0, 0, 0, 1, 0, 0},
-    {"tunes_fc3s", 2400, 300, 10, 0, 1, 1, 1, "touge", 1, "dthwsh_mazda_rx7_fc3s_sr20", 0, 0, 0, 1, 0, 0},
-    {"tunes_supra", 2400, 300, 10, 0, 1, 1, 1, "touge", 1, "ks_toyota_supra_mkiv_drift", 0, 0, 0, 1, 0, 0},   // two adjustable turbos: TURBO_n
+    {"tunes", 2400, 300, 10, 0, 1, 1, 1, "touge", 1, nullptr, 0, 0, 0, 1, 0, 0, 0},
+    {"tunes_fc3s", 2400, 300, 10, 0, 1, 1, 1, "touge", 1, "dthwsh_mazda_rx7_fc3s_sr20", 0, 0, 0, 1, 0, 0, 0},
+    {"tunes_supra", 2400, 300, 10, 0, 1, 1, 1, "touge", 1, "ks_toyota_supra_mkiv_drift", 0, 0, 0, 1, 0, 0, 0},   // two adjustable turbos: TURBO_n
     // Car::teleportToSpline at arbitrary distances, in mid-flight (teleportCarToSpline, PyProjectD.cpp:274-281)
-    {"teleports", 2600, 300, 10, 0, 1, 1, 1, "touge", 1, nullptr, 0, 0, 500, 0, 1, 0},
+    {"teleports", 2600, 300, 10, 0, 1, 1, 1, "touge", 1, nullptr, 0, 0, 500, 0, 1, 0, 0},
     // ScoringSystem::computeAgentReward with every weight in play (the env zeroes most of them): on the road and then off it,
     // through the manual-gearbox script (grinding, stalling), and down the walled strip (collision penalty)
-    {"rewards", 3000, 300, 10, 0, 1, 1, 1, "touge", 1, nullptr, 0, 0, 0, 0, 0, 1},
-    {"rewards_manual", 2600, 300, 10, 1, 0, 0, 0, "flat", 0, nullptr, 1, 0, 0, 0, 0, 1},
-    {"rewards_walled", 2150, 0, 3, 0, 1, 1, 1, "walled", 0, nullptr, 0, 1, 0, 0, 0, 1},
+    {"rewards", 3000, 300, 10, 0, 1, 1, 1, "touge", 1, nullptr, 0, 0, 0, 0, 0, 1, 0},
+    {"rewards_manual", 2600, 300, 10, 1, 0, 0, 0, "flat", 0, nullptr, 1, 0, 0, 0, 0, 1, 0},
+    {"rewards_walled", 2150, 0, 3, 0, 1, 1, 1, "walled", 0, nullptr, 0, 1, 0, 0, 0, 1, 0},
     // the other shipped tracks that come with their mesh (build container only): real surface kinds, sectors, pit lanes, traced sides
-    {"ebisu", 3000, 300, 10, 0, 1, 1, 1, "ebisu_touge", 1, nullptr, 0, 0, 0, 0, 0, 0},
-    {"yamanashi", 3000, 300, 10, 0, 1, 1, 1, "yamanashi_short", 1, "ks_mazda_rx7_tuned", 0, 0, 0, 0, 0, 0},
-    {"euphoria", 3000, 300, 10, 0, 1, 1, 1, "euphoria_hillside_park", 1, "gravygarage_street_ae86_readie", 0, 0, 0, 0, 0, 0},
+    {"ebisu", 3000, 300, 10, 0, 1, 1, 1, "ebisu_touge", 1, nullptr, 0, 0, 0, 0, 0, 0, 0},
+    {"yamanashi", 3000, 300, 10, 0, 1, 1, 1, "yamanashi_short", 1, "ks_mazda_rx7_tuned", 0, 0, 0, 0, 0, 0, 0},
+    {"euphoria", 3000, 300, 10, 0, 1, 1, 1, "euphoria_hillside_park", 1, "gravygarage_street_ae86_readie", 0, 0, 0, 0, 0, 0, 0},
+    // into the wall across the road at 180 km/h: Engine::blowUp above 150 (Car.cpp:979-980) and the dead engine afterwards
+    {"crash", 2100, 0, 3, 0, 1, 1, 1, "walled", 0, nullptr, 0, 1, 0, 0, 0, 0, 1650},
 };
-static const int kNumScenarios = 29;
+static const int kNumScenarios = 30;
 static const float kTeleDist[4] = {0.13f, 0.41f, 0.77f, 0.95f};
 struct ScoreVar { const char* name; float value; };
 static const ScoreVar kScoringSetA[] = {
@@ -110,7 +113,7 @@ inline void scenarioAction(int sid, int tick, float& a0, float& a1) {
     const double t = (double)tick * (1.0 / 333.0);
     switch (sid) {
     case 0: a0 = 0.0f; a1 = -1.0f; break;
-    case 1: case 15: case 25: a0 = 0.0f; a1 = 1.0f; break;
+    case 1: case 15: case 25: case 29: a0 = 0.0f; a1 = 1.0f; break;
     case 2: a0 = 0.35f; a1 = 0.2f; break;
     default:   // slalom (3), the rx7 run (7), the fc3s run (9)
         a0 = (float)(0.4 * sin(6.283185307179586 * t / 2.0));
