@@ -1,8 +1,8 @@
 #!/usr/bin/env python3
 """ORACLE / TEST INFRASTRUCTURE (build container only).  Regenerates tests/golden/*.npz from the
 reference-TU harness: build oracle/_ref/refharness (oracle/refharness/Makefile), assemble the base
-directory (make_base.py), run every scripted scenario (oracle/scenarios.h) on the synthetic flat
-track, and store the probe records.  A fixture is data: actions in, reference-computed values out."""
+directory (make_base.py: synthetic tracks, derived cars, copies of the shipped tracks that come with their mesh), run every
+scripted scenario (oracle/scenarios.h) and store the probe records.  A fixture is data: actions in, reference-computed values out."""
 import os, subprocess, sys, numpy as np
 here = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, here)
