@@ -117,6 +117,10 @@ static void fillConst(const pdb_car_params& P, DevConst& K, int actionMode) {
     for (int j = P.numJoints; j <= PDB_MAX_JOINTS; ++j) K.rowStart[j] = r;
     for (int j = 0; j < P.numJoints; ++j)
         for (int rr = K.rowStart[j]; rr < K.rowStart[j + 1] && rr < PDB_MAX_ROWS; ++rr) { K.rowB0[rr] = P.joints[j].b0; K.rowB1[rr] = P.joints[j].b1; }
+    for (int b = 0; b < PDB_MAX_BODIES; ++b) {
+        K.invMass[b] = (b < P.numBodies) ? 1.0f / P.bodies[b].mass : 0.0f;
+        for (int k = 0; k < 3; ++k) K.invInertia[b][k] = (b < P.numBodies) ? 1.0f / P.bodies[b].inertia[k] : 0.0f;
+    }
     K.actionMode = actionMode;
     K.wantCarState = 0;
 }

@@ -15,6 +15,7 @@ struct DevConst {
     int rowB0[PDB_MAX_ROWS], rowB1[PDB_MAX_ROWS];   // bodies of each constraint row (static per model: scalar loads in the A assembly)
     float dt;
     float fps;   // 1.0f / dt
+    float invMass[PDB_MAX_BODIES], invInertia[PDB_MAX_BODIES][3];   // 1.0f / mass, 1.0f / inertia: divided once on the host (IEEE single division on both sides)
     double dtD;
     int actionMode;
     int wantCarState;
