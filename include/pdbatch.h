@@ -15,6 +15,10 @@
  *   pdb_step / pdb_step_host setCarControls + stepSimulator + getCarState   :297-305,160-180,319-326
  *   pdb_get_car_state        getCarState                       :319-326 (664-byte CarState per car)
  *   pdb_reset                teleportCarByMode(mode=Start) for a mask of cars (projectd_env.py:216-227)
+ *   pdb_step_ring / pdb_step_partition / pdb_set_partitions   no counterpart: N stepSimulator loops of N independent
+ *                            simulators, which the reference runs as N processes, here as free-running car ranges
+ *   body contacts            PhysicsEngineODE::collisionStep + Car::onCollisionCallback run inside every step entry point
+ *                            (pdb_car_params.collider, loaded by pdb_build_car_model from colliders.ini / collider.bin)
  *
  * Conventions: plain pointers and sizes, caller-owned buffers, no exceptions across the ABI.
  * Functions returning int give 0 on success and a negative pdb_status on failure;
