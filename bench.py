@@ -59,6 +59,7 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--partitions', type=int, default=2,
                     help='free-running car ranges per GPU, one HIP stream each (pdb_set_partitions / pdb_step_ring; constant policy only -- a per-tick policy joins the ranges every tick); 1 = one launch per tick')
+    ap.add_argument('--walls', action='store_true', help='touge workload: line both edges of the road with WALL surfaces (configs[4] shape: hull-vs-wall narrow phase next to the guard rails)')
     ap.add_argument('--spline-step', type=float, default=0.0, help='touge workload: metres between spline points (default 5 m = 891 points; 0.9 = 4.9 k points, the density of the reference tracks)')
     ap.add_argument('--no-body-contacts', action='store_true', help='diagnostic A/B: switch the collision pass off in the car block (never the bench line)')
     ap.add_argument('--policy', choices=['constant', 'feedback', 'mlp'], default=None,
@@ -96,7 +97,12 @@ def main():
     P = pdbatch.packed_params()
     if args.no_body_contacts:
         P.collider.enabled = 0
-    trk = pdbatch.synthetic_track(args.workload, **({'step': args.spline_step} if args.spline_step else {}))
+    gen_args = {}
+    if args.spline_step:
+        gen_args['step'] = args.spline_step
+    if args.walls:
+        gen_args['walls'] = True
+    trk = pdbatch.synthetic_track(args.workload, **gen_args)
     lib = pc.load_product()
     S0 = pc.DynState()
     assert lib.pdb_initial_state(C.byref(P), trk, C.byref(S0)) == 0

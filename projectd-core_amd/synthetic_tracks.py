@@ -112,10 +112,11 @@ TOUGE_SURFACES = [dict(grip=0.97), dict(grip=0.98), dict(grip=0.95, sin_height=0
                   dict(grip=0.8, damping=0.01, dirt=1.0, valid=0), dict(grip=0.9, granularity=1.0, dirt=0.1)]
 
 
-def gen_touge(out, step=5.0, side=5.0, margin=4.0, bank_gain=6.0, bank_max=0.08, points_per_surface=40):
+def gen_touge(out, step=5.0, side=5.0, margin=4.0, bank_gain=6.0, bank_max=0.08, points_per_surface=40, walls=False):
     """Synthetic "Akina-like" closed mountain road (BASELINE configs[2] shape): curvy ring with hills and curvature-
     proportional banking; ribbon mesh (two triangles per spline interval) cut into surfaces of points_per_surface intervals
-    that cycle through six kinds of surface properties, spline every `step` metres with symmetric sides, CLOSED_LOOP=1."""
+    that cycle through six kinds of surface properties, spline every `step` metres with symmetric sides, CLOSED_LOOP=1.
+    walls=True lines both edges of the ribbon with a 1.3 m WALL surface (category 2): BASELINE configs[4] shape, a wall-lined road."""
     os.makedirs(out, exist_ok=True)
     c = touge_centreline(step)
     n = len(c)
@@ -152,6 +153,16 @@ def gen_touge(out, step=5.0, side=5.0, margin=4.0, bank_gain=6.0, bank_max=0.08,
                     idx.extend(tri if ny > 0 else (tri[0], tri[2], tri[1]))      # front face up
             write_surface(f, [tuple(float(x) for x in v) for v in verts], idx, sector=i0 // points_per_surface,
                           **TOUGE_SURFACES[(i0 // points_per_surface) % len(TOUGE_SURFACES)])
+            if walls:
+                for sgn in (-1.0, 1.0):
+                    wv, wi = [], []
+                    for k in range(cnt + 1):
+                        e = edge((i0 + k) % n, sgn)
+                        wv.append((float(e[0]), float(e[1]) - 0.3, float(e[2]))); wv.append((float(e[0]), float(e[1]) + 1.0, float(e[2])))
+                    for k in range(cnt):
+                        a, b, cc, d = 2 * k, 2 * k + 1, 2 * k + 2, 2 * k + 3
+                        wi.extend((a, b, d, a, d, cc))
+                    write_surface(f, wv, wi, sector=1000 + i0 // points_per_surface, category=2, valid=0)
             i0 += cnt
     with open(os.path.join(out, 'spline.bin'), 'wb') as f:
         for p in c:

@@ -122,3 +122,18 @@ def test_gpu_matches_oracle_on_the_walled_strip(built, model):
     worst = parity_util.run_parity(n_cars=48, ticks=2600, seed=99, track='walled', model=model, check_every=7, on_tick=on_tick)
     assert worst == 0.0, worst
     assert seen['flag'] > 100 and seen['dmg'] > 100, seen
+
+
+@pytest.mark.gpu
+def test_gpu_matches_oracle_on_the_wall_lined_road(built):
+    """the synthetic mountain road with guard rails (WALL surfaces along both edges, configs[4] shape): 32 cars with constant
+    actions run wide into the rails within a few seconds -- hull contacts on a curved, banked, hilly mesh, bit for bit"""
+    import parity_util, pdbatch
+    blob = pdbatch.synthetic_track('touge', walls=True)
+    seen = {'dmg': 0}
+
+    def on_tick(t, i, sg, sc):
+        seen['dmg'] += int(sg.damageZoneLevel[4] > 0)
+    worst = parity_util.run_parity(n_cars=32, ticks=1800, seed=3, track=blob, check_every=9, on_tick=on_tick)
+    assert worst == 0.0, worst
+    assert seen['dmg'] > 10, seen
