@@ -282,8 +282,22 @@ typedef struct pdb_dyn_state {
     int32_t simFrame;        /* PhysicsEngineODE::currentFrame: dynamic-vs-static pairs are collided on odd frames only (:230-241) */
     int32_t damageChanged;   /* some damageZoneLevel moved by more than 0.001 this tick (ScoringSystem::validateDrift, :360-368) */
     float damageZoneLevel[5];   /* Car.h:204 */
-    int32_t _pad[3];         /* record size is a multiple of 16 bytes (coalesced 16-byte-per-lane copies) */
+    int32_t numContacts;     /* contact joints alive in the engine's contactGroupDynamic (the car's row of the pdb_contact array) */
+    int32_t _pad[2];         /* record size is a multiple of 16 bytes (coalesced 16-byte-per-lane copies) */
 } pdb_dyn_state;
+
+/* One contact joint between the chassis and the static world (what PhysicsEngineODE::onCollision hands to
+ * dJointCreateContact, PhysicsEngineODE.cpp:283-331): created by the collision pass on odd frames, alive in the solve of that
+ * tick and of the following even one (the group is emptied only when it is refilled, :228-243).  World coordinates.
+ * kind 0: hull vs WALL (surface.mode 28692, mu 0.25, bounce 0.01, soft_cfm 1e-4); kind 1: belly box vs TRACK (mode 28700,
+ * mu 0.1, soft_erp 0.714285731, soft_cfm 0.000952380942).  A car keeps its PDB_MAX_CONTACTS deepest contact points. */
+#define PDB_MAX_CONTACTS 10
+typedef struct pdb_contact {
+    float pos[3];
+    float depth;
+    float normal[3];   /* unit, pointing into the car */
+    int32_t kind;
+} pdb_contact;
 
 /* per-tick outputs (compact) */
 typedef struct pdb_step_out {
@@ -337,5 +351,6 @@ static_assert(sizeof(pdb_car_state) == 664, "pdb_car_state must equal the refere
 static_assert(sizeof(pdb_car_params) == 12392, "pdb_car_params layout");
 static_assert(sizeof(pdb_dyn_state) == 2256, "pdb_dyn_state layout (multiple of 16 bytes)");
 static_assert(sizeof(pdb_step_out) == 104, "pdb_step_out layout");
+static_assert(sizeof(pdb_contact) == 32, "pdb_contact layout");
 #endif
 #endif

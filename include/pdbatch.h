@@ -82,6 +82,11 @@ int pdb_num_cars(const pdb_batch* b);
 int pdb_set_state_all(pdb_batch* b, const pdb_dyn_state* state);
 int pdb_set_state(pdb_batch* b, int first, int count, const pdb_dyn_state* states);
 int pdb_get_state(pdb_batch* b, int first, int count, pdb_dyn_state* states);
+/* the cars' live contact joints (PhysicsEngineODE's contactGroupDynamic): PDB_MAX_CONTACTS pdb_contact per car, the first
+ * pdb_dyn_state.numContacts of a car's row are alive.  A snapshot that must replay bit for bit across an odd -> even frame
+ * boundary carries them next to the state records. */
+int pdb_get_contacts(pdb_batch* b, int first, int count, pdb_contact* out);
+int pdb_set_contacts(pdb_batch* b, int first, int count, const pdb_contact* in);
 /* teleportCarByMode(Start) for cars with mask[i] != 0 (mask == NULL: all cars); host mask */
 int pdb_reset(pdb_batch* b, const uint8_t* mask);
 /* device pointers owned by the batch: float actions[N][2], pdb_step_out out[N] */

@@ -34,6 +34,17 @@ void* cpuref_create(const pdb_car_params* P, const void* trackBlob, uint64_t tra
 void cpuref_destroy(void* hh) { delete (CpuRefHandle*)hh; }
 void cpuref_set_state(void* hh, const pdb_dyn_state* s) { ((CpuRefHandle*)hh)->car.loadState(*s); }
 void cpuref_get_state(void* hh, pdb_dyn_state* s) { *s = ((CpuRefHandle*)hh)->car.S; }
+// the contact joints alive in the engine's group: PDB_MAX_CONTACTS entries, the first S.numContacts meaningful
+void cpuref_get_contacts(void* hh, pdb_contact* c) { ((CpuRefHandle*)hh)->car.getContacts(c); }
+void cpuref_set_contacts(void* hh, const pdb_contact* c, int n) { ((CpuRefHandle*)hh)->car.setContacts(c, n); }
+// contact rows of the last tick's solve (3 per contact: normal, friction 1, friction 2): lambda, lo, hi; returns the row count
+int cpuref_last_contact_rows(void* hh, float* lambda, float* lo, float* hi, int cap, int* iterations) {
+    const pdrb::World& w = ((CpuRefHandle*)hh)->car.w;
+    const int n = (int)w.lastContactLambda.size();
+    for (int i = 0; i < n && i < cap; ++i) { lambda[i] = w.lastContactLambda[i]; lo[i] = w.lastContactLo[i]; hi[i] = w.lastContactHi[i]; }
+    if (iterations) *iterations = w.lastLcpIterations;
+    return n;
+}
 // controls-level step: steer, gas
 void cpuref_step(void* hh, float steer, float gas) {
     ((CpuRefHandle*)hh)->car.step(steer, gas, (float)(1.0 / 333.0), 1.0 / 333.0);
@@ -138,6 +149,23 @@ int cpuref_last_system(void* hh, float* A, float* rhs, float* lambda, int cap) {
     if (rhs) memcpy(rhs, W.lastRhs.data(), sizeof(float) * m);
     if (lambda) memcpy(lambda, W.lastLambda.data(), sizeof(float) * m);
     return m;
+}
+// A lone box body (mass, box sides) with contact joints against the static world, stepped once by pdrb: for the closed-form
+// checks of the contact rows in tests/test_contacts.py.  state = pos[3], lvel[3], avel[3]; contacts = n x pdb_contact;
+// out = lvel[3], avel[3], pos[3] after the step, then lambda / lo / hi of the 3n contact rows
+int cpuref_contact_unit(float mass, const float* sides, const float* state, const pdb_contact* contacts, int n, float dt, int gravityOn, float* out) {
+    pdrb::World W;
+    const int b = W.createBody();
+    W.bodies[b].setMassBoxTotal(mass, sides[0], sides[1], sides[2]);
+    for (int k = 0; k < 3; ++k) { W.bodies[b].pos[k] = state[k]; W.bodies[b].lvel[k] = state[3 + k]; W.bodies[b].avel[k] = state[6 + k]; }
+    if (!gravityOn) { W.gravity[0] = 0; W.gravity[1] = 0; W.gravity[2] = 0; }
+    W.contacts.resize(n);
+    for (int i = 0; i < n; ++i) memcpy(&W.contacts[i], &contacts[i], sizeof(pdb_contact));
+    W.contactBody = b;
+    W.step(dt);
+    for (int k = 0; k < 3; ++k) { out[k] = W.bodies[b].lvel[k]; out[3 + k] = W.bodies[b].avel[k]; out[6 + k] = W.bodies[b].pos[k]; }
+    for (int i = 0; i < 3 * n; ++i) { out[9 + i] = W.lastContactLambda[i]; out[9 + 3 * n + i] = W.lastContactLo[i]; out[9 + 6 * n + i] = W.lastContactHi[i]; }
+    return W.lastLcpIterations;
 }
 const char* cpuref_scenario_name(int sid) { return pdoracle::kScenarios[sid].name; }
 const char* cpuref_scenario_track(int sid) { return pdoracle::kScenarios[sid].track; }

@@ -184,6 +184,17 @@ void Car::loadState(const pdb_dyn_state& s) {
     stepTime = S.physicsTime;
     locClutch = S.locClutch;
 }
+void Car::setContacts(const pdb_contact* c, int n) {
+    contactSet.clear();
+    if (n > pdcol::MAX_CONTACTS) n = pdcol::MAX_CONTACTS;
+    for (int i = 0; i < n; ++i) { memcpy(&contactSet.c[i], &c[i], sizeof(pdb_contact)); contactSet.id[i] = 0; }
+    contactSet.n = n;
+    S.numContacts = n;
+}
+void Car::getContacts(pdb_contact* c) const {
+    memset(c, 0, sizeof(pdb_contact) * PDB_MAX_CONTACTS);
+    for (int i = 0; i < contactSet.n && i < S.numContacts; ++i) memcpy(&c[i], &contactSet.c[i], sizeof(pdb_contact));
+}
 void Car::storeState() {
     for (int i = 0; i < P->numBodies; ++i) {
         const Body& b = w.bodies[i];
@@ -1259,14 +1270,18 @@ static void drivetrainStep(Car& c, float dt) {
 //   * hull vs triangle: every edge of one triangle that pierces the other is a contact at the piercing point, with the
 //     wall triangle's normal turned towards the chassis origin;
 //   * each contact raises collisionFlag; hull contacts feed relative speed -> damage zones / engine blow-up.
-// What is NOT built: the contact joints themselves (no collision response in the solve).
+//   * contact joints (PhysicsEngineODE::onCollision :283-331): every contact point (oracle/rb/pdcollide.h: box corners / edge
+//     midpoints, hull piercing points, each with a depth) is a candidate; the car's PDB_MAX_CONTACTS deepest are kept and stay
+//     in the solve until the group is refilled on the next odd frame (:228-243); oracle/rb/pdrb.cpp solves them.
 // ------------------------------------------------------------------------------------------------
 void Car::collisionStep() {
     const pdb_collider& C = P->collider;
     const int frame = S.simFrame;
     S.simFrame = frame + 1;
     S.damageChanged = 0;
-    if (!C.enabled || !(frame & 1)) return;
+    if (!C.enabled) { S.numContacts = 0; contactSet.clear(); return; }
+    if (!(frame & 1)) return;
+    contactSet.clear();   // dJointGroupEmpty(contactGroupDynamic)
     const Body& body = w.bodies[PDB_BODY_CHASSIS];
     pdcol::Pose pose;
     memcpy(pose.pos, body.pos, 12); memcpy(pose.R, body.R, 36);
@@ -1287,10 +1302,13 @@ void Car::collisionStep() {
             if (!pdcol::triMeetsAabb(p0, p1, p2, aLo, aHi)) continue;
             if (boxPair) {
                 float ny;
-                if (pdcol::boxContact(pose, C.boxCentre, C.boxHalf, p0, p1, p2, ny) && ny >= 0.9f) flag = true;   // PhysicsEngineODE.cpp:303-312
+                if (pdcol::boxContacts(pose, C.boxCentre, C.boxHalf, p0, p1, p2, ny, [&](const pdcol::V& pw, const pdcol::V& nw, float depth, int item) {
+                        contactSet.insert(pw, nw, depth, 1, (unsigned)t * pdcol::ID_STRIDE + (unsigned)item);
+                    }) && ny >= 0.9f) flag = true;   // PhysicsEngineODE.cpp:303-312
             }
             if (meshPair)
-                pdcol::hullContacts(pose, C.verts, C.tris, C.numTris, p0, p1, p2, [&](const pdcol::V& nrm, const pdcol::V& hitp) {
+                pdcol::hullContacts(pose, C.verts, C.tris, C.numTris, p0, p1, p2, [&](const pdcol::V& nrm, const pdcol::V& hitp, float depth, int item) {
+                    contactSet.insert(hitp, nrm, depth, 0, (unsigned)t * pdcol::ID_STRIDE + (unsigned)item);
                     // Car::onCollisionCallback (Car.cpp:960-1003)
                     flag = true;
                     const V3 n(nrm.x, nrm.y, nrm.z), hit(hitp.x, hitp.y, hitp.z);
@@ -1309,6 +1327,7 @@ void Car::collisionStep() {
                 });
         }
     }
+    S.numContacts = contactSet.n;
     if (flag) S.collisionFlag = 1;
     if (blow) S.lifeLeft = -100.0f;   // Engine::blowUp (Engine.cpp:406-409)
     for (int i = 0; i < 5; ++i) {
@@ -1754,6 +1773,8 @@ void Car::stepControls(const pdb_controls& c, float dt, double dtD) {
     S.speed = getVelocity(w.bodies[PDB_BODY_CHASSIS]).len();   // Car::stepPreCacheValues (Car.cpp:414-417)
     carStep(dt);
     collisionStep();   // PhysicsEngineODE::step: collisionStep, then dWorldStep (PhysicsEngineODE.cpp:216-224)
+    w.contacts.resize(S.numContacts);
+    for (int i = 0; i < S.numContacts; ++i) memcpy(&w.contacts[i], &contactSet.c[i], sizeof(pdrb::ContactJoint));
     w.step(dt);
     postStep(dt);
     storeState();

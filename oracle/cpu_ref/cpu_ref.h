@@ -14,6 +14,7 @@
 #pragma once
 #include "pdb_types.h"
 #include "../rb/pdrb.h"
+#include "../rb/pdcollide.h"
 #include "../probe.h"
 #include <vector>
 #include <cstdint>
@@ -61,9 +62,12 @@ struct Car {
     double stepTime = 0;   // sim->physicsTime seen by the last step (before += dt)
     int acSeqCount = 0;
     std::vector<int> nearby;
+    pdcol::ContactSet contactSet;   // the engine's contactGroupDynamic for this car (S.numContacts of them are alive)
 
     void init(const pdb_car_params* P, const TrackData* T, const pdb_dyn_state& s0);
-    void loadState(const pdb_dyn_state& s);     // pdb_dyn_state -> bodies
+    void loadState(const pdb_dyn_state& s);     // pdb_dyn_state -> bodies (contactSet: setContacts)
+    void setContacts(const pdb_contact* c, int n);
+    void getContacts(pdb_contact* c) const;     // PDB_MAX_CONTACTS entries, the first S.numContacts alive
     void storeState();                          // bodies -> S
     void step(float steer, float gas, float dt, double dtD);   // one env tick (setCarControls + stepSimulator)
     void stepControls(const pdb_controls& c, float dt, double dtD);   // same with every CarControls field given

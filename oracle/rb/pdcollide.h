@@ -7,6 +7,14 @@
 //     test in the box frame; one contact per intersecting triangle, normal = the triangle's turned towards the box centre;
 //   * hull vs triangle: every edge of one triangle that pierces the other is a contact at the piercing point, normal = the
 //     static triangle's turned towards the body origin.
+//   * contact POINTS for the response (the joints PhysicsEngineODE::onCollision creates, :283-331), each with a depth:
+//       box: every box corner behind the triangle's plane whose projection falls inside the triangle (depth = distance behind
+//            the plane) and, per triangle edge, the midpoint of the part of the edge inside the box (depth = distance from there
+//            to where the ray against the normal leaves the box);
+//       hull: the piercing points, depth = how far the piercing hull edge's deeper end (hull edges) or the pierced hull
+//            triangle's deepest vertex (wall edges) lies behind the wall triangle's plane.
+//     A car keeps its PDB_MAX_CONTACTS deepest contact points (ties: lowest id = triangle * 2048 + item), which makes the kept
+//     set independent of the order in which triangles are visited (ODE keeps the first 32 per geom pair in ITS order).
 // Used by the CPU restatement (cpu_ref: feeds its restatement of Car::onCollisionCallback) and by the fixture harness's
 // engine (refharness: feeds the REFERENCE's own Simulator/Car::onCollisionCallback), so that what the reference does with
 // a contact is pinned even though where contacts come from is not.
@@ -111,6 +119,83 @@ static inline bool boxContact(const Pose& P, const float* centre, const float* h
 }
 
 // hull (body-frame vertices, uint8 index triples) against one triangle: emit(normal, pos) per contact
+// one contact point = what a dContactGeom carries into dJointCreateContact (layout = pdb_contact, include/pdb_types.h)
+struct Contact { float pos[3]; float depth; float normal[3]; int kind; };   // kind 0: hull vs WALL (mode 28692), 1: box vs TRACK (mode 28700)
+enum { MAX_CONTACTS = 10, ITEM_BOX_CORNER = 1152, ITEM_BOX_EDGE = 1160, ID_STRIDE = 2048 };
+static inline bool contactBefore(float da, unsigned ia, float db, unsigned ib) { return da > db || (da == db && ia < ib); }
+struct ContactSet {
+    int n = 0;
+    Contact c[MAX_CONTACTS];
+    unsigned id[MAX_CONTACTS];
+    void clear() { n = 0; }
+    void insert(const V& pos, const V& nrm, float depth, int kind, unsigned kid) {
+        if (!(depth >= 0.0f) || !(depth < 1.0e30f)) return;
+        int p = 0;
+        while (p < n && contactBefore(c[p].depth, id[p], depth, kid)) ++p;
+        if (p >= MAX_CONTACTS) return;
+        const int last = n < MAX_CONTACTS ? n : MAX_CONTACTS - 1;
+        for (int i = last; i > p; --i) { c[i] = c[i - 1]; id[i] = id[i - 1]; }
+        Contact k; k.pos[0] = pos.x; k.pos[1] = pos.y; k.pos[2] = pos.z; k.depth = depth; k.normal[0] = nrm.x; k.normal[1] = nrm.y; k.normal[2] = nrm.z; k.kind = kind;
+        c[p] = k; id[p] = kid;
+        if (n < MAX_CONTACTS) ++n;
+    }
+};
+
+// belly box against one triangle, with contact points: returns like boxContact (intersects; body-local normal.y); when the
+// normal passes the reference's filter (>= 0.9, PhysicsEngineODE.cpp:303-312) emit(posWorld, normalWorld, depth, item)
+template <typename Emit>
+static inline bool boxContacts(const Pose& P, const float* centre, const float* half, const V& p0, const V& p1, const V& p2, float& localNormalY, Emit emit) {
+    if (!boxContact(P, centre, half, p0, p1, p2, localNormalY)) return false;
+    if (!(localNormalY >= 0.9f)) return true;
+    const V bc = ld(centre), bh = ld(half);
+    const V q0 = toLocal(P, p0) - bc, q1 = toLocal(P, p1) - bc, q2 = toLocal(P, p2) - bc;
+    const V n0 = cross(q1 - q0, q2 - q0);
+    const float l = len(n0);
+    const float inv = 1.0f / l;
+    V nh = mk(n0.x * inv, n0.y * inv, n0.z * inv);
+    if (dot(n0, q0) > 0.0f) nh = nh * -1.0f;
+    const float* R = P.R;
+    const V nW = mk(R[0] * nh.x + R[1] * nh.y + R[2] * nh.z, R[3] * nh.x + R[4] * nh.y + R[5] * nh.z, R[6] * nh.x + R[7] * nh.y + R[8] * nh.z);
+    for (int k = 0; k < 8; ++k) {
+        const V v = mk((k & 1) ? bh.x : -bh.x, (k & 2) ? bh.y : -bh.y, (k & 4) ? bh.z : -bh.z);
+        const float s = dot(nh, v - q0);
+        if (!(s < 0.0f)) continue;
+        const V pp = v - nh * s;
+        if (!(dot(cross(q1 - q0, pp - q0), n0) >= 0.0f && dot(cross(q2 - q1, pp - q1), n0) >= 0.0f && dot(cross(q0 - q2, pp - q2), n0) >= 0.0f)) continue;
+        emit(toWorld(P, v + bc), nW, -s, (int)ITEM_BOX_CORNER + k);
+    }
+    const V q[4] = {q0, q1, q2, q0};
+    const float hh[3] = {bh.x, bh.y, bh.z};
+    for (int j = 0; j < 3; ++j) {
+        const V a = q[j], dd = q[j + 1] - q[j];
+        const float av[3] = {a.x, a.y, a.z}, dv[3] = {dd.x, dd.y, dd.z};
+        float t0 = 0.0f, t1 = 1.0f;
+        bool ok = true;
+        for (int i = 0; i < 3; ++i) {
+            if (dv[i] == 0.0f) { if (av[i] < -hh[i] || av[i] > hh[i]) ok = false; }
+            else {
+                float ta = (-hh[i] - av[i]) / dv[i], tb = (hh[i] - av[i]) / dv[i];
+                if (ta > tb) { const float t = ta; ta = tb; tb = t; }
+                if (ta > t0) t0 = ta;
+                if (tb < t1) t1 = tb;
+            }
+        }
+        if (!ok || t0 > t1) continue;
+        const float tm = (t0 + t1) * 0.5f;
+        const V pm = mk(a.x + dd.x * tm, a.y + dd.y * tm, a.z + dd.z * tm);
+        const float pv[3] = {pm.x, pm.y, pm.z}, nv[3] = {nh.x, nh.y, nh.z};
+        float depth = 3.0e38f;
+        for (int i = 0; i < 3; ++i) {
+            const float dir = -nv[i];
+            float te;
+            if (dir > 0.0f) te = (hh[i] - pv[i]) / dir; else if (dir < 0.0f) te = (-hh[i] - pv[i]) / dir; else continue;
+            if (te < depth) depth = te;
+        }
+        emit(toWorld(P, pm + bc), nW, depth, (int)ITEM_BOX_EDGE + j);
+    }
+    return true;
+}
+
 template <typename Emit>
 static inline void hullContacts(const Pose& P, const float (*verts)[3], const unsigned char (*tris)[3], int numTris, const V& p0, const V& p1, const V& p2, Emit emit) {
     const V nw = norm(cross(p1 - p0, p2 - p0));
@@ -124,7 +209,12 @@ static inline void hullContacts(const Pose& P, const float (*verts)[3], const un
             if (!got) continue;
             V n = nw;
             if (dot(n, ld(P.pos) - hit) < 0.0f) n = n * -1.0f;
-            emit(n, hit);
+            // depth behind the wall triangle's plane (through p0, normal n): the piercing hull edge's ends (e < 3), or the
+            // pierced hull triangle's vertices (wall edges, e >= 3)
+            float m;
+            if (e < 3) { const V a = (e == 0) ? c0 : (e == 1) ? c1 : c2, b = (e == 0) ? c1 : (e == 1) ? c2 : c0; m = tmin(dot(n, a - p0), dot(n, b - p0)); }
+            else m = tmin(dot(n, c0 - p0), tmin(dot(n, c1 - p0), dot(n, c2 - p0)));
+            emit(n, hit, (m < 0.0f) ? -m : 0.0f, ct * 6 + e);
         }
     }
 }

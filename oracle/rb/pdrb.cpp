@@ -487,6 +487,176 @@ static inline float sinc_ode(float x) {
     return m_sinf(x) / x;
 }
 
+// ---------------------------------------------------------------------------------------------
+// Contact joints (ODE joints/contact.cpp getInfo1/getInfo2) and the mixed LCP they turn dWorldStep into (ODE lcp.cpp).
+//
+// Rows of contact c (3: mu > 0 and finite): normal n (lo 0, hi inf, rhs = min(fps*erp*depth, maxCorrectingVel), raised to
+// bounce * approach speed when dContactBounce; cfm = soft_cfm), then the two friction directions of dPlaneSpace(n) with
+// lo/hi = -/+ mu and findex = the normal row (dContactApprox1: Dantzig fixes the friction limits to mu * |lambda_n| when it
+// reaches the first friction row, from the solution of all the other rows WITHOUT friction; they are not updated afterwards).
+//
+// Solution method (this project's; ODE uses Dantzig's pivoting on the whole matrix -- same unique solution of the same two
+// LCPs, different rounding): every contact is on ONE body (the chassis), so with the unbounded rows eliminated first (which is
+// also what Dantzig does: nub rows first) the contact rows see a 6x6 "effective inverse mass" of that body,
+//     K = Minv_b - G^T Auu^-1 G,   G = the body's block of J_u Minv,
+// S = Jc K Jc^T + cfm/h, rhs_c = c/h - Jc (tmp1_b + G^T lambda0).  The box LCP on S is solved by block principal pivoting
+// (Judice & Pires: flip every infeasible row; after 3 non-improving rounds fall back to flipping the infeasible row of highest
+// index, which terminates for the symmetric positive definite S), each round = one masked LDL^T of the free rows in row order.
+// Stage 1: normal rows only (the friction rows are Dantzig's "don't care" rows, x = 0); stage 2: all rows with the limits fixed.
+// Then lambda_u = lambda0 - (Auu^-1 G) (Jc^T lambda_c).
+// ---------------------------------------------------------------------------------------------
+static inline float dot6c(const float* a, const float* b) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2] + a[3] * b[3] + a[4] * b[4] + a[5] * b[5]; }
+enum { ST_FREE = 0, ST_LO = 1, ST_HI = 2, ST_FIXED = 3, ST_OFF = 4 };
+
+static void solveContacts(World& w, float fps, int m, const int* rb0, const int* rb1, const float* JinvM, const float* L, const float* dinv,
+                          const float* invIwB, const float* tmp1B, float* lambda, float* contactForce) {
+    const int nc = (int)w.contacts.size();
+    const int nr = 3 * nc;
+    const int cb = w.contactBody;
+    const Body& B = w.bodies[cb];
+    std::vector<float> Jc(nr * 6), cv(nr), cfmc(nr), lo(nr), hi(nr), mu(nr);
+    for (int c = 0; c < nc; ++c) {
+        const ContactJoint& cj = w.contacts[c];
+        const bool box = cj.kind == 1;
+        const float muC = box ? 0.1f : 0.25f, bounce = box ? 0.0f : 0.01f, softCfm = box ? 0.000952380942f : 0.0001f;
+        const float erpN = box ? 0.714285731f : w.erp;
+        const float n[3] = {cj.normal[0], cj.normal[1], cj.normal[2]};
+        const float c1[3] = {cj.pos[0] - B.pos[0], cj.pos[1] - B.pos[1], cj.pos[2] - B.pos[2]};
+        float t1[3], t2[3];
+        planeSpace(n, t1, t2);
+        const float* dir[3] = {n, t1, t2};
+        for (int k = 0; k < 3; ++k) {
+            float* J = &Jc[(3 * c + k) * 6];
+            J[0] = dir[k][0]; J[1] = dir[k][1]; J[2] = dir[k][2];
+            cross3(J + 3, c1, dir[k]);
+        }
+        const float kk = fps * erpN;
+        float depth = cj.depth - w.contactSurfaceLayer;
+        if (depth < 0.0f) depth = 0.0f;
+        const float pushout = kk * depth;
+        float cN = pushout > w.contactMaxCorrectingVel ? w.contactMaxCorrectingVel : pushout;
+        const float* Jn = &Jc[(3 * c) * 6];
+        const float outgoing = dot3(Jn + 3, B.avel) + dot3(n, B.lvel);
+        const float negOut = -outgoing;
+        if (negOut > 0.0f) {   // bounce_vel = 0 (memzero'd dContact)
+            const float newc = bounce * negOut;
+            if (newc > cN) cN = newc;
+        }
+        cv[3 * c] = cN; cv[3 * c + 1] = 0.0f; cv[3 * c + 2] = 0.0f;
+        cfmc[3 * c] = softCfm; cfmc[3 * c + 1] = w.cfm; cfmc[3 * c + 2] = w.cfm;
+        lo[3 * c] = 0.0f; hi[3 * c] = 3.0e38f;
+        mu[3 * c] = 0.0f; mu[3 * c + 1] = muC; mu[3 * c + 2] = muC;
+    }
+    // G = the contact body's block of J_u Minv; W = Auu^-1 G (six more right-hand sides through the factor)
+    std::vector<float> G(m * 6 + 1, 0.0f), W(m * 6 + 1, 0.0f);
+    for (int i = 0; i < m; ++i) {
+        const float* src = (rb0[i] == cb) ? &JinvM[i * 12] : (rb1[i] == cb) ? &JinvM[i * 12 + 6] : nullptr;
+        for (int a = 0; a < 6; ++a) { G[i * 6 + a] = src ? src[a] : 0.0f; W[i * 6 + a] = G[i * 6 + a]; }
+    }
+    for (int a = 0; a < 6; ++a) {
+        for (int k = 0; k < m; ++k)
+            for (int i = k + 1; i < m; ++i) W[i * 6 + a] = fmaf(-L[i * m + k], W[k * 6 + a], W[i * 6 + a]);
+        for (int k = 0; k < m; ++k) W[k * 6 + a] *= dinv[k];
+        for (int k = m - 1; k >= 0; --k)
+            for (int i = 0; i < k; ++i) W[i * 6 + a] = fmaf(-L[k * m + i], W[k * 6 + a], W[i * 6 + a]);
+    }
+    float K[36], u[6];
+    for (int a = 0; a < 6; ++a) {
+        for (int b = 0; b < 6; ++b) {
+            float minv = 0.0f;
+            if (a < 3 && b < 3) minv = (a == b) ? B.invMass : 0.0f;
+            else if (a >= 3 && b >= 3) minv = invIwB[(a - 3) * 3 + (b - 3)];
+            float acc = 0.0f;
+            for (int i = 0; i < m; ++i) acc += G[i * 6 + a] * W[i * 6 + b];
+            K[a * 6 + b] = minv - acc;
+        }
+        float acc = 0.0f;
+        for (int i = 0; i < m; ++i) acc += G[i * 6 + a] * lambda[i];
+        u[a] = tmp1B[a] + acc;
+    }
+    // S (lower triangle), right-hand side
+    std::vector<float> S(nr * nr, 0.0f), bt(nr), KJ(nr * 6);
+    for (int r = 0; r < nr; ++r) {
+        const float* J = &Jc[r * 6];
+        for (int a = 0; a < 6; ++a) KJ[r * 6 + a] = dot6c(&K[a * 6], J);
+        for (int s2 = 0; s2 <= r; ++s2) S[r * nr + s2] = dot6c(&KJ[r * 6], &Jc[s2 * 6]);
+        S[r * nr + r] += cfmc[r] * fps;
+        float rr = cv[r] * fps;
+        rr -= dot6c(J, u);
+        bt[r] = rr;
+    }
+    auto Sat = [&](int r, int s2) { return r >= s2 ? S[r * nr + s2] : S[s2 * nr + r]; };
+    std::vector<int> state(nr);
+    std::vector<float> x(nr, 0.0f), work(nr * nr), y(nr), di(nr);
+    int iterations = 0;
+    auto bpp = [&]() {
+        int ninf = nr + 1, p = 3;
+        for (int it = 0; it < 64; ++it) {
+            ++iterations;
+            for (int r = 0; r < nr; ++r) { if (state[r] == ST_LO) x[r] = lo[r]; else if (state[r] == ST_HI) x[r] = hi[r]; else if (state[r] != ST_FREE) x[r] = 0.0f; }
+            for (int r = 0; r < nr; ++r) {
+                if (state[r] != ST_FREE) continue;
+                float acc = bt[r];
+                for (int s2 = 0; s2 < nr; ++s2) if (state[s2] == ST_LO || state[s2] == ST_HI || state[s2] == ST_FIXED) acc = acc - Sat(r, s2) * x[s2];
+                y[r] = acc;
+                for (int s2 = 0; s2 <= r; ++s2) work[r * nr + s2] = S[r * nr + s2];
+            }
+            for (int k = 0; k < nr; ++k) {
+                if (state[k] != ST_FREE) continue;
+                const float id = 1.0f / work[k * nr + k];
+                di[k] = id;
+                for (int i = k + 1; i < nr; ++i) {
+                    if (state[i] != ST_FREE) continue;
+                    const float lik = work[i * nr + k] * id;
+                    for (int j = k + 1; j <= i; ++j) if (state[j] == ST_FREE) work[i * nr + j] = fmaf(-lik, work[j * nr + k], work[i * nr + j]);
+                }
+                for (int i = k + 1; i < nr; ++i) if (state[i] == ST_FREE) work[i * nr + k] *= id;
+            }
+            for (int k = 0; k < nr; ++k) { if (state[k] != ST_FREE) continue; for (int i = k + 1; i < nr; ++i) if (state[i] == ST_FREE) y[i] = fmaf(-work[i * nr + k], y[k], y[i]); }
+            for (int k = 0; k < nr; ++k) if (state[k] == ST_FREE) y[k] *= di[k];
+            for (int k = nr - 1; k >= 0; --k) { if (state[k] != ST_FREE) continue; for (int i = 0; i < k; ++i) if (state[i] == ST_FREE) y[i] = fmaf(-work[k * nr + i], y[k], y[i]); }
+            for (int r = 0; r < nr; ++r) if (state[r] == ST_FREE) x[r] = y[r];
+            // infeasible rows and where they go
+            int k = 0, last = -1;
+            std::vector<int> to(nr, -1);
+            for (int r = 0; r < nr; ++r) {
+                if (state[r] == ST_FREE) { if (x[r] < lo[r]) to[r] = ST_LO; else if (x[r] > hi[r]) to[r] = ST_HI; }
+                else if (state[r] == ST_LO || state[r] == ST_HI) {
+                    float acc = 0.0f;
+                    for (int s2 = 0; s2 < nr; ++s2) if (state[s2] != ST_OFF) acc += Sat(r, s2) * x[s2];
+                    const float wr = acc - bt[r];
+                    if (state[r] == ST_LO ? (wr < 0.0f) : (wr > 0.0f)) to[r] = ST_FREE;
+                }
+                if (to[r] >= 0) { ++k; last = r; }
+            }
+            if (k == 0) break;
+            bool all = true;
+            if (k < ninf) { ninf = k; p = 3; } else if (p > 0) --p; else all = false;
+            for (int r = 0; r < nr; ++r) if (to[r] >= 0 && (all || r == last)) state[r] = to[r];
+        }
+        for (int r = 0; r < nr; ++r) { if (state[r] == ST_LO) x[r] = lo[r]; else if (state[r] == ST_HI) x[r] = hi[r]; else if (state[r] != ST_FREE) x[r] = 0.0f; }
+    };
+    for (int r = 0; r < nr; ++r) state[r] = (r % 3 == 0) ? ST_FREE : ST_OFF;
+    bpp();
+    for (int r = 0; r < nr; ++r) {
+        if (r % 3 == 0) continue;
+        const float h2 = fabsf(mu[r] * x[r - r % 3]);
+        hi[r] = h2; lo[r] = -h2;
+        state[r] = (h2 > 0.0f) ? ST_FREE : ST_FIXED;
+    }
+    bpp();
+    // back to the unbounded rows and the body
+    float yv[6];
+    for (int a = 0; a < 6; ++a) {
+        float acc = 0.0f;
+        for (int r = 0; r < nr; ++r) acc += Jc[r * 6 + a] * x[r];
+        yv[a] = acc;
+        contactForce[a] = acc;
+    }
+    for (int i = 0; i < m; ++i) lambda[i] = lambda[i] - dot6c(&W[i * 6], yv);
+    w.lastContactLambda = x; w.lastContactLo = lo; w.lastContactHi = hi; w.lastLcpIterations = iterations;
+}
+
 void World::step(float h) {
     if (orderDirty) buildOrder();
     const int nb = (int)bodies.size();
@@ -553,10 +723,20 @@ void World::step(float h) {
         jofs[jointOrder.size()] = o;
     }
 
+    // tmp1 = v*fps + invM fe
+    static thread_local std::vector<float> tmp1; tmp1.assign(nb * 6, float());
+    for (int bi = 0; bi < nb; ++bi) {
+        const Body& b = bodies[bi];
+        float* t = &tmp1[bi * 6];
+        for (int k = 0; k < 3; ++k) t[k] = b.facc[k] * b.invMass + b.lvel[k] * fps;
+        mul0_331(t + 3, &invIw[bi * 9], b.tacc);
+        for (int k = 0; k < 3; ++k) t[3 + k] += b.avel[k] * fps;
+    }
     static thread_local std::vector<float> lambda; lambda.assign(m, 0.0f);
+    static thread_local std::vector<float> JinvM, Am, dinv;
     if (m > 0) {
         // JinvM
-        static thread_local std::vector<float> JinvM; JinvM.assign(m * 12, float());
+        JinvM.assign(m * 12, float());
         for (int i = 0; i < m; ++i) {
             const float* J = rows[i].J;
             float* o = &JinvM[i * 12];
@@ -572,7 +752,7 @@ void World::step(float h) {
             }
         }
         // A = JinvM J^T (lower triangle), + cfm*fps on the diagonal
-        static thread_local std::vector<float> Am; Am.assign(m * m, 0.0f);
+        Am.assign(m * m, 0.0f);
         auto dot6 = [](const float* a, const float* b) {
             return a[0] * b[0] + a[1] * b[1] + a[2] * b[2] + a[3] * b[3] + a[4] * b[4] + a[5] * b[5];
         };
@@ -593,15 +773,7 @@ void World::step(float h) {
             }
             Am[i * m + i] += rows[i].cfm * fps;
         }
-        // rhs = c*fps - J (v*fps + invM fe)
-        static thread_local std::vector<float> tmp1; tmp1.assign(nb * 6, float());
-        for (int bi = 0; bi < nb; ++bi) {
-            const Body& b = bodies[bi];
-            float* t = &tmp1[bi * 6];
-            for (int k = 0; k < 3; ++k) t[k] = b.facc[k] * b.invMass + b.lvel[k] * fps;
-            mul0_331(t + 3, &invIw[bi * 9], b.tacc);
-            for (int k = 0; k < 3; ++k) t[3 + k] += b.avel[k] * fps;
-        }
+        // rhs = c*fps - J tmp1
         static thread_local std::vector<float> rhs; rhs.assign(m, float());
         for (int i = 0; i < m; ++i) {
             float r = rows[i].c * fps;
@@ -612,7 +784,7 @@ void World::step(float h) {
         lastA = Am;
         lastRhs = rhs;
         // right-looking LDL^T, lower triangle, explicit fmaf
-        static thread_local std::vector<float> dinv; dinv.assign(m, float());
+        dinv.assign(m, float());
         for (int k = 0; k < m; ++k) {
             const float d = Am[k * m + k];
             const float id = 1.0f / d;
@@ -632,6 +804,9 @@ void World::step(float h) {
             for (int i = 0; i < k; ++i) rhs[i] = fmaf(-Am[k * m + i], rhs[k], rhs[i]);
         lambda = rhs;
     }
+    float contactForce[6] = {0, 0, 0, 0, 0, 0};
+    lastContactLambda.clear(); lastContactLo.clear(); lastContactHi.clear(); lastLcpIterations = 0;
+    if (!contacts.empty()) solveContacts(*this, fps, m, rb0.data(), rb1.data(), JinvM.data(), Am.data(), dinv.data(), &invIw[contactBody * 9], &tmp1[contactBody * 6], lambda.data(), contactForce);
     lastLambda = lambda;
 
     // cforce = J^T lambda (per joint, per component: sum over the joint's rows, then accumulate)
@@ -649,6 +824,7 @@ void World::step(float h) {
             cf[j.b1 * 6 + k] += s1;
         }
     }
+    for (int k = 0; k < 6; ++k) cf[contactBody * 6 + k] += contactForce[k];   // the contact joints come last (their group is the newest)
     // velocity update, position update (dxStepBody, finite rotation mode 1, no finite-rotation axis:
     // RigidBodyODE.cpp:15-16), zero accumulators
     for (int bi = 0; bi < nb; ++bi) {

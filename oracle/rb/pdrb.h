@@ -72,10 +72,20 @@ struct Joint {
     int rows() const { return type == JT_FIXED ? 6 : type == JT_BALL ? 3 : type == JT_SLIDER ? 5 : 1; }
 };
 
+// A contact joint of the current contact group (PhysicsEngineODE::onCollision, PhysicsEngineODE.cpp:283-331): always between
+// body `World::contactBody` and the static world.  kind 0 = every pair but box-trimesh (mode 28692: Bounce | SoftCFM | Approx1,
+// mu 0.25, bounce 0.01, soft_cfm 1e-4); kind 1 = box-trimesh (mode 28700: + SoftERP, mu 0.1, bounce 0, soft_cfm 0.000952380942,
+// soft_erp 0.714285731).
+struct ContactJoint { float pos[3]; float depth; float normal[3]; int kind; };
+
 struct World {
     float gravity[3] = {0.0f, -9.80665f, 0.0f};  // PhysicsEngineODE.cpp:23
     float erp = 0.3f;                            // :24
     float cfm = 1.0e-7f;                         // :25
+    float contactMaxCorrectingVel = 3.0f;        // :26
+    float contactSurfaceLayer = 0.0f;            // :27
+    std::vector<ContactJoint> contacts;          // contactGroupDynamic: refilled on odd frames, alive until then (:228-243)
+    int contactBody = 0;
     std::vector<Body> bodies;
     std::vector<Joint> joints;
     std::vector<int> jointOrder;  // island traversal order (see buildOrder)
@@ -100,6 +110,9 @@ struct World {
     std::vector<float> lastLambda;
     std::vector<float> lastA;  // m*m, before factorisation (lower triangle meaningful)
     std::vector<float> lastRhs;
+    // contact rows of the last step (3 per contact: normal, friction 1, friction 2), for the invariants tests
+    std::vector<float> lastContactLambda, lastContactLo, lastContactHi;
+    int lastLcpIterations = 0;
 };
 
 // shared small math (also used by the oracle's car code so evaluation order is identical)

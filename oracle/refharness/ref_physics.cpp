@@ -8,7 +8,8 @@
 // onCollision, PhysicsEngineODE.cpp:228-341) is optional (ref_set_collide): the frame parity, the category / mask pairing, the
 // body-local normal.y filter of box contacts and the callback into the reference's Simulator / Car::onCollisionCallback follow
 // the reference; the contacts themselves come from this project's own generator (oracle/rb/pdcollide.h -- ODE's dCollide is
-// not available), and no contact joints are created (no collision response).
+// not available).  onCollision's contact joints (:283-331) go into pdrb::World::contacts (the body's deepest
+// pdcol::MAX_CONTACTS contact points, alive until the next odd frame refills the group); pdrb solves them.
 #include "Physics/PhysicsFactory.h"
 #include "Physics/IPhysicsEngine.h"
 #include "Core/Diag.h"
@@ -128,6 +129,7 @@ struct EnginePD : public IPhysicsEngine {
     std::vector<DynMesh> meshes;
     bool collide = false;
     int currentFrame = 0;
+    pdcol::ContactSet contactSet;   // contactGroupDynamic (one car per simulator: one body carries every contact)
     void collisionStep();
 
     IRigidBodyPtr createRigidBody() override { return std::make_shared<BodyPD>(this, world.createBody()); }
@@ -209,6 +211,8 @@ void BodyPD::addMeshCollider(ITriMeshPtr tm, const mat44f& o, unsigned int, unsi
 void EnginePD::collisionStep() {
     const int frame = currentFrame++;
     if (!(frame & 1)) return;   // even frames collide dynamic geoms with each other (one car: nothing), odd ones dynamic vs static
+    contactSet.clear();         // dJointGroupEmpty(contactGroupDynamic)
+    world.contacts.clear();
     // one broad-phase box per body: around all of its geoms, in the body frame
     std::vector<BodyPD*> bodies;
     for (auto& b : boxes) if (std::find(bodies.begin(), bodies.end(), b.body) == bodies.end()) bodies.push_back(b.body);
@@ -226,15 +230,19 @@ void EnginePD::collisionStep() {
         memcpy(pose.pos, body->b().pos, 12); memcpy(pose.R, body->b().R, 36);
         pdcol::V aLo, aHi;
         pdcol::worldAabb(pose, lo, hi, aLo, aHi);
-        for (size_t si = 0; si < statics.size(); ++si) {
+        unsigned triBase = 0;   // triangle ids run over the static meshes in creation order (= the track blob's triangle order)
+        for (size_t si = 0; si < statics.size(); triBase += (unsigned)(statics[si].indices.size() / 3), ++si) {
             const pdrb::StaticMesh& sm = statics[si];
             for (size_t ti = 0; ti + 2 < sm.indices.size(); ti += 3) {
+                const unsigned tid = (triBase + (unsigned)(ti / 3)) * pdcol::ID_STRIDE;
                 const pdcol::V p0 = pdcol::ld(&sm.verts[3 * sm.indices[ti]]), p1 = pdcol::ld(&sm.verts[3 * sm.indices[ti + 1]]), p2 = pdcol::ld(&sm.verts[3 * sm.indices[ti + 2]]);
                 if (!pdcol::triMeetsAabb(p0, p1, p2, aLo, aHi)) continue;
                 for (auto& b : boxes) {
                     if (b.body != body || !((b.cat & sm.mask) && (sm.category & b.mask))) continue;   // collisionNearCallback, :258-264
                     float ny;
-                    if (!pdcol::boxContact(pose, b.centre, b.half, p0, p1, p2, ny) || ny < 0.9f) continue;   // onCollision, :303-312
+                    if (!pdcol::boxContacts(pose, b.centre, b.half, p0, p1, p2, ny, [&](const pdcol::V& pw, const pdcol::V& nw, float depth, int item) {
+                            contactSet.insert(pw, nw, depth, 1, tid + (unsigned)item);
+                        }) || ny < 0.9f) continue;   // onCollision, :303-312
                     pdcol::V n = pdcol::norm(pdcol::cross(p1 - p0, p2 - p0));
                     const pdcol::V cw = pdcol::toWorld(pose, pdcol::ld(b.centre));
                     if (pdcol::dot(n, cw - p0) < 0.0f) n = n * -1.0f;
@@ -243,13 +251,17 @@ void EnginePD::collisionStep() {
                 for (auto& m : meshes) {
                     if (m.body != body || !((m.shape->cat & sm.mask) && (sm.category & m.shape->mask))) continue;
                     pdcol::hullContacts(pose, reinterpret_cast<const float (*)[3]>(m.verts.data()), reinterpret_cast<const unsigned char (*)[3]>(m.tris.data()), (int)(m.tris.size() / 3),
-                                        p0, p1, p2, [&](const pdcol::V& n, const pdcol::V& hit) {
+                                        p0, p1, p2, [&](const pdcol::V& n, const pdcol::V& hit, float depth, int item) {
+                        contactSet.insert(hit, n, depth, 0, tid + (unsigned)item);
                         if (cb) cb->onCollisionCallback(body, m.shape.get(), nullptr, staticColliders[si].get(), vec3f(n.x, n.y, n.z), vec3f(hit.x, hit.y, hit.z), 0.0f);
                     });
                 }
             }
         }
+        world.contactBody = body->id;
     }
+    world.contacts.resize(contactSet.n);
+    for (int i = 0; i < contactSet.n; ++i) memcpy(&world.contacts[i], &contactSet.c[i], sizeof(pdrb::ContactJoint));
 }
 
 void JointPD::setERPCFM(float erp, float cfm) {

@@ -63,8 +63,12 @@ static const Scenario kScenarios[] = {
     {"euphoria", 3000, 300, 10, 0, 1, 1, 1, "euphoria_hillside_park", 1, "gravygarage_street_ae86_readie", 0, 0, 0, 0, 0, 0, 0},
     // into the wall across the road at 180 km/h: Engine::blowUp above 150 (Car.cpp:979-980) and the dead engine afterwards
     {"crash", 2100, 0, 3, 0, 1, 1, 1, "walled", 0, nullptr, 0, 1, 0, 0, 0, 0, 1650},
+    // collision RESPONSE (contact joints, oracle/rb/pdrb.cpp solveContacts): a gentle lock takes the car into the side wall and along
+    // it (hull contacts with friction, many ticks in contact); then full throttle into the wall across the road, again and again
+    {"scrape", 3000, 0, 3, 0, 1, 1, 1, "walled", 0, nullptr, 0, 1, 0, 0, 0, 0, 0},
+    {"wallpush", 3900, 0, 3, 0, 1, 1, 1, "walled", 0, "ks_toyota_supra_mkiv_drift", 0, 1, 0, 0, 0, 0, 0},
 };
-static const int kNumScenarios = 30;
+static const int kNumScenarios = 32;
 static const float kTeleDist[4] = {0.13f, 0.41f, 0.77f, 0.95f};
 struct ScoreVar { const char* name; float value; };
 static const ScoreVar kScoringSetA[] = {
@@ -115,6 +119,8 @@ inline void scenarioAction(int sid, int tick, float& a0, float& a1) {
     case 0: a0 = 0.0f; a1 = -1.0f; break;
     case 1: case 15: case 25: case 29: a0 = 0.0f; a1 = 1.0f; break;
     case 2: a0 = 0.35f; a1 = 0.2f; break;
+    case 30: a0 = 0.04f; a1 = 0.8f; break;
+    case 31: a0 = 0.0f; a1 = 1.0f; break;
     default:   // slalom (3), the rx7 run (7), the fc3s run (9)
         a0 = (float)(0.4 * sin(6.283185307179586 * t / 2.0));
         a1 = (float)(0.6 * sin(6.283185307179586 * t / 5.0 + 1.0));

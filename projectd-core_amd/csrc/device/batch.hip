@@ -15,25 +15,37 @@
 #define PDB_KROWS 33
 #define PDB_KNS k33
 #define PDB_KMINWAVES 6
+#define PDB_KMINWAVES_C 4
 #define PDB_KERNEL_EXACT pdb_step_kernel
 #define PDB_KERNEL_GUARDED pdb_step_kernel_generic
+#define PDB_KERNEL_EXACT_C pdb_contact_kernel
+#define PDB_KERNEL_GUARDED_C pdb_contact_kernel_generic
 #include "step_kernel.hip.inc"
 #undef PDB_KROWS
 #undef PDB_KNS
 #undef PDB_KMINWAVES
 #undef PDB_KERNEL_EXACT
 #undef PDB_KERNEL_GUARDED
+#undef PDB_KERNEL_EXACT_C
+#undef PDB_KERNEL_GUARDED_C
+#undef PDB_KMINWAVES_C
 #define PDB_KROWS 40
 #define PDB_KNS k40
 #define PDB_KMINWAVES 5
+#define PDB_KMINWAVES_C 4
 #define PDB_KERNEL_EXACT pdb_step_kernel_wide40
 #define PDB_KERNEL_GUARDED pdb_step_kernel_wide
+#define PDB_KERNEL_EXACT_C pdb_contact_kernel_wide40
+#define PDB_KERNEL_GUARDED_C pdb_contact_kernel_wide
 #include "step_kernel.hip.inc"
 #undef PDB_KROWS
 #undef PDB_KNS
 #undef PDB_KMINWAVES
 #undef PDB_KERNEL_EXACT
 #undef PDB_KERNEL_GUARDED
+#undef PDB_KERNEL_EXACT_C
+#undef PDB_KERNEL_GUARDED_C
+#undef PDB_KMINWAVES_C
 
 
 namespace pdb { void setError(const std::string& s); }
@@ -64,6 +76,8 @@ struct pdb_batch {
     pdb_car_params* dParams = nullptr;
     DevConst* dK = nullptr;
     uint8_t* dTrack = nullptr;
+    int* dQueue[PDB_MAX_PARTS + 1] = {nullptr, nullptr, nullptr, nullptr, nullptr};   // RedoQueue per launch site: count, done, list[blocks]
+    pdb_contact* dContacts = nullptr;   // [n][PDB_MAX_CONTACTS]: each car's live contact joints (the first pdb_dyn_state.numContacts of its row)
     hipEvent_t ev0 = nullptr, ev1 = nullptr, tev0 = nullptr, tev1 = nullptr;
     bool ownStream = true;
     double kernelMs = 0;
@@ -125,10 +139,32 @@ static void fillConst(const pdb_car_params& P, DevConst& K, int actionMode) {
     K.wantCarState = 0;
 }
 
-typedef void (*StepKernel)(pdb_dyn_state*, const float*, pdb_step_out*, pdb_car_state*, const pdb_car_params*, const DevConst*, const uint8_t*, int);
-static StepKernel stepKernelFor(const pdb_batch* b) {
-    const int m = b->params.numRows;
-    return (m == 33) ? k33::pdb_step_kernel : (m < 33) ? k33::pdb_step_kernel_generic : k40::pdb_step_kernel_wide;
+// One tick of the cars [c0, c1) on `st`: the first pass over every car, then -- when the car model has body colliders -- the
+// contact pass over the blocks the first pass queued (cars with live contact joints or fresh contacts; a small fixed grid that
+// finds an empty queue on almost every tick).  `q` = which of the batch's queues this launch site uses (one per partition
+// stream, one for the batch's own stream: launches that can be in flight together never share a queue).
+#define PDB_CONTACT_GRID 128
+static void launchTick(pdb_batch* b, hipStream_t st, int c0, int c1, pdb_step_out* out, int q) {
+    const int nblk = (c1 - c0 + PDB_CPB - 1) / PDB_CPB, m = b->params.numRows;
+    pdb_dyn_state* S = b->dStates + c0;
+    const float* A = b->dActions + (size_t)c0 * b->actionStride;
+    pdb_step_out* O = out + c0;
+    pdb_car_state* CS = b->dCarStates ? b->dCarStates + c0 : nullptr;
+    pdb_contact* CT = b->dContacts + (size_t)c0 * PDB_MAX_CONTACTS;
+    void* Q = b->dQueue[q];
+    const int n = c1 - c0;
+    const bool contacts = b->params.collider.enabled != 0;
+    const dim3 grid(nblk), block(PDB_BLOCK_THREADS), cgrid(nblk < PDB_CONTACT_GRID ? nblk : PDB_CONTACT_GRID);
+    if (m == 33) {
+        hipLaunchKernelGGL(k33::pdb_step_kernel, grid, block, 0, st, S, A, O, CS, b->dParams, b->dK, b->dTrack, (k33::RedoQueue*)Q, n);
+        if (contacts) hipLaunchKernelGGL(k33::pdb_contact_kernel, cgrid, block, 0, st, S, A, O, CS, b->dParams, b->dK, b->dTrack, CT, (k33::RedoQueue*)Q, n);
+    } else if (m < 33) {
+        hipLaunchKernelGGL(k33::pdb_step_kernel_generic, grid, block, 0, st, S, A, O, CS, b->dParams, b->dK, b->dTrack, (k33::RedoQueue*)Q, n);
+        if (contacts) hipLaunchKernelGGL(k33::pdb_contact_kernel_generic, cgrid, block, 0, st, S, A, O, CS, b->dParams, b->dK, b->dTrack, CT, (k33::RedoQueue*)Q, n);
+    } else {
+        hipLaunchKernelGGL(k40::pdb_step_kernel_wide, grid, block, 0, st, S, A, O, CS, b->dParams, b->dK, b->dTrack, (k40::RedoQueue*)Q, n);
+        if (contacts) hipLaunchKernelGGL(k40::pdb_contact_kernel_wide, cgrid, block, 0, st, S, A, O, CS, b->dParams, b->dK, b->dTrack, CT, (k40::RedoQueue*)Q, n);
+    }
 }
 
 static int launch(pdb_batch* b, float dt, bool wantCarState) {
@@ -139,8 +175,7 @@ static int launch(pdb_batch* b, float dt, bool wantCarState) {
         b->K.wantCarState = wantCarState ? 1 : 0;
         HIPCHK(hipMemcpyAsync(b->dK, &b->K, sizeof(DevConst), hipMemcpyHostToDevice, b->stream));
     }
-    hipLaunchKernelGGL(stepKernelFor(b), dim3((b->n + PDB_CPB - 1) / PDB_CPB), dim3(PDB_BLOCK_THREADS), 0, b->stream, b->dStates, b->dActions, b->dOutActive, b->dCarStates, b->dParams, b->dK,
-                       b->dTrack, b->n);
+    launchTick(b, b->stream, 0, b->n, b->dOutActive, PDB_MAX_PARTS);
     HIPCHK(hipGetLastError());
     return PDB_OK;
 }
@@ -182,6 +217,13 @@ pdb_batch* pdb_create(int device, int n_cars, const pdb_car_params* params, cons
     ok = ok && hipMalloc(&b->dParams, sizeof(pdb_car_params)) == hipSuccess;
     ok = ok && hipMalloc(&b->dK, sizeof(DevConst)) == hipSuccess;
     ok = ok && hipMalloc(&b->dTrack, track_bytes) == hipSuccess;
+    ok = ok && hipMalloc(&b->dContacts, sizeof(pdb_contact) * PDB_MAX_CONTACTS * (size_t)n_cars) == hipSuccess;
+    ok = ok && hipMemset(b->dContacts, 0, sizeof(pdb_contact) * PDB_MAX_CONTACTS * (size_t)n_cars) == hipSuccess;
+    for (int q = 0; q <= PDB_MAX_PARTS; ++q) {
+        const size_t qb = sizeof(int) * (size_t)(4 + (n_cars + PDB_CPB - 1) / PDB_CPB);
+        ok = ok && hipMalloc(&b->dQueue[q], qb) == hipSuccess;
+        ok = ok && hipMemset(b->dQueue[q], 0, qb) == hipSuccess;
+    }
     ok = ok && hipEventCreate(&b->ev0) == hipSuccess && hipEventCreate(&b->ev1) == hipSuccess;
     ok = ok && hipEventCreate(&b->tev0) == hipSuccess && hipEventCreate(&b->tev1) == hipSuccess;
     if (ok) {
@@ -213,7 +255,8 @@ void pdb_destroy(pdb_batch* b) {
     (void)hipSetDevice(b->device);
     if (b->graphExec) (void)hipGraphExecDestroy(b->graphExec);
     if (b->stream) (void)hipStreamSynchronize(b->stream);
-    (void)hipFree(b->dStates); (void)hipFree(b->dActions); (void)hipFree(b->dOut); (void)hipFree(b->dCarStates); (void)hipFree(b->dParams); (void)hipFree(b->dK); (void)hipFree(b->dTrack);
+    (void)hipFree(b->dStates); (void)hipFree(b->dActions); (void)hipFree(b->dOut); (void)hipFree(b->dCarStates); (void)hipFree(b->dParams); (void)hipFree(b->dK); (void)hipFree(b->dTrack); (void)hipFree(b->dContacts);
+    for (int q = 0; q <= PDB_MAX_PARTS; ++q) (void)hipFree(b->dQueue[q]);
     if (b->ev0) (void)hipEventDestroy(b->ev0);
     if (b->ev1) (void)hipEventDestroy(b->ev1);
     if (b->tev0) (void)hipEventDestroy(b->tev0);
@@ -249,6 +292,21 @@ int pdb_get_state(pdb_batch* b, int first, int count, pdb_dyn_state* states) {
     if (!b || !states || first < 0 || count < 0 || first + count > b->n) { pdb::setError("bad range"); return PDB_ERR_ARG; }
     if (int rcj = joinParts(b)) return rcj;
     HIPCHK(hipMemcpyAsync(states, b->dStates + first, sizeof(pdb_dyn_state) * (size_t)count, hipMemcpyDeviceToHost, b->stream));
+    HIPCHK(hipStreamSynchronize(b->stream));
+    return PDB_OK;
+}
+
+int pdb_get_contacts(pdb_batch* b, int first, int count, pdb_contact* out) {
+    if (!b || !out || first < 0 || count < 0 || first + count > b->n) { pdb::setError("bad range"); return PDB_ERR_ARG; }
+    if (int rcj = joinParts(b)) return rcj;
+    HIPCHK(hipMemcpyAsync(out, b->dContacts + (size_t)first * PDB_MAX_CONTACTS, sizeof(pdb_contact) * PDB_MAX_CONTACTS * (size_t)count, hipMemcpyDeviceToHost, b->stream));
+    HIPCHK(hipStreamSynchronize(b->stream));
+    return PDB_OK;
+}
+int pdb_set_contacts(pdb_batch* b, int first, int count, const pdb_contact* in) {
+    if (!b || !in || first < 0 || count < 0 || first + count > b->n) { pdb::setError("bad range"); return PDB_ERR_ARG; }
+    if (int rcj = joinParts(b)) return rcj;
+    HIPCHK(hipMemcpyAsync(b->dContacts + (size_t)first * PDB_MAX_CONTACTS, in, sizeof(pdb_contact) * PDB_MAX_CONTACTS * (size_t)count, hipMemcpyHostToDevice, b->stream));
     HIPCHK(hipStreamSynchronize(b->stream));
     return PDB_OK;
 }
@@ -313,8 +371,7 @@ int pdb_step_n(pdb_batch* b, float dt, int n) {
         hipGraph_t g = nullptr;
         HIPCHK(hipStreamBeginCapture(b->stream, hipStreamCaptureModeThreadLocal));
         for (int i = 0; i < n; ++i)
-            hipLaunchKernelGGL(stepKernelFor(b), dim3((b->n + PDB_CPB - 1) / PDB_CPB), dim3(PDB_BLOCK_THREADS), 0, b->stream, b->dStates, b->dActions, b->dOutActive, b->dCarStates, b->dParams,
-                               b->dK, b->dTrack, b->n);
+            launchTick(b, b->stream, 0, b->n, b->dOutActive, PDB_MAX_PARTS);
         HIPCHK(hipStreamEndCapture(b->stream, &g));
         HIPCHK(hipGraphInstantiate(&b->graphExec, g, nullptr, nullptr, 0));
         (void)hipGraphDestroy(g);
@@ -375,8 +432,7 @@ int pdb_step_ring(pdb_batch* b, float dt, int n_ticks, pdb_step_out* ring, int r
         if (forked && b->partMark) HIPCHK(hipEventRecord(b->partStart[p], st));
         for (int i = 0; i < n_ticks; ++i) {
             pdb_step_out* out = ring ? ring + (size_t)((first_slot + i) % ring_slots) * (size_t)b->n : b->dOutActive;
-            hipLaunchKernelGGL(stepKernelFor(b), dim3((c1 - c0 + PDB_CPB - 1) / PDB_CPB), dim3(PDB_BLOCK_THREADS), 0, st, b->dStates + c0, b->dActions + (size_t)c0 * b->actionStride,
-                               out + c0, b->dCarStates ? b->dCarStates + c0 : nullptr, b->dParams, b->dK, b->dTrack, c1 - c0);
+            launchTick(b, st, c0, c1, out, forked ? p : PDB_MAX_PARTS);
         }
         HIPCHK(hipGetLastError());
         if (forked) { HIPCHK(hipEventRecord(b->partEnd[p], st)); if (join) HIPCHK(hipStreamWaitEvent(b->stream, b->partEnd[p], 0)); }
@@ -399,8 +455,7 @@ int pdb_step_partition(pdb_batch* b, float dt, int part, pdb_step_out* out) {
     hipStream_t st = b->partStream[part];
     if (b->partMark) { for (int p = 0; p < b->parts; ++p) HIPCHK(hipEventRecord(b->partStart[p], b->partStream[p])); b->partMark = false; }
     pdb_step_out* o = out ? out : b->dOutActive;
-    hipLaunchKernelGGL(stepKernelFor(b), dim3((c1 - c0 + PDB_CPB - 1) / PDB_CPB), dim3(PDB_BLOCK_THREADS), 0, st, b->dStates + c0, b->dActions + (size_t)c0 * b->actionStride,
-                       o + c0, b->dCarStates ? b->dCarStates + c0 : nullptr, b->dParams, b->dK, b->dTrack, c1 - c0);
+    launchTick(b, st, c0, c1, o, part);
     HIPCHK(hipGetLastError());
     HIPCHK(hipEventRecord(b->partEnd[part], st));
     b->partDirty = true;

@@ -107,8 +107,12 @@ class DynState(C.Structure):
         [(n, C.c_int32) for n in ('oldPointId', 'oldSplinePointId', 'drifting', 'driftExtreme', 'driftInvalid', 'driftComboCounter', 'collisionFlag', 'oldCollisionFlag',
                                   'outOfTrackFlag')] + \
         [('gasUsage', C.c_float), ('locClutch', C.c_float), ('turboRotation', C.c_float * 3), ('simFrame', C.c_int32), ('damageChanged', C.c_int32),
-         ('damageZoneLevel', C.c_float * 5), ('_pad', C.c_int32 * 3)]
+         ('damageZoneLevel', C.c_float * 5), ('numContacts', C.c_int32), ('_pad', C.c_int32 * 2)]
 assert C.sizeof(DynState) % 16 == 0
+MAX_CONTACTS = 10
+class Contact(C.Structure):   # pdb_contact
+    _fields_ = [('pos', C.c_float * 3), ('depth', C.c_float), ('normal', C.c_float * 3), ('kind', C.c_int32)]
+assert C.sizeof(Contact) == 32
 class StepOut(C.Structure):
     _fields_ = [('obs', C.c_float * 24), ('reward', C.c_float), ('flags', C.c_int32)]
 
@@ -135,6 +139,8 @@ def load_product(host_only=False):
         lib.pdb_set_state_all.argtypes = [C.c_void_p, C.c_void_p]
         lib.pdb_set_state.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]
         lib.pdb_get_state.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+        lib.pdb_get_contacts.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+        lib.pdb_set_contacts.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]
         lib.pdb_reset.argtypes = [C.c_void_p, C.c_void_p]
         lib.pdb_actions_device.restype = C.c_void_p; lib.pdb_actions_device.argtypes = [C.c_void_p]
         lib.pdb_out_device.restype = C.c_void_p; lib.pdb_out_device.argtypes = [C.c_void_p]

@@ -127,6 +127,16 @@ class Batch:
     def set_state(self, states, first=0):
         self._chk(self.lib.pdb_set_state(self.h, first, len(states), C.byref(states)))
 
+    def get_contacts(self, first=0, count=None):
+        """the cars' live contact joints: [count][MAX_CONTACTS] pdb_contact, the first DynState.numContacts of a row alive"""
+        count = self.n - first if count is None else count
+        ct = ((pc.Contact * pc.MAX_CONTACTS) * count)()
+        self._chk(self.lib.pdb_get_contacts(self.h, first, count, C.byref(ct)))
+        return ct
+
+    def set_contacts(self, contacts, first=0):
+        self._chk(self.lib.pdb_set_contacts(self.h, first, len(contacts), C.byref(contacts)))
+
     def get_car_state(self, first=0, count=None):
         count = self.n - first if count is None else count
         cs = (pc.CarState * count)()

@@ -26,6 +26,10 @@ def load_oracle(portable_math=False):
     lib.cpuref_scenario_info.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
     lib.cpuref_solver_freeflight.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
     lib.cpuref_last_system.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
+    lib.cpuref_get_contacts.argtypes = [C.c_void_p, C.c_void_p]
+    lib.cpuref_set_contacts.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+    lib.cpuref_last_contact_rows.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
+    lib.cpuref_contact_unit.argtypes = [C.c_float, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_float, C.c_int, C.c_void_p]
     lib.cpuref_get_out.argtypes = [C.c_void_p, C.c_void_p]
     lib.cpuref_get_car_state.argtypes = [C.c_void_p, C.c_void_p]
     lib.cpuref_env_gas.restype = C.c_float; lib.cpuref_env_gas.argtypes = [C.c_float]

@@ -125,18 +125,27 @@ def run_parity(n_cars=8, ticks=200, seed=1234, resync=False, verbose=False, chec
             a = acts if actions_fn is None else actions_fn(t, acts)
             if resync and t > 0:
                 arr = (pc.DynState * n_cars)()
+                cts = ((pc.Contact * pc.MAX_CONTACTS) * n_cars)()
                 for i in range(n_cars):
                     orc.cpuref_get_state(hs[i], C.byref(arr[i]))
+                    orc.cpuref_get_contacts(hs[i], C.byref(cts[i]))
                 b.set_state(arr)
+                b.set_contacts(cts)
             b.step_host(a)
             for i in range(n_cars):
                 orc.cpuref_step_env(hs[i], float(a[i, 0]), float(a[i, 1]))
             if (t % check_every) == 0 or t == ticks - 1:
                 sg = b.get_state()
+                cg = b.get_contacts()
                 for i in range(n_cars):
                     sc = pc.DynState()
                     orc.cpuref_get_state(hs[i], C.byref(sc))
                     rel, name, vg, vc, bad_int = compare_states(sg[i], sc)
+                    if sc.numContacts > 0 and not bad_int:   # the live contact joints, bit for bit
+                        cc = (pc.Contact * pc.MAX_CONTACTS)()
+                        orc.cpuref_get_contacts(hs[i], C.byref(cc))
+                        if bytes(cc)[:32 * sc.numContacts] != bytes(cg[i])[:32 * sc.numContacts]:
+                            raise AssertionError('contact joints differ: car %d tick %d' % (i, t))
                     if bad_int:
                         raise AssertionError('integer state mismatch car %d tick %d: %s' % (i, t, bad_int[:5]))
                     if rel > worst:
