@@ -216,7 +216,8 @@ typedef struct pdb_car_params {
     int32_t numTurbos;
     pdb_turbo turbos[PDB_MAX_TURBOS];
     float turboBoostDamageThreshold, turboBoostDamageK;
-    int32_t _padEngine;
+    int32_t autoTeleport;     /* setCarAutoTeleport (PyProjectD.cpp:292-295; Car.h teleportOnCollision / teleportOnBadLocation / teleportMode):
+                               * bit 0 teleport on collision, bit 1 teleport on bad location, bits 2-3 mode (0 Start, 1 Nearest, 2 Random) */
     /* assists */
     float acRpmMin, acRpmMax, acClutchSpeed;
     int32_t acUseOnChange, acUseOnStart, autoShiftActive, autoBlipActive, autoBlipElectronic;
@@ -283,7 +284,8 @@ typedef struct pdb_dyn_state {
     int32_t damageChanged;   /* some damageZoneLevel moved by more than 0.001 this tick (ScoringSystem::validateDrift, :360-368) */
     float damageZoneLevel[5];   /* Car.h:204 */
     int32_t numContacts;     /* contact joints alive in the engine's contactGroupDynamic (the car's row of the pdb_contact array) */
-    int32_t _pad[2];         /* record size is a multiple of 16 bytes (coalesced 16-byte-per-lane copies) */
+    int32_t randState;       /* the car's C-runtime rand() state (Core/Math.h:49-52 randR -> Car::teleportByMode(Random)); srand(1) at creation */
+    int32_t _pad[1];         /* record size is a multiple of 16 bytes (coalesced 16-byte-per-lane copies) */
 } pdb_dyn_state;
 
 /* One contact joint between the chassis and the static world (what PhysicsEngineODE::onCollision hands to

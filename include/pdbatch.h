@@ -10,11 +10,15 @@
  *   pdb_build_track          loadTrack(simId, name)            :186-203 -> Track::init
  *   pdb_initial_state        addCar + teleportCarByMode(Start) :219-237,283-290
  *   pdb_teleport_to_spline   teleportCarToSpline               :274-281
+ *   pdb_teleport_by_mode     teleportCarByMode(simId, carId, mode)  :283-290 -> Car::teleportByMode (Start / Nearest / Random)
+ *   pdb_set_auto_teleport    setCarAutoTeleport                :292-295 (teleport inside the tick, ScoringSystem.cpp:194-225)
  *   pdb_create / pdb_destroy createSimulator / destroySimulator:111-149 (x N)
  *   pdb_set_assists          setCarAssists                     :307-317
  *   pdb_step / pdb_step_host setCarControls + stepSimulator + getCarState   :297-305,160-180,319-326
  *   pdb_get_car_state        getCarState                       :319-326 (664-byte CarState per car)
- *   pdb_reset                teleportCarByMode(mode=Start) for a mask of cars (projectd_env.py:216-227)
+ *   pdb_reset / pdb_reset_mode / pdb_reset_device / pdb_reset_mask_device
+ *                            teleportCarByMode for a mask of cars (projectd_env.py:216-227), on the device
+ *   pdb_set_seed             setSeed                           :50-53
  *   pdb_step_ring / pdb_step_partition / pdb_set_partitions   no counterpart: N stepSimulator loops of N independent
  *                            simulators, which the reference runs as N processes, here as free-running car ranges
  *   body contacts            PhysicsEngineODE::collisionStep + Car::onCollisionCallback run inside every step entry point
@@ -72,6 +76,11 @@ int pdb_build_track_opts(const char* base_path, const char* track_name, int flag
 void pdb_free(void* p);
 int pdb_initial_state(const pdb_car_params* params, const void* track_blob, pdb_dyn_state* out);
 int pdb_teleport_to_spline(const pdb_car_params* params, const void* track_blob, float distance_norm, pdb_dyn_state* inout);
+/* Car::teleportByMode: mode 0 = Start, 1 = Nearest (the car's trackLocation), 2 = Random (the car's own rand() state,
+ * pdb_dyn_state.randState: the C runtime's generator of the reference build, seeded 1 like an unseeded process) */
+int pdb_teleport_by_mode(const pdb_car_params* params, const void* track_blob, int mode, pdb_dyn_state* inout);
+/* setCarAutoTeleport: teleport by `mode` inside the tick that raises the collision flag / finds the car off the track */
+int pdb_set_auto_teleport(pdb_car_params* params, int on_collision, int on_bad_location, int mode);
 
 /* ---- device batch ---- */
 pdb_batch* pdb_create(int device, int n_cars, const pdb_car_params* params, const void* track_blob, uint64_t track_bytes,
@@ -87,8 +96,23 @@ int pdb_get_state(pdb_batch* b, int first, int count, pdb_dyn_state* states);
  * boundary carries them next to the state records. */
 int pdb_get_contacts(pdb_batch* b, int first, int count, pdb_contact* out);
 int pdb_set_contacts(pdb_batch* b, int first, int count, const pdb_contact* in);
-/* teleportCarByMode(Start) for cars with mask[i] != 0 (mask == NULL: all cars); host mask */
+/* teleportCarByMode(Start) for cars with mask[i] != 0 (mask == NULL: all cars); host mask.  The teleport itself runs on the
+ * device (only the mask crosses PCIe); returns when it is done. */
 int pdb_reset(pdb_batch* b, const uint8_t* mask);
+/* the same for any Car::teleportByMode mode: 0 Start, 1 Nearest (each car's trackLocation), 2 Random (each car's rand() state) */
+int pdb_reset_mode(pdb_batch* b, const uint8_t* mask, int mode);
+/* the same with the mask already on the device (e.g. a learner's `terminated` tensor): asynchronous on pdb_stream, no host
+ * round trip */
+int pdb_reset_device(pdb_batch* b, const uint8_t* device_mask, int mode);
+/* Deferred resets without any extra launch: a device array of n_cars bytes owned by the batch; a car whose byte is 1 + mode is
+ * teleported at the top of its next tick (which then steps it: with the env's zero action this is projectd_env.py:216-227
+ * `reset()` = teleport + step([0,0])), and that tick clears the byte.  Asking for the pointer arms the check in the step
+ * kernels. */
+uint8_t* pdb_reset_mask_device(pdb_batch* b);
+/* seconds without a new track point before pdb_step_out.flags bit 2 (stuck) rises: projectd_env.py stuck_timeout, default 5 */
+int pdb_set_stuck_timeout(pdb_batch* b, double seconds);
+/* setSeed (PyProjectD.cpp:50-53 = srand) per car: the state of the car's own C-runtime rand(), used by the Random teleport mode */
+int pdb_set_seed(pdb_batch* b, const uint32_t* seeds);
 /* device pointers owned by the batch: float actions[N][2], pdb_step_out out[N] */
 float* pdb_actions_device(pdb_batch* b);
 pdb_step_out* pdb_out_device(pdb_batch* b);

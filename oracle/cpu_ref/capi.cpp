@@ -18,6 +18,7 @@ struct CpuRefHandle {
     cpuref::TrackData T;
     pdb_dyn_state s0;
     cpuref::Car car;
+    void (*hook)(pdb_dyn_state*, int) = nullptr;
 };
 
 extern "C" {
@@ -34,6 +35,8 @@ void* cpuref_create(const pdb_car_params* P, const void* trackBlob, uint64_t tra
 void cpuref_destroy(void* hh) { delete (CpuRefHandle*)hh; }
 void cpuref_set_state(void* hh, const pdb_dyn_state* s) { ((CpuRefHandle*)hh)->car.loadState(*s); }
 void cpuref_get_state(void* hh, pdb_dyn_state* s) { *s = ((CpuRefHandle*)hh)->car.S; }
+// Car::teleportByMode for the in-tick auto-teleport (pdb_car_params.autoTeleport): the product's pdb_teleport_by_mode, handed in by the test
+void cpuref_set_auto_teleport_hook(void* hh, void (*hook)(pdb_dyn_state*, int)) { ((CpuRefHandle*)hh)->car.autoTeleportHook = hook; ((CpuRefHandle*)hh)->hook = hook; }
 // the contact joints alive in the engine's group: PDB_MAX_CONTACTS entries, the first S.numContacts meaningful
 void cpuref_get_contacts(void* hh, pdb_contact* c) { ((CpuRefHandle*)hh)->car.getContacts(c); }
 void cpuref_set_contacts(void* hh, const pdb_contact* c, int n) { ((CpuRefHandle*)hh)->car.setContacts(c, n); }
@@ -172,6 +175,7 @@ const char* cpuref_scenario_track(int sid) { return pdoracle::kScenarios[sid].tr
 const char* cpuref_scenario_car(int sid) { return pdoracle::kScenarios[sid].car ? pdoracle::kScenarios[sid].car : PDORACLE_DEFAULT_CAR; }
 int cpuref_num_scenarios(void) { return pdoracle::kNumScenarios; }
 int cpuref_scenario_collide(int sid) { return pdoracle::kScenarios[sid].collide; }
+int cpuref_scenario_auto_teleport(int sid) { return pdoracle::kScenarios[sid].autoTele; }
 int cpuref_scenario_resets(int sid) { return pdoracle::kScenarios[sid].resetEvery; }
 int cpuref_scenario_scoring(int sid, int i, const char** name, float* value) {
     if (!pdoracle::kScenarios[sid].scoringSet || i < 0 || i >= pdoracle::kNumScoringSetA) return 0;
@@ -199,6 +203,7 @@ int cpuref_run_scenario_cb(void* hh, int sid, const char* outPath, void (*telepo
     h->P.smoothSteer = sc.rawSteer ? 0 : 1;
     h->car = cpuref::Car();
     h->car.init(&h->P, &h->T, h->s0);
+    h->car.autoTeleportHook = h->hook;
     pdoracle::ProbeFile pf;
     h->car.step(0.0f, pdoracle::envGas(0.0f), (float)(1.0 / 333.0), 1.0 / 333.0);   // env.reset(): teleport (already in s0) + step([0,0])
     { pdoracle::Probe P; P.names = &pf.names; h->car.fillProbe(P); pf.add(-1, 0.0f, 0.0f, P); }

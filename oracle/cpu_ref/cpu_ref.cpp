@@ -1743,11 +1743,21 @@ void Car::postStep(float dt) {
             for (int i = 0; i < PDB_NUM_PROBES; ++i) { const float dist = probeHits[i]; if (closestProbe > dist && dist > 0.0f) closestProbe = dist; }
             if (closestProbe < sv.ApproachDistance) reward -= sv.ObstApproachPenalty * (1.0f - linscalef(closestProbe, sv.CriticalDistance, sv.ApproachDistance, 0.0f, 1.0f));
         }
-        if (S.collisionFlag) reward -= sv.CollisionPenalty;
+        // setCarAutoTeleport (PyProjectD.cpp:292-295): Car::teleportByMode inside the reward computation (ScoringSystem.cpp:194-225).
+        // The teleport itself is the PRODUCT's host function, handed in by the test (autoTeleportHook), so that this path pins it.
+        auto autoTeleport = [&]() {
+            if (!autoTeleportHook) return;
+            storeState();
+            autoTeleportHook(&S, (P->autoTeleport >> 2) & 3);
+            const pdb_dyn_state st = S;
+            loadState(st);
+            for (int i = 0; i < 4; ++i) ts[i].feedbackTorque = 0;   // Tyre::reset (Tyre.cpp:419): per-tick scratch here, seen by the probe only
+        };
+        if (S.collisionFlag) { reward -= sv.CollisionPenalty; if (P->autoTeleport & 1) autoTeleport(); }
         const int tp = S.nearestTrackPointId;
         if (tp >= 0 && tp < Tk.h->numFat) {
             const V3 center(Tk.fat + 15 * tp + 9);
-            if ((getPos(body) - center).len() > Tk.h->computedTrackWidth * sv.OutOfTrackThreshold) { S.outOfTrackFlag = 1; reward -= sv.OffTrackPenalty; }
+            if ((getPos(body) - center).len() > Tk.h->computedTrackWidth * sv.OutOfTrackThreshold) { S.outOfTrackFlag = 1; reward -= sv.OffTrackPenalty; if (P->autoTeleport & 2) autoTeleport(); }
             const float x = S.bodyVsTrack;
             const float thresh = tclamp(sv.DirectionThreshold, 0.1f, 1.0f);
             if (x > thresh) reward += sv.DirectionBonus * linscalef(x, thresh, 1.0f, 0.0f, 1.0f);

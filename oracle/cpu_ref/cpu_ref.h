@@ -62,6 +62,7 @@ struct Car {
     double stepTime = 0;   // sim->physicsTime seen by the last step (before += dt)
     int acSeqCount = 0;
     std::vector<int> nearby;
+    void (*autoTeleportHook)(pdb_dyn_state*, int mode) = nullptr;   // Car::teleportByMode on a state record (the product's pdb_teleport_by_mode)
     pdcol::ContactSet contactSet;   // the engine's contactGroupDynamic for this car (S.numContacts of them are alive)
 
     void init(const pdb_car_params* P, const TrackData* T, const pdb_dyn_state& s0);

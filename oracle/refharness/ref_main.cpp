@@ -223,6 +223,8 @@ int main(int argc, char** argv) {
             env.init(base, track, sc.car ? std::string(sc.car) : model, sc.autoClutch != 0, sc.autoShift != 0, sc.autoBlip != 0);
             env.smooth = sc.rawSteer == 0;
             ref_set_collide(env.sim->physics.get(), sc.collide != 0);
+            if (sc.autoTele) { env.car->teleportOnCollision = sc.autoTele & 1; env.car->teleportOnBadLocation = (sc.autoTele >> 1) & 1; env.car->teleportMode = (sc.autoTele >> 2) & 3; }   // setCarAutoTeleport, PyProjectD.cpp:286-295
+            ref_msvc_srand(1);   // every scenario starts like a fresh process
             if (sc.scoringSet) for (int i = 0; i < pdoracle::kNumScoringSetA; ++i) env.car->scoring->config->setVar(pdoracle::kScoringSetA[i].name, pdoracle::kScoringSetA[i].value);   // PyProjectD.cpp:347-355
             if (sc.tuneSet) for (int i = 0; i < pdoracle::kNumTuneSetA; ++i) env.car->setup->setTune(pdoracle::kTuneSetA[i].name, pdoracle::kTuneSetA[i].value);   // PyProjectD.cpp:328-335
             pdoracle::ProbeFile pf;

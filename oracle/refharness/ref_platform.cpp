@@ -166,3 +166,8 @@ SharedMemory::SharedMemory() {}
 SharedMemory::~SharedMemory() {}
 void SharedMemory::allocate(const wchar_t*, size_t) {}
 }
+
+// MSVC C runtime rand() / srand() (see compat/pre.h)
+static unsigned int g_holdrand = 1;
+extern "C" int ref_msvc_rand(void) { g_holdrand = g_holdrand * 214013u + 2531011u; return (int)((g_holdrand >> 16) & 0x7fffu); }
+extern "C" void ref_msvc_srand(unsigned int seed) { g_holdrand = seed; }

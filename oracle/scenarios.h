@@ -17,7 +17,8 @@ struct Scenario { const char* name; int ticks; int denseTicks; int stride; int f
                   int tuneSet; /* apply kTuneSetA through setCarTune after the env's own tunes */
                   int teleDist; /* the resets teleport to kTeleDist[k % 4] along the spline (teleportCarToSpline) instead of to the start */
                   int scoringSet; /* kScoringSetA through setScoringVar: every reward weight and threshold non-default and non-zero */
-                  int boostAt; /* before this tick every body's linear velocity z is set to 50 m/s (180 km/h); 0 = never */ };
+                  int boostAt; /* before this tick every body's linear velocity z is set to 50 m/s (180 km/h); 0 = never */
+                  int autoTele; /* setCarAutoTeleport: bit 0 on collision, bit 1 on bad location, bits 2-3 mode (0 Start, 1 Nearest, 2 Random) */ };
 
 static const Scenario kScenarios[] = {
     {"idle", 600, 200, 10, 0, 1, 1, 1, "flat", 0, nullptr, 0, 0, 0, 0, 0, 0, 0},
@@ -67,8 +68,14 @@ static const Scenario kScenarios[] = {
     // it (hull contacts with friction, many ticks in contact); then full throttle into the wall across the road, again and again
     {"scrape", 3000, 0, 3, 0, 1, 1, 1, "walled", 0, nullptr, 0, 1, 0, 0, 0, 0, 0},
     {"wallpush", 3900, 0, 3, 0, 1, 1, 1, "walled", 0, "ks_toyota_supra_mkiv_drift", 0, 1, 0, 0, 0, 0, 0},
+    // setCarAutoTeleport (PyProjectD.cpp:286-295): Car::teleportByMode INSIDE the tick (ScoringSystem.cpp:194-225) -- on the
+    // walled strip back to the nearest spline point at every wall contact; on the mountain road to a random point of the lap
+    // (the C runtime's rand()) whenever the fixed lock takes the car off the road; full throttle into the wall, back to the start
+    {"autotele_near", 3000, 0, 3, 0, 1, 1, 1, "walled", 0, nullptr, 0, 1, 0, 0, 0, 0, 0, 1 | 2 | (1 << 2)},
+    {"autotele_rand", 3600, 300, 10, 0, 1, 1, 1, "touge", 1, nullptr, 0, 0, 0, 0, 0, 0, 0, 2 | (2 << 2)},
+    {"autotele_start", 3900, 0, 3, 0, 1, 1, 1, "walled", 0, nullptr, 0, 1, 0, 0, 0, 0, 0, 1 | (0 << 2)},
 };
-static const int kNumScenarios = 32;
+static const int kNumScenarios = 35;
 static const float kTeleDist[4] = {0.13f, 0.41f, 0.77f, 0.95f};
 struct ScoreVar { const char* name; float value; };
 static const ScoreVar kScoringSetA[] = {
@@ -107,6 +114,7 @@ inline void scenarioFeedback(int sid, int tick, const float* obs, float& a0, flo
     float g = 0.3f * (12.0f - v);
     if (g < -1.0f) g = -1.0f;
     if (g > 1.0f) g = 1.0f;
+    if (sid == 33 && (tick % 900) > 600) s = 0.45f;   // `autotele_rand`: every so often a fixed lock takes the car off the road
     if (sid == 23 && tick > 1500) s = 0.45f;   // `rewards`: then a fixed lock takes the car off the road, to meet the off-track / direction terms
     a0 = s; a1 = g;
 }
@@ -119,8 +127,8 @@ inline void scenarioAction(int sid, int tick, float& a0, float& a1) {
     case 0: a0 = 0.0f; a1 = -1.0f; break;
     case 1: case 15: case 25: case 29: a0 = 0.0f; a1 = 1.0f; break;
     case 2: a0 = 0.35f; a1 = 0.2f; break;
-    case 30: a0 = 0.04f; a1 = 0.8f; break;
-    case 31: a0 = 0.0f; a1 = 1.0f; break;
+    case 30: case 32: a0 = 0.04f; a1 = 0.8f; break;
+    case 31: case 34: a0 = 0.0f; a1 = 1.0f; break;
     default:   // slalom (3), the rx7 run (7), the fc3s run (9)
         a0 = (float)(0.4 * sin(6.283185307179586 * t / 2.0));
         a1 = (float)(0.6 * sin(6.283185307179586 * t / 5.0 + 1.0));

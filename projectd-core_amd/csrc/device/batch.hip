@@ -9,6 +9,7 @@
 #include <vector>
 
 #include "dev_const.hpp"
+#include "reset_core.hpp"   // Car::teleportByMode / Car::reset on a record: the host library's source, compiled for the device too
 
 // two LDS size classes of the same kernel source: 33 constraint rows (the strut / live-axle and the all-double-wishbone
 // cars; 8 KB of LDS per car, 6 workgroups per CU) and 40 rows (strut front + double wishbone rear: 38 rows; 5 per CU)
@@ -77,6 +78,9 @@ struct pdb_batch {
     DevConst* dK = nullptr;
     uint8_t* dTrack = nullptr;
     int* dQueue[PDB_MAX_PARTS + 1] = {nullptr, nullptr, nullptr, nullptr, nullptr};   // RedoQueue per launch site: count, done, list[blocks]
+    uint8_t* dResetScratch = nullptr;   // device copy of a host mask (pdb_reset)
+    uint8_t* dResetMask = nullptr;   // [n]: 1 + teleport mode for cars to be reset at the top of their next tick (consumed and cleared by that tick)
+    bool resetMaskArmed = false;     // pdb_reset_mask_device was asked for: the step kernels look at the mask
     pdb_contact* dContacts = nullptr;   // [n][PDB_MAX_CONTACTS]: each car's live contact joints (the first pdb_dyn_state.numContacts of its row)
     hipEvent_t ev0 = nullptr, ev1 = nullptr, tev0 = nullptr, tev1 = nullptr;
     bool ownStream = true;
@@ -137,6 +141,7 @@ static void fillConst(const pdb_car_params& P, DevConst& K, int actionMode) {
     }
     K.actionMode = actionMode;
     K.wantCarState = 0;
+    K.stuckTimeout = 5.0;   // projectd_env.py:47
 }
 
 // One tick of the cars [c0, c1) on `st`: the first pass over every car, then -- when the car model has body colliders -- the
@@ -152,18 +157,20 @@ static void launchTick(pdb_batch* b, hipStream_t st, int c0, int c1, pdb_step_ou
     pdb_car_state* CS = b->dCarStates ? b->dCarStates + c0 : nullptr;
     pdb_contact* CT = b->dContacts + (size_t)c0 * PDB_MAX_CONTACTS;
     void* Q = b->dQueue[q];
+    uint8_t* RM = b->resetMaskArmed ? b->dResetMask + c0 : nullptr;
     const int n = c1 - c0;
-    const bool contacts = b->params.collider.enabled != 0;
+    // the contact pass also serves episode resets asked for through the reset mask and the in-tick auto-teleport
+    const bool contacts = b->params.collider.enabled != 0 || b->resetMaskArmed || b->params.autoTeleport != 0;
     const dim3 grid(nblk), block(PDB_BLOCK_THREADS), cgrid(nblk < PDB_CONTACT_GRID ? nblk : PDB_CONTACT_GRID);
     if (m == 33) {
-        hipLaunchKernelGGL(k33::pdb_step_kernel, grid, block, 0, st, S, A, O, CS, b->dParams, b->dK, b->dTrack, (k33::RedoQueue*)Q, n);
-        if (contacts) hipLaunchKernelGGL(k33::pdb_contact_kernel, cgrid, block, 0, st, S, A, O, CS, b->dParams, b->dK, b->dTrack, CT, (k33::RedoQueue*)Q, n);
+        hipLaunchKernelGGL(k33::pdb_step_kernel, grid, block, 0, st, S, A, O, CS, b->dParams, b->dK, b->dTrack, (k33::RedoQueue*)Q, RM, n);
+        if (contacts) hipLaunchKernelGGL(k33::pdb_contact_kernel, cgrid, block, 0, st, S, A, O, CS, b->dParams, b->dK, b->dTrack, CT, (k33::RedoQueue*)Q, RM, n);
     } else if (m < 33) {
-        hipLaunchKernelGGL(k33::pdb_step_kernel_generic, grid, block, 0, st, S, A, O, CS, b->dParams, b->dK, b->dTrack, (k33::RedoQueue*)Q, n);
-        if (contacts) hipLaunchKernelGGL(k33::pdb_contact_kernel_generic, cgrid, block, 0, st, S, A, O, CS, b->dParams, b->dK, b->dTrack, CT, (k33::RedoQueue*)Q, n);
+        hipLaunchKernelGGL(k33::pdb_step_kernel_generic, grid, block, 0, st, S, A, O, CS, b->dParams, b->dK, b->dTrack, (k33::RedoQueue*)Q, RM, n);
+        if (contacts) hipLaunchKernelGGL(k33::pdb_contact_kernel_generic, cgrid, block, 0, st, S, A, O, CS, b->dParams, b->dK, b->dTrack, CT, (k33::RedoQueue*)Q, RM, n);
     } else {
-        hipLaunchKernelGGL(k40::pdb_step_kernel_wide, grid, block, 0, st, S, A, O, CS, b->dParams, b->dK, b->dTrack, (k40::RedoQueue*)Q, n);
-        if (contacts) hipLaunchKernelGGL(k40::pdb_contact_kernel_wide, cgrid, block, 0, st, S, A, O, CS, b->dParams, b->dK, b->dTrack, CT, (k40::RedoQueue*)Q, n);
+        hipLaunchKernelGGL(k40::pdb_step_kernel_wide, grid, block, 0, st, S, A, O, CS, b->dParams, b->dK, b->dTrack, (k40::RedoQueue*)Q, RM, n);
+        if (contacts) hipLaunchKernelGGL(k40::pdb_contact_kernel_wide, cgrid, block, 0, st, S, A, O, CS, b->dParams, b->dK, b->dTrack, CT, (k40::RedoQueue*)Q, RM, n);
     }
 }
 
@@ -219,6 +226,8 @@ pdb_batch* pdb_create(int device, int n_cars, const pdb_car_params* params, cons
     ok = ok && hipMalloc(&b->dTrack, track_bytes) == hipSuccess;
     ok = ok && hipMalloc(&b->dContacts, sizeof(pdb_contact) * PDB_MAX_CONTACTS * (size_t)n_cars) == hipSuccess;
     ok = ok && hipMemset(b->dContacts, 0, sizeof(pdb_contact) * PDB_MAX_CONTACTS * (size_t)n_cars) == hipSuccess;
+    ok = ok && hipMalloc(&b->dResetMask, (size_t)n_cars) == hipSuccess;
+    ok = ok && hipMemset(b->dResetMask, 0, (size_t)n_cars) == hipSuccess;
     for (int q = 0; q <= PDB_MAX_PARTS; ++q) {
         const size_t qb = sizeof(int) * (size_t)(4 + (n_cars + PDB_CPB - 1) / PDB_CPB);
         ok = ok && hipMalloc(&b->dQueue[q], qb) == hipSuccess;
@@ -255,7 +264,7 @@ void pdb_destroy(pdb_batch* b) {
     (void)hipSetDevice(b->device);
     if (b->graphExec) (void)hipGraphExecDestroy(b->graphExec);
     if (b->stream) (void)hipStreamSynchronize(b->stream);
-    (void)hipFree(b->dStates); (void)hipFree(b->dActions); (void)hipFree(b->dOut); (void)hipFree(b->dCarStates); (void)hipFree(b->dParams); (void)hipFree(b->dK); (void)hipFree(b->dTrack); (void)hipFree(b->dContacts);
+    (void)hipFree(b->dStates); (void)hipFree(b->dActions); (void)hipFree(b->dOut); (void)hipFree(b->dCarStates); (void)hipFree(b->dParams); (void)hipFree(b->dK); (void)hipFree(b->dTrack); (void)hipFree(b->dContacts); (void)hipFree(b->dResetMask); (void)hipFree(b->dResetScratch);
     for (int q = 0; q <= PDB_MAX_PARTS; ++q) (void)hipFree(b->dQueue[q]);
     if (b->ev0) (void)hipEventDestroy(b->ev0);
     if (b->ev1) (void)hipEventDestroy(b->ev1);
@@ -311,25 +320,71 @@ int pdb_set_contacts(pdb_batch* b, int first, int count, const pdb_contact* in) 
     return PDB_OK;
 }
 
-int pdb_reset(pdb_batch* b, const uint8_t* mask) {
-    if (!b) { pdb::setError("null argument"); return PDB_ERR_ARG; }
-    // teleportCarByMode(Start): Car::teleportToSpline(0) edits applied to each masked car's current record
-    // only the masked lanes cross PCIe, one contiguous run of lanes at a time (episode ends are sparse)
-    pdb::TrackView tv(b->track.data());
-    std::vector<pdb_dyn_state> st;
-    for (int i = 0; i < b->n;) {
-        if (mask && !mask[i]) { ++i; continue; }
-        int j = i;
-        while (j < b->n && (!mask || mask[j])) ++j;
-        st.resize((size_t)(j - i));
-        int rc = pdb_get_state(b, i, j - i, st.data());
-        if (rc != PDB_OK) return rc;
-        for (auto& s : st) pdb::teleportToSpline(b->params, tv, 0.0f, s);
-        rc = pdb_set_state(b, i, j - i, st.data());
-        if (rc != PDB_OK) return rc;
-        i = j;
-    }
+// Car::teleportByMode for the cars whose mask byte is non-zero (mask == nullptr: every car), one thread per car on the records in
+// HBM; mode >= 0: that mode for every masked car, mode < 0: the byte is 1 + mode.  clear: zero the consumed bytes.
+extern "C" __global__ void pdb_reset_kernel(pdb_dyn_state* __restrict__ states, uint8_t* __restrict__ mask, const pdb_car_params* __restrict__ Pp,
+                                            const uint8_t* __restrict__ trackBlob, int n, int mode, int clear) {
+    const int i = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+    if (i >= n) return;
+    const int rq = mask ? (int)mask[i] : 1;
+    if (rq == 0) return;
+    k33::DevTrack T;
+    T.h = reinterpret_cast<const pdb_track_header*>(trackBlob);
+    T.surfaces = reinterpret_cast<const pdb_surface*>(trackBlob + T.h->offSurfaces);
+    T.tris = reinterpret_cast<const float*>(trackBlob + T.h->offTris);
+    T.fat = reinterpret_cast<const float*>(trackBlob + T.h->offFat);
+    T.fatDist = reinterpret_cast<const float*>(trackBlob + T.h->offFatDist);
+    T.nodes = reinterpret_cast<const float*>(trackBlob + T.h->offNodes);
+    T.nodeDist = reinterpret_cast<const float*>(trackBlob + T.h->offNodeDist);
+    k33::teleportByModeDev(*Pp, T, mode >= 0 ? mode : rq - 1, states + i);
+    if (mask && clear) mask[i] = 0;
+}
+static int resetLaunch(pdb_batch* b, uint8_t* dMask, int mode, int clear) {
+    if (int rcj = joinParts(b)) return rcj;
+    hipLaunchKernelGGL(pdb_reset_kernel, dim3((b->n + 63) / 64), dim3(64), 0, b->stream, b->dStates, dMask, b->dParams, b->dTrack, b->n, mode, clear);
+    HIPCHK(hipGetLastError());
     return PDB_OK;
+}
+int pdb_reset_mode(pdb_batch* b, const uint8_t* mask, int mode) {
+    if (!b || mode < 0 || mode > 2) { pdb::setError("pdb_reset_mode: bad argument"); return PDB_ERR_ARG; }
+    // teleportCarByMode: Car::teleportToSpline + Car::reset applied to each masked car's record, on the device (the host hands
+    // over the mask only)
+    if (!mask) { int rc = resetLaunch(b, nullptr, mode, 0); if (rc != PDB_OK) return rc; HIPCHK(hipStreamSynchronize(b->stream)); return PDB_OK; }
+    if (int rcj = joinParts(b)) return rcj;
+    if (!b->dResetScratch) HIPCHK(hipMalloc(&b->dResetScratch, (size_t)b->n));
+    HIPCHK(hipMemcpyAsync(b->dResetScratch, mask, (size_t)b->n, hipMemcpyHostToDevice, b->stream));
+    int rc = resetLaunch(b, b->dResetScratch, mode, 0);
+    if (rc != PDB_OK) return rc;
+    HIPCHK(hipStreamSynchronize(b->stream));   // the caller's mask may be reused at once
+    return PDB_OK;
+}
+int pdb_reset(pdb_batch* b, const uint8_t* mask) { return pdb_reset_mode(b, mask, 0); }
+int pdb_reset_device(pdb_batch* b, const uint8_t* device_mask, int mode) {
+    if (!b || !device_mask || mode < 0 || mode > 2) { pdb::setError("pdb_reset_device: bad argument"); return PDB_ERR_ARG; }
+    return resetLaunch(b, const_cast<uint8_t*>(device_mask), mode, 0);   // asynchronous on the batch's stream: no host round trip
+}
+uint8_t* pdb_reset_mask_device(pdb_batch* b) {
+    if (!b) return nullptr;
+    b->resetMaskArmed = true;
+    if (b->graphExec) { (void)hipGraphExecDestroy(b->graphExec); b->graphExec = nullptr; }   // captured launches carry the old argument
+    return b->dResetMask;
+}
+int pdb_set_stuck_timeout(pdb_batch* b, double seconds) {
+    if (!b || !(seconds >= 0.0)) { pdb::setError("pdb_set_stuck_timeout: bad argument"); return PDB_ERR_ARG; }
+    if (int rcj = joinParts(b)) return rcj;
+    for (int p = 0; p < b->parts; ++p) if (b->partStream[p]) HIPCHK(hipStreamSynchronize(b->partStream[p]));
+    HIPCHK(hipStreamSynchronize(b->stream));
+    b->K.stuckTimeout = seconds;
+    HIPCHK(hipMemcpy(b->dK, &b->K, sizeof(DevConst), hipMemcpyHostToDevice));
+    return PDB_OK;
+}
+int pdb_set_seed(pdb_batch* b, const uint32_t* seeds) {
+    if (!b || !seeds) { pdb::setError("null argument"); return PDB_ERR_ARG; }
+    std::vector<pdb_dyn_state> st((size_t)b->n);
+    int rc = pdb_get_state(b, 0, b->n, st.data());
+    if (rc != PDB_OK) return rc;
+    for (int i = 0; i < b->n; ++i) st[(size_t)i].randState = (int32_t)seeds[i];   // setSeed = srand (PyProjectD.cpp:50-53), one C runtime per car
+    return pdb_set_state(b, 0, b->n, st.data());
 }
 
 float* pdb_actions_device(pdb_batch* b) { return b ? b->dActions : nullptr; }

@@ -17,6 +17,7 @@ struct DevConst {
     float fps;   // 1.0f / dt
     float invMass[PDB_MAX_BODIES], invInertia[PDB_MAX_BODIES][3];   // 1.0f / mass, 1.0f / inertia: divided once on the host (IEEE single division on both sides)
     double dtD;
+    double stuckTimeout;   // seconds without a new track point before pdb_step_out.flags bit 2 rises (projectd_env.py stuck_timeout = 5.0)
     int actionMode;
     int wantCarState;
     unsigned long long* stamps;   // diagnostic build only (-DPDB_STAMPS): [car][16] shader-clock stamps

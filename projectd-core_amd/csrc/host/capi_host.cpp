@@ -85,6 +85,20 @@ int pdb_teleport_to_spline(const pdb_car_params* params, const void* track_blob,
     PDB_CATCH(PDB_ERR_IO)
 }
 
+int pdb_teleport_by_mode(const pdb_car_params* params, const void* track_blob, int mode, pdb_dyn_state* inout) {
+    if (!params || !track_blob || !inout || mode < 0 || mode > 2) { pdb::setError("pdb_teleport_by_mode: bad argument"); return PDB_ERR_ARG; }
+    PDB_TRY
+    pdb::TrackView tv(static_cast<const uint8_t*>(track_blob));
+    pdb::teleportByMode(*params, tv, mode, *inout);
+    return PDB_OK;
+    PDB_CATCH(PDB_ERR_IO)
+}
+int pdb_set_auto_teleport(pdb_car_params* params, int on_collision, int on_bad_location, int mode) {
+    if (!params || mode < 0 || mode > 2) { pdb::setError("pdb_set_auto_teleport: bad argument"); return PDB_ERR_ARG; }
+    params->autoTeleport = (on_collision ? 1 : 0) | (on_bad_location ? 2 : 0) | (mode << 2);
+    return PDB_OK;
+}
+
 // reproducible elementary functions of the step (device/pmath.hpp compiled for the host): lets a maintainer check,
 // on any platform, that host and device evaluate them identically (the kernel's constants come from these too)
 int pdb_math_eval(int fn, const float* x, const float* y, float* out, int n) {

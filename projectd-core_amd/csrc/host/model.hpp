@@ -42,5 +42,7 @@ RayHitH rayCastTrack(const TrackView& tv, const float* origin, const float* dir,
 void initialState(const pdb_car_params& P, const TrackView& tv, pdb_dyn_state& S);
 // the state edits of Car::teleportToSpline(distanceNorm) applied to an existing state
 void teleportToSpline(const pdb_car_params& P, const TrackView& tv, float distanceNorm, pdb_dyn_state& S);
+// Car::teleportByMode: 0 Start, 1 Nearest (trackLocation), 2 Random (the car's own rand() state)
+void teleportByMode(const pdb_car_params& P, const TrackView& tv, int mode, pdb_dyn_state& S);
 
 }  // namespace pdb

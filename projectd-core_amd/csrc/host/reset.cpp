@@ -9,128 +9,25 @@
 // Episode resets are rare (once per episode) and sequential; they edit the per-car record on the
 // host and the batch uploads it -- the per-tick path never runs on the host.
 #include "model.hpp"
-#include "rbmath.hpp"
-#include <cstring>
-#include <cmath>
+#include "reset_core.hpp"
 
 namespace pdb {
 
-static void toHBody(const pdb_body_state& s, HBody& b) {
-    memcpy(b.pos, s.pos, 12); memcpy(b.q, s.q, 16); memcpy(b.R, s.R, 36);
-}
-static void fromHBody(const HBody& b, pdb_body_state& s) {
-    memcpy(s.pos, b.pos, 12); memcpy(s.q, b.q, 16); memcpy(s.R, b.R, 36);
-}
-static void stopBody(pdb_body_state& s) { for (int k = 0; k < 3; ++k) { s.lvel[k] = 0; s.avel[k] = 0; } }
-static inline float v3len(const float* a) { return sqrtf(a[0] * a[0] + a[1] * a[1] + a[2] * a[2]); }
-static inline void v3norm(float* a) { const float l = v3len(a); if (l != 0.0f) { const float s = 1.0f / l; a[0] *= s; a[1] *= s; a[2] *= s; } }
-
-// ISuspension::attach() for every wheel (joints already exist => setPositions only)
-static void attachAll(const pdb_car_params& P, pdb_dyn_state& S) {
-    HBody body; toHBody(S.body[PDB_BODY_CHASSIS], body);
-    float Mb[9]; hWorldMatrix3(body, Mb);
-    for (int i = 0; i < 4; ++i) {
-        const pdb_susp& su = P.susp[i];
-        if (su.type == PDB_SUSP_STRUT) {
-            HBody hub, strut;
-            toHBody(S.body[su.hubBody], hub); toHBody(S.body[su.strutBody], strut);
-            float vPos[3]; hLocalToWorld(body, su.basePosition, vPos);
-            hSetRotationM(hub, Mb);
-            memcpy(hub.pos, vPos, 12);
-            float vCarStrut[3], vTyreStrut[3], vNorm[3];
-            hLocalToWorld(body, su.carStrut, vCarStrut);
-            hLocalToWorld(hub, su.tyreStrut, vTyreStrut);
-            for (int k = 0; k < 3; ++k) vNorm[k] = vTyreStrut[k] - vCarStrut[k];
-            v3norm(vNorm);
-            const float vM3[3] = {Mb[6] * -1.0f, Mb[7] * -1.0f, Mb[8] * -1.0f};
-            float vM3N[3], vM3NN[3];
-            hCross(vM3N, vM3, vNorm);
-            hCross(vM3NN, vM3N, vNorm); v3norm(vM3NN);
-            const float Ms[9] = {vM3NN[0], vM3NN[1], vM3NN[2], -vM3N[0], -vM3N[1], -vM3N[2], -vNorm[0], -vNorm[1], -vNorm[2]};
-            hSetRotationM(strut, Ms);
-            for (int k = 0; k < 3; ++k) strut.pos[k] = (vNorm[k] * su.strutBodyLength) * 0.5f + vCarStrut[k];
-            fromHBody(hub, S.body[su.hubBody]); fromHBody(strut, S.body[su.strutBody]);
-        } else if (su.type == PDB_SUSP_DW || su.type == PDB_SUSP_ML) {   // SuspensionDW::attach (SuspensionDW.cpp:156-162), SuspensionML::attach (:95-99)
-            HBody hub; toHBody(S.body[su.hubBody], hub);
-            hSetRotationM(hub, Mb);
-            hLocalToWorld(body, su.basePosition, hub.pos);
-            fromHBody(hub, S.body[su.hubBody]);
-        } else if (su.type == PDB_SUSP_AXLE && su.sideSign > 0.0f) {
-            HBody axle; toHBody(S.body[su.hubBody], axle);
-            hSetRotationM(axle, Mb);
-            hLocalToWorld(body, su.axleBasePos, axle.pos);
-            fromHBody(axle, S.body[su.hubBody]);
-        }
+struct HostRayDown {
+    const TrackView& tv;
+    bool operator()(const float* o, float& hitY) const {
+        const float d[3] = {0, -1, 0};
+        const RayHitH hit = rayCastTrack(tv, o, d, 1000.0f);
+        if (hit.has) hitY = hit.pos[1];
+        return hit.has;
     }
-}
-
-static void tyreReset(const pdb_car_params& P, pdb_tyre_state& t) {
-    t.slipAngleRAD = 0; t.slipRatio = 0; t.angularVelocity = 0; t.Fy = 0; t.Fx = 0; t.Mz = 0;
-    t.isLocked = 1; t.inflation = 1; t.flatSpot = 0;
-    t.dirtyLevel = 0; t.virtualKM = 0;
-    t.coreTemp = P.ambientTemperature;
-    for (int k = 0; k < 36; ++k) t.T[k] = P.ambientTemperature;
-    t.phase = 0;
-}
+};
 
 void teleportToSpline(const pdb_car_params& P, const TrackView& tv, float distanceNorm, pdb_dyn_state& S) {
-    const int n = tv.h->numFat;
-    if (!n) return;
-    // Track::getPointIdAtDistance (Track.cpp:556-570)
-    if (distanceNorm < 0.0f) distanceNorm += 1.0f; else if (distanceNorm > 1.0f) distanceNorm -= 1.0f;
-    const float dn = distanceNorm < 0.0f ? 0.0f : (distanceNorm > 1.0f ? 1.0f : distanceNorm);
-    const size_t pointId = (size_t)(dn * (float)(n - 1));
-    if (pointId >= (size_t)n) return;
-    const float* pt = tv.fat + 15 * pointId;
-    const float* center = pt + 9;
-    const float* fwd = pt + 12;
-
-    // ---- forceRotation(heading) ----
-    {
-        const float ihed[3] = {fwd[0] * -1.0f, fwd[1] * -1.0f, fwd[2] * -1.0f};
-        const float vM13 = ihed[0], vM11 = -ihed[2], vM12 = 0;
-        const float v6 = sqrtf((vM12 * vM12) + (vM11 * vM11) + (vM13 * vM13));
-        const float s = 1.0f / v6;
-        const float M[9] = {vM11 * s, vM12 * s, vM13 * s, 0, 1, 0, -ihed[0], -ihed[1], -ihed[2]};
-        HBody b; toHBody(S.body[PDB_BODY_CHASSIS], b);
-        hSetRotationM(b, M); fromHBody(b, S.body[PDB_BODY_CHASSIS]);
-        HBody t; toHBody(S.body[PDB_BODY_TANK], t);
-        hSetRotationM(t, M); fromHBody(t, S.body[PDB_BODY_TANK]);
-        attachAll(P, S);
-        stopBody(S.body[PDB_BODY_CHASSIS]); stopBody(S.body[PDB_BODY_TANK]);
-    }
-    // ---- forcePosition(center) ----
-    {
-        float bodyPos[3] = {center[0], center[1], center[2]};
-        const float o[3] = {center[0] + 0.0f, center[1] + 10.0f, center[2] + 0.0f};
-        const float d[3] = {0, -1, 0};
-        RayHitH hit = rayCastTrack(tv, o, d, 1000.0f);
-        if (hit.has) bodyPos[1] = hit.pos[1];
-        bodyPos[1] += (P.baseCarHeight + 0.0f + 0.01f);
-        // Car::reset()
-        S.waterT = 60.0f;
-        S.fuel = P.fuel;
-        S.collisionFlag = 0; S.oldCollisionFlag = 0; S.outOfTrackFlag = 0;
-        S.lastTrackPointTimestamp = (float)S.physicsTime;
-        S.nearestTrackPointId = 0; S.oldTrackPointId = 0; S.splinePointId = 0;
-        S.trackLocation = 0; S.oldTrackLocation = 0;
-        for (int i = 0; i < 5; ++i) S.damageZoneLevel[i] = 0;   // Car.cpp:403-407 (the simulator's collision frame counter runs on)
-        S.damageChanged = 0;
-        S.totalReward = 0; S.stepReward = 0; S.oldPointId = 0; S.oldSplinePointId = 0;   // ScoringSystem::reset
-        stopBody(S.body[PDB_BODY_CHASSIS]);
-        memcpy(S.body[PDB_BODY_CHASSIS].pos, bodyPos, 12);
-        HBody b; toHBody(S.body[PDB_BODY_CHASSIS], b);
-        hLocalToWorld(b, P.fuelTankPos, S.body[PDB_BODY_TANK].pos);
-        for (int i = 0; i < 4; ++i) stopBody(S.body[P.susp[i].hubBody]);   // ISuspension::stop(): hub / axle only
-        attachAll(P, S);
-        // Drivetrain::reset + Engine::reset
-        S.clutchOpenState = 1; S.rootVelocity = 0; S.engineVel = 0; S.outShaftLVel = 0; S.outShaftRVel = 0; S.driveVel = 0;
-        S.gearReqRequest = 0; S.validShiftRPMWindow = P.validShiftRPMWindow; S.lifeLeft = 1000.0f;
-        for (int i = 0; i < PDB_MAX_TURBOS; ++i) S.turboRotation[i] = 0.0f;   // Engine::reset -> Turbo::reset (Engine.cpp:160-166, Turbo.cpp:42-45)
-        for (int i = 0; i < 4; ++i) tyreReset(P, S.tyre[i]);
-        S.isGearGrinding = 0; S.currentGear = 1;   // setCurrentGear(1, true)
-        stopBody(S.body[PDB_BODY_CHASSIS]); stopBody(S.body[PDB_BODY_TANK]);
-    }
+    teleportToSplineT(P, tv.h->numFat, tv.fat, HostRayDown{tv}, distanceNorm, S);
+}
+void teleportByMode(const pdb_car_params& P, const TrackView& tv, int mode, pdb_dyn_state& S) {
+    teleportByModeT(P, tv.h->numFat, tv.fat, HostRayDown{tv}, mode, S);
 }
 
 void initialState(const pdb_car_params& P, const TrackView& tv, pdb_dyn_state& S) {
@@ -156,6 +53,7 @@ void initialState(const pdb_car_params& P, const TrackView& tv, pdb_dyn_state& S
     S.acSeqIsDone = 1;
     S.locClutch = 1.0f;                              // Drivetrain.h:137
     S.pointCachePos[0] = 0; S.pointCachePos[1] = -10000.0f; S.pointCachePos[2] = 0;   // Track.cpp:203
+    S.randState = 1;                                 // the C runtime's default seed (srand(1))
     teleportToSpline(P, tv, 0.0f, S);
 }
 

@@ -69,7 +69,6 @@ struct Sim {
     pdb_batch* batch = nullptr;   // 1-car device batch, created at the first step
     bool paramsDirty = false;
     CarControls controls;
-    bool teleOnCollision = false, teleOnBadLoc = false; int teleMode = 0;
     CarState state;
     double physicsTime = 0;
     int device = 0;
@@ -93,10 +92,11 @@ struct Sim {
         if (pdb_teleport_to_spline(&P, track.data(), d, &S) != PDB_OK) logf("EXCEPTION: %s", pdb_last_error());
         pushState();
     }
-    void teleportByMode(int mode) {   // Car::teleportByMode (Car.cpp:1342-1358)
-        if (mode == 0) teleportSpline(0.0f);
-        else if (mode == 1) { pullState(); teleportSpline(S.trackLocation); }
-        else if (mode == 2) teleportSpline((float)rand() / (float)RAND_MAX);
+    void teleportByMode(int mode) {   // Car::teleportByMode (Car.cpp:1320-1336); Random draws from the car's own C-runtime rand() state
+        if (!hasCar || track.empty() || mode < 0 || mode > 2) return;
+        pullState();
+        if (pdb_teleport_by_mode(&P, track.data(), mode, &S) != PDB_OK) logf("EXCEPTION: %s", pdb_last_error());
+        pushState();
     }
 };
 
@@ -116,11 +116,18 @@ Sim* getCarSim(int simId, int carId) { Sim* s = getSim(simId); return (s && s->h
 Batch* getBatch(int id) { auto it = g_batches.find(id); return it == g_batches.end() ? nullptr : it->second.get(); }
 
 // ---- logging / seed (:50-68) ----
-void setSeed(unsigned int seed) { srand(seed); }
+// srand of the process' C runtime in the reference; here every simulator (and every lane of a batch made from it) carries its
+// own generator state in its record: setSeed seeds the simulators that exist and the ones created afterwards
+unsigned int g_seed = 1;
+void setSeed(unsigned int seed);
 void setLogFile(const std::string& filename, bool overwrite) { g_logFile = filename; if (overwrite) { if (FILE* f = fopen(filename.c_str(), "w")) fclose(f); } }
 void clearLogFile() { if (!g_logFile.empty()) { if (FILE* f = fopen(g_logFile.c_str(), "w")) fclose(f); } }
 void writeLog(const std::string& msg) { logf("%s", msg.c_str()); }
 
+void setSeed(unsigned int seed) {
+    g_seed = seed;
+    for (auto& kv : g_sims) { Sim* s = kv.second.get(); if (s->hasCar) { s->pullState(); s->S.randState = (int32_t)seed; s->pushState(); } }
+}
 // ---- simulator (:111-180) ----
 int createSimulator(const std::string& basePath) {
     std::ifstream ini(basePath + "/cfg/sim.ini");
@@ -147,9 +154,7 @@ void stepSimulator(int simId, double dt) {
     if (pdb_step_host(s->batch, a, (float)dt, &o) != PDB_OK) { logf("EXCEPTION: %s", pdb_last_error()); return; }
     pdb_car_state cs;
     if (pdb_get_car_state(s->batch, 0, 1, &cs) == PDB_OK) { memcpy(&s->state, &cs, sizeof(cs)); s->state.carId = 0; s->state.simId = s->id; }
-    s->physicsTime += dt;
-    // ScoringSystem::step teleports inside the tick (ScoringSystem.cpp:194-226); here the pose edit follows the tick
-    if ((s->teleOnCollision && (o.flags & 1)) || (s->teleOnBadLoc && (o.flags & 2))) s->teleportByMode(s->teleMode);
+    s->physicsTime += dt;   // (setCarAutoTeleport: the teleport happens inside the tick, in the kernel, like ScoringSystem.cpp:194-226)
 }
 
 // ---- track (:186-215) ----
@@ -176,6 +181,7 @@ int addCar(int simId, const std::string& modelName) {
     if (s->track.empty()) { logf("EXCEPTION: addCar needs a loaded track"); return -1; }
     if (pdb_build_car_model(s->base.c_str(), modelName.c_str(), &s->P) != PDB_OK) { logf("EXCEPTION: %s", pdb_last_error()); return -1; }
     if (pdb_initial_state(&s->P, s->track.data(), &s->S) != PDB_OK) { logf("EXCEPTION: %s", pdb_last_error()); return -1; }
+    s->S.randState = (int32_t)g_seed;
     s->model = modelName; s->hasCar = true;
     return 0;
 }
@@ -185,7 +191,7 @@ void teleportCarToPits(int simId, int carId, int) { if (Sim* s = getCarSim(simId
 void teleportCarToSpline(int simId, int carId, float d) { if (Sim* s = getCarSim(simId, carId)) s->teleportSpline(d); }
 void teleportCarByMode(int simId, int carId, int mode) { if (Sim* s = getCarSim(simId, carId)) s->teleportByMode(mode); }
 void setCarAutoTeleport(int simId, int carId, bool collision, bool badLoc, int mode) {
-    if (Sim* s = getCarSim(simId, carId)) { s->teleOnCollision = collision; s->teleOnBadLoc = badLoc; s->teleMode = mode; }
+    if (Sim* s = getCarSim(simId, carId)) { if (pdb_set_auto_teleport(&s->P, collision, badLoc, mode) == PDB_OK) s->paramsDirty = true; }
 }
 void setCarControls(int simId, int carId, bool smooth, const CarControls& controls) {
     Sim* s = getCarSim(simId, carId);
@@ -239,12 +245,17 @@ py::array_t<float> stepBatch(int id, py::array_t<float, py::array::c_style | py:
     memcpy(r.mutable_data(), B->out.data(), sizeof(pdb_step_out) * (size_t)B->n);
     return r;
 }
-void resetBatch(int id, py::object mask) {
+void resetBatch(int id, py::object mask, int mode) {   // teleportCarByMode(mode) for the masked lanes
     Batch* B = getBatch(id);
     if (!B) return;
-    if (mask.is_none()) { pdb_reset(B->b, nullptr); return; }
+    if (mask.is_none()) { pdb_reset_mode(B->b, nullptr, mode); return; }
     auto m = py::array_t<uint8_t, py::array::c_style | py::array::forcecast>::ensure(mask);
-    if (m && m.size() == B->n) pdb_reset(B->b, m.data());
+    if (m && m.size() == B->n) pdb_reset_mode(B->b, m.data(), mode);
+}
+void setBatchStuckTimeout(int id, double seconds) { if (Batch* B = getBatch(id)) pdb_set_stuck_timeout(B->b, seconds); }
+void setBatchSeeds(int id, py::array_t<uint32_t, py::array::c_style | py::array::forcecast> seeds) {   // one setSeed per lane
+    Batch* B = getBatch(id);
+    if (B && seeds.size() == B->n) pdb_set_seed(B->b, seeds.data());
 }
 void getBatchCarState(int id, int lane, CarState& state) {
     Batch* B = getBatch(id);
@@ -343,6 +354,8 @@ PYBIND11_MODULE(PyProjectD, m) {
     m.def("createBatch", &createBatch, "", py::arg("simId"), py::arg("nCars"), py::arg("device") = 0);
     m.def("destroyBatch", &destroyBatch, "");
     m.def("stepBatch", &stepBatch, "", py::arg("batchId"), py::arg("actions"), py::arg("dt") = 1.0 / 333.0);
-    m.def("resetBatch", &resetBatch, "", py::arg("batchId"), py::arg("mask") = py::none());
+    m.def("resetBatch", &resetBatch, "", py::arg("batchId"), py::arg("mask") = py::none(), py::arg("mode") = 0);
+    m.def("setBatchStuckTimeout", &setBatchStuckTimeout, "");
+    m.def("setBatchSeeds", &setBatchSeeds, "");
     m.def("getBatchCarState", &getBatchCarState, "");
 }

@@ -80,7 +80,7 @@ class CarParams(C.Structure):
                                    'validShiftRPMWindow', 'damageRpmWindow', 'clutchMaxTorque', 'clutchInertia', 'driveInertia', 'engineInertiaInit', 'outShaftInertiaL', 'outShaftInertiaR')] + \
         [('powerCurve', Curve), ('throttleCurve', Curve), ('engMinimum', C.c_int32), ('engLimiter', C.c_int32), ('engLimiterCycles', C.c_int32)] + \
         [(n, C.c_float) for n in ('engCoast1', 'engCoast2', 'engInertia', 'limiterMultiplier', 'rpmDamageThreshold', 'rpmDamageK', 'bovThreshold', 'maxPowerRPM', 'maxTorqueRPM')] + \
-        [('heave', Heave * 2), ('numTurbos', C.c_int32), ('turbos', Turbo * 3), ('turboBoostDamageThreshold', C.c_float), ('turboBoostDamageK', C.c_float), ('_padEngine', C.c_int32)] + \
+        [('heave', Heave * 2), ('numTurbos', C.c_int32), ('turbos', Turbo * 3), ('turboBoostDamageThreshold', C.c_float), ('turboBoostDamageK', C.c_float), ('autoTeleport', C.c_int32)] + \
         [(n, C.c_float) for n in ('acRpmMin', 'acRpmMax', 'acClutchSpeed')] + \
         [(n, C.c_int32) for n in ('acUseOnChange', 'acUseOnStart', 'autoShiftActive', 'autoBlipActive', 'autoBlipElectronic')] + \
         [('upshiftProfile', Curve), ('downshiftProfile', Curve), ('blipProfile', Curve), ('blipPerformTime', C.c_double), ('asChangeUpRpm', C.c_int32), ('asChangeDnRpm', C.c_int32),
@@ -107,7 +107,7 @@ class DynState(C.Structure):
         [(n, C.c_int32) for n in ('oldPointId', 'oldSplinePointId', 'drifting', 'driftExtreme', 'driftInvalid', 'driftComboCounter', 'collisionFlag', 'oldCollisionFlag',
                                   'outOfTrackFlag')] + \
         [('gasUsage', C.c_float), ('locClutch', C.c_float), ('turboRotation', C.c_float * 3), ('simFrame', C.c_int32), ('damageChanged', C.c_int32),
-         ('damageZoneLevel', C.c_float * 5), ('numContacts', C.c_int32), ('_pad', C.c_int32 * 2)]
+         ('damageZoneLevel', C.c_float * 5), ('numContacts', C.c_int32), ('randState', C.c_int32), ('_pad', C.c_int32 * 1)]
 assert C.sizeof(DynState) % 16 == 0
 MAX_CONTACTS = 10
 class Contact(C.Structure):   # pdb_contact
@@ -131,6 +131,8 @@ def load_product(host_only=False):
     lib.pdb_set_car_tune.argtypes = [C.c_void_p, C.c_char_p, C.c_char_p, C.c_char_p, C.c_float, C.c_int]
     lib.pdb_set_scoring_var.argtypes = [C.c_void_p, C.c_char_p, C.c_float]
     lib.pdb_teleport_to_spline.argtypes = [C.c_void_p, C.c_void_p, C.c_float, C.c_void_p]
+    lib.pdb_teleport_by_mode.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
+    lib.pdb_set_auto_teleport.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int]
     if not host_only:
         lib.pdb_create.restype = C.c_void_p
         lib.pdb_create.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_uint64, C.c_int]
@@ -142,6 +144,11 @@ def load_product(host_only=False):
         lib.pdb_get_contacts.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]
         lib.pdb_set_contacts.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]
         lib.pdb_reset.argtypes = [C.c_void_p, C.c_void_p]
+        lib.pdb_reset_mode.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+        lib.pdb_reset_device.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+        lib.pdb_reset_mask_device.restype = C.c_void_p; lib.pdb_reset_mask_device.argtypes = [C.c_void_p]
+        lib.pdb_set_stuck_timeout.argtypes = [C.c_void_p, C.c_double]
+        lib.pdb_set_seed.argtypes = [C.c_void_p, C.c_void_p]
         lib.pdb_actions_device.restype = C.c_void_p; lib.pdb_actions_device.argtypes = [C.c_void_p]
         lib.pdb_out_device.restype = C.c_void_p; lib.pdb_out_device.argtypes = [C.c_void_p]
         lib.pdb_set_out_device.argtypes = [C.c_void_p, C.c_void_p]

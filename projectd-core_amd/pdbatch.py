@@ -143,12 +143,28 @@ class Batch:
         self._chk(self.lib.pdb_get_car_state(self.h, first, count, C.byref(cs)))
         return cs
 
-    def reset(self, mask=None):
+    def reset(self, mask=None, mode=0):
+        """teleportCarByMode(mode) for the masked cars (host mask; the teleport runs on the device): 0 Start, 1 Nearest, 2 Random"""
         if mask is None:
-            self._chk(self.lib.pdb_reset(self.h, None))
+            self._chk(self.lib.pdb_reset_mode(self.h, None, mode))
         else:
             m = np.ascontiguousarray(mask, dtype=np.uint8)
-            self._chk(self.lib.pdb_reset(self.h, m.ctypes.data_as(C.c_void_p)))
+            self._chk(self.lib.pdb_reset_mode(self.h, m.ctypes.data_as(C.c_void_p), mode))
+
+    def reset_device(self, mask_ptr, mode=0):
+        """the same with a uint8 mask that already lives on the device: asynchronous on the batch's stream, no host round trip"""
+        self._chk(self.lib.pdb_reset_device(self.h, C.c_void_p(mask_ptr), mode))
+
+    def reset_mask_ptr(self):
+        """device array of n bytes: a car whose byte is 1 + mode is teleported at the top of its next tick, which clears the byte"""
+        return self.lib.pdb_reset_mask_device(self.h)
+
+    def set_stuck_timeout(self, seconds):
+        self._chk(self.lib.pdb_set_stuck_timeout(self.h, C.c_double(seconds)))
+
+    def set_seed(self, seeds):
+        s = np.ascontiguousarray(seeds, dtype=np.uint32).reshape(self.n)
+        self._chk(self.lib.pdb_set_seed(self.h, s.ctypes.data_as(C.c_void_p)))
 
     def kernel_time_us(self):
         us = C.c_double(); n = C.c_int()

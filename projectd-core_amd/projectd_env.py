@@ -111,6 +111,8 @@ class ProjectDVecEnv:
         if self.batch < 0:
             pd.destroySimulator(self.sim)
             raise RuntimeError('createBatch failed (no GPU? there is no CPU fallback)')
+        if self.cfg.stuck_timeout != 5.0:
+            pd.setBatchStuckTimeout(self.batch, float(self.cfg.stuck_timeout))
         self.total_reward = np.zeros(self.num_envs, dtype=np.float64)
         self.step_id = np.zeros(self.num_envs, dtype=np.int64)
         self.pending_reset = np.zeros(self.num_envs, dtype=bool)
@@ -160,7 +162,7 @@ class ProjectDVecEnv:
         if self.auto_reset and terminated.any():
             info['episode_reward'] = self.total_reward.copy()
             if cfg.teleport_on_reset:
-                pd.resetBatch(self.batch, terminated.astype(np.uint8))
+                pd.resetBatch(self.batch, terminated.astype(np.uint8), int(cfg.teleport_mode))
             self.pending_reset |= terminated
         return obs, reward.astype(np.float32), terminated, truncated, info
 
@@ -169,13 +171,13 @@ class ProjectDVecEnv:
         the masked lanes: they are teleported now and take their zero-action reset tick inside the next step()."""
         if mask is None:
             if self.cfg.teleport_on_reset:
-                pd.resetBatch(self.batch, None)
+                pd.resetBatch(self.batch, None, int(self.cfg.teleport_mode))
             obs, _, _ = self._raw_step(np.zeros((self.num_envs, 2), np.float32))
             self.total_reward[:] = 0.0; self.step_id[:] = 0; self.pending_reset[:] = False
             return obs
         m = np.ascontiguousarray(mask).astype(bool)
         if self.cfg.teleport_on_reset:
-            pd.resetBatch(self.batch, m.astype(np.uint8))
+            pd.resetBatch(self.batch, m.astype(np.uint8), int(self.cfg.teleport_mode))
         self.pending_reset |= m
         return None
 

@@ -1,9 +1,10 @@
 """Device-resident vector env for learners that live on the GPU: actions, observations, rewards and episode flags are torch
 tensors on the batch's device; the step kernel reads the action tensor and writes the observation block in place (zero copy
 through pdb_actions_device / pdb_out_device), and the reference env's reward / termination bookkeeping
-(pyprojectd/projectd_env.py:173-227) runs as a handful of elementwise torch ops on the same stream.  The host is involved only
-when an episode ends (the reset pose is computed by the host loader, sparse transfers).  PyTorch here is plumbing: device
-tensors and streams, no physics."""
+(pyprojectd/projectd_env.py:173-227) runs as a handful of elementwise torch ops on the same stream.  Episode ends never reach
+the host: the `terminated` mask is written into the batch's reset mask on the device and the next tick teleports those cars
+(Car::teleportByMode + Car::reset) before it steps them -- step() contains no host synchronisation.  PyTorch here is plumbing:
+device tensors and streams, no physics."""
 import ctypes as C
 import numpy as np
 import torch
@@ -20,11 +21,18 @@ class _DevView:
 
 class ProjectDTorchVecEnv:
     def __init__(self, num_envs, params, track_blob, device=0, **settings):
-        self.cfg = E.EnvConfig(**settings)
+        self.cfg = cfg = E.EnvConfig(**settings)
         self.num_envs = n = int(num_envs)
         self.dev = torch.device('cuda:%d' % device)
+        # setCarAutoTeleport (projectd_env.py:124): the teleport inside the tick that raises the flag
+        lib = pc.load_product()
+        if lib.pdb_set_auto_teleport(C.byref(params), int(cfg.teleport_on_hit), int(cfg.teleport_off_track), int(cfg.teleport_mode)) != 0:
+            raise ValueError(lib.pdb_last_error().decode())
         self.batch = pdbatch.Batch(n, params, track_blob, device=device, action_mode=1)
         self.batch.set_stream(torch.cuda.current_stream(self.dev).cuda_stream)
+        if cfg.stuck_timeout != 5.0:
+            self.batch.set_stuck_timeout(cfg.stuck_timeout)
+        self.reset_mask = torch.as_tensor(_DevView(self.batch.reset_mask_ptr(), (n,), '|u1'), device=self.dev)
         self.act = torch.as_tensor(_DevView(self.batch.actions_device_ptr(), (n, 2)), device=self.dev)
         self.out = torch.as_tensor(_DevView(self.batch.out_device_ptr(), (n, 26)), device=self.dev)
         self.flags = torch.as_tensor(_DevView(self.batch.out_device_ptr(), (n, 26), '<i4'), device=self.dev)[:, 25]
@@ -36,7 +44,8 @@ class ProjectDTorchVecEnv:
         self.batch.close()
 
     def reset(self):
-        self.batch.reset(None)
+        if self.cfg.teleport_on_reset:
+            self.batch.reset(None, self.cfg.teleport_mode)
         self.act.zero_()
         self.batch.step_async()
         self.total_reward.zero_(); self.step_id.zero_(); self.pending_reset.zero_()
@@ -70,7 +79,6 @@ class ProjectDTorchVecEnv:
         self.total_reward = torch.where(fresh, torch.zeros_like(self.total_reward), self.total_reward)
         self.step_id = torch.where(fresh, torch.zeros_like(self.step_id), self.step_id)
         self.pending_reset = terminated.clone()
-        if bool(terminated.any()):                       # the only host round trip: lanes whose episode ended
-            if cfg.teleport_on_reset:
-                self.batch.reset(terminated.to(torch.uint8).cpu().numpy())
+        if cfg.teleport_on_reset:   # the next tick teleports these lanes first (value = 1 + Car::teleportByMode's mode), then steps them
+            self.reset_mask.copy_(terminated.to(torch.uint8) * (1 + int(cfg.teleport_mode)))
         return obs, reward.to(torch.float32), terminated, torch.zeros_like(terminated)

@@ -118,6 +118,13 @@ def run_parity(n_cars=8, ticks=200, seed=1234, resync=False, verbose=False, chec
     assert lib.pdb_initial_state(C.byref(P), trk, C.byref(S0)) == 0
     b = pdbatch.Batch(n_cars, P, trk, device=0, action_mode=1)
     hs = [orc.cpuref_create(C.byref(P), trk, len(trk), C.byref(S0)) for _ in range(n_cars)]
+    hook = None
+    if P.autoTeleport:   # setCarAutoTeleport: the oracle's in-tick Car::teleportByMode is the product's HOST function
+        def _tele(state_ptr, mode):
+            assert lib.pdb_teleport_by_mode(C.byref(P), trk, mode, C.c_void_p(state_ptr)) == 0
+        hook = C.CFUNCTYPE(None, C.c_void_p, C.c_int)(_tele)
+        for h in hs:
+            orc.cpuref_set_auto_teleport_hook(h, C.cast(hook, C.c_void_p))
     acts = make_actions(n_cars, seed)
     worst = 0.0; worst_info = None
     try:
