@@ -2,18 +2,28 @@
 """Headline benchmark: env-steps/s of the batched 333 Hz vehicle step (BASELINE.json metric).
 
     python bench.py --gpus N --steps K --warmup W
-    (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+    N > 1 either under a launcher (python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...) or
+    plainly: without WORLD_SIZE in the environment bench.py starts its own N rank processes (before anything touches a GPU),
+    one per GPU, rendezvous on 127.0.0.1, and relays rank 0's JSON line.
 
-One "step" = one physics tick (dt = 1/333 s) of every car resident on the GPU = one launch of the HIP step kernel.
+One "step" = one physics tick (dt = 1/333 s) of every car resident on the GPU = one launch of the HIP step kernel per car range.
 Workload = BASELINE.json configs[1]: 4096 AE86 cars per GPU on the synthetic flat-plane track, per-car constant random
 actions (steer ~ U(-0.3,0.3), a1 ~ U(-1,1), numpy RandomState(1234) indexed by GLOBAL car id).  State, actions and
-outputs are resident in HBM before the timed region.  On each GPU the cars step as --partitions free-running ranges (one HIP
+outputs are resident in HBM before the timed region; the cars have settled on their springs and are driving (--settle ticks
+of state preparation, outside warm-up and timing).  On each GPU the cars step as --partitions free-running ranges (one HIP
 stream each: cars are independent, the ranges' kernels overlap).  Multi-GPU: cars are sharded contiguously (weak scaling,
 4096 per GPU); the only collective is the RCCL all-gather of k-tick trajectory rings of the [N,26] observation/reward/flag
 block to the learner, on a side stream.
-Prints ONE JSON line on rank 0.
+
+Timing: W untimed warm-up steps, then EXACTLY K timed steps between barrier + synchronize on both sides, max over ranks.  A
+region shorter than 0.2 s is repeated (same K steps each time, same bracketing) until 0.25 s of timed work has accumulated;
+`ms_per_step` / `value` are then the median region's, `repeats` and `timed_region_s` say what was measured.
+
+Prints ONE JSON line on rank 0; at N = 1 it also carries `cpu_baseline` and an `extra` block: the other BASELINE configs'
+shapes measured the same way in the same process (16384 cars on the dense mountain-road spline, guard rails + MLP policy,
+the 8192-car shard of configs[3], per-tick gather + action scatter, episodes with terminations and resets).
 """
-import argparse, ctypes as C, json, os, sys, time
+import argparse, ctypes as C, json, os, socket, subprocess, sys, time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.join(ROOT, 'projectd-core_amd'))
@@ -21,8 +31,9 @@ sys.path.insert(0, os.path.join(ROOT, 'tests'))
 
 CARS_PER_GPU = 4096
 # algorithmic bytes per car-tick (DESIGN.md "Algorithmic bytes"): record read + record write + action + output row
-B_ALG = 2256 + 2256 + 8 + 104   # sizeof(pdb_dyn_state) in and out, float[2] action, pdb_step_out (checked against the ctypes mirrors in main)
+B_ALG = 2256 + 2256 + 8 + 104   # sizeof(pdb_dyn_state) in and out, float[2] action, pdb_step_out (checked against the ctypes mirrors in measure)
 HBM_PEAK_GBS = 8000.0
+PROFILE_TAG = 'r02'
 
 
 def cpu_baseline(P, trk, S0, actions, seconds_target=15.0):
@@ -50,49 +61,23 @@ def cpu_baseline(P, trk, S0, actions, seconds_target=15.0):
             "all_cores_value": n3 * 333 / t3, "all_cores": ncores}
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=3000)
-    ap.add_argument('--warmup', type=int, default=333)
-    ap.add_argument('--cars', type=int, default=CARS_PER_GPU)
-    ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--partitions', type=int, default=2,
-                    help='free-running car ranges per GPU, one HIP stream each (pdb_set_partitions / pdb_step_ring; constant policy only -- a per-tick policy joins the ranges every tick); 1 = one launch per tick')
-    ap.add_argument('--walls', action='store_true', help='touge workload: line both edges of the road with WALL surfaces (configs[4] shape: hull-vs-wall narrow phase next to the guard rails)')
-    ap.add_argument('--spline-step', type=float, default=0.0, help='touge workload: metres between spline points (default 5 m = 891 points; 0.9 = 4.9 k points, the density of the reference tracks)')
-    ap.add_argument('--no-body-contacts', action='store_true', help='diagnostic A/B: switch the collision pass off in the car block (never the bench line)')
-    ap.add_argument('--policy', choices=['constant', 'feedback', 'mlp'], default=None,
-                    help='where actions come from each tick: constant (configs[1]), feedback (probe controller on the GPU, default for touge), '
-                         'mlp (configs[4] shape: a SAC-sized 24-256-256-2 tanh MLP with fixed random weights, evaluated with torch on the GPU from the observation block)')
-    ap.add_argument('--gather-ticks', type=int, default=32, help='ticks per trajectory ring gathered to the learner (N > 1): 1 = plain per-tick gather')
-    ap.add_argument('--force-gather', action='store_true', help='run the observation all-gather even with one rank (exercises the RCCL + side-stream path on a single GPU)')
-    ap.add_argument('--backend', default='nccl', help='torch.distributed backend for N > 1 (nccl = RCCL; gloo only to exercise the multi-rank path on a single-GPU box)')
-    ap.add_argument('--workload', choices=['flat', 'touge'], default='flat',
-                    help='flat = BASELINE configs[1] (the bench line); touge = configs[2] shape: closed hilly road, cars spread around the lap, probe-feedback steering computed on the GPU each tick')
-    args = ap.parse_args()
+class _Arr:   # zero-copy torch view of a library-owned device block
+    def __init__(self, ptr, shape, typestr='<f4'):
+        self.__cuda_array_interface__ = {'shape': shape, 'typestr': typestr, 'data': (ptr, False), 'version': 2}
 
+
+def measure(args, world, rank, local_rank, dist, want_cpu=False):
+    """one configuration, measured by the contract's rule; returns the result dict on rank 0 (None elsewhere)"""
     import numpy as np
     import torch
     import pdbatch, pdb_ctypes as pc, sharding
 
-    world = int(os.environ.get('WORLD_SIZE', '1'))
-    rank = int(os.environ.get('RANK', '0'))
-    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
-    if args.gpus > 1 and world != args.gpus:
-        raise SystemExit('launch with torch.distributed.run --nproc-per-node %d' % args.gpus)
-    if not torch.cuda.is_available():
-        raise SystemExit('bench.py needs an MI355X: there is no CPU fallback for the product path')
     ndev = torch.cuda.device_count()
     dev_index = local_rank % ndev          # one rank per GPU on the driver's node; ranks share devices only in the single-GPU gloo test
     torch.cuda.set_device(dev_index)
-    dist = None
-    if world > 1 or args.force_gather:
-        import torch.distributed as dist
-        dist.init_process_group(args.backend, init_method='env://')
-
+    dev = 'cuda:%d' % dev_index
     n = args.cars
-    policy = args.policy or ('feedback' if args.workload == 'touge' else 'constant')
+    policy = args.policy or ('feedback' if (args.workload == 'touge' or args.episodes) else 'constant')
     assert B_ALG == 2 * C.sizeof(pc.DynState) + 8 + C.sizeof(pc.StepOut), 'B_ALG is stale: update it with the record layout'
     P = pdbatch.packed_params()
     if args.no_body_contacts:
@@ -121,37 +106,45 @@ def main():
             C.memmove(C.byref(st[i]), C.byref(s), C.sizeof(s))
         b.set_state(st)
 
-    class _Arr:   # zero-copy torch view of the library-owned output block
-        def __init__(self, ptr, shape):
-            self.__cuda_array_interface__ = {'shape': shape, 'typestr': '<f4', 'data': (ptr, False), 'version': 2}
-    out_t = torch.as_tensor(_Arr(b.out_device_ptr(), (n, 26)), device='cuda:%d' % dev_index)
-    gather = sharding.TrajectoryGather(n, world, 'cuda:%d' % dev_index, dist, k=args.gather_ticks, force=args.force_gather, producer_wait=b.wait_partitions)
-    act_t = torch.as_tensor(_Arr(b.actions_device_ptr(), (n, 2)), device='cuda:%d' % dev_index)
+    out_t = torch.as_tensor(_Arr(b.out_device_ptr(), (n, 26)), device=dev)
+    gather = sharding.TrajectoryGather(n, world, dev, dist, k=args.gather_ticks, force=args.force_gather, producer_wait=b.wait_partitions)
+    act_t = torch.as_tensor(_Arr(b.actions_device_ptr(), (n, 2)), device=dev)
+    do_scatter = bool(args.scatter_actions and gather.active)   # configs[3]: the learner (rank 0) scatters every tick's actions back
+    scatter_src = torch.from_numpy(all_actions).to(dev) if (do_scatter and rank == 0) else None
 
     if policy == 'mlp':
         g = torch.Generator(device='cpu'); g.manual_seed(4567)
-        dev = 'cuda:%d' % dev_index
         w1 = (torch.randn(24, 256, generator=g) / 24 ** 0.5).to(dev); b1 = torch.zeros(256, device=dev)
         w2 = (torch.randn(256, 256, generator=g) / 16.0).to(dev); b2 = torch.zeros(256, device=dev)
         w3 = (torch.randn(256, 2, generator=g) / 16.0).to(dev); b3 = torch.tensor([0.0, 0.5], device=dev)
         import projectd_env
         obs_scale = (1.0 / torch.from_numpy(projectd_env.obs_bounds(projectd_env.EnvConfig())[1])).to(dev)
     tick_id = [0]
+    episodes = [None]
 
-    def tick():
-        t = tick_id[0]; tick_id[0] = t + 1
-        out_t = gather.slot(t)                  # the kernel writes tick t straight into its trajectory-ring slot
-        if part_loops:     # every partition runs its own closed loop (kernel, then the policy on its rows) on its own stream
-            for p in range(args.partitions):
-                f, c = part_rng[p]
-                with torch.cuda.stream(part_st[p]):
-                    b.step_partition(p, out_t.data_ptr())
-                    policy_step(out_t[f:f + c], act_t[f:f + c])
-            return
-        b.set_out_device_ptr(out_t.data_ptr())
-        b.step_async()
-        policy_step(out_t, act_t)
-        gather.after_tick(t)
+    # --episodes: the env's own bookkeeping on the device (projectd_env.py:173-227: penalties, terminations, low-reward rule) and
+    # episode resets through the batch's reset mask -- teleport at the top of the terminated cars' next tick, no host round trip
+    if args.episodes:
+        import projectd_env as E
+        cfg = E.EnvConfig()
+        reset_mask = torch.as_tensor(_Arr(b.reset_mask_ptr(), (n,), '|u1'), device=dev)
+        total_reward = torch.zeros(n, dtype=torch.float64, device=dev)
+        pending = torch.zeros(n, dtype=torch.bool, device=dev)
+        ends = torch.zeros((), dtype=torch.int64, device=dev)
+        episodes[0] = ends
+
+        def episode_step(o, a):
+            nonlocal total_reward, pending
+            fl = o[:, 25].view(torch.int32)                 # pdb_step_out.flags of the slot this tick wrote
+            hit = (fl & 1) != 0; off = (fl & 2) != 0; stuck = (fl & 4) != 0
+            reward = o[:, 24].to(torch.float64) - cfg.terminate_hit_penalty * hit - cfg.terminate_off_track_penalty * off - cfg.terminate_stuck_penalty * stuck
+            total_reward = total_reward + reward
+            term = (hit | off | stuck | (total_reward < cfg.terminate_low_reward)) & ~pending
+            total_reward = torch.where(pending | term, torch.zeros_like(total_reward), total_reward)
+            pending = term
+            reset_mask.copy_(term.to(torch.uint8))          # 1 + mode Start
+            ends.add_(term.sum())
+            a.mul_((~term)[:, None])                        # the reset tick steps with the zero action
 
     def policy_step(o, a):
         if policy == 'feedback':   # oracle/scenarios.h scenarioFeedback as elementwise device ops on the observation block
@@ -162,16 +155,37 @@ def main():
             h1 = torch.relu(x @ w1 + b1)
             h2 = torch.relu(h1 @ w2 + b2)
             torch.tanh(h2 @ w3 + b3, out=a)
+        elif policy == 'random':   # fresh uniform actions every tick (an untrained agent: ends episodes quickly)
+            a.uniform_(-1.0, 1.0)
 
-    use_ring = policy == 'constant' and args.partitions > 1
+    use_ring = policy == 'constant' and args.partitions > 1 and not do_scatter
     # a per-tick policy: per-partition closed loops, unless a gather has to see whole ticks (N > 1)
     # and only where a tick is long enough to hide the doubled number of (small) policy launches: the host enqueues ~10 per partition and tick
-    part_loops = policy != 'constant' and args.partitions > 1 and not gather.active and n >= 8192
+    part_loops = policy != 'constant' and args.partitions > 1 and not gather.active and n >= 8192 and not args.episodes
     if use_ring or part_loops:
         b.set_partitions(args.partitions)
     if part_loops:
-        part_st = [torch.cuda.ExternalStream(b.partition_stream(p), device='cuda:%d' % dev_index) for p in range(args.partitions)]
+        part_st = [torch.cuda.ExternalStream(b.partition_stream(p), device=dev) for p in range(args.partitions)]
         part_rng = [b.partition_range(p) for p in range(args.partitions)]
+
+    def tick():
+        t = tick_id[0]; tick_id[0] = t + 1
+        o = gather.slot(t)                  # the kernel writes tick t straight into its trajectory-ring slot
+        if part_loops:     # every partition runs its own closed loop (kernel, then the policy on its rows) on its own stream
+            for p in range(args.partitions):
+                f, c = part_rng[p]
+                with torch.cuda.stream(part_st[p]):
+                    b.step_partition(p, o.data_ptr())
+                    policy_step(o[f:f + c], act_t[f:f + c])
+            return
+        if do_scatter:
+            act_t.copy_(sharding.scatter_actions(scatter_src, n, world, rank, dev, dist))
+        b.set_out_device_ptr(o.data_ptr())
+        b.step_async()
+        policy_step(o, act_t)
+        if args.episodes:
+            episode_step(o, act_t)
+        gather.after_tick(t)
 
     def run(nsteps):
         """enqueue nsteps ticks: one by one, or (free-running partitions) a trajectory ring at a time"""
@@ -189,8 +203,15 @@ def main():
             gather.after_tick(t - 1)                              # a full ring starts its all-gather (N > 1)
         tick_id[0] = end
 
-    # bring the GPU out of its idle power state before anything is timed (the timed region is a quarter of a second)
-    _spin = torch.randn(2048, 2048, device='cuda:%d' % dev_index)
+    def fence():
+        b.wait_partitions()                   # the batch's stream (= torch's current one) waits for every partition's last kernel
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    # bring the GPU out of its idle power state before anything is timed
+    _spin = torch.randn(2048, 2048, device=dev)
     _t = time.perf_counter()
     while time.perf_counter() - _t < 0.4:
         for _ in range(20):
@@ -199,46 +220,58 @@ def main():
     del _spin
     torch.cuda.synchronize()              # set-up done before any partition stream starts
     gather.warm()
+    run(args.settle)                      # state preparation: off the springs and rolling (not warm-up, not timed)
+    fence()
     run(args.warmup)
-    b.wait_partitions()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    b.event_record(0)
-    if use_ring or part_loops:
-        b.partition_mark()
-    t0 = time.perf_counter()
-    run(args.steps)
-    b.wait_partitions()                   # the batch's stream (= torch's current one) waits for every partition's last kernel
-    b.event_record(1)
-    gather.finish()                       # outstanding gathers belong to the timed region
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t1 = time.perf_counter()
-    elapsed = t1 - t0
-    region_ms = b.event_elapsed_ms()
-    elapsed = sharding.max_over_ranks(elapsed, 'cuda:%d' % dev_index, dist, world)
+    fence()
 
+    regions = []          # (wall seconds (max over ranks), event ms on the batch stream, partition-0 event ms, cars per launch)
+    total = 0.0
+    while True:
+        b.event_record(0)
+        if use_ring or part_loops:
+            b.partition_mark()
+        t0 = time.perf_counter()
+        run(args.steps)
+        b.wait_partitions()
+        b.event_record(1)
+        gather.finish()                       # outstanding gathers belong to the timed region
+        fence()
+        elapsed = sharding.max_over_ranks(time.perf_counter() - t0, dev, dist, world)
+        region_ms = b.event_elapsed_ms()
+        part = b.partition_elapsed_ms(0) if (use_ring or part_loops) else (None, n)
+        regions.append((elapsed, region_ms, part[0], part[1]))
+        total += elapsed
+        if regions[0][0] >= 0.2 or total >= 0.25 or len(regions) >= 400:   # the same decision on every rank (max-over-ranks times)
+            break
+    regions.sort(key=lambda r: r[0])
+    elapsed, region_ms, part_ms, launch_cars = regions[len(regions) // 2]
+
+    res = None
     if rank == 0:
-        traffic = None; valu_busy = None
-        try:   # memory-side bytes per launch from the committed PMC passes of this same command (profiles/, tools/profile_round.sh)
-            pm = json.load(open(os.path.join(ROOT, 'profiles', 'r01_pmc.json')))
-            pc_cfg = pm.get('bench', {}).get('config', {})
-            if args.workload == 'flat' and n == CARS_PER_GPU and pc_cfg.get('cars_per_gpu') == n and pc_cfg.get('partitions', 1) == (args.partitions if (use_ring or part_loops) else 1):
-                traffic = pm.get('traffic_bytes_per_launch')
-                valu_busy = pm.get('valu_busy_frac_approx')
-        except Exception:
-            traffic = None
-        launch_cars, conc = n, 1
+        traffic = None; valu_busy = None; prof = None
+        for tag in (PROFILE_TAG, 'r01'):
+            try:   # memory-side bytes per launch from the committed PMC passes of this same command (profiles/, tools/profile_round.sh)
+                pm = json.load(open(os.path.join(ROOT, 'profiles', tag + '_pmc.json')))
+                pc_cfg = pm.get('bench', {}).get('config', {})
+                if args.workload == 'flat' and n == CARS_PER_GPU and pc_cfg.get('cars_per_gpu') == n and pc_cfg.get('partitions', 1) == (args.partitions if (use_ring or part_loops) else 1):
+                    traffic = pm.get('traffic_bytes_per_launch'); valu_busy = pm.get('valu_issue_busy_frac', pm.get('valu_busy_frac_approx')); prof = tag
+                    break
+            except Exception:
+                continue
+        conc = 1
         kernel_us = region_ms * 1000.0 / args.steps          # HIP events on the kernel's stream around the timed region
         if use_ring or part_loops:   # one launch = one partition's cars; HIP events on that partition's own stream
-            part_ms, launch_cars = b.partition_elapsed_ms(0)
             kernel_us = part_ms * 1000.0 / args.steps
             conc = args.partitions
+        else:
+            launch_cars = n
         achieved = B_ALG * launch_cars / (kernel_us * 1e-6) / 1e9
+        wl = ("configs[1]: %d cars/GPU, AE86, flat-plane track, %s, dt=1/333 s" % (n, "per-car constant random actions" if policy == "constant" else "policy=" + policy)) if args.workload == 'flat' else \
+             ("configs[2] shape: %d cars/GPU, AE86, synthetic closed mountain road (%s%s), policy=%s on the GPU, dt=1/333 s" %
+              (n, "spline point every %.1f m" % args.spline_step if args.spline_step else "1782 triangles, 891 spline points", ", guard rails (WALL surfaces) along both edges" if args.walls else "", policy))
+        if args.episodes:
+            wl += "; episodes: the env's terminations (hit / off track / stuck / low reward) with penalties, resets through the device reset mask"
         res = {
             "metric": "env-steps/sec (333 Hz tick, 4-wheel car)",
             "value": n * world * args.steps / elapsed,
@@ -247,23 +280,139 @@ def main():
             "ms_per_step": elapsed * 1000.0 / args.steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32 (+f64 drivetrain)", "data": "synthetic",
-            "config": {"workload": ("configs[1]: %d cars/GPU, AE86, flat-plane track, %s, dt=1/333 s" % (n, "per-car constant random actions" if policy == "constant" else "policy=" + policy)) if args.workload == 'flat' else
-                                   ("configs[2] shape: %d cars/GPU, AE86, synthetic closed mountain road (1782 triangles, 891 spline points), policy=%s on the GPU, dt=1/333 s" % (n, policy)),
-                       "cars_per_gpu": n, "partitions": (args.partitions if (use_ring or part_loops) else 1), "collective": ("RCCL all-gather of %d-tick trajectory rings [k,N,26] obs/reward/flags on a side stream, kernel writes the ring in place" % args.gather_ticks) if (world > 1 or args.force_gather) else "none",
-                       "parity": "bit-exact vs CPU oracle (tests/test_gpu_parity.py)"},
+            "repeats": len(regions), "timed_region_s": total,
+            "config": {"workload": wl, "cars_per_gpu": n, "partitions": (args.partitions if (use_ring or part_loops) else 1), "settle_ticks": args.settle,
+                       "collective": ("RCCL all-gather of %d-tick trajectory rings [k,N,26] obs/reward/flags on a side stream, kernel writes the ring in place%s" %
+                                      (args.gather_ticks, "; actions scattered from rank 0 every tick" if args.scatter_actions else "")) if (world > 1 or args.force_gather) else "none",
+                       "parity": "bit-exact vs CPU oracle (tests/, -m gpu); rigid-body solver and contact generation unpinned (ODE absent from the reference tree)"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": traffic, "traffic_source": ("profiles/r01_pmc.json: (2*FETCH_SIZE + WRITE_SIZE)*1024 per launch, rocprofv3 --pmc passes of this command" if traffic else None),
+                         "traffic": traffic, "traffic_source": ("profiles/%s_pmc.json: (2*FETCH_SIZE + WRITE_SIZE)*1024 per launch, rocprofv3 --pmc passes of this command" % prof if traffic else None),
                          "kernel": "pdb_step_kernel", "kernel_avg_us": kernel_us, "alg_bytes_per_car_tick": B_ALG, "cars_per_launch": launch_cars,
                          "concurrent_launches": conc, "device_achieved": achieved * conc, "device_frac": achieved * conc / HBM_PEAK_GBS,
-                         "valu_issue_busy_frac": valu_busy,   # the resource that actually bounds the kernel (profiles/r01_pmc.json, SQ_ACTIVE_INST_VALU over all SIMD cycles)
+                         "valu_issue_busy_frac": valu_busy,   # the resource that actually bounds the kernel (profiles/*_pmc.json; definition in DESIGN.md section 3)
                          "note": ("one launch = one partition (%d cars); %d partitions step concurrently on their own streams, so the device moves concurrent_launches x achieved" % (launch_cars, conc)) if conc > 1 else None},
         }
-        if not args.no_cpu_baseline and world == 1:   # the CPU leg is timed at N = 1 only
+        if args.episodes:
+            res["episodes_ended"] = int(episodes[0].item())
+        if want_cpu:   # the CPU leg is timed at N = 1 only
             res["cpu_baseline"] = cpu_baseline(P, trk, S0, all_actions)
-        print(json.dumps(res))
     b.close()
+    return res
+
+
+EXTRA = [   # (key, argv) -- the other BASELINE configs' shapes, each measured by measure() in this process at N = 1
+    ("configs2_16384_dense_spline", ['--workload', 'touge', '--cars', '16384', '--spline-step', '0.9', '--steps', '300', '--warmup', '50', '--settle', '200']),
+    ("configs2_16384", ['--workload', 'touge', '--cars', '16384', '--steps', '300', '--warmup', '50', '--settle', '200']),
+    ("configs4_shape_16384_walls_mlp", ['--workload', 'touge', '--cars', '16384', '--walls', '--policy', 'mlp', '--steps', '300', '--warmup', '50', '--settle', '200']),
+    ("configs3_shard_8192", ['--cars', '8192', '--steps', '600', '--warmup', '100']),
+    ("configs3_shard_8192_gather_k1_scatter", ['--cars', '8192', '--steps', '300', '--warmup', '50', '--force-gather', '--gather-ticks', '1', '--scatter-actions']),
+    ("configs3_shard_8192_gather_k32", ['--cars', '8192', '--steps', '600', '--warmup', '100', '--force-gather', '--gather-ticks', '32']),
+    ("episodes_4096", ['--workload', 'touge', '--walls', '--cars', '4096', '--episodes', '--steps', '600', '--warmup', '100', '--settle', '200', '--partitions', '1']),
+    ("episodes_4096_reset_free", ['--workload', 'touge', '--walls', '--cars', '4096', '--policy', 'feedback', '--steps', '600', '--warmup', '100', '--settle', '200', '--partitions', '1']),
+    ("episodes_16384", ['--workload', 'touge', '--walls', '--cars', '16384', '--episodes', '--steps', '300', '--warmup', '50', '--settle', '200', '--partitions', '1']),
+    ("episodes_16384_reset_free", ['--workload', 'touge', '--walls', '--cars', '16384', '--policy', 'feedback', '--steps', '300', '--warmup', '50', '--settle', '200', '--partitions', '1']),
+]
+
+
+def parser():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=3000)
+    ap.add_argument('--warmup', type=int, default=333)
+    ap.add_argument('--settle', type=int, default=333, help='ticks of state preparation before warm-up (cars come off their springs and get rolling); neither warm-up nor timed')
+    ap.add_argument('--cars', type=int, default=CARS_PER_GPU)
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-extra', action='store_true', help='skip the `extra` block (the other configs measured in the same run)')
+    ap.add_argument('--partitions', type=int, default=2,
+                    help='free-running car ranges per GPU, one HIP stream each (pdb_set_partitions / pdb_step_ring; constant policy only -- a per-tick policy joins the ranges every tick); 1 = one launch per tick')
+    ap.add_argument('--walls', action='store_true', help='touge workload: line both edges of the road with WALL surfaces (configs[4] shape: hull-vs-wall narrow phase next to the guard rails)')
+    ap.add_argument('--spline-step', type=float, default=0.0, help='touge workload: metres between spline points (default 5 m = 891 points; 0.9 = 4.9 k points, the density of the reference tracks)')
+    ap.add_argument('--no-body-contacts', action='store_true', help='diagnostic A/B: switch the collision pass off in the car block (never the bench line)')
+    ap.add_argument('--policy', choices=['constant', 'feedback', 'mlp', 'random'], default=None,
+                    help='where actions come from each tick: constant (configs[1]), feedback (probe controller on the GPU, default for touge), '
+                         'mlp (configs[4] shape: a SAC-sized 24-256-256-2 tanh MLP with fixed random weights, evaluated with torch on the GPU from the observation block), random')
+    ap.add_argument('--episodes', action='store_true', help='run the env loop: terminations with penalties like projectd_env.py, resets through the device reset mask')
+    ap.add_argument('--gather-ticks', type=int, default=32, help='ticks per trajectory ring gathered to the learner (N > 1): 1 = plain per-tick gather')
+    ap.add_argument('--scatter-actions', action='store_true', help='with a gather: rank 0 scatters the [N,2] action block back every tick (configs[3] as SURVEY 8d words it)')
+    ap.add_argument('--force-gather', action='store_true', help='run the observation all-gather even with one rank (exercises the RCCL + side-stream path on a single GPU)')
+    ap.add_argument('--backend', default='nccl', help='torch.distributed backend for N > 1 (nccl = RCCL; gloo only to exercise the multi-rank path on a single-GPU box)')
+    ap.add_argument('--workload', choices=['flat', 'touge'], default='flat',
+                    help='flat = BASELINE configs[1] (the bench line); touge = configs[2] shape: closed hilly road, cars spread around the lap, probe-feedback steering computed on the GPU each tick')
+    return ap
+
+
+def spawn_ranks(n):
+    """`python bench.py --gpus N` without a launcher: N rank processes of this same command, started before this process has
+    touched a GPU (it never does); rank 0's stdout is relayed, the others' goes to stderr."""
+    s = socket.socket(); s.bind(('127.0.0.1', 0)); port = s.getsockname()[1]; s.close()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, WORLD_SIZE=str(n), RANK=str(r), LOCAL_RANK=str(r), MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+        env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=(subprocess.PIPE if r == 0 else sys.stderr), stderr=sys.stderr))
+    out, _ = procs[0].communicate()
+    rc = procs[0].returncode
+    for p in procs[1:]:
+        rc = p.wait() or rc
+    sys.stdout.write(out.decode() if out else '')
+    sys.stdout.flush()
+    sys.exit(rc)
+
+
+def main():
+    ap = parser()
+    args = ap.parse_args()
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        spawn_ranks(args.gpus)
+
+    import torch
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if args.gpus > 1 and world != args.gpus:
+        raise SystemExit('WORLD_SIZE=%d but --gpus %d' % (world, args.gpus))
+    if not torch.cuda.is_available():
+        raise SystemExit('bench.py needs an MI355X: there is no CPU fallback for the product path')
+    dist = None
     if world > 1 or args.force_gather:
+        import torch.distributed as dist
+        if world == 1:
+            os.environ.setdefault('MASTER_ADDR', '127.0.0.1'); os.environ.setdefault('MASTER_PORT', '29511')
+            os.environ.setdefault('RANK', '0'); os.environ.setdefault('WORLD_SIZE', '1')
+        torch.cuda.set_device(local_rank % torch.cuda.device_count())
+        dist.init_process_group(args.backend, init_method='env://')
+
+    res = measure(args, world, rank, local_rank, dist, want_cpu=(not args.no_cpu_baseline and world == 1))
+    is_headline = world == 1 and not args.no_extra and args.workload == 'flat' and args.cars == CARS_PER_GPU and not args.episodes and not args.force_gather
+    if is_headline:
+        extra = {}
+        for key, argv in EXTRA:
+            a = parser().parse_args(argv + ['--no-cpu-baseline', '--no-extra'])
+            d2 = None
+            try:
+                if a.force_gather:
+                    import torch.distributed as d2
+                    if not d2.is_initialized():
+                        os.environ.setdefault('MASTER_ADDR', '127.0.0.1'); os.environ.setdefault('MASTER_PORT', '29512')
+                        os.environ.setdefault('RANK', '0'); os.environ.setdefault('WORLD_SIZE', '1')
+                        d2.init_process_group(args.backend, init_method='env://')
+                r = measure(a, 1, 0, 0, d2)
+                extra[key] = {"value": r["value"], "ms_per_step": r["ms_per_step"], "steps": r["steps"], "repeats": r["repeats"], "workload": r["config"]["workload"],
+                              "partitions": r["config"]["partitions"], "collective": r["config"]["collective"], "kernel_avg_us": r["roofline"]["kernel_avg_us"]}
+                if "episodes_ended" in r:
+                    extra[key]["episodes_ended"] = r["episodes_ended"]
+            except Exception as e:   # an extra line must never cost the headline
+                extra[key] = {"error": repr(e)[:200]}
+        res["extra"] = extra
+    if rank == 0:
+        print(json.dumps(res))
+    if dist is not None and dist.is_initialized():
         dist.destroy_process_group()
+    elif is_headline:
+        import torch.distributed as d3
+        if d3.is_initialized():
+            d3.destroy_process_group()
 
 
 if __name__ == '__main__':

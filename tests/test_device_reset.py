@@ -107,35 +107,35 @@ def test_in_tick_auto_teleport_matches_the_oracle(built, track, auto, ticks):
 
 
 def test_torch_env_runs_episodes_without_the_host(built):
-    """ProjectDTorchVecEnv: terminations -> reset mask on the device -> teleport at the top of the next tick; equals the numpy
-    ProjectDVecEnv (host-mask resets) lane for lane over a few hundred ticks with many episode ends"""
-    import torch, tempfile, synthetic_tracks, pdbatch, projectd_torch_env, projectd_env
-    d = tempfile.mkdtemp(prefix='pdb_envs_')
-    synthetic_tracks.make_base(d, tracks=('walled',))
-    import shutil, os
-    n = 32
-    P = pdbatch.packed_params()
+    """ProjectDTorchVecEnv: terminations -> reset mask on the device -> teleport at the top of the next tick; equals the same
+    bookkeeping done on the host with pdb_reset_mode between the ticks, lane for lane, over many episode ends (half the cars idle
+    and get `stuck` after stuck_timeout = 0.4 s, the others run into the walls of the strip)"""
+    import torch, pdbatch, projectd_torch_env, projectd_env
+    n, T = 32, 900
     trk = pdbatch.synthetic_track('walled')
-    te = projectd_torch_env.ProjectDTorchVecEnv(n, P, trk, device=0, terminate_low_reward=-30.0)
+    kw = dict(stuck_timeout=0.4, terminate_low_reward=-1.0e9)
+    te = projectd_torch_env.ProjectDTorchVecEnv(n, pdbatch.packed_params(), trk, device=0, **kw)
     rng = np.random.RandomState(3)
     base = rng.uniform(-1, 1, (n, 2)).astype(np.float32); base[:, 0] *= 0.2
-    o0 = te.reset().clone()
+    base[::2, 1] = -1.0      # gas 0.1: creeps, no new track point within 0.4 s
+    base[1::2, 1] = 1.0; base[1::2, 0] = np.where(np.arange(n // 2) % 2 == 0, 0.06, -0.06)   # full throttle into a side wall
+    te.reset()
     ends = 0
     hist = []
-    for t in range(700):
-        o, r, term, trunc = te.step(torch.from_numpy(base).cuda())
+    act = torch.from_numpy(base).cuda()
+    for t in range(T):
+        o, r, term, trunc = te.step(act)
         hist.append((o.clone().cpu().numpy(), r.cpu().numpy(), term.cpu().numpy()))
         ends += int(term.sum().item())
     te.close()
-    assert ends >= 5, ends
-    # replay with host-side bookkeeping through the C ABI: same observations / rewards / terminations
-    import pdbatch as pb
-    b = pb.Batch(n, pdbatch.packed_params(), trk, device=0, action_mode=1)
-    cfg = projectd_env.EnvConfig(terminate_low_reward=-30.0)
+    assert ends >= 40, ends
+    b = pdbatch.Batch(n, pdbatch.packed_params(), trk, device=0, action_mode=1)
+    b.set_stuck_timeout(0.4)
+    cfg = projectd_env.EnvConfig(**kw)
     b.reset(None, 0)
-    out = b.step_host(np.zeros((n, 2), np.float32))
+    b.step_host(np.zeros((n, 2), np.float32))
     total = np.zeros(n); pending = np.zeros(n, bool)
-    for t in range(700):
+    for t in range(T):
         a = base.copy(); a[pending] = 0.0
         out = b.step_host(a)
         obs = np.array(out['obs']); rew = np.array(out['reward'], dtype=np.float64); fl = np.array(out['flags'])
@@ -145,9 +145,9 @@ def test_torch_env_runs_episodes_without_the_host(built):
         total += rew; term |= total < cfg.terminate_low_reward
         rew[pending] = 0.0; term[pending] = False; total[pending] = 0.0
         ho, hr, ht = hist[t]
+        assert np.array_equal(ht, term), t
         assert np.array_equal(ho, obs), t
         assert np.array_equal(hr, rew.astype(np.float32)), t
-        assert np.array_equal(ht, term), t
         pending = term.copy()
         if term.any():
             b.reset(term.astype(np.uint8), 0)

@@ -313,7 +313,7 @@ def test_bench_rccl_gather_side_stream_on_one_gpu(built):
     assert d['n_gpus'] == 1 and 'side stream' in d['config']['collective'] and d['value'] > 1e6
 
 
-@pytest.mark.parametrize('n_cars,track', [(4099, 'flat'), (16384, 'touge')])
+@pytest.mark.parametrize('n_cars,track', [(4099, 'flat'), (8192, 'flat'), (16384, 'touge')])   # configs[1] (+ a ragged tail), the per-GPU shard of configs[3], configs[2]
 def test_full_size_batches_by_replication(built, n_cars, track):
     """BASELINE configs[1] / configs[2] sizes (and a car count that is not a multiple of the 3 cars per workgroup): 37 distinct
     constant actions tiled over the whole batch.  Size-independent properties: (1) every replica of an action ends in the
