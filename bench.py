@@ -31,7 +31,7 @@ sys.path.insert(0, os.path.join(ROOT, 'tests'))
 
 CARS_PER_GPU = 4096
 # algorithmic bytes per car-tick (DESIGN.md "Algorithmic bytes"): record read + record write + action + output row
-B_ALG = 2256 + 2256 + 8 + 104   # sizeof(pdb_dyn_state) in and out, float[2] action, pdb_step_out (checked against the ctypes mirrors in measure)
+B_ALG = 2272 + 2272 + 8 + 104   # sizeof(pdb_dyn_state) in and out, float[2] action, pdb_step_out (checked against the ctypes mirrors in measure)
 HBM_PEAK_GBS = 8000.0
 PROFILE_TAG = 'r02'
 
@@ -120,31 +120,13 @@ def measure(args, world, rank, local_rank, dist, want_cpu=False):
         import projectd_env
         obs_scale = (1.0 / torch.from_numpy(projectd_env.obs_bounds(projectd_env.EnvConfig())[1])).to(dev)
     tick_id = [0]
-    episodes = [None]
 
-    # --episodes: the env's own bookkeeping on the device (projectd_env.py:173-227: penalties, terminations, low-reward rule) and
-    # episode resets through the batch's reset mask -- teleport at the top of the terminated cars' next tick, no host round trip
+    # --episodes: the env loop -- rewards with penalties, terminations (hit / off track / stuck / low reward) and the reset tick
+    # (teleport + zero action) are evaluated inside the step kernel (pdb_set_env = projectd_env.py:173-227 per car), so a tick of
+    # the env is the same launches as a tick of the bare stepper
     if args.episodes:
         import projectd_env as E
-        cfg = E.EnvConfig()
-        reset_mask = torch.as_tensor(_Arr(b.reset_mask_ptr(), (n,), '|u1'), device=dev)
-        total_reward = torch.zeros(n, dtype=torch.float64, device=dev)
-        pending = torch.zeros(n, dtype=torch.bool, device=dev)
-        ends = torch.zeros((), dtype=torch.int64, device=dev)
-        episodes[0] = ends
-
-        def episode_step(o, a):
-            nonlocal total_reward, pending
-            fl = o[:, 25].view(torch.int32)                 # pdb_step_out.flags of the slot this tick wrote
-            hit = (fl & 1) != 0; off = (fl & 2) != 0; stuck = (fl & 4) != 0
-            reward = o[:, 24].to(torch.float64) - cfg.terminate_hit_penalty * hit - cfg.terminate_off_track_penalty * off - cfg.terminate_stuck_penalty * stuck
-            total_reward = total_reward + reward
-            term = (hit | off | stuck | (total_reward < cfg.terminate_low_reward)) & ~pending
-            total_reward = torch.where(pending | term, torch.zeros_like(total_reward), total_reward)
-            pending = term
-            reset_mask.copy_(term.to(torch.uint8))          # 1 + mode Start
-            ends.add_(term.sum())
-            a.mul_((~term)[:, None])                        # the reset tick steps with the zero action
+        b.set_env(E.EnvConfig())
 
     def policy_step(o, a):
         if policy == 'feedback':   # oracle/scenarios.h scenarioFeedback as elementwise device ops on the observation block
@@ -161,7 +143,7 @@ def measure(args, world, rank, local_rank, dist, want_cpu=False):
     use_ring = policy == 'constant' and args.partitions > 1 and not do_scatter
     # a per-tick policy: per-partition closed loops, unless a gather has to see whole ticks (N > 1)
     # and only where a tick is long enough to hide the doubled number of (small) policy launches: the host enqueues ~10 per partition and tick
-    part_loops = policy != 'constant' and args.partitions > 1 and not gather.active and n >= 8192 and not args.episodes
+    part_loops = policy != 'constant' and args.partitions > 1 and not gather.active and n >= 8192
     if use_ring or part_loops:
         b.set_partitions(args.partitions)
     if part_loops:
@@ -183,8 +165,6 @@ def measure(args, world, rank, local_rank, dist, want_cpu=False):
         b.set_out_device_ptr(o.data_ptr())
         b.step_async()
         policy_step(o, act_t)
-        if args.episodes:
-            episode_step(o, act_t)
         gather.after_tick(t)
 
     def run(nsteps):
@@ -271,7 +251,7 @@ def measure(args, world, rank, local_rank, dist, want_cpu=False):
              ("configs[2] shape: %d cars/GPU, AE86, synthetic closed mountain road (%s%s), policy=%s on the GPU, dt=1/333 s" %
               (n, "spline point every %.1f m" % args.spline_step if args.spline_step else "1782 triangles, 891 spline points", ", guard rails (WALL surfaces) along both edges" if args.walls else "", policy))
         if args.episodes:
-            wl += "; episodes: the env's terminations (hit / off track / stuck / low reward) with penalties, resets through the device reset mask"
+            wl += "; episodes: the env's rewards, terminations (hit / off track / stuck / low reward) and reset ticks inside the step kernel (pdb_set_env)"
         res = {
             "metric": "env-steps/sec (333 Hz tick, 4-wheel car)",
             "value": n * world * args.steps / elapsed,
@@ -292,8 +272,12 @@ def measure(args, world, rank, local_rank, dist, want_cpu=False):
                          "valu_issue_busy_frac": valu_busy,   # the resource that actually bounds the kernel (profiles/*_pmc.json; definition in DESIGN.md section 3)
                          "note": ("one launch = one partition (%d cars); %d partitions step concurrently on their own streams, so the device moves concurrent_launches x achieved" % (launch_cars, conc)) if conc > 1 else None},
         }
-        if args.episodes:
-            res["episodes_ended"] = int(episodes[0].item())
+        if args.episodes:   # how often episodes end in this workload: counted over 300 more ticks, outside the timed region
+            ends = torch.zeros((), dtype=torch.int64, device=dev)
+            for _ in range(300):
+                tick()
+                ends += ((gather.slot(tick_id[0] - 1)[:, 25].view(torch.int32) & 8) != 0).sum()
+            res["episode_ends_per_tick"] = float(ends.item()) / 300.0
         if want_cpu:   # the CPU leg is timed at N = 1 only
             res["cpu_baseline"] = cpu_baseline(P, trk, S0, all_actions)
     b.close()
@@ -307,10 +291,10 @@ EXTRA = [   # (key, argv) -- the other BASELINE configs' shapes, each measured b
     ("configs3_shard_8192", ['--cars', '8192', '--steps', '600', '--warmup', '100']),
     ("configs3_shard_8192_gather_k1_scatter", ['--cars', '8192', '--steps', '300', '--warmup', '50', '--force-gather', '--gather-ticks', '1', '--scatter-actions']),
     ("configs3_shard_8192_gather_k32", ['--cars', '8192', '--steps', '600', '--warmup', '100', '--force-gather', '--gather-ticks', '32']),
-    ("episodes_4096", ['--workload', 'touge', '--walls', '--cars', '4096', '--episodes', '--steps', '600', '--warmup', '100', '--settle', '200', '--partitions', '1']),
-    ("episodes_4096_reset_free", ['--workload', 'touge', '--walls', '--cars', '4096', '--policy', 'feedback', '--steps', '600', '--warmup', '100', '--settle', '200', '--partitions', '1']),
-    ("episodes_16384", ['--workload', 'touge', '--walls', '--cars', '16384', '--episodes', '--steps', '300', '--warmup', '50', '--settle', '200', '--partitions', '1']),
-    ("episodes_16384_reset_free", ['--workload', 'touge', '--walls', '--cars', '16384', '--policy', 'feedback', '--steps', '300', '--warmup', '50', '--settle', '200', '--partitions', '1']),
+    ("episodes_4096", ['--workload', 'touge', '--walls', '--cars', '4096', '--episodes', '--steps', '600', '--warmup', '100', '--settle', '200']),
+    ("episodes_4096_reset_free", ['--workload', 'touge', '--walls', '--cars', '4096', '--policy', 'feedback', '--steps', '600', '--warmup', '100', '--settle', '200']),
+    ("episodes_16384", ['--workload', 'touge', '--walls', '--cars', '16384', '--episodes', '--steps', '300', '--warmup', '50', '--settle', '200']),
+    ("episodes_16384_reset_free", ['--workload', 'touge', '--walls', '--cars', '16384', '--policy', 'feedback', '--steps', '300', '--warmup', '50', '--settle', '200']),
 ]
 
 
@@ -400,8 +384,8 @@ def main():
                 r = measure(a, 1, 0, 0, d2)
                 extra[key] = {"value": r["value"], "ms_per_step": r["ms_per_step"], "steps": r["steps"], "repeats": r["repeats"], "workload": r["config"]["workload"],
                               "partitions": r["config"]["partitions"], "collective": r["config"]["collective"], "kernel_avg_us": r["roofline"]["kernel_avg_us"]}
-                if "episodes_ended" in r:
-                    extra[key]["episodes_ended"] = r["episodes_ended"]
+                if "episode_ends_per_tick" in r:
+                    extra[key]["episode_ends_per_tick"] = r["episode_ends_per_tick"]
             except Exception as e:   # an extra line must never cost the headline
                 extra[key] = {"error": repr(e)[:200]}
         res["extra"] = extra

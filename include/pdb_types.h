@@ -261,6 +261,7 @@ typedef struct pdb_dyn_state {
     double engineVel, driveVel, outShaftLVel, outShaftRVel, rootVelocity;
     double gearReqTimeAccumulator, gearReqTimeout, cutOff, lastRatio, validShiftRPMWindow;
     double blipStartTime, fuel;
+    double envTotalReward;   /* env mode (pdb_set_env): the episode's cumulative reward, python-float arithmetic (projectd_env.py:199) */
     pdb_body_state body[PDB_MAX_BODIES];
     pdb_tyre_state tyre[4];
     /* car */
@@ -285,6 +286,9 @@ typedef struct pdb_dyn_state {
     float damageZoneLevel[5];   /* Car.h:204 */
     int32_t numContacts;     /* contact joints alive in the engine's contactGroupDynamic (the car's row of the pdb_contact array) */
     int32_t randState;       /* the car's C-runtime rand() state (Core/Math.h:49-52 randR -> Car::teleportByMode(Random)); srand(1) at creation */
+    int32_t envPending;      /* env mode: 1 = the episode ended on the last tick: the next tick is the reset tick (teleport + step([0,0]),
+                              * projectd_env.py:216-227); 2 = reset tick whose teleport the caller has already done */
+    int32_t envStepId;       /* env mode: ticks since the episode's reset tick (projectd_env.py step_id) */
     int32_t _pad[1];         /* record size is a multiple of 16 bytes (coalesced 16-byte-per-lane copies) */
 } pdb_dyn_state;
 
@@ -304,9 +308,22 @@ typedef struct pdb_contact {
 /* per-tick outputs (compact) */
 typedef struct pdb_step_out {
     float obs[PDB_OBS_DIM];   /* projectd_env.py:237-275 order */
-    float reward;             /* CarState.stepReward */
-    int32_t flags;            /* bit0 collisionFlag, bit1 outOfTrackFlag, bit2 stuck (lastTrackPointTimestamp + 5 < timestamp) */
+    float reward;             /* CarState.stepReward; in env mode the env's reward (penalties applied, 0 on a reset tick) */
+    int32_t flags;            /* bit0 collisionFlag, bit1 outOfTrackFlag, bit2 stuck (lastTrackPointTimestamp + stuck_timeout < timestamp);
+                               * env mode: bit3 terminated (the episode ended on this tick), bit4 this was the episode's reset tick */
 } pdb_step_out;
+
+/* Env mode: the reward / termination / reset bookkeeping of pyprojectd/projectd_env.py:173-227, per car, inside the tick --
+ * reward = stepReward minus the penalties of the rules that fired, terminate on hit / off track / stuck / cumulative reward below
+ * low_reward; the tick after a termination is the env's reset(): teleport by teleport_mode (if teleport_on_reset) at its top, the
+ * zero action, its reward and termination discarded, the episode sums cleared.  One kernel launch = one VecEnv.step(). */
+typedef struct pdb_env_config {
+    int32_t enabled;
+    int32_t terminate_on_hit, terminate_off_track, terminate_when_stuck;
+    double hit_penalty, off_track_penalty, stuck_penalty;
+    double low_reward;
+    int32_t teleport_on_reset, teleport_mode;
+} pdb_env_config;
 
 /* ---------------------------------------------------------------------------------------------
  * Track blob: header followed by arrays (offsets in bytes from the start of the blob)
@@ -351,7 +368,7 @@ typedef struct pdb_track_header {
 /* sizes are part of the ABI (tests/test_abi.py reads these numbers) */
 static_assert(sizeof(pdb_car_state) == 664, "pdb_car_state must equal the reference CarState (pack 4)");
 static_assert(sizeof(pdb_car_params) == 12392, "pdb_car_params layout");
-static_assert(sizeof(pdb_dyn_state) == 2256, "pdb_dyn_state layout (multiple of 16 bytes)");
+static_assert(sizeof(pdb_dyn_state) == 2272, "pdb_dyn_state layout (multiple of 16 bytes)");
 static_assert(sizeof(pdb_step_out) == 104, "pdb_step_out layout");
 static_assert(sizeof(pdb_contact) == 32, "pdb_contact layout");
 #endif

@@ -111,6 +111,10 @@ int pdb_reset_device(pdb_batch* b, const uint8_t* device_mask, int mode);
 uint8_t* pdb_reset_mask_device(pdb_batch* b);
 /* seconds without a new track point before pdb_step_out.flags bit 2 (stuck) rises: projectd_env.py stuck_timeout, default 5 */
 int pdb_set_stuck_timeout(pdb_batch* b, double seconds);
+/* Env mode: the reward / termination / reset bookkeeping of pyprojectd/projectd_env.py:173-227 per car inside the tick (see
+ * pdb_env_config): pdb_step_out.reward is the env's reward, flags bit 3 = terminated, bit 4 = reset tick; a terminated car's next
+ * tick teleports it (teleport_on_reset) and steps it with the zero action.  ProjectDVecEnv.step() = one launch. */
+int pdb_set_env(pdb_batch* b, const pdb_env_config* cfg);
 /* setSeed (PyProjectD.cpp:50-53 = srand) per car: the state of the car's own C-runtime rand(), used by the Random teleport mode */
 int pdb_set_seed(pdb_batch* b, const uint32_t* seeds);
 /* device pointers owned by the batch: float actions[N][2], pdb_step_out out[N] */

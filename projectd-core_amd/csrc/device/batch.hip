@@ -378,6 +378,19 @@ int pdb_set_stuck_timeout(pdb_batch* b, double seconds) {
     HIPCHK(hipMemcpy(b->dK, &b->K, sizeof(DevConst), hipMemcpyHostToDevice));
     return PDB_OK;
 }
+int pdb_set_env(pdb_batch* b, const pdb_env_config* cfg) {
+    if (!b || !cfg || cfg->teleport_mode < 0 || cfg->teleport_mode > 2) { pdb::setError("pdb_set_env: bad argument"); return PDB_ERR_ARG; }
+    if (int rcj = joinParts(b)) return rcj;
+    for (int p = 0; p < b->parts; ++p) if (b->partStream[p]) HIPCHK(hipStreamSynchronize(b->partStream[p]));
+    HIPCHK(hipStreamSynchronize(b->stream));
+    DevConst& K = b->K;
+    K.envMode = cfg->enabled ? 1 : 0;
+    K.envTermHit = cfg->terminate_on_hit ? 1 : 0; K.envTermOff = cfg->terminate_off_track ? 1 : 0; K.envTermStuck = cfg->terminate_when_stuck ? 1 : 0;
+    K.envHitPenalty = cfg->hit_penalty; K.envOffPenalty = cfg->off_track_penalty; K.envStuckPenalty = cfg->stuck_penalty; K.envLowReward = cfg->low_reward;
+    K.envTeleportOnReset = cfg->teleport_on_reset ? 1 : 0; K.envTeleportMode = cfg->teleport_mode;
+    HIPCHK(hipMemcpy(b->dK, &b->K, sizeof(DevConst), hipMemcpyHostToDevice));
+    return PDB_OK;
+}
 int pdb_set_seed(pdb_batch* b, const uint32_t* seeds) {
     if (!b || !seeds) { pdb::setError("null argument"); return PDB_ERR_ARG; }
     std::vector<pdb_dyn_state> st((size_t)b->n);

@@ -18,6 +18,9 @@ struct DevConst {
     float invMass[PDB_MAX_BODIES], invInertia[PDB_MAX_BODIES][3];   // 1.0f / mass, 1.0f / inertia: divided once on the host (IEEE single division on both sides)
     double dtD;
     double stuckTimeout;   // seconds without a new track point before pdb_step_out.flags bit 2 rises (projectd_env.py stuck_timeout = 5.0)
+    // env mode (pdb_set_env): projectd_env.py:173-227 evaluated per car inside the tick
+    double envHitPenalty, envOffPenalty, envStuckPenalty, envLowReward;
+    int envMode, envTermHit, envTermOff, envTermStuck, envTeleportOnReset, envTeleportMode;
     int actionMode;
     int wantCarState;
     unsigned long long* stamps;   // diagnostic build only (-DPDB_STAMPS): [car][16] shader-clock stamps

@@ -10,7 +10,8 @@
 // the pose helpers and the reset edits (reset_core.hpp) are compiled for the host library (g++) and, unchanged, for the HIP
 // kernels (hipcc): IEEE single precision, contraction off on both sides, so both produce the same bits
 #if defined(__HIPCC__)
-#define PDB_HD __host__ __device__
+#include <hip/hip_runtime.h>
+#define PDB_HD __host__ __device__ __attribute__((always_inline))
 #else
 #define PDB_HD
 #endif

@@ -147,9 +147,11 @@ PDB_HD inline float randR01(uint32_t& holdrand) {
 // Car::teleportByMode (Car.cpp:1320-1336): 0 Start, 1 Nearest (the car's trackLocation), 2 Random
 template <class RayDown>
 PDB_HD inline void teleportByModeT(const pdb_car_params& P, int numFat, const float* fat, RayDown rayDown, int mode, pdb_dyn_state& S) {
-    if (mode == 0) teleportToSplineT(P, numFat, fat, rayDown, 0.0f, S);
-    else if (mode == 1) teleportToSplineT(P, numFat, fat, rayDown, S.trackLocation, S);
-    else if (mode == 2) { uint32_t h = (uint32_t)S.randState; const float d = randR01(h); S.randState = (int32_t)h; teleportToSplineT(P, numFat, fat, rayDown, d, S); }
+    float d = 0.0f;
+    if (mode == 1) d = S.trackLocation;
+    else if (mode == 2) { uint32_t h = (uint32_t)S.randState; d = randR01(h); S.randState = (int32_t)h; }
+    else if (mode != 0) return;
+    teleportToSplineT(P, numFat, fat, rayDown, d, S);
 }
 
 }  // namespace pdb

@@ -252,6 +252,35 @@ void resetBatch(int id, py::object mask, int mode) {   // teleportCarByMode(mode
     auto m = py::array_t<uint8_t, py::array::c_style | py::array::forcecast>::ensure(mask);
     if (m && m.size() == B->n) pdb_reset_mode(B->b, m.data(), mode);
 }
+// the env's reward / termination / reset rules evaluated inside the tick (pdb_set_env): one stepBatch = one VecEnv.step()
+void setBatchEnv(int id, bool enabled, bool termHit, bool termOff, bool termStuck, double hitPenalty, double offPenalty, double stuckPenalty, double lowReward,
+                 bool teleportOnReset, int teleportMode) {
+    Batch* B = getBatch(id);
+    if (!B) return;
+    pdb_env_config c{};
+    c.enabled = enabled; c.terminate_on_hit = termHit; c.terminate_off_track = termOff; c.terminate_when_stuck = termStuck;
+    c.hit_penalty = hitPenalty; c.off_track_penalty = offPenalty; c.stuck_penalty = stuckPenalty; c.low_reward = lowReward;
+    c.teleport_on_reset = teleportOnReset; c.teleport_mode = teleportMode;
+    if (pdb_set_env(B->b, &c) != PDB_OK) logf("EXCEPTION: %s", pdb_last_error());
+}
+// env mode: the masked lanes were teleported by resetBatch; their next tick is the episode's reset tick (zero action, reward and
+// termination discarded, sums cleared) -- envPending = 2: reset tick, pose already set
+void markBatchResetTick(int id, py::array_t<uint8_t, py::array::c_style | py::array::forcecast> mask) {
+    Batch* B = getBatch(id);
+    if (!B || mask.size() != B->n) return;
+    std::vector<pdb_dyn_state> st((size_t)B->n);
+    if (pdb_get_state(B->b, 0, B->n, st.data()) != PDB_OK) return;
+    for (int i = 0; i < B->n; ++i) if (mask.data()[i]) st[(size_t)i].envPending = 2;
+    pdb_set_state(B->b, 0, B->n, st.data());
+}
+void clearBatchEpisodes(int id) {   // a fresh episode in every lane: the env-mode sums of the records
+    Batch* B = getBatch(id);
+    if (!B) return;
+    std::vector<pdb_dyn_state> st((size_t)B->n);
+    if (pdb_get_state(B->b, 0, B->n, st.data()) != PDB_OK) return;
+    for (auto& s : st) { s.envTotalReward = 0.0; s.envPending = 0; s.envStepId = 0; }
+    pdb_set_state(B->b, 0, B->n, st.data());
+}
 void setBatchStuckTimeout(int id, double seconds) { if (Batch* B = getBatch(id)) pdb_set_stuck_timeout(B->b, seconds); }
 void setBatchSeeds(int id, py::array_t<uint32_t, py::array::c_style | py::array::forcecast> seeds) {   // one setSeed per lane
     Batch* B = getBatch(id);
@@ -356,6 +385,9 @@ PYBIND11_MODULE(PyProjectD, m) {
     m.def("stepBatch", &stepBatch, "", py::arg("batchId"), py::arg("actions"), py::arg("dt") = 1.0 / 333.0);
     m.def("resetBatch", &resetBatch, "", py::arg("batchId"), py::arg("mask") = py::none(), py::arg("mode") = 0);
     m.def("setBatchStuckTimeout", &setBatchStuckTimeout, "");
+    m.def("setBatchEnv", &setBatchEnv, "");
+    m.def("clearBatchEpisodes", &clearBatchEpisodes, "");
+    m.def("markBatchResetTick", &markBatchResetTick, "");
     m.def("setBatchSeeds", &setBatchSeeds, "");
     m.def("getBatchCarState", &getBatchCarState, "");
 }

@@ -96,7 +96,7 @@ class TyreState(C.Structure):
          ('practicalTemp', C.c_float), ('T', C.c_float * 36), ('isLocked', C.c_int32), ('inputT0', C.c_float)]
 class DynState(C.Structure):
     _fields_ = [(n, C.c_double) for n in ('physicsTime', 'engineVel', 'driveVel', 'outShaftLVel', 'outShaftRVel', 'rootVelocity', 'gearReqTimeAccumulator', 'gearReqTimeout',
-                                          'cutOff', 'lastRatio', 'validShiftRPMWindow', 'blipStartTime', 'fuel')] + \
+                                          'cutOff', 'lastRatio', 'validShiftRPMWindow', 'blipStartTime', 'fuel', 'envTotalReward')] + \
         [('body', BodyState * MAX_BODIES), ('tyre', TyreState * 4), ('smoothSteerValue', C.c_float), ('lastVelocity', C.c_float * 3), ('waterT', C.c_float),
          ('lastTrackPointTimestamp', C.c_float), ('trackLocation', C.c_float), ('oldTrackLocation', C.c_float), ('bodyVsTrack', C.c_float), ('velocityVsTrack', C.c_float),
          ('pointCachePos', C.c_float * 3), ('speed', C.c_float)] + \
@@ -107,12 +107,16 @@ class DynState(C.Structure):
         [(n, C.c_int32) for n in ('oldPointId', 'oldSplinePointId', 'drifting', 'driftExtreme', 'driftInvalid', 'driftComboCounter', 'collisionFlag', 'oldCollisionFlag',
                                   'outOfTrackFlag')] + \
         [('gasUsage', C.c_float), ('locClutch', C.c_float), ('turboRotation', C.c_float * 3), ('simFrame', C.c_int32), ('damageChanged', C.c_int32),
-         ('damageZoneLevel', C.c_float * 5), ('numContacts', C.c_int32), ('randState', C.c_int32), ('_pad', C.c_int32 * 1)]
+         ('damageZoneLevel', C.c_float * 5), ('numContacts', C.c_int32), ('randState', C.c_int32), ('envPending', C.c_int32), ('envStepId', C.c_int32), ('_pad', C.c_int32 * 1)]
 assert C.sizeof(DynState) % 16 == 0
 MAX_CONTACTS = 10
 class Contact(C.Structure):   # pdb_contact
     _fields_ = [('pos', C.c_float * 3), ('depth', C.c_float), ('normal', C.c_float * 3), ('kind', C.c_int32)]
 assert C.sizeof(Contact) == 32
+class EnvConfig(C.Structure):   # pdb_env_config
+    _fields_ = [('enabled', C.c_int32), ('terminate_on_hit', C.c_int32), ('terminate_off_track', C.c_int32), ('terminate_when_stuck', C.c_int32),
+                ('hit_penalty', C.c_double), ('off_track_penalty', C.c_double), ('stuck_penalty', C.c_double), ('low_reward', C.c_double),
+                ('teleport_on_reset', C.c_int32), ('teleport_mode', C.c_int32)]
 class StepOut(C.Structure):
     _fields_ = [('obs', C.c_float * 24), ('reward', C.c_float), ('flags', C.c_int32)]
 
@@ -149,6 +153,7 @@ def load_product(host_only=False):
         lib.pdb_reset_mask_device.restype = C.c_void_p; lib.pdb_reset_mask_device.argtypes = [C.c_void_p]
         lib.pdb_set_stuck_timeout.argtypes = [C.c_void_p, C.c_double]
         lib.pdb_set_seed.argtypes = [C.c_void_p, C.c_void_p]
+        lib.pdb_set_env.argtypes = [C.c_void_p, C.c_void_p]
         lib.pdb_actions_device.restype = C.c_void_p; lib.pdb_actions_device.argtypes = [C.c_void_p]
         lib.pdb_out_device.restype = C.c_void_p; lib.pdb_out_device.argtypes = [C.c_void_p]
         lib.pdb_set_out_device.argtypes = [C.c_void_p, C.c_void_p]

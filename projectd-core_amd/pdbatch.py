@@ -159,6 +159,21 @@ class Batch:
         """device array of n bytes: a car whose byte is 1 + mode is teleported at the top of its next tick, which clears the byte"""
         return self.lib.pdb_reset_mask_device(self.h)
 
+    def set_env(self, cfg=None, **kw):
+        """env mode (pdb_set_env): the reward / termination / reset rules of projectd_env.py:173-227 inside the tick.  cfg: an object with
+        the reference env's attribute names (projectd_env.EnvConfig), or keyword overrides; set_env(enabled=False) switches it off."""
+        g = lambda k, d: kw.get(k, getattr(cfg, k, d) if cfg is not None else d)
+        c = pc.EnvConfig()
+        c.enabled = 1 if kw.get('enabled', True) else 0
+        c.terminate_on_hit = int(g('terminate_on_hit', True)); c.terminate_off_track = int(g('terminate_off_track', True)); c.terminate_when_stuck = int(g('terminate_when_stuck', True))
+        c.hit_penalty = float(g('terminate_hit_penalty', 50.0)); c.off_track_penalty = float(g('terminate_off_track_penalty', 50.0)); c.stuck_penalty = float(g('terminate_stuck_penalty', 50.0))
+        c.low_reward = float(g('terminate_low_reward', -200.0))
+        c.teleport_on_reset = int(g('teleport_on_reset', True)); c.teleport_mode = int(g('teleport_mode', 0))
+        self._chk(self.lib.pdb_set_env(self.h, C.byref(c)))
+        st = g('stuck_timeout', 5.0)
+        if st != 5.0:
+            self.set_stuck_timeout(st)
+
     def set_stuck_timeout(self, seconds):
         self._chk(self.lib.pdb_set_stuck_timeout(self.h, C.c_double(seconds)))
 

@@ -113,11 +113,20 @@ class ProjectDVecEnv:
             raise RuntimeError('createBatch failed (no GPU? there is no CPU fallback)')
         if self.cfg.stuck_timeout != 5.0:
             pd.setBatchStuckTimeout(self.batch, float(self.cfg.stuck_timeout))
+        self._set_kernel_env(self.auto_reset)
         self.total_reward = np.zeros(self.num_envs, dtype=np.float64)
         self.step_id = np.zeros(self.num_envs, dtype=np.int64)
         self.pending_reset = np.zeros(self.num_envs, dtype=bool)
         self.observation_bounds = obs_bounds(self.cfg)
         self.action_bounds = (np.array([-1.0, -1.0], np.float32), np.array([1.0, 1.0], np.float32))
+
+    def _set_kernel_env(self, on):
+        """auto_reset: the reward / termination / reset-tick rules below run inside the step kernel (pdb_set_env), step() only unpacks"""
+        c = self.cfg
+        pd.setBatchEnv(self.batch, bool(on), bool(c.terminate_on_hit), bool(c.terminate_off_track), bool(c.terminate_when_stuck),
+                       float(c.terminate_hit_penalty), float(c.terminate_off_track_penalty), float(c.terminate_stuck_penalty), float(c.terminate_low_reward),
+                       bool(c.teleport_on_reset), int(c.teleport_mode))
+        self.kernel_env = bool(on)
 
     def close(self):
         if self.batch >= 0:
@@ -137,6 +146,14 @@ class ProjectDVecEnv:
         step([0,0]), clear the episode sums), its reward is 0 and the observation returned is the new episode's first."""
         cfg = self.cfg
         a = np.array(actions, dtype=np.float32).reshape(self.num_envs, 2)
+        if self.kernel_env:   # everything below happened inside the kernel (flags bit 3 = terminated, bit 4 = this was the reset tick)
+            obs, reward, flags = self._raw_step(a)
+            terminated = (flags & 8) != 0
+            fresh = (flags & 16) != 0
+            self.total_reward += reward; self.total_reward[fresh] = 0.0
+            self.step_id += 1; self.step_id[fresh] = 0
+            info = {'episode_reward': self.total_reward.copy()} if terminated.any() else {}
+            return obs, reward.astype(np.float32), terminated, np.zeros(self.num_envs, dtype=bool), info
         fresh = self.pending_reset.copy()
         a[fresh] = 0.0
         obs, reward, flags = self._raw_step(a)
@@ -170,12 +187,23 @@ class ProjectDVecEnv:
         """Reset every lane (mask None) -- teleport + one zero-action tick, returns the first observations -- or schedule
         the masked lanes: they are teleported now and take their zero-action reset tick inside the next step()."""
         if mask is None:
+            was = self.kernel_env
+            if was:
+                self._set_kernel_env(False)
             if self.cfg.teleport_on_reset:
                 pd.resetBatch(self.batch, None, int(self.cfg.teleport_mode))
             obs, _, _ = self._raw_step(np.zeros((self.num_envs, 2), np.float32))
             self.total_reward[:] = 0.0; self.step_id[:] = 0; self.pending_reset[:] = False
+            if was:
+                pd.clearBatchEpisodes(self.batch)
+                self._set_kernel_env(True)
             return obs
         m = np.ascontiguousarray(mask).astype(bool)
+        if self.kernel_env:   # teleport now; the kernel treats the lanes' next tick as their reset tick
+            if self.cfg.teleport_on_reset:
+                pd.resetBatch(self.batch, m.astype(np.uint8), int(self.cfg.teleport_mode))
+            pd.markBatchResetTick(self.batch, m.astype(np.uint8))
+            return None
         if self.cfg.teleport_on_reset:
             pd.resetBatch(self.batch, m.astype(np.uint8), int(self.cfg.teleport_mode))
         self.pending_reset |= m

@@ -19,6 +19,9 @@ class _DevView:
         self.__cuda_array_interface__ = {'shape': shape, 'typestr': typestr, 'data': (ptr, False), 'version': 2}
 
 
+FLAG_TERMINATED, FLAG_RESET_TICK = 8, 16   # pdb_step_out.flags in env mode (include/pdb_types.h)
+
+
 class ProjectDTorchVecEnv:
     def __init__(self, num_envs, params, track_blob, device=0, **settings):
         self.cfg = cfg = E.EnvConfig(**settings)
@@ -30,55 +33,35 @@ class ProjectDTorchVecEnv:
             raise ValueError(lib.pdb_last_error().decode())
         self.batch = pdbatch.Batch(n, params, track_blob, device=device, action_mode=1)
         self.batch.set_stream(torch.cuda.current_stream(self.dev).cuda_stream)
-        if cfg.stuck_timeout != 5.0:
-            self.batch.set_stuck_timeout(cfg.stuck_timeout)
-        self.reset_mask = torch.as_tensor(_DevView(self.batch.reset_mask_ptr(), (n,), '|u1'), device=self.dev)
+        self.batch.set_env(cfg)   # rewards with penalties, terminations, the reset tick: all inside the step kernel
         self.act = torch.as_tensor(_DevView(self.batch.actions_device_ptr(), (n, 2)), device=self.dev)
         self.out = torch.as_tensor(_DevView(self.batch.out_device_ptr(), (n, 26)), device=self.dev)
         self.flags = torch.as_tensor(_DevView(self.batch.out_device_ptr(), (n, 26), '<i4'), device=self.dev)[:, 25]
-        self.total_reward = torch.zeros(n, dtype=torch.float64, device=self.dev)
-        self.pending_reset = torch.zeros(n, dtype=torch.bool, device=self.dev)
-        self.step_id = torch.zeros(n, dtype=torch.int64, device=self.dev)
 
     def close(self):
         self.batch.close()
 
     def reset(self):
+        """every lane: teleport + the zero-action tick (projectd_env.py:216-227); returns the first observations"""
+        self.batch.set_env(self.cfg, enabled=False)
         if self.cfg.teleport_on_reset:
             self.batch.reset(None, self.cfg.teleport_mode)
         self.act.zero_()
         self.batch.step_async()
-        self.total_reward.zero_(); self.step_id.zero_(); self.pending_reset.zero_()
+        self.batch.sync()
+        st = self.batch.get_state()
+        for s in st:
+            s.envTotalReward = 0.0; s.envPending = 0; s.envStepId = 0
+        self.batch.set_state(st)
+        self.batch.set_env(self.cfg)
         return self.out[:, :E.OBS_DIM]
 
     def step(self, actions):
-        """actions: float32 tensor [N, 2] on the device.  Returns views / tensors on the device: obs [N, 24] (a view of the
-        batch's output block: consume it before the next step), reward [N], terminated [N], truncated [N]."""
-        cfg = self.cfg
-        fresh = self.pending_reset
-        self.act.copy_(torch.where(fresh[:, None], torch.zeros_like(actions), actions))
+        """actions: float32 tensor [N, 2] on the device.  One kernel launch (plus the contact pass's): the env's reward with its
+        penalties, the terminations, and -- on the tick after a termination -- the teleport and the zero action of the env's
+        reset() all happen inside it.  Returns views on the batch's output block (consume them before the next step): obs [N, 24],
+        reward [N], terminated [N] (bool), truncated [N].  No host synchronisation."""
+        self.act.copy_(actions)
         self.batch.step_async()
-        obs = self.out[:, :E.OBS_DIM]
-        reward = self.out[:, 24].to(torch.float64)
-        fl = self.flags
-        terminated = torch.zeros(self.num_envs, dtype=torch.bool, device=self.dev)
-        if cfg.terminate_on_hit:
-            hit = (fl & E.FLAG_COLLISION) != 0
-            reward = reward - cfg.terminate_hit_penalty * hit; terminated = terminated | hit
-        if cfg.terminate_off_track:
-            off = (fl & E.FLAG_OFFTRACK) != 0
-            reward = reward - cfg.terminate_off_track_penalty * off; terminated = terminated | off
-        if cfg.terminate_when_stuck:
-            stuck = (fl & E.FLAG_STUCK) != 0
-            reward = reward - cfg.terminate_stuck_penalty * stuck; terminated = terminated | stuck
-        self.total_reward += reward
-        terminated = terminated | (self.total_reward < cfg.terminate_low_reward)
-        self.step_id += 1
-        reward = torch.where(fresh, torch.zeros_like(reward), reward)
-        terminated = terminated & ~fresh
-        self.total_reward = torch.where(fresh, torch.zeros_like(self.total_reward), self.total_reward)
-        self.step_id = torch.where(fresh, torch.zeros_like(self.step_id), self.step_id)
-        self.pending_reset = terminated.clone()
-        if cfg.teleport_on_reset:   # the next tick teleports these lanes first (value = 1 + Car::teleportByMode's mode), then steps them
-            self.reset_mask.copy_(terminated.to(torch.uint8) * (1 + int(cfg.teleport_mode)))
-        return obs, reward.to(torch.float32), terminated, torch.zeros_like(terminated)
+        terminated = (self.flags & FLAG_TERMINATED) != 0
+        return self.out[:, :E.OBS_DIM], self.out[:, 24], terminated, torch.zeros_like(terminated)
