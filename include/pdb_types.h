@@ -310,7 +310,8 @@ typedef struct pdb_step_out {
     float obs[PDB_OBS_DIM];   /* projectd_env.py:237-275 order */
     float reward;             /* CarState.stepReward; in env mode the env's reward (penalties applied, 0 on a reset tick) */
     int32_t flags;            /* bit0 collisionFlag, bit1 outOfTrackFlag, bit2 stuck (lastTrackPointTimestamp + stuck_timeout < timestamp);
-                               * env mode: bit3 terminated (the episode ended on this tick), bit4 this was the episode's reset tick */
+                               * env mode: bit3 terminated (the episode ended on this tick), bit4 this was the episode's reset tick;
+                               * bit5 fault: the chassis pose or velocity is not finite (the car needs a reset) */
 } pdb_step_out;
 
 /* Env mode: the reward / termination / reset bookkeeping of pyprojectd/projectd_env.py:173-227, per car, inside the tick --

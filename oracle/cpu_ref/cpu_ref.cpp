@@ -1845,6 +1845,11 @@ void Car::fillStepOut(pdb_step_out& o) const {
     for (int i = 0; i < 7; ++i) o.obs[k++] = cs.probes[i];
     o.reward = cs.stepReward;
     o.flags = (cs.collisionFlag ? 1 : 0) | (cs.outOfTrackFlag ? 2 : 0) | (((double)cs.lastTrackPointTimestamp + 5.0 < (double)cs.timestamp) ? 4 : 0);
+    {   // fault bit (include/pdb_types.h): non-finite chassis pose / velocity
+        const Body& b = w.bodies[PDB_BODY_CHASSIS];
+        const float chk = ((b.pos[0] + b.pos[1]) + (b.pos[2] + b.q[0])) + ((b.q[1] + b.q[2]) + (b.q[3] + b.lvel[0])) + ((b.lvel[1] + b.lvel[2]) + (b.avel[0] + b.avel[1])) + b.avel[2];
+        if (!std::isfinite(chk)) o.flags |= 32;
+    }
 }
 
 void Car::fillProbe(pdoracle::Probe& Pr) const {

@@ -134,7 +134,7 @@ static void fillConst(const pdb_car_params& P, DevConst& K, int actionMode) {
     }
     for (int j = P.numJoints; j <= PDB_MAX_JOINTS; ++j) K.rowStart[j] = r;
     for (int j = 0; j < P.numJoints; ++j)
-        for (int rr = K.rowStart[j]; rr < K.rowStart[j + 1] && rr < PDB_MAX_ROWS; ++rr) { K.rowB0[rr] = P.joints[j].b0; K.rowB1[rr] = P.joints[j].b1; }
+        for (int rr = K.rowStart[j]; rr < K.rowStart[j + 1] && rr < PDB_MAX_ROWS; ++rr) { K.rowB0[rr] = P.joints[j].b0; K.rowB1[rr] = P.joints[j].b1; K.rowFirst[rr] = (rr == K.rowStart[j]) ? 1 : 0; }
     for (int b = 0; b < PDB_MAX_BODIES; ++b) {
         K.invMass[b] = (b < P.numBodies) ? 1.0f / P.bodies[b].mass : 0.0f;
         for (int k = 0; k < 3; ++k) K.invInertia[b][k] = (b < P.numBodies) ? 1.0f / P.bodies[b].inertia[k] : 0.0f;
@@ -428,14 +428,26 @@ int pdb_step_n(pdb_batch* b, float dt, int n) {
     if (!b || n <= 0) { pdb::setError("bad argument"); return PDB_ERR_ARG; }
     if (int rcj = joinParts(b)) return rcj;
     if (n == 1) return pdb_step(b, dt);
+    // the constants are made current before any graph launch, not only when the graph is rebuilt (a pdb_step_host in between
+    // leaves wantCarState = 1 behind); the capture must not contain the H2D copy
+    if (b->K.dt != dt || b->K.wantCarState != 0) {
+        b->K.dt = dt; b->K.fps = 1.0f / dt; b->K.dtD = (dt == (float)(1.0 / 333.0)) ? (1.0 / 333.0) : (double)dt; b->K.wantCarState = 0;
+        HIPCHK(hipMemcpyAsync(b->dK, &b->K, sizeof(DevConst), hipMemcpyHostToDevice, b->stream));
+        HIPCHK(hipStreamSynchronize(b->stream));
+    }
+    if (b->stream == nullptr) {   // the legacy default stream (a caller's pdb_set_stream) cannot be captured: n plain launches
+        HIPCHK(hipEventRecord(b->ev0, b->stream));
+        for (int i = 0; i < n; ++i) launchTick(b, b->stream, 0, b->n, b->dOutActive, PDB_MAX_PARTS);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipEventRecord(b->ev1, b->stream));
+        HIPCHK(hipEventSynchronize(b->ev1));
+        float ms0 = 0;
+        HIPCHK(hipEventElapsedTime(&ms0, b->ev0, b->ev1));
+        b->kernelMs += ms0; b->kernelLaunches += n;
+        return PDB_OK;
+    }
     if (!b->graphExec || b->graphTicks != n || b->graphDt != dt) {
         if (b->graphExec) { (void)hipGraphExecDestroy(b->graphExec); b->graphExec = nullptr; }
-        // make sure the constants are current before capture (the capture must not contain the H2D copy)
-        if (b->K.dt != dt || b->K.wantCarState != 0) {
-            b->K.dt = dt; b->K.fps = 1.0f / dt; b->K.dtD = (dt == (float)(1.0 / 333.0)) ? (1.0 / 333.0) : (double)dt; b->K.wantCarState = 0;
-            HIPCHK(hipMemcpyAsync(b->dK, &b->K, sizeof(DevConst), hipMemcpyHostToDevice, b->stream));
-            HIPCHK(hipStreamSynchronize(b->stream));
-        }
         hipGraph_t g = nullptr;
         HIPCHK(hipStreamBeginCapture(b->stream, hipStreamCaptureModeThreadLocal));
         for (int i = 0; i < n; ++i)
@@ -473,6 +485,8 @@ int pdb_set_stream(pdb_batch* b, void* hip_stream) {
 int pdb_set_partitions(pdb_batch* b, int parts) {
     if (!b || parts < 1 || parts > PDB_MAX_PARTS) { pdb::setError("pdb_set_partitions: 1..4 parts"); return PDB_ERR_ARG; }
     HIPCHK(hipSetDevice(b->device));
+    if (int rcj = joinParts(b)) return rcj;
+    for (int p = 0; p < PDB_MAX_PARTS; ++p) if (b->partStream[p]) HIPCHK(hipStreamSynchronize(b->partStream[p]));   // the old cut's kernels
     HIPCHK(hipStreamSynchronize(b->stream));
     for (int p = 0; p < parts; ++p) {
         if (!b->partStream[p]) HIPCHK(hipStreamCreateWithFlags(&b->partStream[p], hipStreamNonBlocking));
@@ -487,6 +501,7 @@ int pdb_set_partitions(pdb_batch* b, int parts) {
 int pdb_step_ring(pdb_batch* b, float dt, int n_ticks, pdb_step_out* ring, int ring_slots, int first_slot, int join) {
     if (!b || n_ticks <= 0 || (ring && (ring_slots <= 0 || first_slot < 0))) { pdb::setError("pdb_step_ring: bad argument"); return PDB_ERR_ARG; }
     if (b->K.dt != dt || b->K.wantCarState != 0) {
+        if (int rcj = joinParts(b)) return rcj;   // the constants change under kernels that may still read them: those first
         b->K.dt = dt; b->K.fps = 1.0f / dt; b->K.dtD = (dt == (float)(1.0 / 333.0)) ? (1.0 / 333.0) : (double)dt; b->K.wantCarState = 0;
         HIPCHK(hipMemcpyAsync(b->dK, &b->K, sizeof(DevConst), hipMemcpyHostToDevice, b->stream));
     }
@@ -579,6 +594,7 @@ int pdb_sync(pdb_batch* b) {
 
 int pdb_step_host(pdb_batch* b, const float* actions, float dt, pdb_step_out* out) {
     if (!b || !actions) { pdb::setError("null argument"); return PDB_ERR_ARG; }
+    if (int rcj = joinParts(b)) return rcj;   // partition kernels still in flight read the action block
     HIPCHK(hipMemcpyAsync(b->dActions, actions, sizeof(float) * b->actionStride * (size_t)b->n, hipMemcpyHostToDevice, b->stream));
     int rc = launch(b, dt, true);
     if (rc != PDB_OK) return rc;

@@ -12,6 +12,7 @@ struct DevConst {
     float camC[4], camS[4], camM33[4];   // cos/sin of the static camber and ((1-c)+c) (mat44f::createFromAxisAngle about z)
     float acos096;                        // pm::acosf_(0.96f)
     int rowStart[PDB_MAX_JOINTS + 1];
+    int rowFirst[PDB_MAX_ROWS];                     // 1: the row is its joint's first
     int rowB0[PDB_MAX_ROWS], rowB1[PDB_MAX_ROWS];   // bodies of each constraint row (static per model: scalar loads in the A assembly)
     float dt;
     float fps;   // 1.0f / dt

@@ -12,8 +12,8 @@
 //   BrakeSystem::init, AeroMap::init, Wing::init              Car/BrakeSystem.cpp:14-73, AeroMap.cpp:15-81, Wing.cpp:19-69
 //   Simulator::init                                           Sim/Simulator.cpp:23-87
 // Joint anchors follow the ODE setters the reference calls (Physics/ODE/JointODE.cpp:21-60).
-// Only STRUT front / AXLE rear, RWD or FWD, no turbo is supported in this round; anything else
-// raises an error (no silent fallback).
+// Supported: STRUT / DWB / ML front with AXLE / DWB / ML rear, RWD or FWD, turbochargers, up to 6 wings, heave springs; anything
+// else in a car's data (dynamic controllers, EBB, 4WD ...) raises an error naming it (no silent fallback).
 #include "model.hpp"
 #include "ini.hpp"
 #include "rbmath.hpp"

@@ -195,6 +195,7 @@ std::vector<uint8_t> buildTrack(const std::string& basePathIn, const std::string
             for (uint32_t t = 0; t < b.numIndices / 3; ++t)
                 for (int k = 0; k < 3; ++k) {
                     float vv[3];
+                    if (ix[3 * t + k] >= b.numVertices) throw std::runtime_error("pdb: surface index out of range in " + trackName + "/surfaces.bin");
                     memcpy(vv, reinterpret_cast<const uint8_t*>(v) + (size_t)ix[3 * t + k] * 12, 12);
                     tris.push_back(vv[0]); tris.push_back(vv[1]); tris.push_back(vv[2]);
                 }

@@ -102,7 +102,8 @@ def _configure_simulator(cfg, base_dir):
 
 
 class ProjectDVecEnv:
-    def __init__(self, num_envs, base_dir, device=0, auto_reset=True, **settings):
+    def __init__(self, num_envs, base_dir=None, device=0, auto_reset=True, **settings):
+        base_dir = base_dir or default_base_dir()
         self.cfg = EnvConfig(**settings)
         self.num_envs = int(num_envs)
         self.auto_reset = auto_reset
@@ -115,6 +116,7 @@ class ProjectDVecEnv:
             pd.setBatchStuckTimeout(self.batch, float(self.cfg.stuck_timeout))
         self._set_kernel_env(self.auto_reset)
         self.total_reward = np.zeros(self.num_envs, dtype=np.float64)
+        self.last_reset_tick = np.zeros(self.num_envs, dtype=bool)
         self.step_id = np.zeros(self.num_envs, dtype=np.int64)
         self.pending_reset = np.zeros(self.num_envs, dtype=bool)
         self.observation_bounds = obs_bounds(self.cfg)
@@ -150,6 +152,7 @@ class ProjectDVecEnv:
             obs, reward, flags = self._raw_step(a)
             terminated = (flags & 8) != 0
             fresh = (flags & 16) != 0
+            self.last_reset_tick = fresh
             self.total_reward += reward; self.total_reward[fresh] = 0.0
             self.step_id += 1; self.step_id[fresh] = 0
             info = {'episode_reward': self.total_reward.copy()} if terminated.any() else {}
@@ -225,10 +228,19 @@ def linscale(x, x0, x1, r0, r1):
     return ((r1 - r0) * (x - x0)) / (x1 - x0) + r0
 
 
+def default_base_dir():
+    """the reference env finds its content next to the module (projectd_env.py:9); here: $PROJECTD_BASE"""
+    d = os.environ.get('PROJECTD_BASE')
+    if not d:
+        raise RuntimeError('no content directory: pass base_dir=... or set PROJECTD_BASE (the directory holding cfg/ and content/)')
+    return d
+
+
 class ProjectDEnv:
     """single env through the classic calls (setCarControls / stepSimulator / getCarState), reference signature"""
 
-    def __init__(self, base_dir, **settings):
+    def __init__(self, base_dir=None, **settings):
+        base_dir = base_dir or default_base_dir()
         self.cfg = EnvConfig(**settings)
         self.sim, self.car = _configure_simulator(self.cfg, base_dir)
         self.dstate = pd.CarState()

@@ -20,7 +20,7 @@ def _boxes(cfg):
 
 
 class ProjectDGymnasium(gym.Env):
-    def __init__(self, base_dir, **settings):
+    def __init__(self, base_dir=None, **settings):
         super().__init__()
         self.impl = E.ProjectDEnv(base_dir, **settings)
         self.observation_space, self.action_space = _boxes(self.impl.cfg)
@@ -40,12 +40,15 @@ class ProjectDGymnasium(gym.Env):
     def close(self):
         self.impl.close()
 
+    def seed(self, seed=None):   # compat with legacy gym (projectd_gymnasium.py:38-40)
+        pass
+
 
 class ProjectDGymnasiumVec:
     """N lanes; step(actions[N,2]) -> obs[N,24], reward[N], terminated[N], truncated[N], infos (gymnasium VectorEnv contract,
     autoreset: a finished lane's next observation is the first of its new episode)."""
 
-    def __init__(self, num_envs, base_dir, device=0, **settings):
+    def __init__(self, num_envs, base_dir=None, device=0, **settings):
         self.impl = E.ProjectDVecEnv(num_envs, base_dir, device=device, auto_reset=True, **settings)
         self.num_envs = num_envs
         obs_box, act_box = _boxes(self.impl.cfg)

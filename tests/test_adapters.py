@@ -1,0 +1,146 @@
+"""Adapters: classic gym (pyprojectd/projectd_gym/projectd_gym.py:10-42, __init__.py:1-8), gymnasium
+(projectd_gymnasium/projectd_gymnasium.py:9-40) and the SB3-shaped VecEnv with sac.yml's observation normalisation.  gym /
+gymnasium / stable_baselines3 are not installed here: the modules run against tests/stubs (see its README) -- enough to execute
+every line of the adapters; construction and spaces on the CPU, stepping under -m gpu."""
+import importlib, os, sys
+import numpy as np
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+@pytest.fixture(scope='module')
+def stubs():
+    for name in ('gym', 'gymnasium'):
+        try:
+            importlib.import_module(name)
+        except ImportError:
+            if os.path.join(HERE, 'stubs') not in sys.path:
+                sys.path.append(os.path.join(HERE, 'stubs'))
+            importlib.import_module(name)
+    return True
+
+
+@pytest.fixture(scope='module')
+def base(built):
+    import tempfile, synthetic_tracks
+    d = tempfile.mkdtemp(prefix='pdb_adapters_')
+    synthetic_tracks.make_base(d, tracks=('flat', 'touge'))
+    synthetic_tracks.install_packed_car(d)
+    os.environ['PROJECTD_BASE'] = d
+    return d
+
+
+def _check_spaces(env):
+    assert env.observation_space.shape == (24,) and env.action_space.shape == (2,)
+    assert env.observation_space.low[6] == 0.0 and env.observation_space.high[0] == 100.0 and env.observation_space.high[17] == 50.0
+    assert list(env.action_space.low) == [-1.0, -1.0] and list(env.action_space.high) == [1.0, 1.0]
+
+
+def test_classic_gym_adapter_constructs_and_registers(stubs, base):
+    import gym, projectd_gym
+    projectd_gym.register()
+    spec = gym.envs.registration.registry['ProjectD-v0']
+    assert (spec['max_episode_steps'] if isinstance(spec, dict) else spec.max_episode_steps) == 80000
+    env = projectd_gym.ProjectDEnvGym(track_name='flat')
+    _check_spaces(env)
+    assert isinstance(env, gym.Env) and isinstance(env.seed(7), list)
+    env.close()
+
+
+def test_gymnasium_adapter_constructs_and_registers(stubs, base):
+    import gymnasium, projectd_gymnasium
+    projectd_gymnasium.register()
+    spec = gymnasium.envs.registration.registry['ProjectD-v0']
+    assert (spec['max_episode_steps'] if isinstance(spec, dict) else spec.max_episode_steps) == 80000
+    env = projectd_gymnasium.ProjectDGymnasium(track_name='flat')
+    _check_spaces(env)
+    assert isinstance(env, gymnasium.Env)
+    env.seed(3)
+    env.close()
+
+
+def test_running_obs_norm_matches_the_batch_statistics():
+    """RunningObsNorm = SB3 RunningMeanStd: after any sequence of batches, mean / var equal those of everything seen"""
+    sys.path.insert(0, os.path.join(os.path.dirname(HERE), 'projectd-core_amd'))
+
+    class Fake:
+        num_envs = 8
+        class observation_space: shape = (5,)
+        action_space = None
+        def __init__(self): self.rng = np.random.RandomState(0); self.seen = []
+        def reset(self): x = self.rng.normal(3, 2, (8, 5)).astype(np.float32); self.seen.append(x); return x
+        def step(self, a):
+            x = self.rng.normal(-1, 5, (8, 5)).astype(np.float32); self.seen.append(x)
+            done = np.zeros(8, bool); done[2] = True
+            return x, np.zeros(8, np.float32), done, [{'terminal_observation': x[i].copy()} if done[i] else {} for i in range(8)]
+        def close(self): pass
+    try:
+        import projectd_sb3
+    except ImportError:
+        pytest.skip('PyProjectD module not built')
+    f = Fake()
+    n = projectd_sb3.RunningObsNorm(f)
+    n.reset()
+    for _ in range(20):
+        o, r, d, infos = n.step(None)
+    allx = np.concatenate(f.seen).astype(np.float64)
+    assert np.allclose(n.mean, allx.mean(0), atol=1e-3) and np.allclose(n.var, allx.var(0), rtol=1e-3)
+    assert o.dtype == np.float32 and np.abs(o).max() <= 10.0 and 'terminal_observation' in infos[2]
+    n.training = False
+    m = n.mean.copy(); n.step(None)
+    assert np.array_equal(m, n.mean)
+
+
+@pytest.mark.gpu
+def test_gym_and_gymnasium_envs_step_like_the_plain_env(stubs, base):
+    import gym, gymnasium, projectd_gym, projectd_gymnasium, projectd_env as E
+    projectd_gym.register(); projectd_gymnasium.register()
+    g = gym.make('ProjectD-v0', track_name='flat')
+    gn = gymnasium.make('ProjectD-v0', track_name='flat')
+    plain = E.ProjectDEnv(track_name='flat')
+    o1 = g.reset(); o2, info = gn.reset(seed=1); o3 = plain.reset()
+    assert np.array_equal(o1, o3) and np.array_equal(o2, o3) and info == {}
+    rng = np.random.RandomState(5)
+    for t in range(120):
+        a = rng.uniform(-1, 1, 2).astype(np.float32)
+        s1 = g.step(a); s2 = gn.step(a); s3 = plain.step(a)
+        assert len(s1) == 4 and len(s2) == 5
+        assert np.array_equal(s1[0], s3[0]) and np.array_equal(s2[0], s3[0])
+        assert s1[1] == s3[1] and s2[1] == s3[1] and s1[2] == (s3[2] or s3[3]) and s2[2] == s3[2]
+        assert g.observation_space.contains(s1[0])
+    g.close(); gn.close(); plain.close()
+
+
+@pytest.mark.gpu
+def test_sb3_vec_env_episode_protocol(stubs, base):
+    """done / terminal_observation / reset_tick / TimeLimit.truncated on the batch, with the observation normaliser on top"""
+    import projectd_sb3
+    n = 16
+    env = projectd_sb3.ProjectDSB3VecEnv(n, track_name='flat', stuck_timeout=0.3, max_episode_steps=100000, terminate_low_reward=-1e9)
+    venv = projectd_sb3.wrap_normalize(env)
+    obs = venv.reset()
+    assert obs.shape == (n, 24) and obs.dtype == np.float32
+    acts = np.zeros((n, 2), np.float32); acts[:, 1] = -1.0       # creeping: no new track point within 0.3 s => the stuck rule ends the episode
+    dones = np.zeros(n, int); resets = np.zeros(n, int); trunc = np.zeros(n, int)
+    pending = np.zeros(n, bool)
+    for t in range(500):
+        if t == 250:
+            env.max_episode_steps = 60                             # from here the time limit comes first
+        obs, rew, done, infos = venv.step(acts)
+        assert obs.shape == (n, 24) and np.abs(obs).max() <= 10.0
+        for i in range(n):
+            if done[i]:
+                assert 'terminal_observation' in infos[i] and infos[i]['terminal_observation'].shape == (24,)
+                trunc[i] += int(infos[i]['TimeLimit.truncated'])
+                if t < 250:
+                    assert not infos[i]['TimeLimit.truncated']
+            if pending[i]:
+                assert infos[i].get('reset_tick') is True and rew[i] == 0.0 and not done[i]
+                resets[i] += 1
+        dones += done; pending = done.copy()
+    assert dones.min() >= 4 and trunc.min() >= 2, (dones, trunc)
+    assert np.array_equal(resets, dones) or np.array_equal(resets + pending, dones)
+    assert env.env_is_wrapped(object) == [False] * n and env.get_attr('track_name') == ['flat'] * n
+    env.seed(11)
+    venv.close()
