@@ -177,6 +177,14 @@ int cpuref_num_scenarios(void) { return pdoracle::kNumScenarios; }
 int cpuref_scenario_collide(int sid) { return pdoracle::kScenarios[sid].collide; }
 int cpuref_scenario_auto_teleport(int sid) { return pdoracle::kScenarios[sid].autoTele; }
 int cpuref_scenario_resets(int sid) { return pdoracle::kScenarios[sid].resetEvery; }
+// the rest of a scenario's script, for drivers that step something else through it (tests/scenario_util.py drives the GPU):
+// out = {resetEvery, teleDist, boostAt, feedback, collide, autoTele, stride, denseTicks}
+void cpuref_scenario_fields(int sid, int* out) {
+    const auto& sc = pdoracle::kScenarios[sid];
+    out[0] = sc.resetEvery; out[1] = sc.teleDist; out[2] = sc.boostAt; out[3] = sc.feedback; out[4] = sc.collide; out[5] = sc.autoTele; out[6] = sc.stride; out[7] = sc.denseTicks;
+}
+float cpuref_scenario_teledist(int k) { return pdoracle::kTeleDist[k & 3]; }
+void cpuref_scenario_action(int sid, int tick, float* a) { pdoracle::scenarioAction(sid, tick, a[0], a[1]); }
 int cpuref_scenario_scoring(int sid, int i, const char** name, float* value) {
     if (!pdoracle::kScenarios[sid].scoringSet || i < 0 || i >= pdoracle::kNumScoringSetA) return 0;
     *name = pdoracle::kScoringSetA[i].name; *value = pdoracle::kScoringSetA[i].value;

@@ -1,0 +1,125 @@
+"""The 35 scripted scenarios of oracle/scenarios.h (the reference-TU goldens' scripts) as a set-up + driver usable from any
+test: car block, track blob, initial state the way tests/test_oracle_golden.py prepares them, and a tick-by-tick driver that
+steps the CPU oracle and -- optionally -- a GPU batch through the same script (actions, mid-run resets / teleports, the boost)."""
+import ctypes as C, os, sys
+import numpy as np
+import pdb_ctypes as pc
+from conftest import car_params
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REF_CONTENT = '/root/reference/content'
+
+
+class Skip(Exception):
+    pass
+
+
+def setup(orc, hostlib, sid, base_dir):
+    """-> dict(name, track, model, P, blob, S0, fields).  Raises Skip when the scenario needs reference content that is absent."""
+    import synthetic_tracks
+    name = orc.cpuref_scenario_name(sid).decode()
+    track = orc.cpuref_scenario_track(sid).decode()
+    model = orc.cpuref_scenario_car(sid).decode()
+    if track in ('flat', 'touge', 'walled'):
+        gen = {'flat': synthetic_tracks.gen_flat, 'touge': synthetic_tracks.gen_touge, 'walled': synthetic_tracks.gen_walled}[track]
+        gen(os.path.join(base_dir, 'content', 'tracks', track))
+        blob = pc.build_track(hostlib, base_dir, track)
+    else:
+        if not os.path.isdir(os.path.join(REF_CONTENT, 'tracks', track)):
+            raise Skip('reference content not present')
+        blob = pc.build_track(hostlib, '/root/reference', track)
+    P = car_params(model)
+    nm = C.c_char_p(); val = C.c_float()
+    if orc.cpuref_scenario_tune(sid, 0, C.byref(nm), C.byref(val)):
+        if not os.path.isdir(os.path.join(REF_CONTENT, 'cars')):
+            raise Skip('reference content not present')
+        P = pc.env_params(hostlib, '/root/reference', model)
+        i = 0
+        while orc.cpuref_scenario_tune(sid, i, C.byref(nm), C.byref(val)):
+            hostlib.pdb_set_car_tune(C.byref(P), b'/root/reference', model.encode(), nm.value, val.value, 0)
+            i += 1
+    i = 0
+    while orc.cpuref_scenario_scoring(sid, i, C.byref(nm), C.byref(val)):
+        assert hostlib.pdb_set_scoring_var(C.byref(P), nm.value, val.value) == 0
+        i += 1
+    P.collider.enabled = orc.cpuref_scenario_collide(sid)
+    at = orc.cpuref_scenario_auto_teleport(sid)
+    assert hostlib.pdb_set_auto_teleport(C.byref(P), at & 1, (at >> 1) & 1, (at >> 2) & 3) == 0
+    ticks = C.c_int(); full = C.c_int(); assists = (C.c_int * 4)()
+    assert orc.cpuref_scenario_info(sid, C.byref(ticks), C.byref(full), assists) == 0
+    hostlib.pdb_set_assists(C.byref(P), assists[0], assists[1], assists[2], assists[3])
+    f = (C.c_int * 8)(); orc.cpuref_scenario_fields(sid, f)
+    S0 = pc.DynState()
+    assert hostlib.pdb_initial_state(C.byref(P), blob, C.byref(S0)) == 0
+    return dict(sid=sid, name=name, track=track, model=model, P=P, blob=blob, S0=S0, ticks=ticks.value, full=full.value,
+                reset_every=f[0], tele_dist=f[1], boost_at=f[2], feedback=f[3], auto_tele=f[5])
+
+
+def drive(orc, hostlib, sc, batch=None, max_ticks=None, on_tick=None):
+    """Step the oracle (handle created here) -- and the 1-car GPU batch, if given -- through scenario sc.  The GPU batch must have
+    been created with action mode FULL for sc['full'] scenarios and ENV otherwise.  on_tick(t, handle, batch) after every tick."""
+    P, blob, sid = sc['P'], sc['blob'], sc['sid']
+    h = orc.cpuref_create(C.byref(P), blob, len(blob), C.byref(sc['S0']))
+
+    def _tele_mode(state_ptr, mode):
+        assert hostlib.pdb_teleport_by_mode(C.byref(P), blob, mode, C.c_void_p(state_ptr)) == 0
+    hook = C.CFUNCTYPE(None, C.c_void_p, C.c_int)(_tele_mode)
+    orc.cpuref_set_auto_teleport_hook(h, C.cast(hook, C.c_void_p))
+    zero2 = np.zeros((1, 2), np.float32); zero8 = np.zeros((1, 8), np.float32); zero8[0, 5] = -1.0
+
+    def step_both(a2=None, a8=None):
+        if a8 is not None:
+            orc.cpuref_step_controls(h, a8.ctypes.data_as(C.c_void_p))
+            if batch is not None:
+                batch.step_host(a8.reshape(1, 8))
+        else:
+            orc.cpuref_step_env(h, float(a2[0]), float(a2[1]))
+            if batch is not None:
+                if sc['full']:   # a FULL-mode batch fed an env action: the env mapping on the host (steer, gas = envGas(a1))
+                    a = zero8.copy(); a[0, 0] = a2[0]; a[0, 4] = orc.cpuref_env_gas(C.c_float(float(a2[1])))
+                    batch.step_host(a)
+                else:
+                    batch.step_host(np.asarray(a2, np.float32).reshape(1, 2))
+
+    def teleport_both(dist):
+        s = pc.DynState(); orc.cpuref_get_state(h, C.byref(s))
+        assert hostlib.pdb_teleport_to_spline(C.byref(P), blob, C.c_float(dist), C.byref(s)) == 0
+        orc.cpuref_set_state(h, C.byref(s))
+        if batch is not None:
+            g = batch.get_state()
+            assert hostlib.pdb_teleport_to_spline(C.byref(P), blob, C.c_float(dist), C.byref(g[0])) == 0
+            batch.set_state(g)
+    step_both(a2=(0.0, 0.0))                      # env.reset(): teleport (already in S0) + step([0, 0])
+    n = sc['ticks'] if max_ticks is None else min(sc['ticks'], max_ticks)
+    o = pc.StepOut()
+    a2 = (C.c_float * 2)(); a8 = np.zeros(8, np.float32)
+    try:
+        for t in range(n):
+            if sc['reset_every'] and t > 0 and t % sc['reset_every'] == 0:
+                teleport_both(orc.cpuref_scenario_teledist(t // sc['reset_every'] - 1) if sc['tele_dist'] else 0.0)
+                step_both(a2=(0.0, 0.0))
+            if sc['boost_at'] and t == sc['boost_at']:
+                s = pc.DynState(); orc.cpuref_get_state(h, C.byref(s))
+                for b in range(P.numBodies):
+                    s.body[b].lvel[2] = 50.0
+                orc.cpuref_set_state(h, C.byref(s))
+                if batch is not None:
+                    g = batch.get_state()
+                    for b in range(P.numBodies):
+                        g[0].body[b].lvel[2] = 50.0
+                    batch.set_state(g)
+            if sc['feedback']:
+                orc.cpuref_get_out(h, C.byref(o))
+                obs = (C.c_float * 24)(*o.obs)
+                orc.cpuref_scenario_feedback(sid, t, obs, a2)
+                step_both(a2=(a2[0], a2[1]))
+            elif sc['full']:
+                orc.cpuref_scenario_controls(sid, t, a8.ctypes.data_as(C.c_void_p))
+                step_both(a8=a8)
+            else:
+                orc.cpuref_scenario_action(sid, t, a2)
+                step_both(a2=(a2[0], a2[1]))
+            if on_tick is not None:
+                on_tick(t, h, batch)
+    finally:
+        orc.cpuref_destroy(h)
