@@ -170,6 +170,46 @@ int cpuref_contact_unit(float mass, const float* sides, const float* state, cons
     for (int i = 0; i < 3 * n; ++i) { out[9 + i] = W.lastContactLambda[i]; out[9 + 3 * n + i] = W.lastContactLo[i]; out[9 + 6 * n + i] = W.lastContactHi[i]; }
     return W.lastLcpIterations;
 }
+// Closed-form joint checks on two-body worlds (tests/test_physics_invariants.py): a heavy anchor body (1e9 kg, at rest at the
+// origin, gravity off and applied by hand to the light body only) and a 1 kg bob.  kind 0: Ball joint at the origin, bob on a rod of
+// length L released at angle theta0 -- returns the bob's x every tick (the test reads the swing period off it); kind 1: Slider along x,
+// constant force F on the bob -- returns x, y, z and the relative rotation's vector part per tick; kind 2: DBall of length L holding
+// the bob under gravity -- returns the anchor distance per tick.  out has ticks * 4 floats.
+int cpuref_joint_unit(int kind, float L, float theta0, float F, int ticks, float* out) {
+    pdrb::World W;
+    W.gravity[0] = 0; W.gravity[1] = 0; W.gravity[2] = 0;
+    const int a = W.createBody(), b = W.createBody();
+    W.bodies[a].setMassBoxTotal(1.0e9f, 1, 1, 1);
+    W.bodies[b].setMassBoxTotal(1.0f, 0.1f, 0.1f, 0.1f);
+    const float g = 9.80665f, h = (float)(1.0 / 333.0);
+    const float z3[3] = {0, 0, 0};
+    if (kind == 0) {
+        W.bodies[b].setPosition(L * sinf(theta0), -L * cosf(theta0), 0);
+        const float c = cosf(theta0), s = sinf(theta0);
+        const float R[9] = {c, -s, 0, s, c, 0, 0, 0, 1};   // rod along the body's -y
+        W.bodies[b].setRotation(R);
+        W.createBall(a, b, z3);
+    } else if (kind == 1) {
+        W.bodies[b].setPosition(0.5f, 0.2f, -0.1f);
+        const float ax[3] = {1, 0, 0};
+        W.createSlider(a, b, ax);
+    } else {
+        W.bodies[b].setPosition(0, -L, 0);
+        const float p2[3] = {0, -L, 0};
+        W.createDBall(a, b, z3, p2);
+    }
+    for (int t = 0; t < ticks; ++t) {
+        pdrb::Body& B = W.bodies[b];
+        if (kind == 1) { const float f[3] = {F, 0, 0}; B.addForceAtPos(f, B.pos); }
+        else { const float f[3] = {0, -g * B.mass, 0}; B.addForceAtPos(f, B.pos); }
+        W.step(h);
+        float* o = out + 4 * t;
+        if (kind == 0) { o[0] = B.pos[0]; o[1] = B.pos[1]; o[2] = sqrtf(B.pos[0] * B.pos[0] + B.pos[1] * B.pos[1] + B.pos[2] * B.pos[2]); o[3] = 0; }
+        else if (kind == 1) { o[0] = B.pos[0]; o[1] = B.pos[1]; o[2] = B.pos[2]; o[3] = sqrtf(B.q[1] * B.q[1] + B.q[2] * B.q[2] + B.q[3] * B.q[3]); }
+        else { o[0] = sqrtf(B.pos[0] * B.pos[0] + B.pos[1] * B.pos[1] + B.pos[2] * B.pos[2]); o[1] = B.pos[0]; o[2] = B.pos[2]; o[3] = W.bodies[a].pos[1]; }
+    }
+    return 0;
+}
 const char* cpuref_scenario_name(int sid) { return pdoracle::kScenarios[sid].name; }
 const char* cpuref_scenario_track(int sid) { return pdoracle::kScenarios[sid].track; }
 const char* cpuref_scenario_car(int sid) { return pdoracle::kScenarios[sid].car ? pdoracle::kScenarios[sid].car : PDORACLE_DEFAULT_CAR; }

@@ -27,6 +27,7 @@ def load_oracle(portable_math=False):
     lib.cpuref_solver_freeflight.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
     lib.cpuref_last_system.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
     lib.cpuref_set_auto_teleport_hook.argtypes = [C.c_void_p, C.c_void_p]
+    lib.cpuref_joint_unit.argtypes = [C.c_int, C.c_float, C.c_float, C.c_float, C.c_int, C.c_void_p]
     lib.cpuref_get_contacts.argtypes = [C.c_void_p, C.c_void_p]
     lib.cpuref_set_contacts.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
     lib.cpuref_last_contact_rows.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]

@@ -114,3 +114,48 @@ def test_fp32_factor_solve_agrees_with_fp64(oracle, hostlib, touge_track, model)
             worst_cond = max(worst_cond, float(w[-1] / w[0]))
     oracle.cpuref_destroy(h)
     assert worst < 2e-4, (worst, worst_cond)     # measured: 9.5e-5 (AE86, condition number 1.2e6), 4e-6 (RX-7), 9e-6 (readie)
+
+
+# ---- closed-form checks of single joints, independent of any car (and of pdrb's own bookkeeping): what a Ball, a Slider and a DBall
+# must do by mechanics alone ----
+def _joint_unit(oracle, kind, L=1.0, theta0=0.0, F=0.0, ticks=2000):
+    out = (C.c_float * (4 * ticks))()
+    assert oracle.cpuref_joint_unit(kind, C.c_float(L), C.c_float(theta0), C.c_float(F), ticks, out) == 0
+    return np.array(out[:], dtype=np.float64).reshape(ticks, 4)
+
+
+def test_ball_joint_pendulum_period(oracle):
+    """a 1 kg cube (10 cm) on a 1 m massless rod through a Ball joint: physical-pendulum period 2 pi sqrt((I + m L^2) / (m g L)),
+    amplitude correction (1 + theta0^2 / 16); the rod length holds to the ERP-bounded tolerance"""
+    L, th = 1.0, 0.1
+    r = _joint_unit(oracle, 0, L=L, theta0=th, ticks=3000)
+    x = r[:, 0]
+    up = np.nonzero((x[:-1] < 0) & (x[1:] >= 0))[0]             # upward zero crossings
+    assert len(up) >= 4
+    frac = up + (-x[up]) / (x[up + 1] - x[up])
+    period = np.diff(frac).mean() / 333.0
+    I = 1.0 / 12.0 * (0.1 ** 2 + 0.1 ** 2)
+    expect = 2 * np.pi * np.sqrt((I + L * L) / (9.80665 * L)) * (1 + th * th / 16)
+    assert abs(period - expect) / expect < 5e-3, (period, expect)
+    assert np.abs(r[:, 2] - L).max() < 2e-3                     # the anchor holds
+
+
+def test_slider_leaves_exactly_its_axis_free(oracle):
+    """constant force along the slider axis: x = x0 + F t^2 / (2 m) (semi-implicit Euler: t (t + h) / 2), nothing moves across the
+    axis, the bodies do not rotate against each other"""
+    F, n = 3.0, 1500
+    r = _joint_unit(oracle, 1, F=F, ticks=n)
+    h = 1.0 / 333.0
+    t = (np.arange(n) + 1) * h
+    expect = 0.5 + 0.5 * F * t * (t + h)
+    assert np.abs(r[:, 0] - expect).max() < 2e-3 * expect.max()
+    assert np.abs(r[:, 1] - 0.2).max() < 1e-4 and np.abs(r[:, 2] + 0.1).max() < 1e-4
+    assert r[:, 3].max() < 1e-5
+
+
+def test_distance_joint_holds_its_length_under_load(oracle):
+    """a DBall carrying 1 kg: the length drifts by no more than cfm * lambda * h / erp (~1e-8 m) plus float rounding"""
+    r = _joint_unit(oracle, 2, L=0.7, ticks=2000)
+    assert np.abs(r[:, 0] - 0.7).max() < 2e-6, np.abs(r[:, 0] - 0.7).max()
+    assert np.abs(r[:, 1]).max() < 1e-6 and np.abs(r[:, 2]).max() < 1e-6
+    assert np.abs(r[:, 3]).max() < 1e-6                         # the 1e9 kg anchor stays put
