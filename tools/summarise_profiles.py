@@ -17,6 +17,28 @@ def rows(pattern):
                 yield r
 
 
+# issue model: tools/issue_rate.hip's own table + the SQ counters of the same launches
+import re
+im = {'source': 'tools/issue_rate.hip on the GPU box (s_memtime; every CU busy, independent instruction streams)', 'cycles_per_inst_per_simd': {}, 'counters_per_instruction': {}}
+ir = os.path.join(src, 'issue_rate.txt')
+if os.path.exists(ir):
+    txt = open(ir).read()
+    open(os.path.join(dst, tag + '_issue_rate.txt'), 'w').write(txt)
+    for m in re.finditer(r'^(.+?)\s+waves/SIMD (\d+): ([0-9.]+) cycles per wave-instruction per SIMD \(wave sees ([0-9.]+)\)', txt, re.M):
+        im['cycles_per_inst_per_simd'].setdefault(m.group(1).strip(), {})[m.group(2)] = float(m.group(3))
+    acc = {}
+    for r in rows('pmc_issue/**/*counter_collection.csv'):
+        if 'stream_kernel' not in r['Kernel_Name']:
+            continue
+        k = (r['Kernel_Name'].split('(')[0], r['Grid_Size'], r['Dispatch_Id'])
+        acc.setdefault(k, {})[r['Counter_Name']] = acc.setdefault(k, {}).get(r['Counter_Name'], 0.0) + float(r['Counter_Value'])
+    for (kn, grid, did), v in acc.items():
+        if v.get('SQ_INSTS_VALU', 0) < 1e7:
+            continue   # the short warm-up launch
+        wps = int(grid) // 256 // 256
+        im['counters_per_instruction'].setdefault(kn, {})[str(wps)] = {'SQ_ACTIVE_INST_VALU_quads_per_VALU_inst': v.get('SQ_ACTIVE_INST_VALU', 0) / v['SQ_INSTS_VALU'],
+                                                                        'SQ_WAVE_CYCLES_quads_per_VALU_inst_per_wave': v.get('SQ_WAVE_CYCLES', 0) / v['SQ_INSTS_VALU']}
+    json.dump(im, open(os.path.join(dst, tag + '_issue_model.json'), 'w'), indent=1)
 summary = {'tag': tag, 'kernel': KERNEL}
 # kernel stats
 ks = [r for r in rows('stats/**/*kernel_stats.csv')]
@@ -56,12 +78,31 @@ if os.path.exists(b):
         bj = json.loads(line[-1]); summary['bench'] = bj
         json.dump(bj, open(os.path.join(dst, tag + '_bench.json'), 'w'), indent=1)
         conc = bj.get('roofline', {}).get('concurrent_launches', 1) or 1
-        if 'SQ_ACTIVE_INST_VALU' in cnt and 'rocprof_avg_us' in summary:
-            # VALU issue roofline.  SQ_ACTIVE_INST_VALU = quad-cycles a SIMD spends issuing VALU work, summed over the launch's waves
-            # (the counter passes serialise the launches, so this is per launch); `conc` launches share the 1024 SIMDs in the
-            # timed run, each taking rocprof_avg_us; 2.4 GHz nominal shader clock.
+        if 'SQ_INSTS_VALU' in cnt and 'rocprof_avg_us' in summary:
+            # VALU issue occupancy, priced with MEASURED issue costs (tools/issue_rate.hip, <tag>_issue_model.json): at this kernel's
+            # 6 waves per SIMD a SIMD issues one fp32 wave-instruction per ISSUE_F32 cycles and one fp64 per ISSUE_F64.
+            # SQ_ACTIVE_INST_VALU is NOT a busy time: the same run shows it is exactly 1 quad-cycle (4 cycles) per VALU
+            # instruction at every occupancy and for fp32 and fp64 alike (2 for v_rcp_f32), i.e. an instruction count.
+            # The counter passes serialise the launches, so counts are per launch; `conc` launches share the 1024 SIMDs in the
+            # timed run, each taking rocprof_avg_us; clock = the in-kernel clock of the bench kernel's own stamps (~2.1 GHz).
+            issue = {}
+            try:
+                issue = json.load(open(os.path.join(dst, tag + '_issue_model.json')))
+            except Exception:
+                pass
+            c32 = issue.get('cycles_per_inst_per_simd', {}).get('v_fma_f32', {}).get('6', 1.46)
+            c64 = issue.get('cycles_per_inst_per_simd', {}).get('v_fma_f64', {}).get('6', 2.34)
+            clk = 2.1e9
+            simd_cycles = summary['rocprof_avg_us'] * 1e-6 * clk * 1024
             summary['concurrent_launches'] = conc
-            summary['valu_busy_frac_approx'] = conc * 4.0 * cnt['SQ_ACTIVE_INST_VALU'] / (summary['rocprof_avg_us'] * 1e-6 * 2.4e9 * 1024)
-            summary['valu_note'] = 'fraction of all SIMD issue cycles spent on VALU instructions with %d launch(es) in flight: the resource that bounds this kernel' % conc
+            summary['valu_issue_busy_frac'] = conc * cnt['SQ_INSTS_VALU'] * c32 / simd_cycles
+            summary['valu_issue_busy_frac_upper'] = conc * cnt['SQ_INSTS_VALU'] * c64 / simd_cycles
+            summary['valu_note'] = ('share of all SIMD issue cycles taken by this kernel\'s VALU instructions with %d launch(es) in flight, if every instruction cost what an '
+                                    'independent v_fma_f32 costs at 6 waves per SIMD (%.2f cycles, measured); _upper: if every one cost a v_fma_f64 (%.2f)' % (conc, c32, c64))
+            if waves:
+                pw = summary['per_wave']
+                tot = pw.get('SQ_WAVE_CYCLES', 0) or 1.0
+                summary['wave_time_split'] = {'issuing (SQ_ACTIVE_INST_ANY)': pw.get('SQ_ACTIVE_INST_ANY', 0) / tot, 'parked on s_waitcnt / barrier / sleep (SQ_WAIT_ANY)': pw.get('SQ_WAIT_ANY', 0) / tot,
+                                              'issue stall (SQ_WAIT_INST_ANY)': pw.get('SQ_WAIT_INST_ANY', 0) / tot}
 json.dump(summary, open(os.path.join(dst, tag + '_pmc.json'), 'w'), indent=1)
 print(json.dumps({k: v for k, v in summary.items() if k != 'bench'}, indent=1))
