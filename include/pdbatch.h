@@ -136,6 +136,10 @@ int pdb_set_out_device(pdb_batch* b, pdb_step_out* out);
  * the partitioning.  pdb_partition_mark / pdb_partition_elapsed_ms: HIP-event time of one part's kernels between the mark
  * and the last pdb_step_ring (synchronises on that part), and the number of cars in the part. */
 int pdb_set_partitions(pdb_batch* b, int parts);
+/* A car block of its own for one partition (NULL: back to the batch's): same car model and rigid-body topology, different tunes,
+ * assists, scoring weights, auto-teleport -- what the reference gives every simulator separately (PyProjectD.cpp:328-365) --
+ * e.g. to randomise the setup over the cars of a batch.  The partition's cars step, reset and teleport with it. */
+int pdb_set_partition_params(pdb_batch* b, int part, const pdb_car_params* params);
 int pdb_step_ring(pdb_batch* b, float dt, int n_ticks, pdb_step_out* ring, int ring_slots, int first_slot, int join);
 int pdb_wait_partitions(pdb_batch* b, void* hip_stream);
 /* Per-partition loops: pdb_step_partition enqueues one tick of one part on that part's stream (pdb_partition_stream), nothing

@@ -77,6 +77,13 @@ struct pdb_batch {
     pdb_car_params* dParams = nullptr;
     DevConst* dK = nullptr;
     uint8_t* dTrack = nullptr;
+    // per-partition car blocks (pdb_set_partition_params: domain randomisation of tunes / scoring weights over the cars of one batch);
+    // partHas[p] == false: the partition steps with the batch's block
+    bool partHas[PDB_MAX_PARTS] = {false, false, false, false};
+    pdb_car_params partParams[PDB_MAX_PARTS];
+    DevConst partK[PDB_MAX_PARTS];
+    pdb_car_params* dPartParams[PDB_MAX_PARTS] = {nullptr, nullptr, nullptr, nullptr};
+    DevConst* dPartK[PDB_MAX_PARTS] = {nullptr, nullptr, nullptr, nullptr};
     int* dQueue[PDB_MAX_PARTS + 1] = {nullptr, nullptr, nullptr, nullptr, nullptr};   // RedoQueue per launch site: count, done, list[blocks]
     uint8_t* dResetScratch = nullptr;   // device copy of a host mask (pdb_reset)
     uint8_t* dResetMask = nullptr;   // [n]: 1 + teleport mode for cars to be reset at the top of their next tick (consumed and cleared by that tick)
@@ -157,21 +164,41 @@ static void launchTick(pdb_batch* b, hipStream_t st, int c0, int c1, pdb_step_ou
     pdb_car_state* CS = b->dCarStates ? b->dCarStates + c0 : nullptr;
     pdb_contact* CT = b->dContacts + (size_t)c0 * PDB_MAX_CONTACTS;
     void* Q = b->dQueue[q];
+    const bool own = q < PDB_MAX_PARTS && b->partHas[q];
+    const pdb_car_params* DP = own ? b->dPartParams[q] : b->dParams;
+    const DevConst* DK = own ? b->dPartK[q] : b->dK;
+    const pdb_car_params& HP = own ? b->partParams[q] : b->params;
     uint8_t* RM = b->resetMaskArmed ? b->dResetMask + c0 : nullptr;
     const int n = c1 - c0;
     // the contact pass also serves episode resets asked for through the reset mask and the in-tick auto-teleport
-    const bool contacts = b->params.collider.enabled != 0 || b->resetMaskArmed || b->params.autoTeleport != 0;
+    const bool contacts = HP.collider.enabled != 0 || b->resetMaskArmed || HP.autoTeleport != 0;
     const dim3 grid(nblk), block(PDB_BLOCK_THREADS), cgrid(nblk < PDB_CONTACT_GRID ? nblk : PDB_CONTACT_GRID);
     if (m == 33) {
-        hipLaunchKernelGGL(k33::pdb_step_kernel, grid, block, 0, st, S, A, O, CS, b->dParams, b->dK, b->dTrack, (k33::RedoQueue*)Q, RM, n);
-        if (contacts) hipLaunchKernelGGL(k33::pdb_contact_kernel, cgrid, block, 0, st, S, A, O, CS, b->dParams, b->dK, b->dTrack, CT, (k33::RedoQueue*)Q, RM, n);
+        hipLaunchKernelGGL(k33::pdb_step_kernel, grid, block, 0, st, S, A, O, CS, DP, DK, b->dTrack, (k33::RedoQueue*)Q, RM, n);
+        if (contacts) hipLaunchKernelGGL(k33::pdb_contact_kernel, cgrid, block, 0, st, S, A, O, CS, DP, DK, b->dTrack, CT, (k33::RedoQueue*)Q, RM, n);
     } else if (m < 33) {
-        hipLaunchKernelGGL(k33::pdb_step_kernel_generic, grid, block, 0, st, S, A, O, CS, b->dParams, b->dK, b->dTrack, (k33::RedoQueue*)Q, RM, n);
-        if (contacts) hipLaunchKernelGGL(k33::pdb_contact_kernel_generic, cgrid, block, 0, st, S, A, O, CS, b->dParams, b->dK, b->dTrack, CT, (k33::RedoQueue*)Q, RM, n);
+        hipLaunchKernelGGL(k33::pdb_step_kernel_generic, grid, block, 0, st, S, A, O, CS, DP, DK, b->dTrack, (k33::RedoQueue*)Q, RM, n);
+        if (contacts) hipLaunchKernelGGL(k33::pdb_contact_kernel_generic, cgrid, block, 0, st, S, A, O, CS, DP, DK, b->dTrack, CT, (k33::RedoQueue*)Q, RM, n);
     } else {
-        hipLaunchKernelGGL(k40::pdb_step_kernel_wide, grid, block, 0, st, S, A, O, CS, b->dParams, b->dK, b->dTrack, (k40::RedoQueue*)Q, RM, n);
-        if (contacts) hipLaunchKernelGGL(k40::pdb_contact_kernel_wide, cgrid, block, 0, st, S, A, O, CS, b->dParams, b->dK, b->dTrack, CT, (k40::RedoQueue*)Q, RM, n);
+        hipLaunchKernelGGL(k40::pdb_step_kernel_wide, grid, block, 0, st, S, A, O, CS, DP, DK, b->dTrack, (k40::RedoQueue*)Q, RM, n);
+        if (contacts) hipLaunchKernelGGL(k40::pdb_contact_kernel_wide, cgrid, block, 0, st, S, A, O, CS, DP, DK, b->dTrack, CT, (k40::RedoQueue*)Q, RM, n);
     }
+}
+
+// the constants blocks to the device: the batch's, and every partition's own (its model-derived part + the batch's run-time part)
+static int pushK(pdb_batch* b, hipStream_t st, bool async) {
+    if (async) HIPCHK(hipMemcpyAsync(b->dK, &b->K, sizeof(DevConst), hipMemcpyHostToDevice, st)); else HIPCHK(hipMemcpy(b->dK, &b->K, sizeof(DevConst), hipMemcpyHostToDevice));
+    for (int p = 0; p < PDB_MAX_PARTS; ++p) {
+        if (!b->partHas[p]) continue;
+        DevConst& K = b->partK[p];
+        fillConst(b->partParams[p], K, b->K.actionMode);
+        K.dt = b->K.dt; K.fps = b->K.fps; K.dtD = b->K.dtD; K.stuckTimeout = b->K.stuckTimeout; K.wantCarState = b->K.wantCarState; K.stamps = b->K.stamps;
+        K.envHitPenalty = b->K.envHitPenalty; K.envOffPenalty = b->K.envOffPenalty; K.envStuckPenalty = b->K.envStuckPenalty; K.envLowReward = b->K.envLowReward;
+        K.envMode = b->K.envMode; K.envTermHit = b->K.envTermHit; K.envTermOff = b->K.envTermOff; K.envTermStuck = b->K.envTermStuck;
+        K.envTeleportOnReset = b->K.envTeleportOnReset; K.envTeleportMode = b->K.envTeleportMode;
+        if (async) HIPCHK(hipMemcpyAsync(b->dPartK[p], &K, sizeof(DevConst), hipMemcpyHostToDevice, st)); else HIPCHK(hipMemcpy(b->dPartK[p], &K, sizeof(DevConst), hipMemcpyHostToDevice));
+    }
+    return PDB_OK;
 }
 
 static int launch(pdb_batch* b, float dt, bool wantCarState) {
@@ -180,7 +207,7 @@ static int launch(pdb_batch* b, float dt, bool wantCarState) {
         b->K.dt = dt; b->K.fps = 1.0f / dt;
         b->K.dtD = (dt == (float)(1.0 / 333.0)) ? (1.0 / 333.0) : (double)dt;   // PyProjectD.cpp:160-173: double dt, float step
         b->K.wantCarState = wantCarState ? 1 : 0;
-        HIPCHK(hipMemcpyAsync(b->dK, &b->K, sizeof(DevConst), hipMemcpyHostToDevice, b->stream));
+        if (int rck = pushK(b, b->stream, true)) return rck;
     }
     launchTick(b, b->stream, 0, b->n, b->dOutActive, PDB_MAX_PARTS);
     HIPCHK(hipGetLastError());
@@ -266,6 +293,7 @@ void pdb_destroy(pdb_batch* b) {
     if (b->stream) (void)hipStreamSynchronize(b->stream);
     (void)hipFree(b->dStates); (void)hipFree(b->dActions); (void)hipFree(b->dOut); (void)hipFree(b->dCarStates); (void)hipFree(b->dParams); (void)hipFree(b->dK); (void)hipFree(b->dTrack); (void)hipFree(b->dContacts); (void)hipFree(b->dResetMask); (void)hipFree(b->dResetScratch);
     for (int q = 0; q <= PDB_MAX_PARTS; ++q) (void)hipFree(b->dQueue[q]);
+    for (int q = 0; q < PDB_MAX_PARTS; ++q) { (void)hipFree(b->dPartParams[q]); (void)hipFree(b->dPartK[q]); }
     if (b->ev0) (void)hipEventDestroy(b->ev0);
     if (b->ev1) (void)hipEventDestroy(b->ev1);
     if (b->tev0) (void)hipEventDestroy(b->tev0);
@@ -341,7 +369,15 @@ extern "C" __global__ void pdb_reset_kernel(pdb_dyn_state* __restrict__ states, 
 }
 static int resetLaunch(pdb_batch* b, uint8_t* dMask, int mode, int clear) {
     if (int rcj = joinParts(b)) return rcj;
-    hipLaunchKernelGGL(pdb_reset_kernel, dim3((b->n + 63) / 64), dim3(64), 0, b->stream, b->dStates, dMask, b->dParams, b->dTrack, b->n, mode, clear);
+    bool any = false;
+    for (int p = 0; p < b->parts; ++p) any = any || b->partHas[p];
+    if (!any) hipLaunchKernelGGL(pdb_reset_kernel, dim3((b->n + 63) / 64), dim3(64), 0, b->stream, b->dStates, dMask, b->dParams, b->dTrack, b->n, mode, clear);
+    else for (int p = 0; p < b->parts; ++p) {   // each partition's cars with the partition's own block (fuel, ride height ...)
+        const int c0 = partFirst(b, p), c1 = partFirst(b, p + 1);
+        if (c1 <= c0) continue;
+        hipLaunchKernelGGL(pdb_reset_kernel, dim3((c1 - c0 + 63) / 64), dim3(64), 0, b->stream, b->dStates + c0, dMask ? dMask + c0 : nullptr,
+                           b->partHas[p] ? b->dPartParams[p] : b->dParams, b->dTrack, c1 - c0, mode, clear);
+    }
     HIPCHK(hipGetLastError());
     return PDB_OK;
 }
@@ -375,8 +411,25 @@ int pdb_set_stuck_timeout(pdb_batch* b, double seconds) {
     for (int p = 0; p < b->parts; ++p) if (b->partStream[p]) HIPCHK(hipStreamSynchronize(b->partStream[p]));
     HIPCHK(hipStreamSynchronize(b->stream));
     b->K.stuckTimeout = seconds;
-    HIPCHK(hipMemcpy(b->dK, &b->K, sizeof(DevConst), hipMemcpyHostToDevice));
+    if (int rck = pushK(b, b->stream, false)) return rck;
     return PDB_OK;
+}
+int pdb_set_partition_params(pdb_batch* b, int part, const pdb_car_params* params) {
+    if (!b || part < 0 || part >= b->parts || b->parts < 2) { pdb::setError("pdb_set_partition_params: no such partition (pdb_set_partitions first)"); return PDB_ERR_ARG; }
+    if (int rcj = joinParts(b)) return rcj;
+    for (int p = 0; p < PDB_MAX_PARTS; ++p) if (b->partStream[p]) HIPCHK(hipStreamSynchronize(b->partStream[p]));
+    HIPCHK(hipStreamSynchronize(b->stream));
+    if (!params) { b->partHas[part] = false; return PDB_OK; }
+    const pdb_car_params& A = b->params;
+    bool same = params->numBodies == A.numBodies && params->numJoints == A.numJoints && params->numRows == A.numRows;
+    for (int j = 0; same && j < A.numJoints; ++j) same = params->joints[j].type == A.joints[j].type && params->joints[j].b0 == A.joints[j].b0 && params->joints[j].b1 == A.joints[j].b1;
+    if (!same) { pdb::setError("pdb_set_partition_params: the block's rigid-body topology differs from the batch's (one kernel variant per batch)"); return PDB_ERR_ARG; }
+    if (!b->dPartParams[part]) { HIPCHK(hipMalloc(&b->dPartParams[part], sizeof(pdb_car_params))); HIPCHK(hipMalloc(&b->dPartK[part], sizeof(DevConst))); }
+    b->partParams[part] = *params;
+    b->partHas[part] = true;
+    HIPCHK(hipMemcpy(b->dPartParams[part], params, sizeof(pdb_car_params), hipMemcpyHostToDevice));
+    if (b->graphExec) { (void)hipGraphExecDestroy(b->graphExec); b->graphExec = nullptr; }
+    return pushK(b, b->stream, false);
 }
 int pdb_set_env(pdb_batch* b, const pdb_env_config* cfg) {
     if (!b || !cfg || cfg->teleport_mode < 0 || cfg->teleport_mode > 2) { pdb::setError("pdb_set_env: bad argument"); return PDB_ERR_ARG; }
@@ -388,7 +441,7 @@ int pdb_set_env(pdb_batch* b, const pdb_env_config* cfg) {
     K.envTermHit = cfg->terminate_on_hit ? 1 : 0; K.envTermOff = cfg->terminate_off_track ? 1 : 0; K.envTermStuck = cfg->terminate_when_stuck ? 1 : 0;
     K.envHitPenalty = cfg->hit_penalty; K.envOffPenalty = cfg->off_track_penalty; K.envStuckPenalty = cfg->stuck_penalty; K.envLowReward = cfg->low_reward;
     K.envTeleportOnReset = cfg->teleport_on_reset ? 1 : 0; K.envTeleportMode = cfg->teleport_mode;
-    HIPCHK(hipMemcpy(b->dK, &b->K, sizeof(DevConst), hipMemcpyHostToDevice));
+    if (int rck = pushK(b, b->stream, false)) return rck;
     return PDB_OK;
 }
 int pdb_set_seed(pdb_batch* b, const uint32_t* seeds) {
@@ -432,7 +485,7 @@ int pdb_step_n(pdb_batch* b, float dt, int n) {
     // leaves wantCarState = 1 behind); the capture must not contain the H2D copy
     if (b->K.dt != dt || b->K.wantCarState != 0) {
         b->K.dt = dt; b->K.fps = 1.0f / dt; b->K.dtD = (dt == (float)(1.0 / 333.0)) ? (1.0 / 333.0) : (double)dt; b->K.wantCarState = 0;
-        HIPCHK(hipMemcpyAsync(b->dK, &b->K, sizeof(DevConst), hipMemcpyHostToDevice, b->stream));
+        if (int rck = pushK(b, b->stream, true)) return rck;
         HIPCHK(hipStreamSynchronize(b->stream));
     }
     if (b->stream == nullptr) {   // the legacy default stream (a caller's pdb_set_stream) cannot be captured: n plain launches
@@ -503,7 +556,7 @@ int pdb_step_ring(pdb_batch* b, float dt, int n_ticks, pdb_step_out* ring, int r
     if (b->K.dt != dt || b->K.wantCarState != 0) {
         if (int rcj = joinParts(b)) return rcj;   // the constants change under kernels that may still read them: those first
         b->K.dt = dt; b->K.fps = 1.0f / dt; b->K.dtD = (dt == (float)(1.0 / 333.0)) ? (1.0 / 333.0) : (double)dt; b->K.wantCarState = 0;
-        HIPCHK(hipMemcpyAsync(b->dK, &b->K, sizeof(DevConst), hipMemcpyHostToDevice, b->stream));
+        if (int rck = pushK(b, b->stream, true)) return rck;
     }
     const bool forked = b->parts > 1 && b->partStream[0];
     if (forked) HIPCHK(hipEventRecord(b->partFork, b->stream));
@@ -530,7 +583,7 @@ int pdb_step_partition(pdb_batch* b, float dt, int part, pdb_step_out* out) {
     if (b->K.dt != dt || b->K.wantCarState != 0) {   // constants change: everything in flight first
         if (int rcj = joinParts(b)) return rcj;
         b->K.dt = dt; b->K.fps = 1.0f / dt; b->K.dtD = (dt == (float)(1.0 / 333.0)) ? (1.0 / 333.0) : (double)dt; b->K.wantCarState = 0;
-        HIPCHK(hipMemcpyAsync(b->dK, &b->K, sizeof(DevConst), hipMemcpyHostToDevice, b->stream));
+        if (int rck = pushK(b, b->stream, true)) return rck;
         HIPCHK(hipStreamSynchronize(b->stream));
     }
     const int c0 = partFirst(b, part), c1 = partFirst(b, part + 1);

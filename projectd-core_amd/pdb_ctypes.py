@@ -154,6 +154,7 @@ def load_product(host_only=False):
         lib.pdb_set_stuck_timeout.argtypes = [C.c_void_p, C.c_double]
         lib.pdb_set_seed.argtypes = [C.c_void_p, C.c_void_p]
         lib.pdb_set_env.argtypes = [C.c_void_p, C.c_void_p]
+        lib.pdb_set_partition_params.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
         lib.pdb_actions_device.restype = C.c_void_p; lib.pdb_actions_device.argtypes = [C.c_void_p]
         lib.pdb_out_device.restype = C.c_void_p; lib.pdb_out_device.argtypes = [C.c_void_p]
         lib.pdb_set_out_device.argtypes = [C.c_void_p, C.c_void_p]

@@ -57,6 +57,10 @@ class Batch:
         """cut the batch into `parts` free-running car ranges, one HIP stream each (pdb_step_ring)"""
         self._chk(self.lib.pdb_set_partitions(self.h, parts))
 
+    def set_partition_params(self, part, params):
+        """a car block of its own for one partition (None: the batch's): same model, different tunes / weights"""
+        self._chk(self.lib.pdb_set_partition_params(self.h, part, C.byref(params) if params is not None else None))
+
     def step_ring(self, n_ticks, ring_ptr=None, ring_slots=1, first_slot=0, join=True):
         """enqueue n_ticks ticks of every car, partition by partition; tick i writes outputs to ring slot (first_slot + i) % ring_slots.
         join=False: the batch's stream is not held back; order consumers with wait_partitions()"""

@@ -459,3 +459,54 @@ def test_every_reward_weight_in_play(built, track):
         assert i == 21
     worst = parity_util.run_parity(n_cars=32, ticks=2300 if track == 'walled' else 1200, seed=11, track=track, check_every=9, params_fn=weights)
     assert worst == 0.0, worst
+
+
+@pytest.mark.gpu
+def test_partitions_with_their_own_car_blocks(built):
+    """pdb_set_partition_params: the second partition's cars run a shorter final drive, a different brake bias and their own
+    reward weights; each partition equals the oracle stepped with its block, bit for bit (incl. a device reset in between)"""
+    import pdbatch, oracle_ctypes
+    n, ticks = 48, 500
+    P = pdbatch.packed_params(); trk = pdbatch.synthetic_track('touge')
+    P2 = pc.CarParams.from_buffer_copy(bytes(P))
+    P2.finalRatio = P.finalRatio * 0.85; P2.frontBias = 0.62; P2.scoring.TravelBonus = 0.7; P2.scoring.SpeedBonus = 0.05; P2.fuel = 12.0
+    lib = pc.load_product(); orc = oracle_ctypes.load_oracle(portable_math=True)
+    S0 = pc.DynState(); assert lib.pdb_initial_state(C.byref(P), trk, C.byref(S0)) == 0
+    S2 = pc.DynState(); assert lib.pdb_initial_state(C.byref(P2), trk, C.byref(S2)) == 0
+    b = pdbatch.Batch(n, P, trk, device=0, action_mode=1)
+    try:
+        b.set_partitions(2)
+        f1, c1 = b.partition_range(1)
+        b.set_partition_params(1, P2)
+        st = b.get_state()
+        for i in range(f1, f1 + c1):
+            C.memmove(C.byref(st[i]), C.byref(S2), C.sizeof(S2))
+        b.set_state(st)
+        acts = parity_util.make_actions(n, 21)
+        b.upload_actions(acts)
+        hs = [orc.cpuref_create(C.byref(P2 if i >= f1 else P), trk, len(trk), C.byref(S2 if i >= f1 else S0)) for i in range(n)]
+        mask = (np.arange(n) % 5 == 0).astype(np.uint8)
+        for phase in range(2):
+            b.step_ring(ticks, None, 1, 0, join=True)
+            b.sync()
+            for i in range(n):
+                for t in range(ticks):
+                    orc.cpuref_step_env(hs[i], float(acts[i, 0]), float(acts[i, 1]))
+            sg = b.get_state()
+            for i in range(n):
+                sc = pc.DynState(); orc.cpuref_get_state(hs[i], C.byref(sc))
+                rel, name, vg, vc, bad_int = parity_util.compare_states(sg[i], sc)
+                assert not bad_int and rel == 0.0, (phase, i, name, vg, vc, bad_int[:3])
+            if phase == 0:   # reset some cars of both partitions on the device: each with its own block (fuel, ride height)
+                b.reset(mask, 0)
+                for i in range(n):
+                    if mask[i]:
+                        sc = pc.DynState(); orc.cpuref_get_state(hs[i], C.byref(sc))
+                        assert lib.pdb_teleport_by_mode(C.byref(P2 if i >= f1 else P), trk, 0, C.byref(sc)) == 0
+                        orc.cpuref_set_state(hs[i], C.byref(sc))
+        diff = sum(1 for i in range(f1, f1 + c1) if sg[i].totalReward != sg[i - f1].totalReward)
+        assert diff > c1 // 2      # the second partition really drives something else
+        for h in hs:
+            orc.cpuref_destroy(h)
+    finally:
+        b.close()
