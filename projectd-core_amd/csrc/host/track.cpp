@@ -384,10 +384,28 @@ std::vector<uint8_t> buildTrack(const std::string& basePathIn, const std::string
     if (h.numTris > 0) {
         float mnx = tris[0], mxx = tris[0], mnz = tris[2], mxz = tris[2];
         for (size_t v = 0; v < tris.size(); v += 3) { mnx = std::min(mnx, tris[v]); mxx = std::max(mxx, tris[v]); mnz = std::min(mnz, tris[v + 2]); mxz = std::max(mxz, tris[v + 2]); }
-        // cell edge: about two triangles per cell on average, at most 2^20 cells
+        // cell edge: start from "two triangles per cell of the bounding box", then -- a road is a thin ribbon in a mostly empty box --
+        // halve it while the cells that hold anything hold more than three list entries on average (not below 1 m, not beyond 2^19 cells).
+        // (The grid only selects candidates: any cell size gives the same hits.)
         float cell = sqrtf(((mxx - mnx) * (mxz - mnz)) / (float)h.numTris * 2.0f);
         if (!(cell > 0.5f)) cell = 0.5f;
-        while ((double)((mxx - mnx) / cell + 1.0f) * (double)((mxz - mnz) / cell + 1.0f) > 1048576.0) cell *= 2.0f;
+        auto cellsAt = [&](float c) { return (double)((mxx - mnx) / c + 1.0f) * (double)((mxz - mnz) / c + 1.0f); };
+        while (cellsAt(cell) > 1048576.0) cell *= 2.0f;
+        for (;;) {
+            const float half = cell * 0.5f;
+            if (half < 1.0f || cellsAt(half) > 524288.0) break;
+            const int nx = (int)floorf((mxx - mnx) / cell) + 1, nz = (int)floorf((mxz - mnz) / cell) + 1;
+            std::vector<int32_t> cnt((size_t)nx * (size_t)nz, 0);
+            size_t entries = 0, nonEmpty = 0;
+            for (int t = 0; t < h.numTris; ++t) {
+                const float* p = tris.data() + 9 * (size_t)t;
+                const int x0 = (int)floorf((std::min(p[0], std::min(p[3], p[6])) - mnx) / cell), x1 = (int)floorf((std::max(p[0], std::max(p[3], p[6])) - mnx) / cell);
+                const int z0 = (int)floorf((std::min(p[2], std::min(p[5], p[8])) - mnz) / cell), z1 = (int)floorf((std::max(p[2], std::max(p[5], p[8])) - mnz) / cell);
+                for (int z = z0; z <= z1; ++z) for (int x = x0; x <= x1; ++x) { if (cnt[(size_t)z * nx + x]++ == 0) ++nonEmpty; ++entries; }
+            }
+            if (nonEmpty == 0 || (double)entries / (double)nonEmpty <= 3.0) break;
+            cell = half;
+        }
         h.gridMinX = mnx; h.gridMinZ = mnz; h.gridCell = cell;
         auto cellOf = [&](float x, float mn) { return (int)floorf((x - mn) / cell); };   // the kernel uses the same expression
         h.gridNx = cellOf(mxx, mnx) + 1; h.gridNz = cellOf(mxz, mnz) + 1;

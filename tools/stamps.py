@@ -28,10 +28,19 @@ def lp(host_only=False):
 pc.load_product = lp
 P = pdbatch.packed_params()
 pc.load_product = orig
-trk = pdbatch.synthetic_track('flat')
+kind = sys.argv[2] if len(sys.argv) > 2 else 'flat'
+gen = {'step': float(sys.argv[3])} if len(sys.argv) > 3 else {}
+trk = pdbatch.synthetic_track(kind, **gen)
 pc.load_product = lp
 b = pdbatch.Batch(n, P, trk, 0, 1)
 a = pu.make_actions(n, 1234)
+if kind == 'touge':   # spread the cars around the lap, drive them with a mild constant action
+    st = b.get_state()
+    hl = pc.load_product(host_only=True)
+    for i in range(n):
+        hl.pdb_teleport_to_spline(C.byref(P), trk, C.c_float((i % 4096) / 4096.0), C.byref(st[i]))
+    b.set_state(st)
+    a[:, 0] = 0.0; a[:, 1] = -0.5
 for _ in range(400): b.step_host(a)
 st = np.zeros((n, 32), dtype=np.uint64)
 lib.pdb_debug_stamps(b.h, st.ctypes.data_as(C.c_void_p))
