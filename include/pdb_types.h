@@ -354,7 +354,7 @@ typedef struct pdb_track_header {
     float gridMinX, gridMinZ, gridCell, _gridPad;
     uint64_t offGridStart;  /* int32[gridNx*gridNz + 1] */
     uint64_t offGridTris;   /* int32[...]  triangle ids */
-    uint64_t offTriSurf;    /* int32[numTris] surface of each triangle */
+    uint64_t offTriSurf;    /* int32[numTris] surface of each triangle (low 24 bits) | its collisionCategory << 24 (version >= 4) */
     /* version >= 3: uniform xz grid over the fat points (cell edge = hashCellSize, the reference's VertexHash cell,
      * Core/VertexHash.h:45-104) for Track::nearbyPoints: cell (ix, iz) lists its points in ascending id; cells are
      * stored row by row, so the lists of the cells ix0..ix1 of one row are one contiguous run of ids. */

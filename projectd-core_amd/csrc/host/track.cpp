@@ -190,6 +190,7 @@ std::vector<uint8_t> buildTrack(const std::string& basePathIn, const std::string
             s.gripMod = b.gripMod; s.damping = b.damping; s.sinHeight = b.sinHeight; s.sinLength = b.sinLength;
             s.granularity = b.granularity; s.dirtAdditiveK = b.dirtAdditiveK;
             s.collisionCategory = (int32_t)b.collisionCategory; s.isValidTrack = b.isValidTrack; s.sectorID = (int32_t)b.sectorID;
+            if (b.collisionCategory > 127u) throw std::runtime_error("pdb: surfaces.bin collision category out of range (the C_CATEGORY_* bits are 1..16)");
             s.triStart = (int32_t)(tris.size() / 9);
             s.triCount = (int32_t)(b.numIndices / 3);
             for (uint32_t t = 0; t < b.numIndices / 3; ++t)
@@ -364,7 +365,7 @@ std::vector<uint8_t> buildTrack(const std::string& basePathIn, const std::string
     // ---- pack ----
     pdb_track_header h;
     memset(&h, 0, sizeof(h));
-    h.magic = 0x4B544450; h.version = 3;
+    h.magic = 0x4B544450; h.version = 4;
     h.numSurfaces = (int32_t)surfaces.size(); h.numTris = (int32_t)(tris.size() / 9);
     h.numFat = (int32_t)fat.size(); h.numNodes = (int32_t)nodes.size();
     h.interpolateStep = steps; h.closedLoop = closedLoop ? 1 : 0;
@@ -380,7 +381,7 @@ std::vector<uint8_t> buildTrack(const std::string& basePathIn, const std::string
     // ---- xz grid over the triangles (see pdb_track_header) ----
     std::vector<int32_t> gridStart, gridTris, triSurf((size_t)h.numTris, 0);
     for (size_t s = 0; s < surfaces.size(); ++s)
-        for (int t = surfaces[s].triStart; t < surfaces[s].triStart + surfaces[s].triCount; ++t) triSurf[(size_t)t] = (int32_t)s;
+        for (int t = surfaces[s].triStart; t < surfaces[s].triStart + surfaces[s].triCount; ++t) triSurf[(size_t)t] = (int32_t)s | (surfaces[s].collisionCategory << 24);
     if (h.numTris > 0) {
         float mnx = tris[0], mxx = tris[0], mnz = tris[2], mxz = tris[2];
         for (size_t v = 0; v < tris.size(); v += 3) { mnx = std::min(mnx, tris[v]); mxx = std::max(mxx, tris[v]); mnz = std::min(mnz, tris[v + 2]); mxz = std::max(mxz, tris[v + 2]); }
