@@ -362,7 +362,21 @@ typedef struct pdb_track_header {
     float fatGridMinX, fatGridMinZ, fatGridCell, _fatGridPad;
     uint64_t offFatGridStart;   /* int32[fatGridNx*fatGridNz + 1] */
     uint64_t offFatGridIds;     /* int32[numFat] */
+    /* version >= 4: the wheel rays' own grid.  Cell (ix, iz) lists, in ascending triangle order, a COPY of every triangle whose
+     * xz projection (not just its bounding box) can contain a point of the cell, so that the candidates of a ray are one
+     * contiguous run of records behind two dependent loads, and a finer cell than the collision grid's costs no accuracy. */
+    int32_t rayNx, rayNz;
+    float rayMinX, rayMinZ, rayCell, _rayPad;
+    uint64_t offRayStart;   /* int32[rayNx*rayNz + 1] */
+    uint64_t offRayRecs;    /* pdb_ray_rec[...] */
 } pdb_track_header;
+
+typedef struct pdb_ray_rec {
+    float v[9];         /* v0, v1, v2 as in offTris */
+    int32_t tri;        /* triangle id */
+    int32_t surface;
+    int32_t _pad;
+} pdb_ray_rec;
 
 #ifdef __cplusplus
 }
@@ -372,5 +386,6 @@ static_assert(sizeof(pdb_car_params) == 12392, "pdb_car_params layout");
 static_assert(sizeof(pdb_dyn_state) == 2272, "pdb_dyn_state layout (multiple of 16 bytes)");
 static_assert(sizeof(pdb_step_out) == 104, "pdb_step_out layout");
 static_assert(sizeof(pdb_contact) == 32, "pdb_contact layout");
+static_assert(sizeof(pdb_ray_rec) == 48, "pdb_ray_rec layout");
 #endif
 #endif

@@ -447,6 +447,68 @@ std::vector<uint8_t> buildTrack(const std::string& basePathIn, const std::string
     }
     h.offFatGridStart = off; off = align(off + fgStart.size() * 4);
     h.offFatGridIds = off; off = align(off + fgIds.size() * 4);
+    // ---- the wheel rays' grid (see pdb_track_header): exact (conservatively inflated) triangle / cell overlap in xz ----
+    std::vector<int32_t> rayStart;
+    std::vector<pdb_ray_rec> rayRecs;
+    if (h.numTris > 0) {
+        double mnx = tris[0], mxx = tris[0], mnz = tris[2], mxz = tris[2], mxa = 0.0;
+        for (size_t v = 0; v < tris.size(); v += 3) {
+            mnx = std::min(mnx, (double)tris[v]); mxx = std::max(mxx, (double)tris[v]); mnz = std::min(mnz, (double)tris[v + 2]); mxz = std::max(mxz, (double)tris[v + 2]);
+            mxa = std::max(mxa, std::max(std::fabs((double)tris[v]), std::fabs((double)tris[v + 2])));
+        }
+        // cell edge: a quarter of the collision grid's, not below half a metre, at most 2^22 cells
+        float cell = h.gridCell * 0.25f;
+        if (!(cell > 0.5f)) cell = 0.5f;
+        auto cellsAt = [&](float c) { return ((mxx - mnx) / c + 1.0) * ((mxz - mnz) / c + 1.0); };
+        while (cellsAt(cell) > 4194304.0) cell *= 2.0f;
+        h.rayMinX = (float)mnx; h.rayMinZ = (float)mnz; h.rayCell = cell;
+        const float fmnx = h.rayMinX, fmnz = h.rayMinZ;
+        auto cellOf = [&](float x, float mn) { return (int)floorf((x - mn) / cell); };   // the kernel uses the same expression
+        h.rayNx = cellOf((float)mxx, fmnx) + 1; h.rayNz = cellOf((float)mxz, fmnz) + 1;
+        // a ray's cell comes out of float arithmetic and so do the inside tests of the hit: every rectangle is inflated by far more
+        // than either can be off (a thousandth of a cell plus 2^-17 of the largest coordinate)
+        const double eps = 1.0e-3 * (double)cell + 7.62939453125e-6 * mxa;
+        auto overlaps = [&](const float* p, int x, int z) {
+            const double rx0 = (double)fmnx + (double)x * cell - eps, rx1 = (double)fmnx + (double)(x + 1) * cell + eps;
+            const double rz0 = (double)fmnz + (double)z * cell - eps, rz1 = (double)fmnz + (double)(z + 1) * cell + eps;
+            const double tx[3] = {p[0], p[3], p[6]}, tz[3] = {p[2], p[5], p[8]};
+            for (int e = 0; e < 3; ++e) {   // separating axis = an edge's normal (the box axes are covered by the cell span)
+                const int f = (e + 1) % 3, g = (e + 2) % 3;
+                const double nx = -(tz[f] - tz[e]), nz = tx[f] - tx[e];
+                if (nx == 0.0 && nz == 0.0) continue;
+                const double side = nx * (tx[g] - tx[e]) + nz * (tz[g] - tz[e]);   // the triangle lies on this side of the edge (or on it)
+                const double c0 = nx * (rx0 - tx[e]) + nz * (rz0 - tz[e]), c1 = nx * (rx1 - tx[e]) + nz * (rz0 - tz[e]);
+                const double c2 = nx * (rx0 - tx[e]) + nz * (rz1 - tz[e]), c3 = nx * (rx1 - tx[e]) + nz * (rz1 - tz[e]);
+                if (side >= 0.0 ? (c0 < 0.0 && c1 < 0.0 && c2 < 0.0 && c3 < 0.0) : (c0 > 0.0 && c1 > 0.0 && c2 > 0.0 && c3 > 0.0)) return false;
+            }
+            return true;
+        };
+        auto span = [&](int t, int& x0, int& x1, int& z0, int& z1) {
+            const float* p = tris.data() + 9 * (size_t)t;
+            const float e = (float)eps;
+            x0 = std::max(cellOf(std::min(p[0], std::min(p[3], p[6])) - e, fmnx), 0); x1 = std::min(cellOf(std::max(p[0], std::max(p[3], p[6])) + e, fmnx), h.rayNx - 1);
+            z0 = std::max(cellOf(std::min(p[2], std::min(p[5], p[8])) - e, fmnz), 0); z1 = std::min(cellOf(std::max(p[2], std::max(p[5], p[8])) + e, fmnz), h.rayNz - 1);
+        };
+        const size_t nc = (size_t)h.rayNx * (size_t)h.rayNz;
+        rayStart.assign(nc + 1, 0);
+        std::vector<std::pair<int32_t, int32_t>> ent;   // (cell, triangle), triangles ascending
+        for (int t = 0; t < h.numTris; ++t) {
+            int x0, x1, z0, z1; span(t, x0, x1, z0, z1);
+            const float* p = tris.data() + 9 * (size_t)t;
+            for (int z = z0; z <= z1; ++z) for (int x = x0; x <= x1; ++x)
+                if (overlaps(p, x, z)) { ent.emplace_back((int32_t)((size_t)z * h.rayNx + x), (int32_t)t); rayStart[(size_t)z * h.rayNx + x + 1]++; }
+        }
+        for (size_t c = 0; c < nc; ++c) rayStart[c + 1] += rayStart[c];
+        rayRecs.resize(ent.size());
+        std::vector<int32_t> fill(rayStart.begin(), rayStart.end() - 1);
+        for (const auto& e : ent) {
+            pdb_ray_rec& r = rayRecs[(size_t)fill[(size_t)e.first]++];
+            memcpy(r.v, tris.data() + 9 * (size_t)e.second, 36);
+            r.tri = e.second; r.surface = triSurf[(size_t)e.second] & 0xFFFFFF; r._pad = 0;
+        }
+    }
+    h.offRayStart = off; off = align(off + rayStart.size() * 4);
+    h.offRayRecs = off; off = align(off + rayRecs.size() * sizeof(pdb_ray_rec));
     h.totalBytes = off;
     std::vector<uint8_t> blob(off, 0);
     memcpy(blob.data(), &h, sizeof(h));
@@ -461,6 +523,8 @@ std::vector<uint8_t> buildTrack(const std::string& basePathIn, const std::string
     if (!triSurf.empty()) memcpy(blob.data() + h.offTriSurf, triSurf.data(), triSurf.size() * 4);
     if (!fgStart.empty()) memcpy(blob.data() + h.offFatGridStart, fgStart.data(), fgStart.size() * 4);
     if (!fgIds.empty()) memcpy(blob.data() + h.offFatGridIds, fgIds.data(), fgIds.size() * 4);
+    if (!rayStart.empty()) memcpy(blob.data() + h.offRayStart, rayStart.data(), rayStart.size() * 4);
+    if (!rayRecs.empty()) memcpy(blob.data() + h.offRayRecs, rayRecs.data(), rayRecs.size() * sizeof(pdb_ray_rec));
     return blob;
 }
 
