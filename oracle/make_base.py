@@ -93,6 +93,11 @@ def main():
             shutil.rmtree(dst)
         shutil.copytree(os.path.join(REF, 'content', 'tracks', trk), dst)
         os.system('chmod -R u+w "%s"' % dst)
+    for trk in ('ek_akina', 'ks_nordschleife'):   # shipped with their spline only: the road is a ribbon around it (synthetic_tracks.gen_ribbon)
+        dst = os.path.join(base, 'content', 'tracks', trk)
+        if os.path.isdir(dst):
+            shutil.rmtree(dst)
+        gen_track.ribbon_track_from(os.path.join(REF, 'content', 'tracks', trk), dst)
     print(base)
 if __name__ == '__main__':
     main()

@@ -74,8 +74,14 @@ static const Scenario kScenarios[] = {
     {"autotele_near", 3000, 0, 3, 0, 1, 1, 1, "walled", 0, nullptr, 0, 1, 0, 0, 0, 0, 0, 1 | 2 | (1 << 2)},
     {"autotele_rand", 3600, 300, 10, 0, 1, 1, 1, "touge", 1, nullptr, 0, 0, 0, 0, 0, 0, 0, 2 | (2 << 2)},
     {"autotele_start", 3900, 0, 3, 0, 1, 1, 1, "walled", 0, nullptr, 0, 1, 0, 0, 0, 0, 0, 1 | (0 << 2)},
+    // the two tracks of BASELINE configs[2] / [4], which ship their spline but not their mesh (build container only): the reference's
+    // own spline.bin -- 5109 points at 0.9 m, 13 323 points at 1.6 m, open, racing-line sides -- with a road ribbon generated around
+    // it (synthetic_tracks.gen_ribbon); the second Akina run is put down at four places along the hill (teleportCarToSpline)
+    {"akina", 3000, 300, 10, 0, 1, 1, 1, "ek_akina", 1, nullptr, 0, 0, 0, 0, 0, 0, 0},
+    {"akina_tele", 3000, 300, 10, 0, 1, 1, 1, "ek_akina", 1, "gravygarage_street_ae86_readie", 0, 0, 600, 0, 1, 0, 0},
+    {"nords", 3000, 300, 10, 0, 1, 1, 1, "ks_nordschleife", 1, "ks_toyota_supra_mkiv_drift", 0, 0, 0, 0, 0, 0, 0},
 };
-static const int kNumScenarios = 35;
+static const int kNumScenarios = 38;
 static const float kTeleDist[4] = {0.13f, 0.41f, 0.77f, 0.95f};
 struct ScoreVar { const char* name; float value; };
 static const ScoreVar kScoringSetA[] = {

@@ -175,6 +175,113 @@ def gen_touge(out, step=5.0, side=5.0, margin=4.0, bank_gain=6.0, bank_max=0.08,
     return n
 
 
+def read_spline_bin(path):
+    """spline.bin: SlimTrackPoint = float[3] best + float[2] sides, no header (Sim/Track.cpp:97-150)"""
+    raw = open(path, 'rb').read()
+    n = len(raw) // 20
+    return [struct.unpack_from('<5f', raw, 20 * i) for i in range(n)]
+
+
+def gen_ribbon(out, points, closed=False, margin=4.0, points_per_surface=40, lead=3):
+    """Road ribbon extruded around a given spline (list of (x, y, z, side_left, side_right), e.g. read_spline_bin of a track that
+    ships its spline but not its mesh): two triangles per spline interval, flat cross-section at the point's height, half widths
+    = the point's sides + margin, surfaces of points_per_surface intervals cycling through TOUGE_SURFACES.  An open spline gets
+    `lead` extrapolated intervals before its first and after its last point (the start pose must have road under the rear
+    wheels).  Writes surfaces.bin only: the spline files stay the caller's."""
+    os.makedirs(out, exist_ok=True)
+    pts = [tuple(float(v) for v in p) for p in points]
+    if not closed:
+        a, b = pts[0], pts[1]
+        head = [tuple(a[c] + (a[c] - b[c]) * k for c in range(3)) + (a[3], a[4]) for k in range(lead, 0, -1)]
+        a, b = pts[-1], pts[-2]
+        tail = [tuple(a[c] + (a[c] - b[c]) * k for c in range(3)) + (a[3], a[4]) for k in range(1, lead + 1)]
+        pts = head + pts + tail
+    n = len(pts)
+    lat = []
+    for i in range(n):
+        p0 = pts[i - 1] if (closed or i > 0) else pts[i]
+        p2 = pts[(i + 1) % n] if (closed or i + 1 < n) else pts[i]
+        fx, fz = p2[0] - p0[0], p2[2] - p0[2]
+        fl = math.hypot(fx, fz)
+        lat.append((fz / fl, -fx / fl) if fl > 0.0 else (lat[-1] if lat else (1.0, 0.0)))
+
+    def edge(i, sgn):
+        p = pts[i]; l = lat[i]
+        w = (p[3] if sgn < 0 else p[4]) + margin
+        return (p[0] + sgn * w * l[0], p[1], p[2] + sgn * w * l[1])
+    nseg = n if closed else n - 1
+    with open(os.path.join(out, 'surfaces.bin'), 'wb') as f:
+        i0 = 0
+        while i0 < nseg:
+            cnt = min(points_per_surface, nseg - i0)
+            verts, idx = [], []
+            for k in range(cnt + 1):
+                i = (i0 + k) % n
+                verts.append(edge(i, -1.0)); verts.append(edge(i, +1.0))
+            for k in range(cnt):
+                a, b, cc, d = 2 * k, 2 * k + 1, 2 * k + 2, 2 * k + 3
+                for tri in ((a, cc, d), (a, d, b)):
+                    v0, v1, v2 = verts[tri[0]], verts[tri[1]], verts[tri[2]]
+                    ny = (v1[2] - v0[2]) * (v2[0] - v0[0]) - (v1[0] - v0[0]) * (v2[2] - v0[2])
+                    idx.extend(tri if ny > 0 else (tri[0], tri[2], tri[1]))      # front face up
+            write_surface(f, verts, idx, sector=i0 // points_per_surface, **TOUGE_SURFACES[(i0 // points_per_surface) % len(TOUGE_SURFACES)])
+            i0 += cnt
+    return n
+
+
+def gen_hillclimb(out, step=0.9, length=4300.0, side=5.0, **kw):
+    """Synthetic stand-in for the reference's ek_akina (SURVEY 8d: 5109 points, ~0.9 m, open): the first `length` metres of the
+    mountain-road centreline as an OPEN spline with uneven point spacing (+-40 %), the best point wandering +-2 m across the road
+    like a racing line and the two sides asymmetric accordingly; road = gen_ribbon around it."""
+    os.makedirs(out, exist_ok=True)
+    fine = touge_centreline(0.1)
+    pts = []
+    s, k = 0.0, 0
+    length = min(length, 0.1 * (len(fine) - 2))
+    while s < length:
+        i = int(s / 0.1)
+        p0, p1 = fine[i - 1], fine[(i + 1) % len(fine)]
+        fx, fz = p1[0] - p0[0], p1[2] - p0[2]
+        fl = math.hypot(fx, fz)
+        lx, lz = fz / fl, -fx / fl
+        r = 2.0 * math.sin(s / 40.0)
+        c = fine[i]
+        pts.append((c[0] + r * lx, c[1], c[2] + r * lz, side + r, side - r))
+        s += step * (1.0 + 0.4 * math.sin(0.7 * k))
+        k += 1
+    with open(os.path.join(out, 'spline.bin'), 'wb') as f:
+        for p in pts:
+            f.write(struct.pack('<5f', *p))
+    with open(os.path.join(out, 'spline.ini'), 'w') as f:
+        f.write('[SPLINE]\nCLOSED_LOOP=0\nTRACE_SIDES=0\n')
+    cch = os.path.join(out, 'spline.cache')
+    if os.path.exists(cch):
+        os.remove(cch)
+    gen_ribbon(out, read_spline_bin(os.path.join(out, 'spline.bin')), closed=False, **kw)
+    return len(pts)
+
+
+def ribbon_track_from(src_track_dir, out, **kw):
+    """A loadable track directory for a track whose mesh is not at hand: its own spline.bin / spline.ini / pits.ini copied, the
+    road generated around the spline (gen_ribbon).  The reference's ek_akina and ks_nordschleife come this way (SURVEY 8d)."""
+    import shutil
+    os.makedirs(out, exist_ok=True)
+    for fn in ('spline.bin', 'spline.ini', 'pits.ini'):
+        sp = os.path.join(src_track_dir, fn)
+        if os.path.exists(sp):
+            shutil.copyfile(sp, os.path.join(out, fn))
+    closed = False
+    ini = os.path.join(out, 'spline.ini')
+    if os.path.exists(ini):
+        for ln in open(ini):
+            if ln.strip().upper().startswith('CLOSED_LOOP'):
+                closed = ln.split('=')[1].strip().split()[0] not in ('0', '')
+    cch = os.path.join(out, 'spline.cache')
+    if os.path.exists(cch):
+        os.remove(cch)
+    return gen_ribbon(out, read_spline_bin(os.path.join(out, 'spline.bin')), closed=closed, **kw)
+
+
 SIM_INI = '''[SIM]
 STEP_HZ=333
 MAX_CARS=2
@@ -238,9 +345,9 @@ def make_base(base, tracks=('flat',)):
     with open(os.path.join(base, 'cfg', 'sim.ini'), 'w') as f:
         f.write(SIM_INI)
     for t in tracks:
-        {'flat': gen_flat, 'touge': gen_touge, 'walled': gen_walled}[t](os.path.join(base, 'content', 'tracks', t))
+        {'flat': gen_flat, 'touge': gen_touge, 'walled': gen_walled, 'hillclimb': gen_hillclimb}[t](os.path.join(base, 'content', 'tracks', t))
     return base
 
 if __name__ == '__main__':
     kind, out = sys.argv[1], sys.argv[2]
-    {'flat': gen_flat, 'touge': gen_touge, 'walled': gen_walled}[kind](out)
+    {'flat': gen_flat, 'touge': gen_touge, 'walled': gen_walled, 'hillclimb': gen_hillclimb}[kind](out)

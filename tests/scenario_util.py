@@ -1,4 +1,4 @@
-"""The 35 scripted scenarios of oracle/scenarios.h (the reference-TU goldens' scripts) as a set-up + driver usable from any
+"""The 38 scripted scenarios of oracle/scenarios.h (the reference-TU goldens' scripts) as a set-up + driver usable from any
 test: car block, track blob, initial state the way tests/test_oracle_golden.py prepares them, and a tick-by-tick driver that
 steps the CPU oracle and -- optionally -- a GPU batch through the same script (actions, mid-run resets / teleports, the boost)."""
 import ctypes as C, os, sys
@@ -14,20 +14,31 @@ class Skip(Exception):
     pass
 
 
+RIBBON_TRACKS = ('ek_akina', 'ks_nordschleife')   # shipped with their spline only: the road is generated around it
+
+
+def track_blob(hostlib, track, base_dir):
+    """the product's track blob for a scenario's track; Skip when it needs reference content that is absent"""
+    import synthetic_tracks
+    if track in ('flat', 'touge', 'walled'):
+        gen = {'flat': synthetic_tracks.gen_flat, 'touge': synthetic_tracks.gen_touge, 'walled': synthetic_tracks.gen_walled}[track]
+        gen(os.path.join(base_dir, 'content', 'tracks', track))
+        return pc.build_track(hostlib, base_dir, track)
+    if not os.path.isdir(os.path.join(REF_CONTENT, 'tracks', track)):
+        raise Skip('reference content not present')
+    if track in RIBBON_TRACKS:
+        synthetic_tracks.ribbon_track_from(os.path.join(REF_CONTENT, 'tracks', track), os.path.join(base_dir, 'content', 'tracks', track))
+        return pc.build_track(hostlib, base_dir, track)
+    return pc.build_track(hostlib, '/root/reference', track)
+
+
 def setup(orc, hostlib, sid, base_dir):
     """-> dict(name, track, model, P, blob, S0, fields).  Raises Skip when the scenario needs reference content that is absent."""
     import synthetic_tracks
     name = orc.cpuref_scenario_name(sid).decode()
     track = orc.cpuref_scenario_track(sid).decode()
     model = orc.cpuref_scenario_car(sid).decode()
-    if track in ('flat', 'touge', 'walled'):
-        gen = {'flat': synthetic_tracks.gen_flat, 'touge': synthetic_tracks.gen_touge, 'walled': synthetic_tracks.gen_walled}[track]
-        gen(os.path.join(base_dir, 'content', 'tracks', track))
-        blob = pc.build_track(hostlib, base_dir, track)
-    else:
-        if not os.path.isdir(os.path.join(REF_CONTENT, 'tracks', track)):
-            raise Skip('reference content not present')
-        blob = pc.build_track(hostlib, '/root/reference', track)
+    blob = track_blob(hostlib, track, base_dir)
     P = car_params(model)
     nm = C.c_char_p(); val = C.c_float()
     if orc.cpuref_scenario_tune(sid, 0, C.byref(nm), C.byref(val)):

@@ -385,6 +385,21 @@ def test_fat_point_grid_on_a_long_dense_spline(built):
 
 
 @pytest.mark.gpu
+def test_open_hill_climb_with_a_racing_line_spline(built):
+    """the shape of the reference's ek_akina / ks_nordschleife splines (tests/golden/ek_akina_*.npz pin the oracle on the real ones, in
+    the build container): OPEN, 0.9 m points unevenly spaced, the best point wandering across the road with asymmetric sides --
+    driven from the start and, for a part of the cars, from four places along the hill (pdb_teleport_to_spline)"""
+    import synthetic_tracks, tempfile, parity_util, pdb_ctypes as pc
+    d = tempfile.mkdtemp(prefix='pdb_hill_')
+    synthetic_tracks.make_base(d, tracks=())
+    n = synthetic_tracks.gen_hillclimb(os.path.join(d, 'content', 'tracks', 'hill'))
+    assert n > 4500
+    blob = pc.build_track(pc.load_product(host_only=True), d, 'hill')
+    worst = parity_util.run_parity(n_cars=24, ticks=1200, seed=11, track=blob, check_every=5)
+    assert worst == 0.0, worst
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize('parts', [2, 3])
 def test_free_running_partitions_equal_plain_stepping(built, parts):
     """pdb_set_partitions + pdb_step_ring: the batch cut into car ranges that step on their own streams, concurrently and
