@@ -369,6 +369,12 @@ typedef struct pdb_track_header {
     float rayMinX, rayMinZ, rayCell, _rayPad;
     uint64_t offRayStart;   /* int32[rayNx*rayNz + 1] */
     uint64_t offRayRecs;    /* pdb_ray_rec[...] */
+    /* version >= 5: what the probe scans read, laid out for one load per candidate.  offFatGridRec: parallel to offFatGridIds,
+     * float[numFat][4] = the listed point's best position and, in the fourth word, its id (int32 bits).  offFatSeg:
+     * float[numFat][8] = the two side segments leaving point i: left(i).xz, left(i+1).xz, right(i).xz, right(i+1).xz
+     * (i+1 wraps to 0, Track.cpp:520-560). */
+    uint64_t offFatGridRec;
+    uint64_t offFatSeg;
 } pdb_track_header;
 
 typedef struct pdb_ray_rec {

@@ -226,7 +226,7 @@ pdb_batch* pdb_create(int device, int n_cars, const pdb_car_params* params, cons
     }
     {
         const pdb_track_header* th = static_cast<const pdb_track_header*>(track_blob);
-        if (track_bytes < sizeof(pdb_track_header) || th->magic != 0x4B544450 || th->version != 4 || th->totalBytes != track_bytes) {
+        if (track_bytes < sizeof(pdb_track_header) || th->magic != 0x4B544450 || th->version != 5 || th->totalBytes != track_bytes) {
             pdb::setError("pdb_create: not a track blob of this version (build it with pdb_build_track)"); return nullptr;
         }
     }

@@ -365,7 +365,7 @@ std::vector<uint8_t> buildTrack(const std::string& basePathIn, const std::string
     // ---- pack ----
     pdb_track_header h;
     memset(&h, 0, sizeof(h));
-    h.magic = 0x4B544450; h.version = 4;
+    h.magic = 0x4B544450; h.version = 5;
     h.numSurfaces = (int32_t)surfaces.size(); h.numTris = (int32_t)(tris.size() / 9);
     h.numFat = (int32_t)fat.size(); h.numNodes = (int32_t)nodes.size();
     h.interpolateStep = steps; h.closedLoop = closedLoop ? 1 : 0;
@@ -447,6 +447,19 @@ std::vector<uint8_t> buildTrack(const std::string& basePathIn, const std::string
     }
     h.offFatGridStart = off; off = align(off + fgStart.size() * 4);
     h.offFatGridIds = off; off = align(off + fgIds.size() * 4);
+    std::vector<float> fgRec(fgIds.size() * 4, 0.0f), fatSeg(fat.size() * 8, 0.0f);
+    for (size_t k = 0; k < fgIds.size(); ++k) {
+        const Fat& f = fat[(size_t)fgIds[k]];
+        fgRec[4 * k] = f.best.x; fgRec[4 * k + 1] = f.best.y; fgRec[4 * k + 2] = f.best.z;
+        memcpy(&fgRec[4 * k + 3], &fgIds[k], 4);
+    }
+    for (size_t i = 0; i < fat.size(); ++i) {
+        const Fat& a = fat[i]; const Fat& b = fat[(i + 1 < fat.size()) ? i + 1 : 0];
+        float* q = &fatSeg[8 * i];
+        q[0] = a.left.x; q[1] = a.left.z; q[2] = b.left.x; q[3] = b.left.z; q[4] = a.right.x; q[5] = a.right.z; q[6] = b.right.x; q[7] = b.right.z;
+    }
+    h.offFatGridRec = off; off = align(off + fgRec.size() * 4);
+    h.offFatSeg = off; off = align(off + fatSeg.size() * 4);
     // ---- the wheel rays' grid (see pdb_track_header): exact (conservatively inflated) triangle / cell overlap in xz ----
     std::vector<int32_t> rayStart;
     std::vector<pdb_ray_rec> rayRecs;
@@ -523,6 +536,8 @@ std::vector<uint8_t> buildTrack(const std::string& basePathIn, const std::string
     if (!triSurf.empty()) memcpy(blob.data() + h.offTriSurf, triSurf.data(), triSurf.size() * 4);
     if (!fgStart.empty()) memcpy(blob.data() + h.offFatGridStart, fgStart.data(), fgStart.size() * 4);
     if (!fgIds.empty()) memcpy(blob.data() + h.offFatGridIds, fgIds.data(), fgIds.size() * 4);
+    if (!fgRec.empty()) memcpy(blob.data() + h.offFatGridRec, fgRec.data(), fgRec.size() * 4);
+    if (!fatSeg.empty()) memcpy(blob.data() + h.offFatSeg, fatSeg.data(), fatSeg.size() * 4);
     if (!rayStart.empty()) memcpy(blob.data() + h.offRayStart, rayStart.data(), rayStart.size() * 4);
     if (!rayRecs.empty()) memcpy(blob.data() + h.offRayRecs, rayRecs.data(), rayRecs.size() * sizeof(pdb_ray_rec));
     return blob;
