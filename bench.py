@@ -307,7 +307,7 @@ def parser():
     ap.add_argument('--cars', type=int, default=CARS_PER_GPU)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-extra', action='store_true', help='skip the `extra` block (the other configs measured in the same run)')
-    ap.add_argument('--partitions', type=int, default=2,
+    ap.add_argument('--partitions', type=int, default=3,
                     help='free-running car ranges per GPU, one HIP stream each (pdb_set_partitions / pdb_step_ring; constant policy only -- a per-tick policy joins the ranges every tick); 1 = one launch per tick')
     ap.add_argument('--walls', action='store_true', help='touge workload: line both edges of the road with WALL surfaces (configs[4] shape: hull-vs-wall narrow phase next to the guard rails)')
     ap.add_argument('--spline-step', type=float, default=0.0, help='touge workload: metres between spline points (default 5 m = 891 points; 0.9 = 4.9 k points, the density of the reference tracks)')
@@ -350,6 +350,12 @@ def main():
     if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
         spawn_ranks(args.gpus)
 
+    # stdout carries the one JSON line and nothing else: whatever a library writes to file descriptor 1 (RCCL prints its version
+    # banner there, through C stdio, flushed at exit -- i.e. AFTER the line) goes to stderr instead
+    sys.stdout.flush()
+    json_out = os.fdopen(os.dup(1), 'w')
+    os.dup2(2, 1)
+
     import torch
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
@@ -390,7 +396,8 @@ def main():
                 extra[key] = {"error": repr(e)[:200]}
         res["extra"] = extra
     if rank == 0:
-        print(json.dumps(res))
+        json_out.write(json.dumps(res) + '\n')
+        json_out.flush()
     if dist is not None and dist.is_initialized():
         dist.destroy_process_group()
     elif is_headline:

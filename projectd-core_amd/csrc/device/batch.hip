@@ -155,7 +155,9 @@ static void fillConst(const pdb_car_params& P, DevConst& K, int actionMode) {
 // contact pass over the blocks the first pass queued (cars with live contact joints or fresh contacts; a small fixed grid that
 // finds an empty queue on almost every tick).  `q` = which of the batch's queues this launch site uses (one per partition
 // stream, one for the batch's own stream: launches that can be in flight together never share a queue).
+#ifndef PDB_CONTACT_GRID
 #define PDB_CONTACT_GRID 32
+#endif
 static void launchTick(pdb_batch* b, hipStream_t st, int c0, int c1, pdb_step_out* out, int q) {
     const int nblk = (c1 - c0 + PDB_CPB - 1) / PDB_CPB, m = b->params.numRows;
     pdb_dyn_state* S = b->dStates + c0;
