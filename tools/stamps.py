@@ -55,7 +55,7 @@ for nm, k in (('record loaded, ERP set', 1), ('world inertia + non-steer joint r
               ('integration done', 11), ('post scans done', 14), ('pack scoring done (barrier)', 12), ('record stored', 13)):
     print('  %-58s %8.0f' % (nm, med(sti[:, k] - t0)))
 print('pack wave (median, relative to the block\'s first car wave start):')
-for nm, k in (('pre-step + steering rods done', 4), ('suspensions + tyres done', 24), ('wings, drivetrain, ARB done', 15), ('post: barrier passed', 25), ('post: locator done', 26), ('post: look-ahead done', 27), ('post: scoring done', 28)):
+for nm, k in (('pre-step + steering rods done', 4), ('tyres done', 24), ('suspensions done', 30), ('drivetrain done', 15), ('tyre tail (thermal) done', 29), ('post: barrier passed', 25), ('post: locator done', 26), ('post: look-ahead done', 27), ('post: scoring done', 28)):
     print('  %-58s %8.0f' % (nm, med(first[:, k] - first[:, 0])))
 print('pack internals (car 0 of the block, wheel 0): pre-step end -> hub matrix %d | ray cast %d | contact + SCTM + forces %d | torque/lock %d | thermal %d ;; drive: tyres end -> before drivetrainStep %d | drivetrainStep %d' % (med(first[:,16]-first[:,4]), med(first[:,17]-first[:,16]), med(first[:,18]-first[:,17]), med(first[:,19]-first[:,18]), med(first[:,20]-first[:,19]), med(first[:,22]-first[:,24]), med(first[:,23]-first[:,22])))
 print('wave lifetime median %.0f clocks' % med(sti[:, 13] - t0))
