@@ -143,15 +143,24 @@ def measure(args, world, rank, local_rank, dist, want_cpu=False):
     use_ring = policy == 'constant' and args.partitions > 1 and not do_scatter
     # a per-tick policy: per-partition closed loops, unless a gather has to see whole ticks (N > 1)
     # and only where a tick is long enough to hide the doubled number of (small) policy launches: the host enqueues ~10 per partition and tick
-    part_loops = policy != 'constant' and args.partitions > 1 and not gather.active and n >= 8192
+    part_loops = policy not in ('constant', 'host') and args.partitions > 1 and not gather.active and n >= 8192
     if use_ring or part_loops:
         b.set_partitions(args.partitions)
     if part_loops:
         part_st = [torch.cuda.ExternalStream(b.partition_stream(p), device=dev) for p in range(args.partitions)]
         part_rng = [b.partition_range(p) for p in range(args.partitions)]
 
+    host_act = [np.ascontiguousarray(actions, dtype=np.float32).copy()]
+
     def tick():
         t = tick_id[0]; tick_id[0] = t + 1
+        if policy == 'host':   # configs[4] as SURVEY 8d words it: the policy lives on the host -- every tick actions go up (H2D), the tick runs,
+            # observations come down (D2H, synchronous) and the host computes the next actions (the probe-feedback law in numpy)
+            o = b.step_host(host_act[0])['obs']
+            a = host_act[0]
+            a[:, 0] = np.clip(0.03 * (o[:, 21] - o[:, 20]) + 0.015 * (o[:, 19] - o[:, 18]) + 0.15 * o[:, 4], -1.0, 1.0)
+            a[:, 1] = np.clip(0.3 * (12.0 - o[:, 2]), -1.0, 1.0)
+            return
         o = gather.slot(t)                  # the kernel writes tick t straight into its trajectory-ring slot
         if part_loops:     # every partition runs its own closed loop (kernel, then the policy on its rows) on its own stream
             for p in range(args.partitions):
@@ -291,6 +300,7 @@ EXTRA = [   # (key, argv) -- the other BASELINE configs' shapes, each measured b
     ("configs3_shard_8192", ['--cars', '8192', '--steps', '600', '--warmup', '100']),
     ("configs3_shard_8192_gather_k1_scatter", ['--cars', '8192', '--steps', '300', '--warmup', '50', '--force-gather', '--gather-ticks', '1', '--scatter-actions']),
     ("configs3_shard_8192_gather_k32", ['--cars', '8192', '--steps', '600', '--warmup', '100', '--force-gather', '--gather-ticks', '32']),
+    ("configs4_shape_16384_walls_host_policy", ['--workload', 'touge', '--cars', '16384', '--walls', '--policy', 'host', '--steps', '200', '--warmup', '30', '--settle', '100']),
     ("episodes_4096", ['--workload', 'touge', '--walls', '--cars', '4096', '--episodes', '--steps', '600', '--warmup', '100', '--settle', '200']),
     ("episodes_4096_reset_free", ['--workload', 'touge', '--walls', '--cars', '4096', '--policy', 'feedback', '--steps', '600', '--warmup', '100', '--settle', '200']),
     ("episodes_16384", ['--workload', 'touge', '--walls', '--cars', '16384', '--episodes', '--steps', '300', '--warmup', '50', '--settle', '200']),
@@ -312,7 +322,7 @@ def parser():
     ap.add_argument('--walls', action='store_true', help='touge workload: line both edges of the road with WALL surfaces (configs[4] shape: hull-vs-wall narrow phase next to the guard rails)')
     ap.add_argument('--spline-step', type=float, default=0.0, help='touge workload: metres between spline points (default 5 m = 891 points; 0.9 = 4.9 k points, the density of the reference tracks)')
     ap.add_argument('--no-body-contacts', action='store_true', help='diagnostic A/B: switch the collision pass off in the car block (never the bench line)')
-    ap.add_argument('--policy', choices=['constant', 'feedback', 'mlp', 'random'], default=None,
+    ap.add_argument('--policy', choices=['constant', 'feedback', 'mlp', 'random', 'host'], default=None,
                     help='where actions come from each tick: constant (configs[1]), feedback (probe controller on the GPU, default for touge), '
                          'mlp (configs[4] shape: a SAC-sized 24-256-256-2 tanh MLP with fixed random weights, evaluated with torch on the GPU from the observation block), random')
     ap.add_argument('--episodes', action='store_true', help='run the env loop: terminations with penalties like projectd_env.py, resets through the device reset mask')
