@@ -119,6 +119,10 @@ def measure(args, world, rank, local_rank, dist, want_cpu=False):
         w3 = (torch.randn(256, 2, generator=g) / 16.0).to(dev); b3 = torch.tensor([0.0, 0.5], device=dev)
         import projectd_env
         obs_scale = (1.0 / torch.from_numpy(projectd_env.obs_bounds(projectd_env.EnvConfig())[1])).to(dev)
+    if policy == 'feedback':
+        fw = np.zeros((24, 2), np.float32)
+        fw[21, 0] = 0.03; fw[20, 0] = -0.03; fw[19, 0] = 0.015; fw[18, 0] = -0.015; fw[4, 0] = 0.15; fw[2, 1] = -0.3
+        fb_w = torch.from_numpy(fw).to(dev); fb_b = torch.tensor([0.0, 0.3 * 12.0], device=dev)
     tick_id = [0]
 
     # --episodes: the env loop -- rewards with penalties, terminations (hit / off track / stuck / low reward) and the reset tick
@@ -129,9 +133,9 @@ def measure(args, world, rank, local_rank, dist, want_cpu=False):
         b.set_env(E.EnvConfig())
 
     def policy_step(o, a):
-        if policy == 'feedback':   # oracle/scenarios.h scenarioFeedback as elementwise device ops on the observation block
-            a[:, 0] = torch.clamp(0.03 * (o[:, 21] - o[:, 20]) + 0.015 * (o[:, 19] - o[:, 18]) + 0.15 * o[:, 4], -1.0, 1.0)
-            a[:, 1] = torch.clamp(0.3 * (12.0 - o[:, 2]), -1.0, 1.0)
+        if policy == 'feedback':   # oracle/scenarios.h scenarioFeedback (a linear law of the observation, clamped) as one addmm + one clamp
+            torch.addmm(fb_b, o[:, :24], fb_w, out=a)
+            a.clamp_(-1.0, 1.0)
         elif policy == 'mlp':      # obs -> normalise -> 256 -> 256 -> 2, tanh-squashed like SAC's actor mean (hyperparams/sac.yml net_arch)
             x = o[:, :24] * obs_scale
             h1 = torch.relu(x @ w1 + b1)
