@@ -117,6 +117,19 @@ class EnvConfig(C.Structure):   # pdb_env_config
     _fields_ = [('enabled', C.c_int32), ('terminate_on_hit', C.c_int32), ('terminate_off_track', C.c_int32), ('terminate_when_stuck', C.c_int32),
                 ('hit_penalty', C.c_double), ('off_track_penalty', C.c_double), ('stuck_penalty', C.c_double), ('low_reward', C.c_double),
                 ('teleport_on_reset', C.c_int32), ('teleport_mode', C.c_int32)]
+class Surface(C.Structure):   # pdb_surface
+    _fields_ = [(n, C.c_float) for n in ('gripMod', 'damping', 'sinHeight', 'sinLength', 'granularity', 'dirtAdditiveK')] + \
+               [(n, C.c_int32) for n in ('collisionCategory', 'isValidTrack', 'triStart', 'triCount', 'sectorID', '_pad')]
+class TrackHeader(C.Structure):   # pdb_track_header (version 5)
+    _fields_ = [(n, C.c_int32) for n in ('magic', 'version', 'numSurfaces', 'numTris', 'numFat', 'numNodes', 'interpolateStep', 'closedLoop')] + \
+               [(n, C.c_float) for n in ('computedTrackLength', 'computedTrackWidth', 'dynamicGripLevel', 'hashCellSize')] + \
+               [(n, C.c_uint64) for n in ('offSurfaces', 'offTris', 'offFat', 'offFatDist', 'offNodes', 'offNodeDist', 'totalBytes')] + \
+               [('gridNx', C.c_int32), ('gridNz', C.c_int32), ('gridMinX', C.c_float), ('gridMinZ', C.c_float), ('gridCell', C.c_float), ('_gridPad', C.c_float)] + \
+               [(n, C.c_uint64) for n in ('offGridStart', 'offGridTris', 'offTriSurf')] + \
+               [('fatGridNx', C.c_int32), ('fatGridNz', C.c_int32), ('fatGridMinX', C.c_float), ('fatGridMinZ', C.c_float), ('fatGridCell', C.c_float), ('_fatGridPad', C.c_float)] + \
+               [(n, C.c_uint64) for n in ('offFatGridStart', 'offFatGridIds')] + \
+               [('rayNx', C.c_int32), ('rayNz', C.c_int32), ('rayMinX', C.c_float), ('rayMinZ', C.c_float), ('rayCell', C.c_float), ('_rayPad', C.c_float)] + \
+               [(n, C.c_uint64) for n in ('offRayStart', 'offRayRecs', 'offFatGridRec', 'offFatSeg')]
 class StepOut(C.Structure):
     _fields_ = [('obs', C.c_float * 24), ('reward', C.c_float), ('flags', C.c_int32)]
 
