@@ -147,7 +147,7 @@ def measure(args, world, rank, local_rank, dist, want_cpu=False):
     use_ring = policy == 'constant' and args.partitions > 1 and not do_scatter
     # a per-tick policy: per-partition closed loops, unless a gather has to see whole ticks (N > 1)
     # and only where a tick is long enough to hide the doubled number of (small) policy launches: the host enqueues ~10 per partition and tick
-    part_loops = policy not in ('constant', 'host') and args.partitions > 1 and not gather.active and n >= 8192
+    part_loops = policy not in ('constant', 'host') and args.partitions > 1 and not gather.active and n >= args.part_loop_min
     if use_ring or part_loops:
         b.set_partitions(args.partitions)
     if part_loops:
@@ -320,6 +320,7 @@ def parser():
     ap.add_argument('--settle', type=int, default=333, help='ticks of state preparation before warm-up (cars come off their springs and get rolling); neither warm-up nor timed')
     ap.add_argument('--cars', type=int, default=CARS_PER_GPU)
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--part-loop-min', type=int, default=8192, help='per-tick policies: from this many cars up every partition runs its own closed loop on its own stream')
     ap.add_argument('--no-extra', action='store_true', help='skip the `extra` block (the other configs measured in the same run)')
     ap.add_argument('--partitions', type=int, default=3,
                     help='free-running car ranges per GPU, one HIP stream each (pdb_set_partitions / pdb_step_ring; constant policy only -- a per-tick policy joins the ranges every tick); 1 = one launch per tick')
