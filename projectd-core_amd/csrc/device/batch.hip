@@ -142,6 +142,10 @@ static void fillConst(const pdb_car_params& P, DevConst& K, int actionMode) {
     for (int j = P.numJoints; j <= PDB_MAX_JOINTS; ++j) K.rowStart[j] = r;
     for (int j = 0; j < P.numJoints; ++j)
         for (int rr = K.rowStart[j]; rr < K.rowStart[j + 1] && rr < PDB_MAX_ROWS; ++rr) { K.rowB0[rr] = P.joints[j].b0; K.rowB1[rr] = P.joints[j].b1; K.rowFirst[rr] = (rr == K.rowStart[j]) ? 1 : 0; }
+    static_assert(PDB_MAX_ROWS <= 48, "cfOff row");
+    for (int b = 0; b < PDB_MAX_BODIES; ++b)
+        for (int rr = 0; rr < 48; ++rr)
+            K.cfOff[b][rr] = (rr < r && rr < PDB_MAX_ROWS) ? (K.rowB0[rr] == b ? 0 : (K.rowB1[rr] == b ? 24 : 255)) : 255;
     for (int b = 0; b < PDB_MAX_BODIES; ++b) {
         K.invMass[b] = (b < P.numBodies) ? 1.0f / P.bodies[b].mass : 0.0f;
         for (int k = 0; k < 3; ++k) K.invInertia[b][k] = (b < P.numBodies) ? 1.0f / P.bodies[b].inertia[k] : 0.0f;

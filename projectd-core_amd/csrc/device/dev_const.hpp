@@ -14,6 +14,9 @@ struct DevConst {
     int rowStart[PDB_MAX_JOINTS + 1];
     int rowFirst[PDB_MAX_ROWS];                     // 1: the row is its joint's first
     int rowB0[PDB_MAX_ROWS], rowB1[PDB_MAX_ROWS];   // bodies of each constraint row (static per model: scalar loads in the A assembly)
+    // per body and row: byte offset of the body's six Jacobian columns inside the row (0 = first body of the row, 24 = second), 255 = the
+    // row does not touch the body.  48 bytes per body: three 16-byte loads per lane in the constraint-force walk (lane = body x component)
+    __attribute__((aligned(16))) unsigned char cfOff[PDB_MAX_BODIES][48];
     float dt;
     float fps;   // 1.0f / dt
     float invMass[PDB_MAX_BODIES], invInertia[PDB_MAX_BODIES][3];   // 1.0f / mass, 1.0f / inertia: divided once on the host (IEEE single division on both sides)
