@@ -566,18 +566,30 @@ int pdb_step_ring(pdb_batch* b, float dt, int n_ticks, pdb_step_out* ring, int r
     }
     const bool forked = b->parts > 1 && b->partStream[0];
     if (forked) HIPCHK(hipEventRecord(b->partFork, b->stream));
-    for (int p = 0; p < (forked ? b->parts : 1); ++p) {
+    // enqueued tick by tick across the partitions, not partition by partition: every range starts (and ends) within a few launches
+    // of the others -- partition-major order left the last range idle for the first hundreds of microseconds of a short call and
+    // alone on the GPU for the last ones
+    const int np = forked ? b->parts : 1;
+    for (int p = 0; p < np; ++p) {
         const int c0 = forked ? partFirst(b, p) : 0, c1 = forked ? partFirst(b, p + 1) : b->n;
         if (c1 <= c0) continue;
         hipStream_t st = forked ? b->partStream[p] : b->stream;
         if (forked) HIPCHK(hipStreamWaitEvent(st, b->partFork, 0));
         if (forked && b->partMark) HIPCHK(hipEventRecord(b->partStart[p], st));
-        for (int i = 0; i < n_ticks; ++i) {
-            pdb_step_out* out = ring ? ring + (size_t)((first_slot + i) % ring_slots) * (size_t)b->n : b->dOutActive;
-            launchTick(b, st, c0, c1, out, forked ? p : PDB_MAX_PARTS);
+    }
+    for (int i = 0; i < n_ticks; ++i) {
+        pdb_step_out* out = ring ? ring + (size_t)((first_slot + i) % ring_slots) * (size_t)b->n : b->dOutActive;
+        for (int p = 0; p < np; ++p) {
+            const int c0 = forked ? partFirst(b, p) : 0, c1 = forked ? partFirst(b, p + 1) : b->n;
+            if (c1 <= c0) continue;
+            launchTick(b, forked ? b->partStream[p] : b->stream, c0, c1, out, forked ? p : PDB_MAX_PARTS);
         }
-        HIPCHK(hipGetLastError());
-        if (forked) { HIPCHK(hipEventRecord(b->partEnd[p], st)); if (join) HIPCHK(hipStreamWaitEvent(b->stream, b->partEnd[p], 0)); }
+    }
+    HIPCHK(hipGetLastError());
+    for (int p = 0; p < np; ++p) {
+        const int c0 = forked ? partFirst(b, p) : 0, c1 = forked ? partFirst(b, p + 1) : b->n;
+        if (c1 <= c0) continue;
+        if (forked) { HIPCHK(hipEventRecord(b->partEnd[p], b->partStream[p])); if (join) HIPCHK(hipStreamWaitEvent(b->stream, b->partEnd[p], 0)); }
     }
     if (forked) { b->partMark = false; if (!join) b->partDirty = true; }
     return PDB_OK;
