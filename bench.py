@@ -77,7 +77,7 @@ def measure(args, world, rank, local_rank, dist, want_cpu=False):
     torch.cuda.set_device(dev_index)
     dev = 'cuda:%d' % dev_index
     n = args.cars
-    policy = args.policy or ('feedback' if (args.workload == 'touge' or args.episodes) else 'constant')
+    policy = args.policy or ('feedback' if (args.workload != 'flat' or args.episodes) else 'constant')
     assert B_ALG == 2 * C.sizeof(pc.DynState) + 8 + C.sizeof(pc.StepOut), 'B_ALG is stale: update it with the record layout'
     P = pdbatch.packed_params()
     if args.no_body_contacts:
@@ -98,6 +98,9 @@ def measure(args, world, rank, local_rank, dist, want_cpu=False):
     stream = torch.cuda.current_stream()
     b.set_stream(stream.cuda_stream)
     b.upload_actions(actions)
+    if args.workload in ('playground', 'nordring'):   # reference-scale meshes: every car to its own random point of the lap, on the device
+        b.set_seed(np.arange(first, first + n, dtype=np.uint32) * 2654435761 % 4294967291 + 1)   # Car::teleportByMode(Random) draws from the car's own rand()
+        b.reset(mode=2)
     if args.workload == 'touge':   # spread the cars around the lap (host-side teleports, once)
         st = (pc.DynState * n)()
         for i in range(n):
@@ -260,7 +263,12 @@ def measure(args, world, rank, local_rank, dist, want_cpu=False):
         else:
             launch_cars = n
         achieved = B_ALG * launch_cars / (kernel_us * 1e-6) / 1e9
-        wl = ("configs[1]: %d cars/GPU, AE86, flat-plane track, %s, dt=1/333 s" % (n, "per-car constant random actions" if policy == "constant" else "policy=" + policy)) if args.workload == 'flat' else \
+        hdr = pc.TrackHeader.from_buffer_copy(trk[:C.sizeof(pc.TrackHeader)])
+        wl = ("configs[4] shape: %d cars/GPU, AE86, %s (%d surfaces, %d triangles, %d spline points, %.1f MB track blob), policy=%s, dt=1/333 s" %
+              (n, {'playground': "synthetic paddock of the reference's driftplayground scale: barriers, tyre stacks, cones, islands as separate WALL meshes",
+                   'nordring': "synthetic open ribbon of the reference's ks_nordschleife scale with guard rails"}[args.workload],
+               hdr.numSurfaces, hdr.numTris, hdr.numFat, len(trk) / 1e6, policy)) if args.workload in ('playground', 'nordring') else \
+             ("configs[1]: %d cars/GPU, AE86, flat-plane track, %s, dt=1/333 s" % (n, "per-car constant random actions" if policy == "constant" else "policy=" + policy)) if args.workload == 'flat' else \
              ("configs[2] shape: %d cars/GPU, AE86, synthetic closed mountain road (%s%s), policy=%s on the GPU, dt=1/333 s" %
               (n, "spline point every %.1f m" % args.spline_step if args.spline_step else "1782 triangles, 891 spline points", ", guard rails (WALL surfaces) along both edges" if args.walls else "", policy))
         if args.episodes:
@@ -305,6 +313,10 @@ EXTRA = [   # (key, argv) -- the other BASELINE configs' shapes, each measured b
     ("configs3_shard_8192_gather_k1_scatter", ['--cars', '8192', '--steps', '300', '--warmup', '50', '--force-gather', '--gather-ticks', '1', '--scatter-actions']),
     ("configs3_shard_8192_gather_k32", ['--cars', '8192', '--steps', '600', '--warmup', '100', '--force-gather', '--gather-ticks', '32']),
     ("configs4_shape_16384_walls_host_policy", ['--workload', 'touge', '--cars', '16384', '--walls', '--policy', 'host', '--steps', '200', '--warmup', '30', '--settle', '100']),
+    ("configs4_playground_16384_mlp", ['--workload', 'playground', '--cars', '16384', '--policy', 'mlp', '--steps', '300', '--warmup', '50', '--settle', '200']),
+    ("configs4_playground_16384_episodes", ['--workload', 'playground', '--cars', '16384', '--episodes', '--steps', '300', '--warmup', '50', '--settle', '200']),
+    ("configs4_nordring_16384_mlp", ['--workload', 'nordring', '--cars', '16384', '--policy', 'mlp', '--steps', '300', '--warmup', '50', '--settle', '200']),
+    ("configs4_nordring_16384_feedback", ['--workload', 'nordring', '--cars', '16384', '--steps', '300', '--warmup', '50', '--settle', '200']),
     ("episodes_4096", ['--workload', 'touge', '--walls', '--cars', '4096', '--episodes', '--steps', '600', '--warmup', '100', '--settle', '200']),
     ("episodes_4096_reset_free", ['--workload', 'touge', '--walls', '--cars', '4096', '--policy', 'feedback', '--steps', '600', '--warmup', '100', '--settle', '200']),
     ("episodes_16384", ['--workload', 'touge', '--walls', '--cars', '16384', '--episodes', '--steps', '300', '--warmup', '50', '--settle', '200']),
@@ -335,7 +347,7 @@ def parser():
     ap.add_argument('--scatter-actions', action='store_true', help='with a gather: rank 0 scatters the [N,2] action block back every tick (configs[3] as SURVEY 8d words it)')
     ap.add_argument('--force-gather', action='store_true', help='run the observation all-gather even with one rank (exercises the RCCL + side-stream path on a single GPU)')
     ap.add_argument('--backend', default='nccl', help='torch.distributed backend for N > 1 (nccl = RCCL; gloo only to exercise the multi-rank path on a single-GPU box)')
-    ap.add_argument('--workload', choices=['flat', 'touge'], default='flat',
+    ap.add_argument('--workload', choices=['flat', 'touge', 'playground', 'nordring'], default='flat',
                     help='flat = BASELINE configs[1] (the bench line); touge = configs[2] shape: closed hilly road, cars spread around the lap, probe-feedback steering computed on the GPU each tick')
     return ap
 

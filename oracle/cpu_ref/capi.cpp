@@ -39,6 +39,7 @@ void cpuref_get_state(void* hh, pdb_dyn_state* s) { *s = ((CpuRefHandle*)hh)->ca
 void cpuref_set_auto_teleport_hook(void* hh, void (*hook)(pdb_dyn_state*, int)) { ((CpuRefHandle*)hh)->car.autoTeleportHook = hook; ((CpuRefHandle*)hh)->hook = hook; }
 // the contact joints alive in the engine's group: PDB_MAX_CONTACTS entries, the first S.numContacts meaningful
 void cpuref_get_contacts(void* hh, pdb_contact* c) { ((CpuRefHandle*)hh)->car.getContacts(c); }
+int cpuref_contact_candidates(void* hh) { return ((CpuRefHandle*)hh)->car.contactCandidates; }
 void cpuref_set_contacts(void* hh, const pdb_contact* c, int n) { ((CpuRefHandle*)hh)->car.setContacts(c, n); }
 // contact rows of the last tick's solve (3 per contact: normal, friction 1, friction 2): lambda, lo, hi; returns the row count
 int cpuref_last_contact_rows(void* hh, float* lambda, float* lo, float* hi, int cap, int* iterations) {

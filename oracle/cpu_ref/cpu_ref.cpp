@@ -1282,6 +1282,7 @@ void Car::collisionStep() {
     if (!C.enabled) { S.numContacts = 0; contactSet.clear(); return; }
     if (!(frame & 1)) return;
     contactSet.clear();   // dJointGroupEmpty(contactGroupDynamic)
+    contactCandidates = 0;
     const Body& body = w.bodies[PDB_BODY_CHASSIS];
     pdcol::Pose pose;
     memcpy(pose.pos, body.pos, 12); memcpy(pose.R, body.R, 36);
@@ -1304,11 +1305,13 @@ void Car::collisionStep() {
                 float ny;
                 if (pdcol::boxContacts(pose, C.boxCentre, C.boxHalf, p0, p1, p2, ny, [&](const pdcol::V& pw, const pdcol::V& nw, float depth, int item) {
                         contactSet.insert(pw, nw, depth, 1, (unsigned)t * pdcol::ID_STRIDE + (unsigned)item);
+                        ++contactCandidates;
                     }) && ny >= 0.9f) flag = true;   // PhysicsEngineODE.cpp:303-312
             }
             if (meshPair)
                 pdcol::hullContacts(pose, C.verts, C.tris, C.numTris, p0, p1, p2, [&](const pdcol::V& nrm, const pdcol::V& hitp, float depth, int item) {
                     contactSet.insert(hitp, nrm, depth, 0, (unsigned)t * pdcol::ID_STRIDE + (unsigned)item);
+                    ++contactCandidates;
                     // Car::onCollisionCallback (Car.cpp:960-1003)
                     flag = true;
                     const V3 n(nrm.x, nrm.y, nrm.z), hit(hitp.x, hitp.y, hitp.z);

@@ -64,6 +64,7 @@ struct Car {
     std::vector<int> nearby;
     void (*autoTeleportHook)(pdb_dyn_state*, int mode) = nullptr;   // Car::teleportByMode on a state record (the product's pdb_teleport_by_mode)
     pdcol::ContactSet contactSet;   // the engine's contactGroupDynamic for this car (S.numContacts of them are alive)
+    int contactCandidates = 0;      // diagnostic: contact points the last odd frame produced, before the PDB_MAX_CONTACTS cut
 
     void init(const pdb_car_params* P, const TrackData* T, const pdb_dyn_state& s0);
     void loadState(const pdb_dyn_state& s);     // pdb_dyn_state -> bodies (contactSet: setContacts)

@@ -206,6 +206,5 @@ def synthetic_track(kind='flat', **gen_args):
     d = tempfile.mkdtemp(prefix='pdb_base_')
     synthetic_tracks.make_base(d, tracks=() if gen_args else (kind,))
     if gen_args:
-        {'flat': synthetic_tracks.gen_flat, 'touge': synthetic_tracks.gen_touge, 'walled': synthetic_tracks.gen_walled,
-         'hillclimb': synthetic_tracks.gen_hillclimb}[kind](os.path.join(d, 'content', 'tracks', kind), **gen_args)
+        synthetic_tracks.GENERATORS[kind](os.path.join(d, 'content', 'tracks', kind), **gen_args)
     return pc.build_track(lib, d, kind)

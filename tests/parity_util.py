@@ -104,9 +104,11 @@ def make_actions(n, seed, lo=-0.3, hi=0.3):
 
 
 def run_parity(n_cars=8, ticks=200, seed=1234, resync=False, verbose=False, check_every=1, actions_fn=None, model='ks_toyota_ae86_drift', track='flat',
-               on_tick=None, params_fn=None):
+               on_tick=None, params_fn=None, spread=None, threads=None):
     """Step `n_cars` cars for `ticks` ticks on the GPU (through the C ABI) and in the CPU oracle, from the same
     initial state.  resync=True re-injects the oracle state into the GPU before every tick (single-tick parity).
+    spread=(lo, hi): car i starts from teleportCarToSpline(lo + (hi - lo) * i / n_cars) (the product's host function, for both
+    sides) instead of the start pose.  threads: step the oracle's cars on that many host threads (the calls release the GIL).
     Returns the worst relative deviation over all cars, ticks and float fields; raises on integer mismatches."""
     import pdbatch
     P = pdbatch.packed_params(model + '.env')
@@ -117,7 +119,19 @@ def run_parity(n_cars=8, ticks=200, seed=1234, resync=False, verbose=False, chec
     S0 = pc.DynState()
     assert lib.pdb_initial_state(C.byref(P), trk, C.byref(S0)) == 0
     b = pdbatch.Batch(n_cars, P, trk, device=0, action_mode=1)
-    hs = [orc.cpuref_create(C.byref(P), trk, len(trk), C.byref(S0)) for _ in range(n_cars)]
+    if spread is None:
+        hs = [orc.cpuref_create(C.byref(P), trk, len(trk), C.byref(S0)) for _ in range(n_cars)]
+    else:
+        init = (pc.DynState * n_cars)()
+        for i in range(n_cars):
+            C.memmove(C.byref(init[i]), C.byref(S0), C.sizeof(S0))
+            assert lib.pdb_teleport_to_spline(C.byref(P), trk, C.c_float(spread[0] + (spread[1] - spread[0]) * i / n_cars), C.byref(init[i])) == 0
+        b.set_state(init)
+        hs = [orc.cpuref_create(C.byref(P), trk, len(trk), C.byref(init[i])) for i in range(n_cars)]
+    pool = None
+    if threads and threads > 1 and not P.autoTeleport:
+        from concurrent.futures import ThreadPoolExecutor
+        pool = ThreadPoolExecutor(threads)
     hook = None
     if P.autoTeleport:   # setCarAutoTeleport: the oracle's in-tick Car::teleportByMode is the product's HOST function
         def _tele(state_ptr, mode):
@@ -139,8 +153,11 @@ def run_parity(n_cars=8, ticks=200, seed=1234, resync=False, verbose=False, chec
                 b.set_state(arr)
                 b.set_contacts(cts)
             b.step_host(a)
-            for i in range(n_cars):
-                orc.cpuref_step_env(hs[i], float(a[i, 0]), float(a[i, 1]))
+            if pool is None:
+                for i in range(n_cars):
+                    orc.cpuref_step_env(hs[i], float(a[i, 0]), float(a[i, 1]))
+            else:
+                list(pool.map(lambda i: orc.cpuref_step_env(hs[i], float(a[i, 0]), float(a[i, 1])), range(n_cars)))
             if (t % check_every) == 0 or t == ticks - 1:
                 sg = b.get_state()
                 cg = b.get_contacts()
@@ -161,6 +178,8 @@ def run_parity(n_cars=8, ticks=200, seed=1234, resync=False, verbose=False, chec
                         on_tick(t, i, sg[i], sc)
     finally:
         b.close()
+        if pool is not None:
+            pool.shutdown()
         for h in hs:
             orc.cpuref_destroy(h)
     if verbose:

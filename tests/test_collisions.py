@@ -139,3 +139,45 @@ def test_gpu_matches_oracle_on_the_wall_lined_road(built):
     worst = parity_util.run_parity(n_cars=32, ticks=1800, seed=3, track=blob, check_every=9, on_tick=on_tick)
     assert worst == 0.0, worst
     assert seen['dmg'] > 10, seen
+
+
+# ---- reference-scale collision meshes (BASELINE configs[4]; SURVEY 8d config 5: driftplayground = 510 surfaces / 112 411
+# triangles / 490 WALL meshes; ks_nordschleife = 13 323 spline points).  The reference's own meshes do not travel to the GPU box;
+# synthetic_tracks.gen_playground / gen_nordring build tracks of the same scale from closed-form geometry.
+def _scale_run(track, model, n_cars, ticks, seed):
+    import parity_util, pdbatch
+    blob = pdbatch.synthetic_track(track)
+    h = pc.TrackHeader.from_buffer_copy(blob[:C.sizeof(pc.TrackHeader)])
+    seen = {'flag': 0, 'dmg': 0, 'cars': set(), 'contacts': 0}
+
+    def on_tick(t, i, sg, sc):
+        seen['flag'] += int(sg.collisionFlag != 0)
+        seen['contacts'] += int(sg.numContacts > 0)
+        if sg.damageZoneLevel[4] > 0:
+            seen['dmg'] += 1; seen['cars'].add(i)
+    # cars spread over the whole lap by teleportCarToSpline, each with its own constant action: they leave the road within
+    # seconds and meet barriers, tyre stacks, islands / the guard rails; no env mode, so nothing terminates on a hit
+    worst = parity_util.run_parity(n_cars=n_cars, ticks=ticks, seed=seed, track=blob, model=model, check_every=8, on_tick=on_tick,
+                                   spread=(0.0, 1.0), threads=8)
+    return h, worst, seen
+
+
+@pytest.mark.gpu
+def test_gpu_matches_oracle_on_the_playground_scale_mesh(built):
+    """24 cars x 1600 ticks on the synthetic paddock (510 surfaces, 118 k triangles, 490 separate WALL meshes, a 48 MB track blob --
+    twelve times one XCD's L2): wheel rays, broad phase, hull-vs-obstacle contact points, the contact solve, damage -- every
+    state scalar and every live contact joint bit for bit"""
+    h, worst, seen = _scale_run('playground', AE86, 24, 1600, 7)
+    assert h.numSurfaces >= 500 and h.numTris >= 100000
+    assert worst == 0.0, worst
+    assert len(seen['cars']) >= 12 and seen['contacts'] > 100, seen
+
+
+@pytest.mark.gpu
+def test_gpu_matches_oracle_on_the_13k_point_walled_ribbon(built):
+    """24 Supras x 1600 ticks spread over the 20.7 km open ribbon with guard rails (13 323 spline points, 1002 surfaces, 80 k
+    triangles in a 6.5 km x 5.8 km box): the locator, the probes and the rails at Nordschleife scale"""
+    h, worst, seen = _scale_run('nordring', 'ks_toyota_supra_mkiv_drift', 24, 1600, 7)
+    assert h.numFat == 13323 and h.numTris >= 79000
+    assert worst == 0.0, worst
+    assert len(seen['cars']) >= 6 and seen['contacts'] > 100, seen

@@ -44,14 +44,22 @@ def ray_hits(tris, ox, oy, oz, max_dist=3.0):
     return np.nonzero(ok)[0]
 
 
-@pytest.mark.parametrize('kind,gen', [('touge', {'step': 0.9}), ('hillclimb', {}), ('walled', {})])
+REF = '/root/reference'
+
+
+@pytest.mark.parametrize('kind,gen', [('touge', {'step': 0.9}), ('hillclimb', {}), ('walled', {}), ('playground', {}), ('nordring', {}),
+                                      ('ref:driftplayground', {})])
 def test_grids_list_everything_brute_force_finds(hostlib, kind, gen):
     import synthetic_tracks
-    d = tempfile.mkdtemp(prefix='pdb_grid_')
-    synthetic_tracks.make_base(d, tracks=())
-    {'flat': synthetic_tracks.gen_flat, 'touge': synthetic_tracks.gen_touge, 'walled': synthetic_tracks.gen_walled,
-     'hillclimb': synthetic_tracks.gen_hillclimb}[kind](os.path.join(d, 'content', 'tracks', 't'), **gen)
-    blob = pc.build_track(hostlib, d, 't')
+    if kind.startswith('ref:'):     # the reference's own 112 411-triangle mesh (build container only)
+        if not os.path.isdir(os.path.join(REF, 'content', 'tracks', kind[4:])):
+            pytest.skip('reference content not present')
+        blob = pc.build_track(hostlib, REF, kind[4:])
+    else:
+        d = tempfile.mkdtemp(prefix='pdb_grid_')
+        synthetic_tracks.make_base(d, tracks=())
+        synthetic_tracks.GENERATORS[kind](os.path.join(d, 'content', 'tracks', 't'), **gen)
+        blob = pc.build_track(hostlib, d, 't')
     h, tris, fat, gs, gt, rs, rr, fgs, fgi, fgr, seg = arrays(blob)
     # records = copies, ascending per cell
     ids = rr[:, 9].view(np.int32)
@@ -87,6 +95,23 @@ def test_grids_list_everything_brute_force_finds(hostlib, kind, gen):
             c2 = jz * h.gridNx + jx
             assert set(hit.tolist()) <= set(gt[gs[c2]:gs[c2 + 1]].tolist()), (ox, oz)
     assert nhit > 50
+    # broad phase of the collision pass: every triangle whose box meets a chassis-sized AABB is listed in the cells under that AABB
+    tmin = np.minimum(np.minimum(tris[:, 0:3], tris[:, 3:6]), tris[:, 6:9]); tmax = np.maximum(np.maximum(tris[:, 0:3], tris[:, 3:6]), tris[:, 6:9])
+    met = 0
+    for k in rng.integers(0, h.numFat, 60):
+        c = fat[k, 0:3] + rng.uniform(-15, 15, 3).astype(f32) * np.array([1, 0.05, 1], f32)
+        lo = (c - np.array([2.6, 0.9, 2.6], f32)).astype(f32); hi = (c + np.array([2.6, 0.9, 2.6], f32)).astype(f32)
+        want = np.nonzero(np.all(tmin <= hi, 1) & np.all(tmax >= lo, 1))[0]
+        met += len(want)
+        cell = lambda v, mn: np.floor((f32(v) - f32(mn)) / f32(h.gridCell))
+        x0 = int(min(max(cell(lo[0], h.gridMinX), 0), h.gridNx)); x1 = int(min(max(cell(hi[0], h.gridMinX), -1), h.gridNx - 1))
+        z0 = int(min(max(cell(lo[2], h.gridMinZ), 0), h.gridNz)); z1 = int(min(max(cell(hi[2], h.gridMinZ), -1), h.gridNz - 1))
+        listed = set()
+        for z in range(z0, z1 + 1):
+            if x0 <= x1:
+                listed |= set(gt[gs[z * h.gridNx + x0]:gs[z * h.gridNx + x1 + 1]].tolist())
+        assert set(want.tolist()) <= listed, (lo, hi)
+    assert met > 100
     # fat points within probe range (50 m) of a query point are all in the cells under the query box
     for k in rng.integers(0, h.numFat, 40):
         q = fat[k, 0:3] + rng.uniform(-20, 20, 3).astype(f32)
