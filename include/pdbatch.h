@@ -138,13 +138,17 @@ int pdb_set_out_device(pdb_batch* b, pdb_step_out* out);
 int pdb_set_partitions(pdb_batch* b, int parts);
 /* A car block of its own for one partition (NULL: back to the batch's): same car model and rigid-body topology, different tunes,
  * assists, scoring weights, auto-teleport -- what the reference gives every simulator separately (PyProjectD.cpp:328-365) --
- * e.g. to randomise the setup over the cars of a batch.  The partition's cars step, reset and teleport with it. */
+ * e.g. to randomise the setup over the cars of a batch.  The partition's cars step, reset and teleport with it, through every
+ * step entry point (the whole-batch ones then issue one launch per partition range). */
 int pdb_set_partition_params(pdb_batch* b, int part, const pdb_car_params* params);
 int pdb_step_ring(pdb_batch* b, float dt, int n_ticks, pdb_step_out* ring, int ring_slots, int first_slot, int join);
 int pdb_wait_partitions(pdb_batch* b, void* hip_stream);
 /* Per-partition loops: pdb_step_partition enqueues one tick of one part on that part's stream (pdb_partition_stream), nothing
  * forked or joined; a caller that also puts its own per-tick work for the part's cars (pdb_partition_range) on that stream --
- * a policy evaluated from the part's observation rows -- keeps each part's whole closed loop independent of the others. */
+ * a policy evaluated from the part's observation rows -- keeps each part's whole closed loop independent of the others.
+ * Ordering: the part's stream is ordered after a pdb_reset_device queued on the batch's stream; any other asynchronous work the
+ * caller puts on the batch's stream (pdb_set_stream) and wants done before the part's tick, the caller orders itself (an event
+ * on pdb_partition_stream). */
 int pdb_step_partition(pdb_batch* b, float dt, int part, pdb_step_out* out);
 void* pdb_partition_stream(pdb_batch* b, int part);
 int pdb_partition_range(pdb_batch* b, int part, int* first, int* count);

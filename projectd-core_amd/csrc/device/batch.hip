@@ -4,6 +4,7 @@
 #include "pdbatch.h"
 #include "model.hpp"
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -61,6 +62,9 @@ namespace pdb { void setError(const std::string& s); }
     } while (0)
 
 #define PDB_MAX_PARTS 4
+#ifndef PDB_CONTACT_GRID
+#define PDB_CONTACT_GRID 32
+#endif
 struct pdb_batch {
     int device = 0;
     int n = 0;
@@ -105,6 +109,8 @@ struct pdb_batch {
     hipEvent_t partFork = nullptr, partEnd[PDB_MAX_PARTS] = {nullptr, nullptr, nullptr, nullptr}, partStart[PDB_MAX_PARTS] = {nullptr, nullptr, nullptr, nullptr};
     bool partMark = false;
     bool partDirty = false;   // partition kernels enqueued that the batch's stream has not been ordered after
+    bool batchDirty = false;  // asynchronous work queued on the batch's stream that pdb_step_partition's streams have not been ordered after
+    int contactGrid = PDB_CONTACT_GRID;   // workgroups of the contact pass (they take the queued blocks in turn); PDB_CONTACT_GRID in the environment overrides (diagnostic)
 };
 static int partFirst(const pdb_batch* b, int p);
 // Every entry point that works through the batch's stream first lets that stream wait for the partitions' kernels still in
@@ -159,9 +165,6 @@ static void fillConst(const pdb_car_params& P, DevConst& K, int actionMode) {
 // contact pass over the blocks the first pass queued (cars with live contact joints or fresh contacts; a small fixed grid that
 // finds an empty queue on almost every tick).  `q` = which of the batch's queues this launch site uses (one per partition
 // stream, one for the batch's own stream: launches that can be in flight together never share a queue).
-#ifndef PDB_CONTACT_GRID
-#define PDB_CONTACT_GRID 32
-#endif
 static void launchTick(pdb_batch* b, hipStream_t st, int c0, int c1, pdb_step_out* out, int q) {
     const int nblk = (c1 - c0 + PDB_CPB - 1) / PDB_CPB, m = b->params.numRows;
     pdb_dyn_state* S = b->dStates + c0;
@@ -178,7 +181,7 @@ static void launchTick(pdb_batch* b, hipStream_t st, int c0, int c1, pdb_step_ou
     const int n = c1 - c0;
     // the contact pass also serves episode resets asked for through the reset mask and the in-tick auto-teleport
     const bool contacts = HP.collider.enabled != 0 || b->resetMaskArmed || HP.autoTeleport != 0;
-    const dim3 grid(nblk), block(PDB_BLOCK_THREADS), cgrid(nblk < PDB_CONTACT_GRID ? nblk : PDB_CONTACT_GRID);
+    const dim3 grid(nblk), block(PDB_BLOCK_THREADS), cgrid(nblk < b->contactGrid ? nblk : b->contactGrid);
     if (m == 33) {
         hipLaunchKernelGGL(k33::pdb_step_kernel, grid, block, 0, st, S, A, O, CS, DP, DK, b->dTrack, (k33::RedoQueue*)Q, RM, n);
         if (contacts) hipLaunchKernelGGL(k33::pdb_contact_kernel, cgrid, block, 0, st, S, A, O, CS, DP, DK, b->dTrack, CT, (k33::RedoQueue*)Q, RM, n);
@@ -188,6 +191,18 @@ static void launchTick(pdb_batch* b, hipStream_t st, int c0, int c1, pdb_step_ou
     } else {
         hipLaunchKernelGGL(k40::pdb_step_kernel_wide, grid, block, 0, st, S, A, O, CS, DP, DK, b->dTrack, (k40::RedoQueue*)Q, RM, n);
         if (contacts) hipLaunchKernelGGL(k40::pdb_contact_kernel_wide, cgrid, block, 0, st, S, A, O, CS, DP, DK, b->dTrack, CT, (k40::RedoQueue*)Q, RM, n);
+    }
+}
+
+// One tick of every car on `st` (the whole-batch entry points: pdb_step, pdb_step_n and its graph, pdb_step_async, pdb_step_host).
+// Partitions with a car block of their own (pdb_set_partition_params) step with it here too: one launch per partition range.
+static void launchWhole(pdb_batch* b, hipStream_t st, pdb_step_out* out) {
+    bool any = false;
+    for (int p = 0; p < b->parts; ++p) any = any || b->partHas[p];
+    if (!any) { launchTick(b, st, 0, b->n, out, PDB_MAX_PARTS); return; }
+    for (int p = 0; p < b->parts; ++p) {
+        const int c0 = partFirst(b, p), c1 = partFirst(b, p + 1);
+        if (c1 > c0) launchTick(b, st, c0, c1, out, p);   // the partition's own queue: its stream is joined (joinParts) before anything is launched here
     }
 }
 
@@ -215,7 +230,7 @@ static int launch(pdb_batch* b, float dt, bool wantCarState) {
         b->K.wantCarState = wantCarState ? 1 : 0;
         if (int rck = pushK(b, b->stream, true)) return rck;
     }
-    launchTick(b, b->stream, 0, b->n, b->dOutActive, PDB_MAX_PARTS);
+    launchWhole(b, b->stream, b->dOutActive);
     HIPCHK(hipGetLastError());
     return PDB_OK;
 }
@@ -244,6 +259,7 @@ pdb_batch* pdb_create(int device, int n_cars, const pdb_car_params* params, cons
     if (hipSetDevice(device) != hipSuccess) { pdb::setError("hipSetDevice failed"); return nullptr; }
     pdb_batch* b = new pdb_batch();
     b->device = device; b->n = n_cars; b->params = *params;
+    if (const char* cg = getenv("PDB_CONTACT_GRID")) { const int v = atoi(cg); if (v > 0) b->contactGrid = v; }
     b->track.assign((const uint8_t*)track_blob, (const uint8_t*)track_blob + track_bytes);
     fillConst(b->params, b->K, action_mode);
     b->K.dt = (float)(1.0 / 333.0); b->K.fps = 1.0f / b->K.dt; b->K.dtD = 1.0 / 333.0;
@@ -403,6 +419,7 @@ int pdb_reset_mode(pdb_batch* b, const uint8_t* mask, int mode) {
 int pdb_reset(pdb_batch* b, const uint8_t* mask) { return pdb_reset_mode(b, mask, 0); }
 int pdb_reset_device(pdb_batch* b, const uint8_t* device_mask, int mode) {
     if (!b || !device_mask || mode < 0 || mode > 2) { pdb::setError("pdb_reset_device: bad argument"); return PDB_ERR_ARG; }
+    b->batchDirty = true;
     return resetLaunch(b, const_cast<uint8_t*>(device_mask), mode, 0);   // asynchronous on the batch's stream: no host round trip
 }
 uint8_t* pdb_reset_mask_device(pdb_batch* b) {
@@ -496,7 +513,7 @@ int pdb_step_n(pdb_batch* b, float dt, int n) {
     }
     if (b->stream == nullptr) {   // the legacy default stream (a caller's pdb_set_stream) cannot be captured: n plain launches
         HIPCHK(hipEventRecord(b->ev0, b->stream));
-        for (int i = 0; i < n; ++i) launchTick(b, b->stream, 0, b->n, b->dOutActive, PDB_MAX_PARTS);
+        for (int i = 0; i < n; ++i) launchWhole(b, b->stream, b->dOutActive);
         HIPCHK(hipGetLastError());
         HIPCHK(hipEventRecord(b->ev1, b->stream));
         HIPCHK(hipEventSynchronize(b->ev1));
@@ -510,7 +527,7 @@ int pdb_step_n(pdb_batch* b, float dt, int n) {
         hipGraph_t g = nullptr;
         HIPCHK(hipStreamBeginCapture(b->stream, hipStreamCaptureModeThreadLocal));
         for (int i = 0; i < n; ++i)
-            launchTick(b, b->stream, 0, b->n, b->dOutActive, PDB_MAX_PARTS);
+            launchWhole(b, b->stream, b->dOutActive);
         HIPCHK(hipStreamEndCapture(b->stream, &g));
         HIPCHK(hipGraphInstantiate(&b->graphExec, g, nullptr, nullptr, 0));
         (void)hipGraphDestroy(g);
@@ -553,6 +570,7 @@ int pdb_set_partitions(pdb_batch* b, int parts) {
         if (!b->partStart[p]) HIPCHK(hipEventCreate(&b->partStart[p]));
     }
     if (!b->partFork) HIPCHK(hipEventCreateWithFlags(&b->partFork, hipEventDisableTiming));
+    if (b->graphExec) { (void)hipGraphExecDestroy(b->graphExec); b->graphExec = nullptr; }   // captured launches follow the old cut
     b->parts = parts;
     return PDB_OK;
 }
@@ -607,6 +625,11 @@ int pdb_step_partition(pdb_batch* b, float dt, int part, pdb_step_out* out) {
     const int c0 = partFirst(b, part), c1 = partFirst(b, part + 1);
     if (c1 <= c0) return PDB_OK;
     hipStream_t st = b->partStream[part];
+    if (b->batchDirty) {   // asynchronous work on the batch's stream since the partitions last forked from it (pdb_reset_device, mask uploads): after it
+        HIPCHK(hipEventRecord(b->partFork, b->stream));
+        for (int p = 0; p < b->parts; ++p) HIPCHK(hipStreamWaitEvent(b->partStream[p], b->partFork, 0));
+        b->batchDirty = false;
+    }
     if (b->partMark) { for (int p = 0; p < b->parts; ++p) HIPCHK(hipEventRecord(b->partStart[p], b->partStream[p])); b->partMark = false; }
     pdb_step_out* o = out ? out : b->dOutActive;
     launchTick(b, st, c0, c1, o, part);

@@ -74,14 +74,15 @@ struct Sim {
     int device = 0;
     ~Sim() { if (batch) pdb_destroy(batch); }
 
-    bool pullState() { return !batch || pdb_get_state(batch, 0, 1, &S) == PDB_OK; }
-    bool pushState() { return !batch || pdb_set_state(batch, 0, 1, &S) == PDB_OK; }
+    pdb_contact contacts[PDB_MAX_CONTACTS] = {};   // the car's live contact joints (the first S.numContacts): they move with the record
+    bool pullState() { return !batch || (pdb_get_state(batch, 0, 1, &S) == PDB_OK && pdb_get_contacts(batch, 0, 1, contacts) == PDB_OK); }
+    bool pushState() { return !batch || (pdb_set_state(batch, 0, 1, &S) == PDB_OK && pdb_set_contacts(batch, 0, 1, contacts) == PDB_OK); }
     bool ensureBatch() {
         if (batch && paramsDirty) { pullState(); pdb_destroy(batch); batch = nullptr; }
         if (!batch) {
             batch = pdb_create(device, 1, &P, track.data(), track.size(), PDB_ACTION_FULL);
             if (!batch) { logf("EXCEPTION: %s", pdb_last_error()); return false; }
-            if (pdb_set_state(batch, 0, 1, &S) != PDB_OK) { logf("EXCEPTION: %s", pdb_last_error()); return false; }
+            if (!pushState()) { logf("EXCEPTION: %s", pdb_last_error()); return false; }
         }
         paramsDirty = false;
         return true;
@@ -229,6 +230,11 @@ int createBatch(int simId, int nCars, int device) {
     if (!B->b) { logf("EXCEPTION: %s", pdb_last_error()); return -1; }
     s->pullState();
     if (pdb_set_state_all(B->b, &s->S) != PDB_OK) { logf("EXCEPTION: %s", pdb_last_error()); return -1; }
+    if (s->S.numContacts > 0) {   // a car that is touching something: every lane starts with its contact joints too
+        std::vector<pdb_contact> all((size_t)nCars * PDB_MAX_CONTACTS);
+        for (int i = 0; i < nCars; ++i) memcpy(&all[(size_t)i * PDB_MAX_CONTACTS], s->contacts, sizeof(s->contacts));
+        if (pdb_set_contacts(B->b, 0, nCars, all.data()) != PDB_OK) { logf("EXCEPTION: %s", pdb_last_error()); return -1; }
+    }
     B->n = nCars; B->out.resize(nCars);
     std::lock_guard<std::mutex> g(g_lock);
     B->id = g_uniqBatchId++;

@@ -170,7 +170,7 @@ def test_gpu_matches_oracle_on_the_playground_scale_mesh(built):
     h, worst, seen = _scale_run('playground', AE86, 24, 1600, 7)
     assert h.numSurfaces >= 500 and h.numTris >= 100000
     assert worst == 0.0, worst
-    assert len(seen['cars']) >= 12 and seen['contacts'] > 100, seen
+    assert len(seen['cars']) >= 12 and seen['contacts'] > 60, seen    # sampled every 8th tick
 
 
 @pytest.mark.gpu
@@ -180,4 +180,4 @@ def test_gpu_matches_oracle_on_the_13k_point_walled_ribbon(built):
     h, worst, seen = _scale_run('nordring', 'ks_toyota_supra_mkiv_drift', 24, 1600, 7)
     assert h.numFat == 13323 and h.numTris >= 79000
     assert worst == 0.0, worst
-    assert len(seen['cars']) >= 6 and seen['contacts'] > 100, seen
+    assert len(seen['cars']) >= 6 and seen['contacts'] > 40, seen     # sampled every 8th tick

@@ -502,7 +502,14 @@ def test_partitions_with_their_own_car_blocks(built):
         hs = [orc.cpuref_create(C.byref(P2 if i >= f1 else P), trk, len(trk), C.byref(S2 if i >= f1 else S0)) for i in range(n)]
         mask = (np.arange(n) % 5 == 0).astype(np.uint8)
         for phase in range(2):
-            b.step_ring(ticks, None, 1, 0, join=True)
+            # the whole-batch entry points step each partition with its own block too (pdb_step_host, pdb_step_n and its graph,
+            # pdb_step_async), not only the ring: a third of the ticks through each
+            for t in range(40):
+                b.step_host(acts)
+            b.step(ticks - 40 - 60)
+            for t in range(10):
+                b.step_async()
+            b.step_ring(50, None, 1, 0, join=True)
             b.sync()
             for i in range(n):
                 for t in range(ticks):
