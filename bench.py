@@ -150,9 +150,16 @@ def measure(args, world, rank, local_rank, dist, want_cpu=False):
     use_ring = policy == 'constant' and args.partitions > 1 and not do_scatter
     # a per-tick policy: per-partition closed loops, unless a gather has to see whole ticks (N > 1)
     # and only where a tick is long enough to hide the doubled number of (small) policy launches: the host enqueues ~10 per partition and tick
-    part_loops = policy not in ('constant', 'host') and args.partitions > 1 and not gather.active and n >= args.part_loop_min
-    if use_ring or part_loops:
+    part_loops = policy not in ('constant', 'host', 'host_sync') and args.partitions > 1 and not gather.active and n >= args.part_loop_min
+    host_pipe = policy == 'host' and args.partitions > 1
+    split = use_ring or part_loops or host_pipe   # the cars step as free-running partitions
+    if split:
         b.set_partitions(args.partitions)
+    if host_pipe:
+        part_rng = [b.partition_range(p) for p in range(args.partitions)]
+        h_act, h_out = b.host_mirrors()
+        h_act[:] = actions
+        host_primed = [False] * args.partitions
     if part_loops:
         part_st = [torch.cuda.ExternalStream(b.partition_stream(p), device=dev) for p in range(args.partitions)]
         part_rng = [b.partition_range(p) for p in range(args.partitions)]
@@ -161,8 +168,20 @@ def measure(args, world, rank, local_rank, dist, want_cpu=False):
 
     def tick():
         t = tick_id[0]; tick_id[0] = t + 1
-        if policy == 'host':   # configs[4] as SURVEY 8d words it: the policy lives on the host -- every tick actions go up (H2D), the tick runs,
-            # observations come down (D2H, synchronous) and the host computes the next actions (the probe-feedback law in numpy)
+        if policy == 'host' and host_pipe:   # configs[4] as SURVEY 8d words it, pipelined over the partitions: while the host works out
+            # partition p's actions from the rows that have just come down, the other partitions' ticks and copies are in flight
+            for p in range(args.partitions):
+                f, c = part_rng[p]
+                if host_primed[p]:
+                    b.wait_host_partition(p)
+                    o = h_out['obs'][f:f + c]; a = h_act[f:f + c]
+                    np.clip(0.03 * (o[:, 21] - o[:, 20]) + 0.015 * (o[:, 19] - o[:, 18]) + 0.15 * o[:, 4], -1.0, 1.0, out=a[:, 0])
+                    np.clip(0.3 * (12.0 - o[:, 2]), -1.0, 1.0, out=a[:, 1])
+                b.step_host_partition(p)
+                host_primed[p] = True
+            return
+        if policy in ('host', 'host_sync'):   # the same loop as one synchronous round trip per tick (pdb_step_host): actions up, the tick,
+            # observations down, then the host computes the next actions (the probe-feedback law in numpy)
             o = b.step_host(host_act[0])['obs']
             a = host_act[0]
             a[:, 0] = np.clip(0.03 * (o[:, 21] - o[:, 20]) + 0.015 * (o[:, 19] - o[:, 18]) + 0.15 * o[:, 4], -1.0, 1.0)
@@ -225,7 +244,7 @@ def measure(args, world, rank, local_rank, dist, want_cpu=False):
     total = 0.0
     while True:
         b.event_record(0)
-        if use_ring or part_loops:
+        if split:
             b.partition_mark()
         t0 = time.perf_counter()
         run(args.steps)
@@ -235,7 +254,7 @@ def measure(args, world, rank, local_rank, dist, want_cpu=False):
         fence()
         elapsed = sharding.max_over_ranks(time.perf_counter() - t0, dev, dist, world)
         region_ms = b.event_elapsed_ms()
-        part = b.partition_elapsed_ms(0) if (use_ring or part_loops) else (None, n)
+        part = b.partition_elapsed_ms(0) if split else (None, n)
         regions.append((elapsed, region_ms, part[0], part[1]))
         total += elapsed
         if regions[0][0] >= 0.2 or total >= 0.25 or len(regions) >= 400:   # the same decision on every rank (max-over-ranks times)
@@ -250,14 +269,14 @@ def measure(args, world, rank, local_rank, dist, want_cpu=False):
             try:   # memory-side bytes per launch from the committed PMC passes of this same command (profiles/, tools/profile_round.sh)
                 pm = json.load(open(os.path.join(ROOT, 'profiles', tag + '_pmc.json')))
                 pc_cfg = pm.get('bench', {}).get('config', {})
-                if args.workload == 'flat' and n == CARS_PER_GPU and pc_cfg.get('cars_per_gpu') == n and pc_cfg.get('partitions', 1) == (args.partitions if (use_ring or part_loops) else 1):
+                if args.workload == 'flat' and n == CARS_PER_GPU and pc_cfg.get('cars_per_gpu') == n and pc_cfg.get('partitions', 1) == (args.partitions if split else 1):
                     traffic = pm.get('traffic_bytes_per_launch'); valu_busy = pm.get('valu_issue_busy_frac', pm.get('valu_busy_frac_approx')); prof = tag
                     break
             except Exception:
                 continue
         conc = 1
         kernel_us = region_ms * 1000.0 / args.steps          # HIP events on the kernel's stream around the timed region
-        if use_ring or part_loops:   # one launch = one partition's cars; HIP events on that partition's own stream
+        if split:   # one launch = one partition's cars; HIP events on that partition's own stream
             kernel_us = part_ms * 1000.0 / args.steps
             conc = args.partitions
         else:
@@ -282,7 +301,7 @@ def measure(args, world, rank, local_rank, dist, want_cpu=False):
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32 (+f64 drivetrain)", "data": "synthetic",
             "repeats": len(regions), "timed_region_s": total,
-            "config": {"workload": wl, "cars_per_gpu": n, "partitions": (args.partitions if (use_ring or part_loops) else 1), "settle_ticks": args.settle,
+            "config": {"workload": wl, "cars_per_gpu": n, "partitions": (args.partitions if split else 1), "settle_ticks": args.settle,
                        "collective": ("RCCL all-gather of %d-tick trajectory rings [k,N,26] obs/reward/flags on a side stream, kernel writes the ring in place%s" %
                                       (args.gather_ticks, "; actions scattered from rank 0 every tick" if args.scatter_actions else "")) if (world > 1 or args.force_gather) else "none",
                        "parity": "bit-exact vs CPU oracle (tests/, -m gpu); rigid-body solver and contact generation unpinned (ODE absent from the reference tree)"},
@@ -313,6 +332,7 @@ EXTRA = [   # (key, argv) -- the other BASELINE configs' shapes, each measured b
     ("configs3_shard_8192_gather_k1_scatter", ['--cars', '8192', '--steps', '300', '--warmup', '50', '--force-gather', '--gather-ticks', '1', '--scatter-actions']),
     ("configs3_shard_8192_gather_k32", ['--cars', '8192', '--steps', '600', '--warmup', '100', '--force-gather', '--gather-ticks', '32']),
     ("configs4_shape_16384_walls_host_policy", ['--workload', 'touge', '--cars', '16384', '--walls', '--policy', 'host', '--steps', '200', '--warmup', '30', '--settle', '100']),
+    ("configs4_shape_16384_walls_host_policy_sync", ['--workload', 'touge', '--cars', '16384', '--walls', '--policy', 'host_sync', '--steps', '200', '--warmup', '30', '--settle', '100']),
     ("configs4_playground_16384_mlp", ['--workload', 'playground', '--cars', '16384', '--policy', 'mlp', '--steps', '300', '--warmup', '50', '--settle', '200']),
     ("configs4_playground_16384_episodes", ['--workload', 'playground', '--cars', '16384', '--episodes', '--steps', '300', '--warmup', '50', '--settle', '200']),
     ("configs4_nordring_16384_mlp", ['--workload', 'nordring', '--cars', '16384', '--policy', 'mlp', '--steps', '300', '--warmup', '50', '--settle', '200']),
@@ -339,9 +359,10 @@ def parser():
     ap.add_argument('--walls', action='store_true', help='touge workload: line both edges of the road with WALL surfaces (configs[4] shape: hull-vs-wall narrow phase next to the guard rails)')
     ap.add_argument('--spline-step', type=float, default=0.0, help='touge workload: metres between spline points (default 5 m = 891 points; 0.9 = 4.9 k points, the density of the reference tracks)')
     ap.add_argument('--no-body-contacts', action='store_true', help='diagnostic A/B: switch the collision pass off in the car block (never the bench line)')
-    ap.add_argument('--policy', choices=['constant', 'feedback', 'mlp', 'random', 'host'], default=None,
+    ap.add_argument('--policy', choices=['constant', 'feedback', 'mlp', 'random', 'host', 'host_sync'], default=None,
                     help='where actions come from each tick: constant (configs[1]), feedback (probe controller on the GPU, default for touge), '
-                         'mlp (configs[4] shape: a SAC-sized 24-256-256-2 tanh MLP with fixed random weights, evaluated with torch on the GPU from the observation block), random')
+                         'mlp (configs[4] shape: a SAC-sized 24-256-256-2 tanh MLP with fixed random weights, evaluated with torch on the GPU from the observation block), random, '
+                         'host (the feedback law in numpy on the HOST, actions up / observations down every tick, pipelined over the partitions), host_sync (the same through the synchronous pdb_step_host)')
     ap.add_argument('--episodes', action='store_true', help='run the env loop: terminations with penalties like projectd_env.py, resets through the device reset mask')
     ap.add_argument('--gather-ticks', type=int, default=32, help='ticks per trajectory ring gathered to the learner (N > 1): 1 = plain per-tick gather')
     ap.add_argument('--scatter-actions', action='store_true', help='with a gather: rank 0 scatters the [N,2] action block back every tick (configs[3] as SURVEY 8d words it)')

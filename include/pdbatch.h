@@ -151,6 +151,18 @@ int pdb_wait_partitions(pdb_batch* b, void* hip_stream);
  * on pdb_partition_stream). */
 int pdb_step_partition(pdb_batch* b, float dt, int part, pdb_step_out* out);
 void* pdb_partition_stream(pdb_batch* b, int part);
+/* A policy that lives on the HOST (BASELINE configs[4]; the reference's loop: projectd_env.py:157-171 under stable-baselines),
+ * pipelined over the partitions instead of one synchronous round trip per tick (pdb_step_host): the library owns page-locked
+ * host mirrors of the action block (pdb_host_actions: float[N][stride]) and of the output block (pdb_host_out: pdb_step_out[N]).
+ * pdb_step_host_partition enqueues, on the partition's stream, the upload of the partition's action rows from the mirror, one
+ * tick of its cars and the download of its output rows into the mirror, and returns at once; pdb_wait_host_partition blocks
+ * until that download has landed.  The host then computes partition p's next actions from its rows while the other
+ * partitions' ticks and copies are in flight: no device-wide synchronisation per tick.  The trajectories are those of
+ * pdb_step_host with the same actions (cars are independent). */
+float* pdb_host_actions(pdb_batch* b);
+pdb_step_out* pdb_host_out(pdb_batch* b);
+int pdb_step_host_partition(pdb_batch* b, float dt, int part);
+int pdb_wait_host_partition(pdb_batch* b, int part);
 int pdb_partition_range(pdb_batch* b, int part, int* first, int* count);
 int pdb_partition_mark(pdb_batch* b);
 int pdb_partition_elapsed_ms(pdb_batch* b, int part, float* ms, int* cars);

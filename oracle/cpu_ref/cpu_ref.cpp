@@ -1308,7 +1308,7 @@ void Car::collisionStep() {
                         ++contactCandidates;
                     }) && ny >= 0.9f) flag = true;   // PhysicsEngineODE.cpp:303-312
             }
-            if (meshPair)
+            if (meshPair && pdcol::triMeetsBounds(pose, C.boundsLo, C.boundsHi, p0, p1, p2))
                 pdcol::hullContacts(pose, C.verts, C.tris, C.numTris, p0, p1, p2, [&](const pdcol::V& nrm, const pdcol::V& hitp, float depth, int item) {
                     contactSet.insert(hitp, nrm, depth, 0, (unsigned)t * pdcol::ID_STRIDE + (unsigned)item);
                     ++contactCandidates;

@@ -6,7 +6,11 @@
 //   * box vs triangle: does the box reach the triangle's plane (world-space evaluation), then the 13-axis separating-axis
 //     test in the box frame; one contact per intersecting triangle, normal = the triangle's turned towards the box centre;
 //   * hull vs triangle: every edge of one triangle that pierces the other is a contact at the piercing point, normal = the
-//     static triangle's turned towards the body origin.
+//     static triangle's turned towards the body origin.  Two rejections come first, both part of the definition (the kernel
+//     evaluates the very same expressions): a wall triangle that does not meet the colliders' bounding box (separating-axis
+//     test in the body frame) meets nothing; a pair (hull triangle, wall triangle) where one triangle's vertices lie strictly
+//     on one side of the other's plane has no piercing edge.  They make the work proportional to what actually touches: the
+//     reference's tracks put hundreds of centimetre-sized wall triangles inside a car's bounding box (driftplayground).
 //   * contact POINTS for the response (the joints PhysicsEngineODE::onCollision creates, :283-331), each with a depth:
 //       box: every box corner behind the triangle's plane whose projection falls inside the triangle (depth = distance behind
 //            the plane) and, per triangle edge, the midpoint of the part of the edge inside the box (depth = distance from there
@@ -196,11 +200,24 @@ static inline bool boxContacts(const Pose& P, const float* centre, const float* 
     return true;
 }
 
+// does the triangle meet the colliders' bounding box [lo, hi] (body frame)?  The hull lies inside it.
+static inline bool triMeetsBounds(const Pose& P, const float* lo, const float* hi, const V& p0, const V& p1, const V& p2) {
+    const V l = ld(lo), h = ld(hi);
+    const V cb = (l + h) * 0.5f, hb = (h - l) * 0.5f;
+    float ny;
+    return boxTri(hb, toLocal(P, p0) - cb, toLocal(P, p1) - cb, toLocal(P, p2) - cb, ny);
+}
+static inline bool strictlyOneSide(float a, float b, float c) { return (a > 0.0f && b > 0.0f && c > 0.0f) || (a < 0.0f && b < 0.0f && c < 0.0f); }
+
 template <typename Emit>
 static inline void hullContacts(const Pose& P, const float (*verts)[3], const unsigned char (*tris)[3], int numTris, const V& p0, const V& p1, const V& p2, Emit emit) {
-    const V nw = norm(cross(p1 - p0, p2 - p0));
+    const V nT = cross(p1 - p0, p2 - p0);
+    const V nw = norm(nT);
     for (int ct = 0; ct < numTris; ++ct) {
         const V c0 = toWorld(P, ld(verts[tris[ct][0]])), c1 = toWorld(P, ld(verts[tris[ct][1]])), c2 = toWorld(P, ld(verts[tris[ct][2]]));
+        if (strictlyOneSide(dot(nT, c0 - p0), dot(nT, c1 - p0), dot(nT, c2 - p0))) continue;   // the hull triangle does not reach the wall triangle's plane
+        const V nH = cross(c1 - c0, c2 - c0);
+        if (strictlyOneSide(dot(nH, p0 - c0), dot(nH, p1 - c0), dot(nH, p2 - c0))) continue;   // nor the other way round
         for (int e = 0; e < 6; ++e) {
             V hit;
             bool got;

@@ -248,8 +248,11 @@ void EnginePD::collisionStep() {
                     if (pdcol::dot(n, cw - p0) < 0.0f) n = n * -1.0f;
                     if (cb) cb->onCollisionCallback(body, nullptr, nullptr, staticColliders[si].get(), vec3f(n.x, n.y, n.z), vec3f(cw.x, cw.y, cw.z), 0.0f);   // a box geom carries no shape data
                 }
+                bool boundsKnown = false, inBounds = false;
                 for (auto& m : meshes) {
                     if (m.body != body || !((m.shape->cat & sm.mask) && (sm.category & m.shape->mask))) continue;
+                    if (!boundsKnown) { inBounds = pdcol::triMeetsBounds(pose, lo, hi, p0, p1, p2); boundsKnown = true; }   // pdcollide.h: a triangle outside the colliders' box meets no hull
+                    if (!inBounds) continue;
                     pdcol::hullContacts(pose, reinterpret_cast<const float (*)[3]>(m.verts.data()), reinterpret_cast<const unsigned char (*)[3]>(m.tris.data()), (int)(m.tris.size() / 3),
                                         p0, p1, p2, [&](const pdcol::V& n, const pdcol::V& hit, float depth, int item) {
                         contactSet.insert(hit, n, depth, 0, tid + (unsigned)item);

@@ -31,6 +31,7 @@
 #undef PDB_KERNEL_EXACT_C
 #undef PDB_KERNEL_GUARDED_C
 #undef PDB_KMINWAVES_C
+#ifndef PDB_FAST_BUILD   /* development builds (make dev) compile the 33-row size class only */
 #define PDB_KROWS 40
 #define PDB_KNS k40
 #define PDB_KMINWAVES 5
@@ -48,6 +49,7 @@
 #undef PDB_KERNEL_EXACT_C
 #undef PDB_KERNEL_GUARDED_C
 #undef PDB_KMINWAVES_C
+#endif
 
 
 namespace pdb { void setError(const std::string& s); }
@@ -110,6 +112,8 @@ struct pdb_batch {
     bool partMark = false;
     bool partDirty = false;   // partition kernels enqueued that the batch's stream has not been ordered after
     bool batchDirty = false;  // asynchronous work queued on the batch's stream that pdb_step_partition's streams have not been ordered after
+    float* hActions = nullptr;          // page-locked host mirrors (pdb_host_actions / pdb_host_out): the pipelined host-policy loop
+    pdb_step_out* hOut = nullptr;
     int contactGrid = PDB_CONTACT_GRID;   // workgroups of the contact pass (they take the queued blocks in turn); PDB_CONTACT_GRID in the environment overrides (diagnostic)
 };
 static int partFirst(const pdb_batch* b, int p);
@@ -189,8 +193,10 @@ static void launchTick(pdb_batch* b, hipStream_t st, int c0, int c1, pdb_step_ou
         hipLaunchKernelGGL(k33::pdb_step_kernel_generic, grid, block, 0, st, S, A, O, CS, DP, DK, b->dTrack, (k33::RedoQueue*)Q, RM, n);
         if (contacts) hipLaunchKernelGGL(k33::pdb_contact_kernel_generic, cgrid, block, 0, st, S, A, O, CS, DP, DK, b->dTrack, CT, (k33::RedoQueue*)Q, RM, n);
     } else {
+#ifndef PDB_FAST_BUILD
         hipLaunchKernelGGL(k40::pdb_step_kernel_wide, grid, block, 0, st, S, A, O, CS, DP, DK, b->dTrack, (k40::RedoQueue*)Q, RM, n);
         if (contacts) hipLaunchKernelGGL(k40::pdb_contact_kernel_wide, cgrid, block, 0, st, S, A, O, CS, DP, DK, b->dTrack, CT, (k40::RedoQueue*)Q, RM, n);
+#endif
     }
 }
 
@@ -314,6 +320,8 @@ void pdb_destroy(pdb_batch* b) {
     if (b->graphExec) (void)hipGraphExecDestroy(b->graphExec);
     if (b->stream) (void)hipStreamSynchronize(b->stream);
     (void)hipFree(b->dStates); (void)hipFree(b->dActions); (void)hipFree(b->dOut); (void)hipFree(b->dCarStates); (void)hipFree(b->dParams); (void)hipFree(b->dK); (void)hipFree(b->dTrack); (void)hipFree(b->dContacts); (void)hipFree(b->dResetMask); (void)hipFree(b->dResetScratch);
+    if (b->hActions) (void)hipHostFree(b->hActions);
+    if (b->hOut) (void)hipHostFree(b->hOut);
     for (int q = 0; q <= PDB_MAX_PARTS; ++q) (void)hipFree(b->dQueue[q]);
     for (int q = 0; q < PDB_MAX_PARTS; ++q) { (void)hipFree(b->dPartParams[q]); (void)hipFree(b->dPartK[q]); }
     if (b->ev0) (void)hipEventDestroy(b->ev0);
@@ -636,6 +644,32 @@ int pdb_step_partition(pdb_batch* b, float dt, int part, pdb_step_out* out) {
     HIPCHK(hipGetLastError());
     HIPCHK(hipEventRecord(b->partEnd[part], st));
     b->partDirty = true;
+    return PDB_OK;
+}
+static int hostMirrors(pdb_batch* b) {
+    if (!b->hActions) { HIPCHK(hipHostMalloc((void**)&b->hActions, sizeof(float) * b->actionStride * (size_t)b->n, hipHostMallocDefault)); memset(b->hActions, 0, sizeof(float) * b->actionStride * (size_t)b->n); }
+    if (!b->hOut) { HIPCHK(hipHostMalloc((void**)&b->hOut, sizeof(pdb_step_out) * (size_t)b->n, hipHostMallocDefault)); memset(b->hOut, 0, sizeof(pdb_step_out) * (size_t)b->n); }
+    return PDB_OK;
+}
+float* pdb_host_actions(pdb_batch* b) { return (b && hostMirrors(b) == PDB_OK) ? b->hActions : nullptr; }
+pdb_step_out* pdb_host_out(pdb_batch* b) { return (b && hostMirrors(b) == PDB_OK) ? b->hOut : nullptr; }
+// actions up, one tick, outputs down -- for one partition, on its stream, nothing waited for
+int pdb_step_host_partition(pdb_batch* b, float dt, int part) {
+    if (!b || part < 0 || part >= b->parts || b->parts < 2 || !b->partStream[part]) { pdb::setError("pdb_step_host_partition: no such partition (pdb_set_partitions first)"); return PDB_ERR_ARG; }
+    if (int rcm = hostMirrors(b)) return rcm;
+    const int c0 = partFirst(b, part), c1 = partFirst(b, part + 1);
+    if (c1 <= c0) return PDB_OK;
+    hipStream_t st = b->partStream[part];
+    HIPCHK(hipMemcpyAsync(b->dActions + (size_t)c0 * b->actionStride, b->hActions + (size_t)c0 * b->actionStride, sizeof(float) * b->actionStride * (size_t)(c1 - c0), hipMemcpyHostToDevice, st));
+    int rc = pdb_step_partition(b, dt, part, nullptr);
+    if (rc != PDB_OK) return rc;
+    HIPCHK(hipMemcpyAsync(b->hOut + c0, b->dOutActive + c0, sizeof(pdb_step_out) * (size_t)(c1 - c0), hipMemcpyDeviceToHost, st));
+    HIPCHK(hipEventRecord(b->partEnd[part], st));   // the partition's end now includes the download
+    return PDB_OK;
+}
+int pdb_wait_host_partition(pdb_batch* b, int part) {
+    if (!b || part < 0 || part >= b->parts || b->parts < 2 || !b->partEnd[part]) { pdb::setError("pdb_wait_host_partition: no such partition"); return PDB_ERR_ARG; }
+    HIPCHK(hipEventSynchronize(b->partEnd[part]));
     return PDB_OK;
 }
 void* pdb_partition_stream(pdb_batch* b, int part) { return (b && part >= 0 && part < b->parts && b->parts > 1) ? (void*)b->partStream[part] : nullptr; }

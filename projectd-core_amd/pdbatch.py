@@ -74,6 +74,22 @@ class Batch:
         """one tick of one partition on its own stream (nothing forked or joined)"""
         self._chk(self.lib.pdb_step_partition(self.h, C.c_float(SIM_DT), part, C.c_void_p(out_ptr) if out_ptr else None))
 
+    def host_mirrors(self):
+        """numpy views of the library's page-locked host mirrors: actions float32[n, stride], outputs (structured pdb_step_out)[n]"""
+        pa = self.lib.pdb_host_actions(self.h); po = self.lib.pdb_host_out(self.h)
+        if not pa or not po:
+            raise RuntimeError(self.lib.pdb_last_error().decode())
+        a = np.ctypeslib.as_array((C.c_float * (self.n * self.stride)).from_address(pa)).reshape(self.n, self.stride)
+        o = np.frombuffer((pc.StepOut * self.n).from_address(po), dtype=np.dtype(pc.StepOut))
+        return a, o
+
+    def step_host_partition(self, part):
+        """enqueue on the partition's stream: its action rows up (from the mirror), one tick, its output rows down (into the mirror)"""
+        self._chk(self.lib.pdb_step_host_partition(self.h, C.c_float(SIM_DT), part))
+
+    def wait_host_partition(self, part):
+        self._chk(self.lib.pdb_wait_host_partition(self.h, part))
+
     def partition_stream(self, part):
         return self.lib.pdb_partition_stream(self.h, part)
 

@@ -532,3 +532,43 @@ def test_partitions_with_their_own_car_blocks(built):
             orc.cpuref_destroy(h)
     finally:
         b.close()
+
+
+def test_pipelined_host_policy_equals_step_host(built):
+    """pdb_step_host_partition / pdb_wait_host_partition (the host-fed policy of BASELINE configs[4], pipelined over the partitions
+    through page-locked mirrors) against the synchronous pdb_step_host with the same closed-loop law: byte-identical records and
+    outputs, the partitions never joined inside the loop"""
+    import pdbatch
+    n, ticks = 96, 400
+    P = pdbatch.packed_params(); trk = pdbatch.synthetic_track('touge', walls=True)
+
+    def law(o, a):
+        np.clip(0.03 * (o[:, 21] - o[:, 20]) + 0.015 * (o[:, 19] - o[:, 18]) + 0.15 * o[:, 4], -1.0, 1.0, out=a[:, 0])
+        np.clip(0.3 * (12.0 - o[:, 2]), -1.0, 1.0, out=a[:, 1])
+    a0 = parity_util.make_actions(n, 5)
+    ref = pdbatch.Batch(n, P, trk, device=0, action_mode=1)
+    pip = pdbatch.Batch(n, P, trk, device=0, action_mode=1)
+    try:
+        a = a0.copy()
+        for t in range(ticks):
+            o = ref.step_host(a)
+            law(o['obs'], a)
+        pip.set_partitions(3)
+        rng = [pip.partition_range(p) for p in range(3)]
+        ha, ho = pip.host_mirrors()
+        ha[:] = a0
+        primed = [False] * 3
+        for t in range(ticks):
+            for p in range(3):
+                f, c = rng[p]
+                if primed[p]:
+                    pip.wait_host_partition(p)
+                    law(ho['obs'][f:f + c], ha[f:f + c])
+                pip.step_host_partition(p)
+                primed[p] = True
+        for p in range(3):
+            pip.wait_host_partition(p)
+        assert bytes(pip.get_state()) == bytes(ref.get_state())
+        assert np.array_equal(ho['obs'], o['obs']) and np.array_equal(ho['reward'], o['reward']) and np.array_equal(ho['flags'], o['flags'])
+    finally:
+        ref.close(); pip.close()

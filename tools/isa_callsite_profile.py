@@ -4,15 +4,18 @@ instruction stream).  Builds the device code with -g, disassembles the kernel, r
 llvm-symbolizer and buckets it by the line of stepBody it was inlined at.  The kernel is almost entirely straight-line code
 (unrolled loops, lane-predicated branches that every wave walks), so static counts are close to what a wave issues; exceptions:
 branches on the car model (suspension types, heave springs), the cold teleport block, the optional CarState output.
-usage: python3 tools/isa_callsite_profile.py [kernel-name]   (build container; no GPU needed)"""
+With `scratch` as second argument: where the kernel's scratch (spill) instructions sit instead -- by stepBody line and innermost
+function -- so that a spill on the path every car takes cannot hide behind the cold blocks' ones.
+usage: python3 tools/isa_callsite_profile.py [kernel-name] [scratch]   (build container; no GPU needed)"""
 import collections, json, os, re, subprocess, sys, tempfile
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 LLVM = '/opt/rocm/lib/llvm/bin'
 kern = sys.argv[1] if len(sys.argv) > 1 else 'pdb_step_kernel'
+only_scratch = len(sys.argv) > 2 and sys.argv[2] == 'scratch'
 tmp = tempfile.mkdtemp(prefix='pdb_isa_')
 csrc = os.path.join(ROOT, 'projectd-core_amd', 'csrc')
 obj, co = os.path.join(tmp, 'k.o'), os.path.join(tmp, 'k.co')
-subprocess.check_call(['/opt/rocm/bin/hipcc', '--offload-arch=gfx950', '-std=c++17', '-O3', '-ffp-contract=off', '-fno-fast-math', '-fPIC', '-g',
+subprocess.check_call(['/opt/rocm/bin/hipcc', '--offload-arch=gfx950', '-std=c++17', '-O3', '-ffp-contract=off', '-fno-fast-math', '-fPIC', '-g', '-DPDB_FAST_BUILD',
                        '-I' + os.path.join(ROOT, 'include'), '-I' + os.path.join(csrc, 'host'), '-I' + os.path.join(csrc, 'device'),
                        '--cuda-device-only', '-c', os.path.join(csrc, 'device', 'batch.hip'), '-o', obj])
 subprocess.check_call([LLVM + '/clang-offload-bundler', '--unbundle', '--type=o', '--input=' + obj, '--targets=hipv4-amdgcn-amd-amdhsa--gfx950', '--output=' + co])
@@ -25,7 +28,7 @@ for l in dis.split('\n'):
         continue
     if inside:
         m = re.match(r'^\s+([a-z_0-9]+)\s.*// ([0-9A-F]+):', l)
-        if m:
+        if m and (not only_scratch or m.group(1).startswith('scratch_')):
             ins.append((int(m.group(2), 16), m.group(1)))
 sym = subprocess.run([LLVM + '/llvm-symbolizer', '--obj=' + co, '--inlines', '--output-style=JSON'], input='\n'.join('0x%x' % a for a, _ in ins),
                      capture_output=True, text=True).stdout
@@ -41,7 +44,7 @@ for (a, op), r in zip(ins, recs):
     if op.startswith('v_'):
         valu[key] += 1
     if idx:
-        callee.setdefault(key, collections.Counter())[short(fr[idx - 1]['FunctionName'])] += 1
+        callee.setdefault(key, collections.Counter())[short(fr[idx - 1]['FunctionName']) + (':%d' % fr[0]['Line'] if only_scratch else '')] += 1
 print('%s: %d instructions' % (kern, len(ins)))
 for k, c in tot.most_common(40):
     cs = ', '.join('%s %d' % kv for kv in callee.get(k, collections.Counter()).most_common(3))
