@@ -1,4 +1,4 @@
-"""The N > 1 path on CPU: two gloo ranks, each stepping its contiguous block of cars, action
+"""The N > 1 path on CPU: 2, 4 and 8 gloo ranks, each stepping its contiguous block of cars, action
 scatter from the learner rank, gather of 8-tick trajectory rings of [n,26] output blocks -- must give exactly what one process gives
 for all cars (results keyed by global car id, invariant to the number of ranks)."""
 import ctypes as C, os, socket, subprocess, sys, tempfile
@@ -35,21 +35,23 @@ def _free_port():
 
 
 @pytest.mark.timeout(600)
-def test_two_rank_gather_equals_single_process(built, oracle):
+@pytest.mark.parametrize('world', [2, 4, 8])
+def test_gather_over_ranks_equals_single_process(built, oracle, world):
+    """world gloo ranks ({1, 2, 4, 8} shards), 16 cars: the gathered last ring equals the single-process one"""
     import _sharding_worker as w
     import pdbatch, oracle_ctypes
-    n_global, ticks = 8, 40
+    n_global, ticks = 16, 40
     port = _free_port()
     with tempfile.TemporaryDirectory() as d:
         out = os.path.join(d, 'gathered.npy')
         env = dict(os.environ, OMP_NUM_THREADS='1')
-        procs = [subprocess.Popen([sys.executable, os.path.join(HERE, '_sharding_worker.py'), str(r), '2', str(port), str(n_global), str(ticks), out], env=env)
-                 for r in range(2)]
+        procs = [subprocess.Popen([sys.executable, os.path.join(HERE, '_sharding_worker.py'), str(r), str(world), str(port), str(n_global), str(ticks), out], env=env)
+                 for r in range(world)]
         rcs = [p.wait(timeout=540) for p in procs]
-        assert rcs == [0, 0]
+        assert rcs == [0] * world
         got = np.load(out)
-    assert got[-1] == 2.0                                   # max over ranks of (1 + rank)
-    got = got[:-1].astype(np.float32).reshape(2, 8, n_global // 2, 26)    # [world, k, n_local, 26]: the last full 8-tick ring
+    assert got[-1] == float(world)                          # max over ranks of (1 + rank)
+    got = got[:-1].astype(np.float32).reshape(world, 8, n_global // world, 26)    # [world, k, n_local, 26]: the last full 8-tick ring
     # single process, all cars
     P = pdbatch.packed_params(); trk = pdbatch.synthetic_track('flat')
     lib = pc.load_product(host_only=True); orc = oracle_ctypes.load_oracle(True)
@@ -61,6 +63,6 @@ def test_two_rank_gather_equals_single_process(built, oracle):
         ring[t % 8] = w.step_block(orc, hs, a)
     for h in hs:
         orc.cpuref_destroy(h)
-    ref = ring.reshape(8, 2, n_global // 2, 26).transpose(1, 0, 2, 3)      # rank-major like the gathered tensor
+    ref = ring.reshape(8, world, n_global // world, 26).transpose(1, 0, 2, 3)      # rank-major like the gathered tensor
     assert np.array_equal(got.view(np.int32), np.ascontiguousarray(ref).view(np.int32))
     assert np.any(ref[..., :24] != 0)
