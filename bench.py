@@ -51,14 +51,24 @@ def cpu_baseline(P, trk, S0, actions, seconds_target=15.0):
     n2 = int(max(16, min(len(actions), rate1 * seconds_target / ticks2)))
     a2 = np.ascontiguousarray(actions[:n2], dtype=np.float32)
     t2 = orc.cpuref_bench(h, n2, ticks2, a2.ctypes.data_as(C.c_void_p), 1, None)
+    # all hardware threads (context only): every car of the bench workload (cars >> threads), as many ticks as make >= 5 s of wall time
+    # at an assumed half-linear speed-up, re-run once if the first estimate was short
     ncores = os.cpu_count() or 1
-    n3 = min(len(actions), max(ncores * 4, 64))
+    n3 = len(actions)
     a3 = np.ascontiguousarray(actions[:n3], dtype=np.float32)
-    t3 = orc.cpuref_bench(h, n3, 333, a3.ctypes.data_as(C.c_void_p), ncores, None)
+    rate_est = (n2 * ticks2 / t2) * max(1.0, 0.5 * ncores)
+    t3 = 0.0; ticks3 = 0
+    for _ in range(2):
+        ticks3 = int(min(3330, max(50, 6.0 * rate_est / n3)))
+        t3 = orc.cpuref_bench(h, n3, ticks3, a3.ctypes.data_as(C.c_void_p), ncores, None)
+        if t3 >= 5.0 or ticks3 >= 3330:
+            break
+        rate_est = n3 * ticks3 / t3
     orc.cpuref_destroy(h)
     return {"value": n2 * ticks2 / t2, "unit": "env-steps/s", "cores": 1, "kind": "port",
             "sample": "%d cars x %d ticks of the bench workload (its first %d cars, %.0f s of CPU work), CPU restatement of Car::step + ODE-equivalent solve, single thread" % (n2, ticks2, n2, t2),
-            "all_cores_value": n3 * 333 / t3, "all_cores": ncores}
+            "all_cores_value": n3 * ticks3 / t3, "all_cores": ncores,
+            "all_cores_sample": "%d cars x %d ticks on %d OpenMP threads, %.1f s of wall time" % (n3, ticks3, ncores, t3)}
 
 
 class _Arr:   # zero-copy torch view of a library-owned device block
@@ -97,6 +107,7 @@ def measure(args, world, rank, local_rank, dist, want_cpu=False):
     b = pdbatch.Batch(n, P, trk, device=dev_index, action_mode=1)
     stream = torch.cuda.current_stream()
     b.set_stream(stream.cuda_stream)
+    b.set_ticks_per_launch(args.ticks_per_launch)
     b.upload_actions(actions)
     if args.workload in ('playground', 'nordring'):   # reference-scale meshes: every car to its own random point of the lap, on the device
         b.set_seed(np.arange(first, first + n, dtype=np.uint32) * 2654435761 % 4294967291 + 1)   # Car::teleportByMode(Random) draws from the car's own rand()
@@ -152,9 +163,17 @@ def measure(args, world, rank, local_rank, dist, want_cpu=False):
     # and only where a tick is long enough to hide the doubled number of (small) policy launches: the host enqueues ~10 per partition and tick
     part_loops = policy not in ('constant', 'host', 'host_sync') and args.partitions > 1 and not gather.active and n >= args.part_loop_min
     host_pipe = policy == 'host' and args.partitions > 1
-    split = use_ring or part_loops or host_pipe   # the cars step as free-running partitions
+    # configs[3] as worded (a gather and an action scatter EVERY tick) over free-running partitions: one set of collectives per partition
+    part_exchange = do_scatter and args.partitions > 1 and policy == 'constant' and n >= args.part_loop_min and (dist is not None) and (world == 1 or dist.get_backend() == 'nccl')
+    split = use_ring or part_loops or host_pipe or part_exchange   # the cars step as free-running partitions
     if split:
         b.set_partitions(args.partitions)
+    if part_exchange:
+        part_st = [torch.cuda.ExternalStream(b.partition_stream(p), device=dev) for p in range(args.partitions)]
+        part_rng = [b.partition_range(p) for p in range(args.partitions)]
+        exch = sharding.PartitionExchange(part_rng, world, rank, dev, dist)
+        if rank == 0:
+            exch.load_actions(torch.from_numpy(all_actions).to(dev))
     if host_pipe:
         part_rng = [b.partition_range(p) for p in range(args.partitions)]
         h_act, h_out = b.host_mirrors()
@@ -186,6 +205,14 @@ def measure(args, world, rank, local_rank, dist, want_cpu=False):
             a = host_act[0]
             a[:, 0] = np.clip(0.03 * (o[:, 21] - o[:, 20]) + 0.015 * (o[:, 19] - o[:, 18]) + 0.15 * o[:, 4], -1.0, 1.0)
             a[:, 1] = np.clip(0.3 * (12.0 - o[:, 2]), -1.0, 1.0)
+            return
+        if part_exchange:   # per partition, on its own stream: actions from the learner, the tick, outputs to the learner
+            for p in range(args.partitions):
+                f, c = part_rng[p]
+                with torch.cuda.stream(part_st[p]):
+                    exch.scatter(p, act_t[f:f + c])
+                    b.step_partition(p, out_t.data_ptr())
+                    exch.gather(p, out_t[f:f + c])
             return
         o = gather.slot(t)                  # the kernel writes tick t straight into its trajectory-ring slot
         if part_loops:     # every partition runs its own closed loop (kernel, then the policy on its rows) on its own stream
@@ -301,8 +328,9 @@ def measure(args, world, rank, local_rank, dist, want_cpu=False):
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32 (+f64 drivetrain)", "data": "synthetic",
             "repeats": len(regions), "timed_region_s": total,
-            "config": {"workload": wl, "cars_per_gpu": n, "partitions": (args.partitions if split else 1), "settle_ticks": args.settle,
-                       "collective": ("RCCL all-gather of %d-tick trajectory rings [k,N,26] obs/reward/flags on a side stream, kernel writes the ring in place%s" %
+            "config": {"workload": wl, "cars_per_gpu": n, "partitions": (args.partitions if split else 1), "settle_ticks": args.settle, "ticks_per_launch": (args.ticks_per_launch if use_ring else 1),
+                       "collective": ("per partition and tick, on the partition's own stream and RCCL communicator: scatter of its [n,2] action rows from rank 0 -> tick -> all-gather of its [n,26] output rows (the partitions are never joined)" if part_exchange else
+                                      "RCCL all-gather of %d-tick trajectory rings [k,N,26] obs/reward/flags on a side stream, kernel writes the ring in place%s" %
                                       (args.gather_ticks, "; actions scattered from rank 0 every tick" if args.scatter_actions else "")) if (world > 1 or args.force_gather) else "none",
                        "parity": "bit-exact vs CPU oracle (tests/, -m gpu); rigid-body solver and contact generation unpinned (ODE absent from the reference tree)"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
@@ -356,6 +384,7 @@ def parser():
     ap.add_argument('--no-extra', action='store_true', help='skip the `extra` block (the other configs measured in the same run)')
     ap.add_argument('--partitions', type=int, default=3,
                     help='free-running car ranges per GPU, one HIP stream each (pdb_set_partitions / pdb_step_ring; constant policy only -- a per-tick policy joins the ranges every tick); 1 = one launch per tick')
+    ap.add_argument('--ticks-per-launch', type=int, default=8, help='constant-action runs (pdb_step_ring): ticks folded into one launch, the records staying in LDS between them (pdb_set_ticks_per_launch); 1 = a launch per tick')
     ap.add_argument('--walls', action='store_true', help='touge workload: line both edges of the road with WALL surfaces (configs[4] shape: hull-vs-wall narrow phase next to the guard rails)')
     ap.add_argument('--spline-step', type=float, default=0.0, help='touge workload: metres between spline points (default 5 m = 891 points; 0.9 = 4.9 k points, the density of the reference tracks)')
     ap.add_argument('--no-body-contacts', action='store_true', help='diagnostic A/B: switch the collision pass off in the car block (never the bench line)')
@@ -443,6 +472,16 @@ def main():
             except Exception as e:   # an extra line must never cost the headline
                 extra[key] = {"error": repr(e)[:200]}
         res["extra"] = extra
+    if world > 1 and not args.scatter_actions and not args.no_extra:   # the other collective variant SURVEY 8d words (a gather + an action scatter every tick), same process, same rule
+        a2 = parser().parse_args(sys.argv[1:] + ['--gather-ticks', '1', '--scatter-actions', '--no-cpu-baseline', '--no-extra'])
+        try:
+            r2 = measure(a2, world, rank, local_rank, dist)
+            if rank == 0:
+                res.setdefault("extra", {})["configs3_gather_k1_scatter"] = {"value": r2["value"], "ms_per_step": r2["ms_per_step"], "steps": r2["steps"], "repeats": r2["repeats"],
+                                                                             "partitions": r2["config"]["partitions"], "collective": r2["config"]["collective"]}
+        except Exception as e:
+            if rank == 0:
+                res.setdefault("extra", {})["configs3_gather_k1_scatter"] = {"error": repr(e)[:200]}
     if rank == 0:
         json_out.write(json.dumps(res) + '\n')
         json_out.flush()

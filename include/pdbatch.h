@@ -136,6 +136,12 @@ int pdb_set_out_device(pdb_batch* b, pdb_step_out* out);
  * the partitioning.  pdb_partition_mark / pdb_partition_elapsed_ms: HIP-event time of one part's kernels between the mark
  * and the last pdb_step_ring (synchronises on that part), and the number of cars in the part. */
 int pdb_set_partitions(pdb_batch* b, int parts);
+/* Ticks folded into one launch by the entry points that step several ticks with the action block as it is (pdb_step_ring,
+ * pdb_step_n): within a launch a car's record stays in LDS from one tick to the next (it is still written back after every tick
+ * -- the contact pass restarts from that copy -- and every tick writes its output row), nothing is launched between the ticks and
+ * the contact pass follows once per launch: a car that meets something at tick j of the launch is finished, j onwards, by that
+ * pass.  1..64, default 8; results do not depend on it. */
+int pdb_set_ticks_per_launch(pdb_batch* b, int ticks);
 /* A car block of its own for one partition (NULL: back to the batch's): same car model and rigid-body topology, different tunes,
  * assists, scoring weights, auto-teleport -- what the reference gives every simulator separately (PyProjectD.cpp:328-365) --
  * e.g. to randomise the setup over the cars of a batch.  The partition's cars step, reset and teleport with it, through every

@@ -64,6 +64,9 @@ namespace pdb { void setError(const std::string& s); }
     } while (0)
 
 #define PDB_MAX_PARTS 4
+#ifndef PDB_MAX_TICKS_PER_LAUNCH
+#define PDB_MAX_TICKS_PER_LAUNCH 8
+#endif
 #ifndef PDB_CONTACT_GRID
 #define PDB_CONTACT_GRID 32
 #endif
@@ -114,7 +117,10 @@ struct pdb_batch {
     bool batchDirty = false;  // asynchronous work queued on the batch's stream that pdb_step_partition's streams have not been ordered after
     float* hActions = nullptr;          // page-locked host mirrors (pdb_host_actions / pdb_host_out): the pipelined host-policy loop
     pdb_step_out* hOut = nullptr;
-    int contactGrid = PDB_CONTACT_GRID;   // workgroups of the contact pass (they take the queued blocks in turn); PDB_CONTACT_GRID in the environment overrides (diagnostic)
+    int ticksPerLaunch = PDB_MAX_TICKS_PER_LAUNCH;   // pdb_step_ring / pdb_step_n: ticks folded into one launch (pdb_set_ticks_per_launch)
+    int contactGrid = 0;   // workgroups of the contact pass: 0 = adaptive (from the queue lengths the last passes saw); PDB_CONTACT_GRID in the environment fixes it (diagnostic)
+    int* hHint = nullptr;  // page-locked, device-visible: per launch site, the number of cars the last contact pass held (written by its last workgroup; read here without waiting)
+    int* dHint = nullptr;
 };
 static int partFirst(const pdb_batch* b, int p);
 // Every entry point that works through the batch's stream first lets that stream wait for the partitions' kernels still in
@@ -169,10 +175,12 @@ static void fillConst(const pdb_car_params& P, DevConst& K, int actionMode) {
 // contact pass over the blocks the first pass queued (cars with live contact joints or fresh contacts; a small fixed grid that
 // finds an empty queue on almost every tick).  `q` = which of the batch's queues this launch site uses (one per partition
 // stream, one for the batch's own stream: launches that can be in flight together never share a queue).
-static void launchTick(pdb_batch* b, hipStream_t st, int c0, int c1, pdb_step_out* out, int q) {
+// nTicks > 1: that many ticks of the range in ONE launch of each pass (the records stay in LDS between the ticks, the actions are
+// those of the action block throughout); tick i writes its outputs to ring slot (firstSlot + i) % ringSlots (slots are b->n records apart)
+static void launchTick(pdb_batch* b, hipStream_t st, int c0, int c1, pdb_step_out* out, int q, int nTicks = 1, int ringSlots = 1, int firstSlot = 0) {
     const int nblk = (c1 - c0 + PDB_CPB - 1) / PDB_CPB, m = b->params.numRows;
     pdb_dyn_state* S = b->dStates + c0;
-    const float* A = b->dActions + (size_t)c0 * b->actionStride;
+    const float* Aact = b->dActions + (size_t)c0 * b->actionStride;
     pdb_step_out* O = out + c0;
     pdb_car_state* CS = b->dCarStates ? b->dCarStates + c0 : nullptr;
     pdb_contact* CT = b->dContacts + (size_t)c0 * PDB_MAX_CONTACTS;
@@ -185,30 +193,47 @@ static void launchTick(pdb_batch* b, hipStream_t st, int c0, int c1, pdb_step_ou
     const int n = c1 - c0;
     // the contact pass also serves episode resets asked for through the reset mask and the in-tick auto-teleport
     const bool contacts = HP.collider.enabled != 0 || b->resetMaskArmed || HP.autoTeleport != 0;
-    const dim3 grid(nblk), block(PDB_BLOCK_THREADS), cgrid(nblk < b->contactGrid ? nblk : b->contactGrid);
+    // the contact pass's grid: enough workgroups for twice the cars its last pass held (a stale number, read without waiting: it only
+    // sizes the grid -- workgroups take the queued cars in turn whatever their number), at least PDB_CONTACT_GRID, at most what is resident at once
+    int cg = b->contactGrid;
+    if (cg <= 0) {
+        const int held = b->hHint ? *(volatile int*)(b->hHint + q) : 0;
+        cg = (2 * held + PDB_CPB - 1) / PDB_CPB;
+        if (cg < PDB_CONTACT_GRID) cg = PDB_CONTACT_GRID;
+        if (cg > 1024) cg = 1024;
+    }
+    int* HN = b->dHint ? b->dHint + q : nullptr;
+    const dim3 grid(nblk), block(PDB_BLOCK_THREADS), cgrid(nblk < cg ? nblk : cg);
+    // the two size classes' argument blocks have the same layout (plain pointers and integers)
+    k33::StepArgs A;
+    A.states = S; A.actions = Aact; A.outs = O; A.carStates = CS; A.Pp = DP; A.Kp = DK; A.trackBlob = b->dTrack; A.contacts = CT;
+    A.queue = (k33::RedoQueue*)Q; A.resetMask = RM; A.hint = HN; A.slotStride = (long long)b->n; A.nCars = n; A.nTicks = nTicks; A.ringSlots = ringSlots; A.firstSlot = firstSlot;
     if (m == 33) {
-        hipLaunchKernelGGL(k33::pdb_step_kernel, grid, block, 0, st, S, A, O, CS, DP, DK, b->dTrack, (k33::RedoQueue*)Q, RM, n);
-        if (contacts) hipLaunchKernelGGL(k33::pdb_contact_kernel, cgrid, block, 0, st, S, A, O, CS, DP, DK, b->dTrack, CT, (k33::RedoQueue*)Q, RM, n);
+        hipLaunchKernelGGL(k33::pdb_step_kernel, grid, block, 0, st, A);
+        if (contacts) hipLaunchKernelGGL(k33::pdb_contact_kernel, cgrid, block, 0, st, A);
     } else if (m < 33) {
-        hipLaunchKernelGGL(k33::pdb_step_kernel_generic, grid, block, 0, st, S, A, O, CS, DP, DK, b->dTrack, (k33::RedoQueue*)Q, RM, n);
-        if (contacts) hipLaunchKernelGGL(k33::pdb_contact_kernel_generic, cgrid, block, 0, st, S, A, O, CS, DP, DK, b->dTrack, CT, (k33::RedoQueue*)Q, RM, n);
+        hipLaunchKernelGGL(k33::pdb_step_kernel_generic, grid, block, 0, st, A);
+        if (contacts) hipLaunchKernelGGL(k33::pdb_contact_kernel_generic, cgrid, block, 0, st, A);
     } else {
 #ifndef PDB_FAST_BUILD
-        hipLaunchKernelGGL(k40::pdb_step_kernel_wide, grid, block, 0, st, S, A, O, CS, DP, DK, b->dTrack, (k40::RedoQueue*)Q, RM, n);
-        if (contacts) hipLaunchKernelGGL(k40::pdb_contact_kernel_wide, cgrid, block, 0, st, S, A, O, CS, DP, DK, b->dTrack, CT, (k40::RedoQueue*)Q, RM, n);
+        k40::StepArgs B;
+        static_assert(sizeof(B) == sizeof(A), "StepArgs layout");
+        memcpy(&B, &A, sizeof(B));
+        hipLaunchKernelGGL(k40::pdb_step_kernel_wide, grid, block, 0, st, B);
+        if (contacts) hipLaunchKernelGGL(k40::pdb_contact_kernel_wide, cgrid, block, 0, st, B);
 #endif
     }
 }
 
 // One tick of every car on `st` (the whole-batch entry points: pdb_step, pdb_step_n and its graph, pdb_step_async, pdb_step_host).
 // Partitions with a car block of their own (pdb_set_partition_params) step with it here too: one launch per partition range.
-static void launchWhole(pdb_batch* b, hipStream_t st, pdb_step_out* out) {
+static void launchWhole(pdb_batch* b, hipStream_t st, pdb_step_out* out, int nTicks = 1) {
     bool any = false;
     for (int p = 0; p < b->parts; ++p) any = any || b->partHas[p];
-    if (!any) { launchTick(b, st, 0, b->n, out, PDB_MAX_PARTS); return; }
+    if (!any) { launchTick(b, st, 0, b->n, out, PDB_MAX_PARTS, nTicks); return; }
     for (int p = 0; p < b->parts; ++p) {
         const int c0 = partFirst(b, p), c1 = partFirst(b, p + 1);
-        if (c1 > c0) launchTick(b, st, c0, c1, out, p);   // the partition's own queue: its stream is joined (joinParts) before anything is launched here
+        if (c1 > c0) launchTick(b, st, c0, c1, out, p, nTicks);   // the partition's own queue: its stream is joined (joinParts) before anything is launched here
     }
 }
 
@@ -284,10 +309,12 @@ pdb_batch* pdb_create(int device, int n_cars, const pdb_car_params* params, cons
     ok = ok && hipMalloc(&b->dResetMask, (size_t)n_cars) == hipSuccess;
     ok = ok && hipMemset(b->dResetMask, 0, (size_t)n_cars) == hipSuccess;
     for (int q = 0; q <= PDB_MAX_PARTS; ++q) {
-        const size_t qb = sizeof(int) * (size_t)(4 + (n_cars + PDB_CPB - 1) / PDB_CPB);
+        const size_t qb = sizeof(int) * (size_t)(4 + n_cars);   // count, done, one entry per car
         ok = ok && hipMalloc(&b->dQueue[q], qb) == hipSuccess;
         ok = ok && hipMemset(b->dQueue[q], 0, qb) == hipSuccess;
     }
+    ok = ok && hipHostMalloc((void**)&b->hHint, sizeof(int) * (PDB_MAX_PARTS + 1), hipHostMallocMapped) == hipSuccess;
+    if (ok) { memset(b->hHint, 0, sizeof(int) * (PDB_MAX_PARTS + 1)); ok = hipHostGetDevicePointer((void**)&b->dHint, b->hHint, 0) == hipSuccess; }
     ok = ok && hipEventCreate(&b->ev0) == hipSuccess && hipEventCreate(&b->ev1) == hipSuccess;
     ok = ok && hipEventCreate(&b->tev0) == hipSuccess && hipEventCreate(&b->tev1) == hipSuccess;
     if (ok) {
@@ -320,6 +347,7 @@ void pdb_destroy(pdb_batch* b) {
     if (b->graphExec) (void)hipGraphExecDestroy(b->graphExec);
     if (b->stream) (void)hipStreamSynchronize(b->stream);
     (void)hipFree(b->dStates); (void)hipFree(b->dActions); (void)hipFree(b->dOut); (void)hipFree(b->dCarStates); (void)hipFree(b->dParams); (void)hipFree(b->dK); (void)hipFree(b->dTrack); (void)hipFree(b->dContacts); (void)hipFree(b->dResetMask); (void)hipFree(b->dResetScratch);
+    if (b->hHint) (void)hipHostFree(b->hHint);
     if (b->hActions) (void)hipHostFree(b->hActions);
     if (b->hOut) (void)hipHostFree(b->hOut);
     for (int q = 0; q <= PDB_MAX_PARTS; ++q) (void)hipFree(b->dQueue[q]);
@@ -521,7 +549,7 @@ int pdb_step_n(pdb_batch* b, float dt, int n) {
     }
     if (b->stream == nullptr) {   // the legacy default stream (a caller's pdb_set_stream) cannot be captured: n plain launches
         HIPCHK(hipEventRecord(b->ev0, b->stream));
-        for (int i = 0; i < n; ++i) launchWhole(b, b->stream, b->dOutActive);
+        for (int i = 0; i < n; i += b->ticksPerLaunch) launchWhole(b, b->stream, b->dOutActive, (n - i < b->ticksPerLaunch) ? n - i : b->ticksPerLaunch);
         HIPCHK(hipGetLastError());
         HIPCHK(hipEventRecord(b->ev1, b->stream));
         HIPCHK(hipEventSynchronize(b->ev1));
@@ -534,8 +562,8 @@ int pdb_step_n(pdb_batch* b, float dt, int n) {
         if (b->graphExec) { (void)hipGraphExecDestroy(b->graphExec); b->graphExec = nullptr; }
         hipGraph_t g = nullptr;
         HIPCHK(hipStreamBeginCapture(b->stream, hipStreamCaptureModeThreadLocal));
-        for (int i = 0; i < n; ++i)
-            launchWhole(b, b->stream, b->dOutActive);
+        for (int i = 0; i < n; i += b->ticksPerLaunch)
+            launchWhole(b, b->stream, b->dOutActive, (n - i < b->ticksPerLaunch) ? n - i : b->ticksPerLaunch);
         HIPCHK(hipStreamEndCapture(b->stream, &g));
         HIPCHK(hipGraphInstantiate(&b->graphExec, g, nullptr, nullptr, 0));
         (void)hipGraphDestroy(g);
@@ -563,6 +591,13 @@ int pdb_set_stream(pdb_batch* b, void* hip_stream) {
     if (b->graphExec) { (void)hipGraphExecDestroy(b->graphExec); b->graphExec = nullptr; b->graphTicks = 0; }
     if (b->ownStream) { (void)hipStreamDestroy(b->stream); b->ownStream = false; }
     b->stream = (hipStream_t)hip_stream;
+    return PDB_OK;
+}
+
+int pdb_set_ticks_per_launch(pdb_batch* b, int ticks) {
+    if (!b || ticks < 1 || ticks > 64) { pdb::setError("pdb_set_ticks_per_launch: 1..64"); return PDB_ERR_ARG; }
+    if (b->graphExec) { (void)hipGraphExecDestroy(b->graphExec); b->graphExec = nullptr; }
+    b->ticksPerLaunch = ticks;
     return PDB_OK;
 }
 
@@ -603,12 +638,16 @@ int pdb_step_ring(pdb_batch* b, float dt, int n_ticks, pdb_step_out* ring, int r
         if (forked) HIPCHK(hipStreamWaitEvent(st, b->partFork, 0));
         if (forked && b->partMark) HIPCHK(hipEventRecord(b->partStart[p], st));
     }
-    for (int i = 0; i < n_ticks; ++i) {
-        pdb_step_out* out = ring ? ring + (size_t)((first_slot + i) % ring_slots) * (size_t)b->n : b->dOutActive;
+    // several ticks per launch (b->ticksPerLaunch): between them a car's record stays in LDS and nothing is launched.  A ring slot
+    // per tick, whatever the chunking.
+    const int per = b->ticksPerLaunch < 1 ? 1 : (b->ticksPerLaunch > 64 ? 64 : b->ticksPerLaunch);
+    for (int i = 0; i < n_ticks; i += per) {
+        const int m = (n_ticks - i < per) ? n_ticks - i : per;
         for (int p = 0; p < np; ++p) {
             const int c0 = forked ? partFirst(b, p) : 0, c1 = forked ? partFirst(b, p + 1) : b->n;
             if (c1 <= c0) continue;
-            launchTick(b, forked ? b->partStream[p] : b->stream, c0, c1, out, forked ? p : PDB_MAX_PARTS);
+            if (ring) launchTick(b, forked ? b->partStream[p] : b->stream, c0, c1, ring, forked ? p : PDB_MAX_PARTS, m, ring_slots, (first_slot + i) % ring_slots);
+            else launchTick(b, forked ? b->partStream[p] : b->stream, c0, c1, b->dOutActive, forked ? p : PDB_MAX_PARTS, m, 1, 0);
         }
     }
     HIPCHK(hipGetLastError());

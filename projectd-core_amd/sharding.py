@@ -116,6 +116,42 @@ class TrajectoryGather:
         return self.gathered[self.last] if (self.active and self.last is not None) else None
 
 
+class PartitionExchange:
+    """BASELINE configs[3] as SURVEY section 8d words it -- EVERY tick the [n, 26] output block goes to the learner and the learner's
+    [n, 2] actions come back -- without joining the free-running partitions of a GPU: each partition has its own process group
+    (its own RCCL communicator and stream) and, per tick, its own three steps in the order of its own HIP stream:
+        scatter of its action rows  ->  the partition's tick  ->  all-gather of its output rows.
+    Nothing orders one partition's collectives against another partition's kernels, so the partitions keep drifting against each
+    other as they do without any exchange.  The learner (rank 0) fills scatter_src[p] ([world, cars of p, 2]) and reads
+    gathered[p] ([world, cars of p, 26]).  Collectives are enqueued under `with torch.cuda.stream(partition stream)`: the
+    partition's stream waits for them (stream-side, the host never does)."""
+
+    def __init__(self, part_ranges, world, rank, device, dist, backend=None):
+        import torch
+        self.dist, self.world, self.rank, self.ranges = dist, world, rank, list(part_ranges)
+        # every rank creates the groups in the same order
+        self.groups = [dist.new_group(ranks=list(range(world)), backend=backend) for _ in self.ranges] if dist is not None else [None] * len(self.ranges)
+        self.gathered = [torch.empty((world, c, OUT_COLS), dtype=torch.float32, device=device) for (f, c) in self.ranges]
+        self.scatter_src = [torch.zeros((world, c, 2), dtype=torch.float32, device=device) for (f, c) in self.ranges] if rank == 0 else None
+
+    def load_actions(self, all_actions):
+        """learner: all_actions [world * n_local, 2] (global car order) -> the per-partition scatter sources"""
+        a = all_actions.reshape(self.world, -1, 2)
+        for p, (f, c) in enumerate(self.ranges):
+            self.scatter_src[p].copy_(a[:, f:f + c])
+
+    def scatter(self, p, act_rows):
+        """this rank's action rows of partition p <- the learner's (act_rows: the [c, 2] view of the batch's action block)"""
+        if self.world == 1:
+            act_rows.copy_(self.scatter_src[p][0])
+        else:
+            self.dist.scatter(act_rows, list(self.scatter_src[p].unbind(0)) if self.rank == 0 else None, src=0, group=self.groups[p])
+
+    def gather(self, p, out_rows):
+        """partition p's output rows of every rank -> gathered[p] (out_rows: the contiguous [c, 26] view of this rank's output block)"""
+        self.dist.all_gather_into_tensor(self.gathered[p].view(-1, OUT_COLS), out_rows, group=self.groups[p])
+
+
 def scatter_actions(all_actions, n_local, world, rank, device, dist=None):
     """Learner (rank 0) -> every rank: this rank's [n_local, 2] slice of the global action tensor."""
     import torch
