@@ -1,7 +1,6 @@
-"""Classic-gym adapter over projectd_env (reference pyprojectd/projectd_gym/projectd_gym.py:10-42 and __init__.py:1-8):
-`ProjectDEnvGym(gym.Env)` with the 4-tuple step / bare reset of gym < 0.26, registered as "ProjectD-v0" with
-max_episode_steps = 80000.  gym is not a dependency of the package: importing this module without it raises ImportError."""
-import numpy as np
+"""Classic-gym face of the env (drop-in for pyprojectd/projectd_gym: class ProjectDEnvGym, id "ProjectD-v0"): gym < 0.26 conventions --
+step returns (obs, reward, done, info), reset returns the observation, seed returns the list of seeds used.  Everything else comes from
+projectd_adapters.SingleCar.  gym is not a dependency of the package: importing this module without it raises ImportError."""
 try:
     import gym
     from gym import spaces as gym_spaces
@@ -9,39 +8,31 @@ try:
 except ImportError as e:   # pragma: no cover
     raise ImportError('projectd_gym needs the gym package (not installed in this image)') from e
 
-import projectd_env as E
+import projectd_adapters as A
 
-MAX_EPISODE_STEPS = 80000
+MAX_EPISODE_STEPS = A.MAX_EPISODE_STEPS
 
 
-class ProjectDEnvGym(gym.Env):
-    def __init__(self, **kwargs):
-        super().__init__()
+class ProjectDEnvGym(A.SingleCar, gym.Env):
+    metadata = {'render.modes': ['human']}
+
+    def __init__(self, **settings):
+        gym.Env.__init__(self)
         self.seed()
-        self.impl = E.ProjectDEnv(**kwargs)
-        obs_low, obs_high = self.impl._get_obs_space()
-        a_low, a_high = self.impl._get_action_space()
-        self.observation_space = gym_spaces.Box(low=obs_low, high=obs_high, dtype=np.float32)
-        self.action_space = gym_spaces.Box(low=a_low, high=a_high, dtype=np.float32)
-
-    def close(self):
-        self.impl.close()
+        self._open(gym_spaces.Box, **settings)
 
     def step(self, action):
-        state, reward, terminate, truncate, info = self.impl.step(action)
-        return state, reward, (terminate or truncate), {}
+        obs, reward, terminated, truncated, _ = self.advance(action)
+        return obs, reward, terminated or truncated, {}
 
     def reset(self):
-        return self.impl.reset()
-
-    def render(self, mode='human'):
-        self.impl.render()
+        return self.restart()
 
     def seed(self, seed=None):
-        self.np_random, seed = gym_seeding.np_random(seed)
-        return [seed]
+        self.np_random, used = gym_seeding.np_random(seed)
+        return [used]
 
 
 def register():
     from gym.envs.registration import register as _register
-    _register(id='ProjectD-v0', entry_point='projectd_gym:ProjectDEnvGym', max_episode_steps=MAX_EPISODE_STEPS)
+    _register(id=A.ENV_ID, entry_point='projectd_gym:ProjectDEnvGym', max_episode_steps=MAX_EPISODE_STEPS)

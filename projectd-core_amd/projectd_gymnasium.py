@@ -10,35 +10,29 @@ except ImportError as e:   # pragma: no cover
     raise ImportError('projectd_gymnasium needs the gymnasium package (not installed in this image)') from e
 
 import projectd_env as E
+import projectd_adapters as A
 
-MAX_EPISODE_STEPS = 80000
+MAX_EPISODE_STEPS = A.MAX_EPISODE_STEPS
 
 
 def _boxes(cfg):
-    lo, hi = E.obs_bounds(cfg)
-    return spaces.Box(low=lo, high=hi, dtype=np.float32), spaces.Box(low=np.array([-1, -1], np.float32), high=np.array([1, 1], np.float32), dtype=np.float32)
+    return A.boxes(cfg, spaces.Box)
 
 
-class ProjectDGymnasium(gym.Env):
+class ProjectDGymnasium(A.SingleCar, gym.Env):
     def __init__(self, base_dir=None, **settings):
-        super().__init__()
-        self.impl = E.ProjectDEnv(base_dir, **settings)
-        self.observation_space, self.action_space = _boxes(self.impl.cfg)
+        gym.Env.__init__(self)
+        self._open(spaces.Box, base_dir, **settings)
 
     def step(self, action):
-        obs, reward, terminated, truncated, info = self.impl.step(action)
-        truncated = truncated or self.impl.step_id >= MAX_EPISODE_STEPS
-        return obs, reward, terminated, truncated, info
+        return self.advance(action)
 
     def reset(self, *, seed=None, options=None):
         super().reset(seed=seed)
-        return self.impl.reset(), {}
+        return self.restart(), {}
 
     def render(self):
         self.impl.render()
-
-    def close(self):
-        self.impl.close()
 
     def seed(self, seed=None):   # compat with legacy gym (projectd_gymnasium.py:38-40)
         pass
@@ -73,4 +67,4 @@ class ProjectDGymnasiumVec:
 
 def register():
     from gymnasium.envs.registration import register as _register
-    _register(id='ProjectD-v0', entry_point='projectd_gymnasium:ProjectDGymnasium', max_episode_steps=MAX_EPISODE_STEPS)
+    _register(id=A.ENV_ID, entry_point='projectd_gymnasium:ProjectDGymnasium', max_episode_steps=MAX_EPISODE_STEPS)

@@ -572,3 +572,42 @@ def test_pipelined_host_policy_equals_step_host(built):
         assert np.array_equal(ho['obs'], o['obs']) and np.array_equal(ho['reward'], o['reward']) and np.array_equal(ho['flags'], o['flags'])
     finally:
         ref.close(); pip.close()
+
+
+@pytest.mark.parametrize('track,model,ticks', [('walled', 'ks_toyota_ae86_drift', 2400), ('touge_walls', 'ks_toyota_supra_mkiv_drift', 900)])
+def test_ticks_per_launch_do_not_change_results(built, track, model, ticks):
+    """pdb_set_ticks_per_launch: 8 and 5 ticks per launch (records staying in LDS between the ticks, ONE contact pass per launch that
+    finishes the cars that met something from the tick they met it at) against a launch per tick -- same records, same contact
+    joints, same output rows in every ring slot; cars driven into walls, rings that wrap, free-running partitions"""
+    import torch, pdbatch
+    n, k = 50, 16
+    P = pdbatch.packed_params(model + '.env')
+    trk = pdbatch.synthetic_track('touge', walls=True) if track == 'touge_walls' else pdbatch.synthetic_track(track)
+    acts = parity_util.make_actions(n, 11)
+    res = []
+    for tpl, parts in ((1, 1), (8, 3), (5, 1)):
+        b = pdbatch.Batch(n, P, trk, device=0, action_mode=1)
+        try:
+            b.set_ticks_per_launch(tpl)
+            if parts > 1:
+                b.set_partitions(parts)
+            b.upload_actions(acts)
+            ring = torch.zeros((k, n, 26), dtype=torch.float32, device='cuda:0')
+            rows = []
+            t = 0
+            for m in (7, 40, 1, 33, 16, ticks - 97):
+                b.step_ring(m, ring.data_ptr(), k, t % k, join=True)
+                b.sync()
+                t += m
+                rows.append(ring.cpu().numpy().copy())
+            b.step(24)          # pdb_step_n: the same folding
+            st = bytes(b.get_state()); ct = b.get_contacts(); sg = b.get_state()
+            live = b''.join(bytes(ct[i])[:32 * sg[i].numContacts] for i in range(n))
+            res.append((st, live, rows, sum(1 for i in range(n) if sg[i].damageZoneLevel[4] > 0)))
+        finally:
+            b.close()
+    assert res[0][3] >= 5, res[0][3]            # cars did meet walls
+    for r in res[1:]:
+        assert r[0] == res[0][0] and r[1] == res[0][1]
+        for a, c in zip(r[2], res[0][2]):
+            assert np.array_equal(a.view(np.int32), c.view(np.int32))
