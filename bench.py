@@ -107,7 +107,8 @@ def measure(args, world, rank, local_rank, dist, want_cpu=False):
     b = pdbatch.Batch(n, P, trk, device=dev_index, action_mode=1)
     stream = torch.cuda.current_stream()
     b.set_stream(stream.cuda_stream)
-    b.set_ticks_per_launch(args.ticks_per_launch)
+    if hasattr(lib, 'pdb_set_ticks_per_launch'):
+        b.set_ticks_per_launch(args.ticks_per_launch)
     b.upload_actions(actions)
     if args.workload in ('playground', 'nordring'):   # reference-scale meshes: every car to its own random point of the lap, on the device
         b.set_seed(np.arange(first, first + n, dtype=np.uint32) * 2654435761 % 4294967291 + 1)   # Car::teleportByMode(Random) draws from the car's own rand()
@@ -340,6 +341,8 @@ def measure(args, world, rank, local_rank, dist, want_cpu=False):
                          "valu_issue_busy_frac": valu_busy,   # the resource that actually bounds the kernel (profiles/*_pmc.json; definition in DESIGN.md section 3)
                          "note": ("one launch = one partition (%d cars); %d partitions step concurrently on their own streams, so the device moves concurrent_launches x achieved" % (launch_cars, conc)) if conc > 1 else None},
         }
+        if hasattr(lib, 'pdb_contact_pass_load'):
+            res["contact_pass_cars"] = [int(lib.pdb_contact_pass_load(b.h, q)) for q in (list(range(args.partitions)) if split else [4])]   # cars the last contact passes held (diagnostic)
         if args.episodes:   # how often episodes end in this workload: counted over 300 more ticks, outside the timed region
             ends = torch.zeros((), dtype=torch.int64, device=dev)
             for _ in range(300):

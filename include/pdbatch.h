@@ -142,6 +142,9 @@ int pdb_set_partitions(pdb_batch* b, int parts);
  * the contact pass follows once per launch: a car that meets something at tick j of the launch is finished, j onwards, by that
  * pass.  1..64, default 8; results do not depend on it. */
 int pdb_set_ticks_per_launch(pdb_batch* b, int ticks);
+/* diagnostic: how many cars the most recent contact pass of a launch site held (site = partition index, 4 = the batch's own
+ * stream); read without waiting for anything, so it lags the launches still in flight */
+int pdb_contact_pass_load(pdb_batch* b, int site);
 /* A car block of its own for one partition (NULL: back to the batch's): same car model and rigid-body topology, different tunes,
  * assists, scoring weights, auto-teleport -- what the reference gives every simulator separately (PyProjectD.cpp:328-365) --
  * e.g. to randomise the setup over the cars of a batch.  The partition's cars step, reset and teleport with it, through every

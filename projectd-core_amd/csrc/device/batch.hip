@@ -594,6 +594,11 @@ int pdb_set_stream(pdb_batch* b, void* hip_stream) {
     return PDB_OK;
 }
 
+// diagnostic: the number of cars the last contact pass of a launch site held (site = partition, PDB_MAX_PARTS = the batch's own stream)
+int pdb_contact_pass_load(pdb_batch* b, int site) {
+    if (!b || site < 0 || site > PDB_MAX_PARTS || !b->hHint) return -1;
+    return *(volatile int*)(b->hHint + site);
+}
 int pdb_set_ticks_per_launch(pdb_batch* b, int ticks) {
     if (!b || ticks < 1 || ticks > 64) { pdb::setError("pdb_set_ticks_per_launch: 1..64"); return PDB_ERR_ARG; }
     if (b->graphExec) { (void)hipGraphExecDestroy(b->graphExec); b->graphExec = nullptr; }

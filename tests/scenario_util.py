@@ -101,6 +101,8 @@ def drive(orc, hostlib, sc, batch=None, max_ticks=None, on_tick=None):
             assert hostlib.pdb_teleport_to_spline(C.byref(P), blob, C.c_float(dist), C.byref(g[0])) == 0
             batch.set_state(g)
     step_both(a2=(0.0, 0.0))                      # env.reset(): teleport (already in S0) + step([0, 0])
+    if on_tick is not None:
+        on_tick(-1, h, batch)                     # the goldens' first record (tick -1) is taken here
     n = sc['ticks'] if max_ticks is None else min(sc['ticks'], max_ticks)
     o = pc.StepOut()
     a2 = (C.c_float * 2)(); a8 = np.zeros(8, np.float32)

@@ -574,7 +574,7 @@ def test_pipelined_host_policy_equals_step_host(built):
         ref.close(); pip.close()
 
 
-@pytest.mark.parametrize('track,model,ticks', [('walled', 'ks_toyota_ae86_drift', 2400), ('touge_walls', 'ks_toyota_supra_mkiv_drift', 900)])
+@pytest.mark.parametrize('track,model,ticks', [('walled', 'ks_toyota_ae86_drift', 2400), ('walled', 'dthwsh_mazda_rx7_fc3s_sr20', 2400)])
 def test_ticks_per_launch_do_not_change_results(built, track, model, ticks):
     """pdb_set_ticks_per_launch: 8 and 5 ticks per launch (records staying in LDS between the ticks, ONE contact pass per launch that
     finishes the cars that met something from the tick they met it at) against a launch per tick -- same records, same contact
@@ -582,7 +582,7 @@ def test_ticks_per_launch_do_not_change_results(built, track, model, ticks):
     import torch, pdbatch
     n, k = 50, 16
     P = pdbatch.packed_params(model + '.env')
-    trk = pdbatch.synthetic_track('touge', walls=True) if track == 'touge_walls' else pdbatch.synthetic_track(track)
+    trk = pdbatch.synthetic_track(track)
     acts = parity_util.make_actions(n, 11)
     res = []
     for tpl, parts in ((1, 1), (8, 3), (5, 1)):

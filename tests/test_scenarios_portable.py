@@ -1,8 +1,8 @@
 """GPU-vs-reference-TU, the whole way: (1) tests/test_oracle_golden.py -- the glibc oracle equals the reference TUs' trajectories
 bit for bit; (2) here, on the CPU -- the portable-math oracle (the GPU's arithmetic) stays within 1e-4 of EVERY probe field of
-EVERY scenario's golden for at least the first 2 records after the reset (25 for the AE86 flat-plane scripts; the run prints
-how long each scenario holds -- before the 1-ulp libm differences have been amplified by the vehicle's knife-edge logic),
-integer-valued fields exactly; (3) under -m gpu -- the GPU equals the portable-math oracle bit for
+EVERY scenario's golden for at least the first 4 records after the reset (25 for the AE86 flat-plane scripts; the run prints
+how long each scenario holds and which field leaves first -- before the 1-ulp libm differences have been amplified by the vehicle's
+knife-edge logic: a one-ulp nudge of the reference arithmetic's own initial state leaves the band sooner), integer-valued fields exactly; (3) under -m gpu -- the GPU equals the portable-math oracle bit for
 bit through every scenario's script (synthetic tracks; env and full controls, feedback, resets, teleports, scoring sets, body
 contacts with their response, in-tick auto-teleport)."""
 import ctypes as C, os, sys, tempfile
@@ -46,16 +46,32 @@ def test_portable_math_oracle_stays_on_the_reference_trajectories(built, hostlib
     orc.cpuref_destroy(h)
     assert p['names'] == g['names'] and np.array_equal(p['ticks'], g['ticks'])
     # how long the two arithmetics stay within 1e-4 of each other in EVERY field depends on the scenario: dozens of records for the
-    # AE86 on the flat plane, fewer where near-zero quantities (a tyre's sliding velocity at rest, an axle's angular velocity) pick
-    # the 1-ulp libm differences up early (a weakly held hub spins about its axle).  Gate: 25 records for the flat AE86 scripts, 2 for
-    # every scenario (integer fields likewise); the printed lengths are the measurement.
-    W = 60
-    MINW = 25 if sid < 4 else 2
-    a, b = p['data'][:W], g['data'][:W]
-    names = g['names']
+    # AE86 on the flat plane, fewer for the cars on the mountain roads.  Gate: 25 records for the flat AE86 scripts, 4 for every
+    # scenario (integer fields likewise); the printed lengths -- and the field that leaves first -- are the measurement.
+    good, good_int, first = held_records(p['data'], g['data'], g['names'])
+    print('%s: all float fields within 1e-4 for the first %d records, all integer fields equal for the first %d%s' % (sc['name'], good, good_int,
+          ('; first to leave, at tick %d: %s = %.6g against %.6g (its vector\'s magnitude there: %.3g)' % ((int(g['ticks'][first[0]]),) + first[1:])) if first else ''))
+    MINW = 25 if sid < 4 else 4
+    assert good >= MINW and good_int >= MINW, (sc['name'], good, good_int, first)
+
+
+W = 60
+
+
+def held_records(a, b, names):
+    """-> (records all float fields stay within 1e-4 for, records all integer-valued fields stay equal for, (record, field, value, reference,
+    scale) of the first float field to leave).  Metric = SURVEY 8d's |x - x_ref| / max(|x_ref|, 1e-3 * scale) with the field's natural
+    scale: the components of ONE vector, quaternion or rotation matrix share the largest |reference component| of that record as
+    denominator -- a hub spinning at 8.6 rad/s about its axle has no meaningful relative error in the 0.006 rad/s it shows about
+    another axis (round 2 measured every component against itself: five scenarios then left 1e-4 after two records, all through such
+    near-null components)."""
+    import re
+    a, b = a[:W], b[:W]
+    names = np.array(names)
     is_int = np.array([any(k in n for k in INT_LIKE) for n in names])
     fa, fb = a[:, ~is_int], b[:, ~is_int]
-    # the metric of SURVEY 8d: |x - x_ref| / max(|x_ref|, 1e-3 * scale), scale = the field's natural magnitude
+    fn = names[~is_int]
+
     def scale(n):
         l = n.lower()
         if any(k in l for k in ('velocity', 'vel.', 'speed', 'lvel')): return 10.0
@@ -64,16 +80,65 @@ def test_portable_math_oracle_stays_on_the_reference_trajectories(built, hostlib
         if 'rpm' in l: return 1000.0
         if any(k in l for k in ('temp', '.t[', 'watert')): return 20.0
         return 1.0
-    floor = 1e-3 * np.array([scale(n) for n in np.array(names)[~is_int]])
-    rel = np.abs(fa - fb) / np.maximum(np.abs(fb), floor)
+    floor = 1e-3 * np.array([scale(n) for n in fn])
+    gid = {}
+    ids = np.array([gid.setdefault(re.sub(r'(\.[xyz]|\[\d+\])$', '', n), len(gid)) for n in fn])
+    gmax = np.zeros((fb.shape[0], len(gid)))
+    for j in range(fb.shape[1]):
+        gmax[:, ids[j]] = np.maximum(gmax[:, ids[j]], np.abs(np.nan_to_num(fb[:, j])))
+    den = np.maximum(gmax[:, ids], floor)
+    rel = np.abs(fa - fb) / den
     rel[np.isnan(fa) & np.isnan(fb)] = 0
     bad_rows = np.nonzero(np.nanmax(rel, axis=1) >= 1e-4)[0]
     good = int(bad_rows[0]) if len(bad_rows) else len(rel)
     int_rows = np.nonzero((np.nan_to_num(a[:, is_int]) != np.nan_to_num(b[:, is_int])).any(axis=1))[0]
     good_int = int(int_rows[0]) if len(int_rows) else len(rel)
-    print('%s: all %d float fields within 1e-4 for the first %d records, all %d integer fields equal for the first %d' % (sc['name'], fa.shape[1], good, int(is_int.sum()), good_int))
-    w = np.unravel_index(np.nanargmax(rel[:MINW]), rel[:MINW].shape)
-    assert good >= MINW and good_int >= MINW, (sc['name'], good, good_int, int(g['ticks'][w[0]]), np.array(names)[~is_int][w[1]], fa[w], fb[w])
+    first = None
+    if len(bad_rows):
+        r = int(bad_rows[0]); j = int(np.nanargmax(rel[r]))
+        first = (r, str(fn[j]), float(fa[r, j]), float(fb[r, j]), float(den[r, j]))
+    return good, good_int, first
+
+
+def _run_script(orc, hostlib, sc, sid, S0):
+    h = orc.cpuref_create(C.byref(sc['P']), sc['blob'], len(sc['blob']), C.byref(S0))
+    P, blob = sc['P'], sc['blob']
+    cb = C.CFUNCTYPE(None, C.c_void_p, C.c_float)(lambda sp, d: hostlib.pdb_teleport_to_spline(C.byref(P), blob, C.c_float(d), C.c_void_p(sp)) and None)
+    cbm = C.CFUNCTYPE(None, C.c_void_p, C.c_int)(lambda sp, m: hostlib.pdb_teleport_by_mode(C.byref(P), blob, m, C.c_void_p(sp)) and None)
+    orc.cpuref_set_auto_teleport_hook(C.c_void_p(h), C.cast(cbm, C.c_void_p))
+    with tempfile.TemporaryDirectory() as d:
+        out = os.path.join(d, 'probe.bin')
+        assert orc.cpuref_run_scenario_cb(h, sid, out.encode(), C.cast(cb, C.c_void_p)) == 0
+        p = probe_io.load(out)
+    orc.cpuref_destroy(h)
+    return p
+
+
+@pytest.mark.parametrize('name', ['readie', 'resets_fc3s', 'akina_tele', 'supra', 'euphoria', 'drive', 'fwd'])
+def test_the_short_bridges_are_rounding_noise_amplified(built, hostlib, base_dir, name):
+    """The scenarios where the portable-math oracle leaves the 1e-4 band around the reference-TU trajectory within a few records:
+    is that a formula that differs, or last-bit noise amplified by the vehicle?  The same script run twice by the GLIBC oracle --
+    the one that reproduces the goldens bit for bit -- once from the scenario's initial state and once with every body placed one
+    float ulp (about 1e-7 m) higher, leaves the band at least as early: the portable arithmetic (correctly rounded elementary functions
+    where glibc's are within an ulp) stays on the reference trajectory at least as long as the reference arithmetic stays on its own
+    after a one-ulp nudge."""
+    glibc = oracle_ctypes.load_oracle(portable_math=False)
+    port = oracle_ctypes.load_oracle(portable_math=True)
+    sid = next(i for i in range(NSC) if glibc.cpuref_scenario_name(i).decode() == name)
+    try:
+        sc = SU.setup(glibc, hostlib, sid, base_dir)
+    except SU.Skip as e:
+        pytest.skip(str(e))
+    ref = _run_script(glibc, hostlib, sc, sid, sc['S0'])
+    S1 = pc.DynState.from_buffer_copy(bytes(sc['S0']))
+    for k in range(sc['P'].numBodies):
+        S1.body[k].pos[1] = float(np.nextafter(np.float32(S1.body[k].pos[1]), np.float32(1e9)))
+    nudged = _run_script(glibc, hostlib, sc, sid, S1)
+    portable = _run_script(port, hostlib, sc, sid, sc['S0'])
+    held_nudged = held_records(nudged['data'], ref['data'], ref['names'])[0]
+    held_portable = held_records(portable['data'], ref['data'], ref['names'])[0]
+    print('%s: glibc nudged by one ulp holds %d records, portable math holds %d' % (name, held_nudged, held_portable))
+    assert held_portable >= held_nudged and held_portable >= 4, (name, held_nudged, held_portable)
 
 
 @pytest.mark.gpu
@@ -105,3 +170,61 @@ def test_every_scenario_gpu_equals_the_portable_oracle(built, sid):
         SU.drive(orc, hostlib, sc, batch=b, max_ticks=1500, on_tick=on_tick)
     finally:
         b.close()
+
+
+def _cs_value(cs, name):
+    """golden probe name 'cs.<field>[.xyz | [k] | N.xyz | N[k]]' -> the value in a pdb_car_state"""
+    import re
+    m = re.match(r'^cs\.([A-Za-z]+?)(\d)?(?:\.([xyz])|\[(\d+)\])?$', name)
+    assert m, name
+    v = getattr(cs, m.group(1))
+    if m.group(2) is not None:
+        v = v[int(m.group(2))]
+    if m.group(3) is not None:
+        v = v['xyz'.index(m.group(3))]
+    elif m.group(4) is not None:
+        v = v[int(m.group(4))]
+    return float(v)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('sid', range(NSC))
+def test_gpu_car_state_stays_on_the_reference_trajectories(built, sid):
+    """GPU against the reference-TU goldens DIRECTLY, every scenario that runs on a synthetic track, all 131 CarState fields the
+    goldens hold (getCarState's record: speeds, accelerations, Euler angles, the four hub matrices, tyre contacts / loads / slips,
+    probes, look-ahead, rewards, gear, track point): within 1e-4 (integers equal) for as many records as the portable-math CPU oracle
+    holds them -- 25 for the flat AE86 scripts, 4 elsewhere -- with the lengths printed."""
+    import pdbatch
+    orc = oracle_ctypes.load_oracle(portable_math=True)
+    hostlib = pc.load_product(host_only=True)
+    base = tempfile.mkdtemp(prefix='pdb_scn_')
+    import synthetic_tracks
+    synthetic_tracks.make_base(base, tracks=())
+    try:
+        sc = SU.setup(orc, hostlib, sid, base)
+    except SU.Skip as e:
+        pytest.skip(str(e))
+    g = load_golden(sc['track'] + '_' + sc['name'])
+    cols = [i for i, n in enumerate(g['names']) if n.startswith('cs.')]
+    names = [g['names'][i] for i in cols]
+    ticks = [int(t) for t in g['ticks'][:W]]
+    want = set(ticks)
+    rows = []
+    b = pdbatch.Batch(1, sc['P'], sc['blob'], device=0, action_mode=2 if sc['full'] else 1)
+    b.set_state((pc.DynState * 1)(sc['S0']))
+
+    def on_tick(t, h, batch):
+        if t in want:
+            cs = batch.get_car_state()[0]
+            rows.append([_cs_value(cs, n) for n in names])
+    try:
+        SU.drive(orc, hostlib, sc, batch=b, max_ticks=ticks[-1] + 1, on_tick=on_tick)
+    finally:
+        b.close()
+    got = np.array(rows, dtype=np.float64)
+    ref = g['data'][:len(rows)][:, cols]
+    good, good_int, first = held_records(got, ref, names)
+    print('%s: GPU CarState (%d fields) within 1e-4 of the reference-TU golden for the first %d records (integers: %d)%s' % (
+        sc['name'], len(names), good, good_int, ('; first to leave: %s' % (first[1:],)) if first else ''))
+    MINW = 25 if sid < 4 else 4
+    assert good >= MINW and good_int >= MINW, (sc['name'], good, good_int, first)
