@@ -107,8 +107,6 @@ def measure(args, world, rank, local_rank, dist, want_cpu=False):
     b = pdbatch.Batch(n, P, trk, device=dev_index, action_mode=1)
     stream = torch.cuda.current_stream()
     b.set_stream(stream.cuda_stream)
-    if hasattr(lib, 'pdb_set_ticks_per_launch'):
-        b.set_ticks_per_launch(args.ticks_per_launch)
     b.upload_actions(actions)
     if args.workload in ('playground', 'nordring'):   # reference-scale meshes: every car to its own random point of the lap, on the device
         b.set_seed(np.arange(first, first + n, dtype=np.uint32) * 2654435761 % 4294967291 + 1)   # Car::teleportByMode(Random) draws from the car's own rand()
@@ -173,6 +171,7 @@ def measure(args, world, rank, local_rank, dist, want_cpu=False):
         part_st = [torch.cuda.ExternalStream(b.partition_stream(p), device=dev) for p in range(args.partitions)]
         part_rng = [b.partition_range(p) for p in range(args.partitions)]
         exch = sharding.PartitionExchange(part_rng, world, rank, dev, dist)
+        out2 = [out_t, torch.zeros_like(out_t)]
         if rank == 0:
             exch.load_actions(torch.from_numpy(all_actions).to(dev))
     if host_pipe:
@@ -212,8 +211,10 @@ def measure(args, world, rank, local_rank, dist, want_cpu=False):
                 f, c = part_rng[p]
                 with torch.cuda.stream(part_st[p]):
                     exch.scatter(p, act_t[f:f + c])
-                    b.step_partition(p, out_t.data_ptr())
-                    exch.gather(p, out_t[f:f + c])
+                    exch.wait(p, t)                                  # the gather of tick t - 2 read this output block
+                    ob = out2[t & 1]
+                    b.step_partition(p, ob.data_ptr())
+                    exch.gather(p, ob[f:f + c], t)                   # asynchronous: overlaps the partition's next tick
             return
         o = gather.slot(t)                  # the kernel writes tick t straight into its trajectory-ring slot
         if part_loops:     # every partition runs its own closed loop (kernel, then the policy on its rows) on its own stream
@@ -279,6 +280,10 @@ def measure(args, world, rank, local_rank, dist, want_cpu=False):
         b.wait_partitions()
         b.event_record(1)
         gather.finish()                       # outstanding gathers belong to the timed region
+        if part_exchange:
+            for p in range(args.partitions):
+                with torch.cuda.stream(part_st[p]):
+                    exch.wait(p, 0); exch.wait(p, 1)
         fence()
         elapsed = sharding.max_over_ranks(time.perf_counter() - t0, dev, dist, world)
         region_ms = b.event_elapsed_ms()
@@ -329,7 +334,7 @@ def measure(args, world, rank, local_rank, dist, want_cpu=False):
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32 (+f64 drivetrain)", "data": "synthetic",
             "repeats": len(regions), "timed_region_s": total,
-            "config": {"workload": wl, "cars_per_gpu": n, "partitions": (args.partitions if split else 1), "settle_ticks": args.settle, "ticks_per_launch": (args.ticks_per_launch if use_ring else 1),
+            "config": {"workload": wl, "cars_per_gpu": n, "partitions": (args.partitions if split else 1), "settle_ticks": args.settle,
                        "collective": ("per partition and tick, on the partition's own stream and RCCL communicator: scatter of its [n,2] action rows from rank 0 -> tick -> all-gather of its [n,26] output rows (the partitions are never joined)" if part_exchange else
                                       "RCCL all-gather of %d-tick trajectory rings [k,N,26] obs/reward/flags on a side stream, kernel writes the ring in place%s" %
                                       (args.gather_ticks, "; actions scattered from rank 0 every tick" if args.scatter_actions else "")) if (world > 1 or args.force_gather) else "none",
@@ -387,7 +392,6 @@ def parser():
     ap.add_argument('--no-extra', action='store_true', help='skip the `extra` block (the other configs measured in the same run)')
     ap.add_argument('--partitions', type=int, default=3,
                     help='free-running car ranges per GPU, one HIP stream each (pdb_set_partitions / pdb_step_ring; constant policy only -- a per-tick policy joins the ranges every tick); 1 = one launch per tick')
-    ap.add_argument('--ticks-per-launch', type=int, default=8, help='constant-action runs (pdb_step_ring): ticks folded into one launch, the records staying in LDS between them (pdb_set_ticks_per_launch); 1 = a launch per tick')
     ap.add_argument('--walls', action='store_true', help='touge workload: line both edges of the road with WALL surfaces (configs[4] shape: hull-vs-wall narrow phase next to the guard rails)')
     ap.add_argument('--spline-step', type=float, default=0.0, help='touge workload: metres between spline points (default 5 m = 891 points; 0.9 = 4.9 k points, the density of the reference tracks)')
     ap.add_argument('--no-body-contacts', action='store_true', help='diagnostic A/B: switch the collision pass off in the car block (never the bench line)')

@@ -136,12 +136,6 @@ int pdb_set_out_device(pdb_batch* b, pdb_step_out* out);
  * the partitioning.  pdb_partition_mark / pdb_partition_elapsed_ms: HIP-event time of one part's kernels between the mark
  * and the last pdb_step_ring (synchronises on that part), and the number of cars in the part. */
 int pdb_set_partitions(pdb_batch* b, int parts);
-/* Ticks folded into one launch by the entry points that step several ticks with the action block as it is (pdb_step_ring,
- * pdb_step_n): within a launch a car's record stays in LDS from one tick to the next (it is still written back after every tick
- * -- the contact pass restarts from that copy -- and every tick writes its output row), nothing is launched between the ticks and
- * the contact pass follows once per launch: a car that meets something at tick j of the launch is finished, j onwards, by that
- * pass.  1..64, default 8; results do not depend on it. */
-int pdb_set_ticks_per_launch(pdb_batch* b, int ticks);
 /* diagnostic: how many cars the most recent contact pass of a launch site held (site = partition index, 4 = the batch's own
  * stream); read without waiting for anything, so it lags the launches still in flight */
 int pdb_contact_pass_load(pdb_batch* b, int site);

@@ -17,7 +17,7 @@
 #define PDB_KROWS 33
 #define PDB_KNS k33
 #define PDB_KMINWAVES 6
-#define PDB_KMINWAVES_C 4
+#define PDB_KMINWAVES_C 2
 #define PDB_KERNEL_EXACT pdb_step_kernel
 #define PDB_KERNEL_GUARDED pdb_step_kernel_generic
 #define PDB_KERNEL_EXACT_C pdb_contact_kernel
@@ -35,7 +35,7 @@
 #define PDB_KROWS 40
 #define PDB_KNS k40
 #define PDB_KMINWAVES 5
-#define PDB_KMINWAVES_C 4
+#define PDB_KMINWAVES_C 2
 #define PDB_KERNEL_EXACT pdb_step_kernel_wide40
 #define PDB_KERNEL_GUARDED pdb_step_kernel_wide
 #define PDB_KERNEL_EXACT_C pdb_contact_kernel_wide40
@@ -64,9 +64,6 @@ namespace pdb { void setError(const std::string& s); }
     } while (0)
 
 #define PDB_MAX_PARTS 4
-#ifndef PDB_MAX_TICKS_PER_LAUNCH
-#define PDB_MAX_TICKS_PER_LAUNCH 8
-#endif
 #ifndef PDB_CONTACT_GRID
 #define PDB_CONTACT_GRID 32
 #endif
@@ -117,7 +114,6 @@ struct pdb_batch {
     bool batchDirty = false;  // asynchronous work queued on the batch's stream that pdb_step_partition's streams have not been ordered after
     float* hActions = nullptr;          // page-locked host mirrors (pdb_host_actions / pdb_host_out): the pipelined host-policy loop
     pdb_step_out* hOut = nullptr;
-    int ticksPerLaunch = PDB_MAX_TICKS_PER_LAUNCH;   // pdb_step_ring / pdb_step_n: ticks folded into one launch (pdb_set_ticks_per_launch)
     int contactGrid = 0;   // workgroups of the contact pass: 0 = adaptive (from the queue lengths the last passes saw); PDB_CONTACT_GRID in the environment fixes it (diagnostic)
     int* hHint = nullptr;  // page-locked, device-visible: per launch site, the number of cars the last contact pass held (written by its last workgroup; read here without waiting)
     int* dHint = nullptr;
@@ -175,9 +171,7 @@ static void fillConst(const pdb_car_params& P, DevConst& K, int actionMode) {
 // contact pass over the blocks the first pass queued (cars with live contact joints or fresh contacts; a small fixed grid that
 // finds an empty queue on almost every tick).  `q` = which of the batch's queues this launch site uses (one per partition
 // stream, one for the batch's own stream: launches that can be in flight together never share a queue).
-// nTicks > 1: that many ticks of the range in ONE launch of each pass (the records stay in LDS between the ticks, the actions are
-// those of the action block throughout); tick i writes its outputs to ring slot (firstSlot + i) % ringSlots (slots are b->n records apart)
-static void launchTick(pdb_batch* b, hipStream_t st, int c0, int c1, pdb_step_out* out, int q, int nTicks = 1, int ringSlots = 1, int firstSlot = 0) {
+static void launchTick(pdb_batch* b, hipStream_t st, int c0, int c1, pdb_step_out* out, int q) {
     const int nblk = (c1 - c0 + PDB_CPB - 1) / PDB_CPB, m = b->params.numRows;
     pdb_dyn_state* S = b->dStates + c0;
     const float* Aact = b->dActions + (size_t)c0 * b->actionStride;
@@ -204,36 +198,29 @@ static void launchTick(pdb_batch* b, hipStream_t st, int c0, int c1, pdb_step_ou
     }
     int* HN = b->dHint ? b->dHint + q : nullptr;
     const dim3 grid(nblk), block(PDB_BLOCK_THREADS), cgrid(nblk < cg ? nblk : cg);
-    // the two size classes' argument blocks have the same layout (plain pointers and integers)
-    k33::StepArgs A;
-    A.states = S; A.actions = Aact; A.outs = O; A.carStates = CS; A.Pp = DP; A.Kp = DK; A.trackBlob = b->dTrack; A.contacts = CT;
-    A.queue = (k33::RedoQueue*)Q; A.resetMask = RM; A.hint = HN; A.slotStride = (long long)b->n; A.nCars = n; A.nTicks = nTicks; A.ringSlots = ringSlots; A.firstSlot = firstSlot;
     if (m == 33) {
-        hipLaunchKernelGGL(k33::pdb_step_kernel, grid, block, 0, st, A);
-        if (contacts) hipLaunchKernelGGL(k33::pdb_contact_kernel, cgrid, block, 0, st, A);
+        hipLaunchKernelGGL(k33::pdb_step_kernel, grid, block, 0, st, S, Aact, O, CS, DP, DK, b->dTrack, (k33::RedoQueue*)Q, RM, n);
+        if (contacts) hipLaunchKernelGGL(k33::pdb_contact_kernel, cgrid, block, 0, st, S, Aact, O, CS, DP, DK, b->dTrack, CT, (k33::RedoQueue*)Q, RM, n, HN);
     } else if (m < 33) {
-        hipLaunchKernelGGL(k33::pdb_step_kernel_generic, grid, block, 0, st, A);
-        if (contacts) hipLaunchKernelGGL(k33::pdb_contact_kernel_generic, cgrid, block, 0, st, A);
+        hipLaunchKernelGGL(k33::pdb_step_kernel_generic, grid, block, 0, st, S, Aact, O, CS, DP, DK, b->dTrack, (k33::RedoQueue*)Q, RM, n);
+        if (contacts) hipLaunchKernelGGL(k33::pdb_contact_kernel_generic, cgrid, block, 0, st, S, Aact, O, CS, DP, DK, b->dTrack, CT, (k33::RedoQueue*)Q, RM, n, HN);
     } else {
 #ifndef PDB_FAST_BUILD
-        k40::StepArgs B;
-        static_assert(sizeof(B) == sizeof(A), "StepArgs layout");
-        memcpy(&B, &A, sizeof(B));
-        hipLaunchKernelGGL(k40::pdb_step_kernel_wide, grid, block, 0, st, B);
-        if (contacts) hipLaunchKernelGGL(k40::pdb_contact_kernel_wide, cgrid, block, 0, st, B);
+        hipLaunchKernelGGL(k40::pdb_step_kernel_wide, grid, block, 0, st, S, Aact, O, CS, DP, DK, b->dTrack, (k40::RedoQueue*)Q, RM, n);
+        if (contacts) hipLaunchKernelGGL(k40::pdb_contact_kernel_wide, cgrid, block, 0, st, S, Aact, O, CS, DP, DK, b->dTrack, CT, (k40::RedoQueue*)Q, RM, n, HN);
 #endif
     }
 }
 
 // One tick of every car on `st` (the whole-batch entry points: pdb_step, pdb_step_n and its graph, pdb_step_async, pdb_step_host).
 // Partitions with a car block of their own (pdb_set_partition_params) step with it here too: one launch per partition range.
-static void launchWhole(pdb_batch* b, hipStream_t st, pdb_step_out* out, int nTicks = 1) {
+static void launchWhole(pdb_batch* b, hipStream_t st, pdb_step_out* out) {
     bool any = false;
     for (int p = 0; p < b->parts; ++p) any = any || b->partHas[p];
-    if (!any) { launchTick(b, st, 0, b->n, out, PDB_MAX_PARTS, nTicks); return; }
+    if (!any) { launchTick(b, st, 0, b->n, out, PDB_MAX_PARTS); return; }
     for (int p = 0; p < b->parts; ++p) {
         const int c0 = partFirst(b, p), c1 = partFirst(b, p + 1);
-        if (c1 > c0) launchTick(b, st, c0, c1, out, p, nTicks);   // the partition's own queue: its stream is joined (joinParts) before anything is launched here
+        if (c1 > c0) launchTick(b, st, c0, c1, out, p);   // the partition's own queue: its stream is joined (joinParts) before anything is launched here
     }
 }
 
@@ -549,7 +536,7 @@ int pdb_step_n(pdb_batch* b, float dt, int n) {
     }
     if (b->stream == nullptr) {   // the legacy default stream (a caller's pdb_set_stream) cannot be captured: n plain launches
         HIPCHK(hipEventRecord(b->ev0, b->stream));
-        for (int i = 0; i < n; i += b->ticksPerLaunch) launchWhole(b, b->stream, b->dOutActive, (n - i < b->ticksPerLaunch) ? n - i : b->ticksPerLaunch);
+        for (int i = 0; i < n; ++i) launchWhole(b, b->stream, b->dOutActive);
         HIPCHK(hipGetLastError());
         HIPCHK(hipEventRecord(b->ev1, b->stream));
         HIPCHK(hipEventSynchronize(b->ev1));
@@ -562,8 +549,8 @@ int pdb_step_n(pdb_batch* b, float dt, int n) {
         if (b->graphExec) { (void)hipGraphExecDestroy(b->graphExec); b->graphExec = nullptr; }
         hipGraph_t g = nullptr;
         HIPCHK(hipStreamBeginCapture(b->stream, hipStreamCaptureModeThreadLocal));
-        for (int i = 0; i < n; i += b->ticksPerLaunch)
-            launchWhole(b, b->stream, b->dOutActive, (n - i < b->ticksPerLaunch) ? n - i : b->ticksPerLaunch);
+        for (int i = 0; i < n; ++i)
+            launchWhole(b, b->stream, b->dOutActive);
         HIPCHK(hipStreamEndCapture(b->stream, &g));
         HIPCHK(hipGraphInstantiate(&b->graphExec, g, nullptr, nullptr, 0));
         (void)hipGraphDestroy(g);
@@ -599,13 +586,6 @@ int pdb_contact_pass_load(pdb_batch* b, int site) {
     if (!b || site < 0 || site > PDB_MAX_PARTS || !b->hHint) return -1;
     return *(volatile int*)(b->hHint + site);
 }
-int pdb_set_ticks_per_launch(pdb_batch* b, int ticks) {
-    if (!b || ticks < 1 || ticks > 64) { pdb::setError("pdb_set_ticks_per_launch: 1..64"); return PDB_ERR_ARG; }
-    if (b->graphExec) { (void)hipGraphExecDestroy(b->graphExec); b->graphExec = nullptr; }
-    b->ticksPerLaunch = ticks;
-    return PDB_OK;
-}
-
 int pdb_set_partitions(pdb_batch* b, int parts) {
     if (!b || parts < 1 || parts > PDB_MAX_PARTS) { pdb::setError("pdb_set_partitions: 1..4 parts"); return PDB_ERR_ARG; }
     HIPCHK(hipSetDevice(b->device));
@@ -643,16 +623,12 @@ int pdb_step_ring(pdb_batch* b, float dt, int n_ticks, pdb_step_out* ring, int r
         if (forked) HIPCHK(hipStreamWaitEvent(st, b->partFork, 0));
         if (forked && b->partMark) HIPCHK(hipEventRecord(b->partStart[p], st));
     }
-    // several ticks per launch (b->ticksPerLaunch): between them a car's record stays in LDS and nothing is launched.  A ring slot
-    // per tick, whatever the chunking.
-    const int per = b->ticksPerLaunch < 1 ? 1 : (b->ticksPerLaunch > 64 ? 64 : b->ticksPerLaunch);
-    for (int i = 0; i < n_ticks; i += per) {
-        const int m = (n_ticks - i < per) ? n_ticks - i : per;
+    for (int i = 0; i < n_ticks; ++i) {
+        pdb_step_out* out = ring ? ring + (size_t)((first_slot + i) % ring_slots) * (size_t)b->n : b->dOutActive;
         for (int p = 0; p < np; ++p) {
             const int c0 = forked ? partFirst(b, p) : 0, c1 = forked ? partFirst(b, p + 1) : b->n;
             if (c1 <= c0) continue;
-            if (ring) launchTick(b, forked ? b->partStream[p] : b->stream, c0, c1, ring, forked ? p : PDB_MAX_PARTS, m, ring_slots, (first_slot + i) % ring_slots);
-            else launchTick(b, forked ? b->partStream[p] : b->stream, c0, c1, b->dOutActive, forked ? p : PDB_MAX_PARTS, m, 1, 0);
+            launchTick(b, forked ? b->partStream[p] : b->stream, c0, c1, out, forked ? p : PDB_MAX_PARTS);
         }
     }
     HIPCHK(hipGetLastError());

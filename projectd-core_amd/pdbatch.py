@@ -57,10 +57,6 @@ class Batch:
         """cut the batch into `parts` free-running car ranges, one HIP stream each (pdb_step_ring)"""
         self._chk(self.lib.pdb_set_partitions(self.h, parts))
 
-    def set_ticks_per_launch(self, ticks):
-        """ticks folded into one launch by step_ring / step(n) (records stay in LDS between them); results do not depend on it"""
-        self._chk(self.lib.pdb_set_ticks_per_launch(self.h, ticks))
-
     def set_partition_params(self, part, params):
         """a car block of its own for one partition (None: the batch's): same model, different tunes / weights"""
         self._chk(self.lib.pdb_set_partition_params(self.h, part, C.byref(params) if params is not None else None))

@@ -131,7 +131,9 @@ class PartitionExchange:
         self.dist, self.world, self.rank, self.ranges = dist, world, rank, list(part_ranges)
         # every rank creates the groups in the same order
         self.groups = [dist.new_group(ranks=list(range(world)), backend=backend) for _ in self.ranges] if dist is not None else [None] * len(self.ranges)
-        self.gathered = [torch.empty((world, c, OUT_COLS), dtype=torch.float32, device=device) for (f, c) in self.ranges]
+        self.gathered2 = [[torch.empty((world, c, OUT_COLS), dtype=torch.float32, device=device) for (f, c) in self.ranges] for _ in range(2)]
+        self.gathered = self.gathered2[0]
+        self.work = [[None] * len(self.ranges) for _ in range(2)]
         self.scatter_src = [torch.zeros((world, c, 2), dtype=torch.float32, device=device) for (f, c) in self.ranges] if rank == 0 else None
 
     def load_actions(self, all_actions):
@@ -147,9 +149,19 @@ class PartitionExchange:
         else:
             self.dist.scatter(act_rows, list(self.scatter_src[p].unbind(0)) if self.rank == 0 else None, src=0, group=self.groups[p])
 
-    def gather(self, p, out_rows):
-        """partition p's output rows of every rank -> gathered[p] (out_rows: the contiguous [c, 26] view of this rank's output block)"""
-        self.dist.all_gather_into_tensor(self.gathered[p].view(-1, OUT_COLS), out_rows, group=self.groups[p])
+    def gather(self, p, out_rows, slot=0):
+        """partition p's output rows of every rank -> gathered[slot & 1][p] (out_rows: the contiguous [c, 26] view of this rank's output
+        block of that tick).  Asynchronous: the partition's next tick is not held back by the collective -- ticks alternate between two
+        output blocks, and a block is only rewritten after wait(p, slot) has put the gather that still reads it in front of the writer."""
+        r = slot & 1
+        self.work[r][p] = self.dist.all_gather_into_tensor(self.gathered2[r][p].view(-1, OUT_COLS), out_rows, group=self.groups[p], async_op=True)
+
+    def wait(self, p, slot):
+        """the caller's current stream waits for the gather of partition p issued with this slot parity (if one is outstanding)"""
+        r = slot & 1
+        if self.work[r][p] is not None:
+            self.work[r][p].wait()
+            self.work[r][p] = None
 
 
 def scatter_actions(all_actions, n_local, world, rank, device, dist=None):

@@ -575,20 +575,19 @@ def test_pipelined_host_policy_equals_step_host(built):
 
 
 @pytest.mark.parametrize('track,model,ticks', [('walled', 'ks_toyota_ae86_drift', 2400), ('walled', 'dthwsh_mazda_rx7_fc3s_sr20', 2400)])
-def test_ticks_per_launch_do_not_change_results(built, track, model, ticks):
-    """pdb_set_ticks_per_launch: 8 and 5 ticks per launch (records staying in LDS between the ticks, ONE contact pass per launch that
-    finishes the cars that met something from the tick they met it at) against a launch per tick -- same records, same contact
-    joints, same output rows in every ring slot; cars driven into walls, rings that wrap, free-running partitions"""
+def test_rings_partitions_and_graph_replay_with_contacts(built, track, model, ticks):
+    """pdb_step_ring into a wrapping ring over free-running partitions, and pdb_step_n's graph, with cars driven into walls (the
+    contact pass packing queued cars of different workgroups together) against plain launches on one stream: same records, same
+    contact joints, same output rows in every ring slot"""
     import torch, pdbatch
     n, k = 50, 16
     P = pdbatch.packed_params(model + '.env')
     trk = pdbatch.synthetic_track(track)
     acts = parity_util.make_actions(n, 11)
     res = []
-    for tpl, parts in ((1, 1), (8, 3), (5, 1)):
+    for parts in (1, 3, 2):
         b = pdbatch.Batch(n, P, trk, device=0, action_mode=1)
         try:
-            b.set_ticks_per_launch(tpl)
             if parts > 1:
                 b.set_partitions(parts)
             b.upload_actions(acts)
@@ -600,7 +599,7 @@ def test_ticks_per_launch_do_not_change_results(built, track, model, ticks):
                 b.sync()
                 t += m
                 rows.append(ring.cpu().numpy().copy())
-            b.step(24)          # pdb_step_n: the same folding
+            b.step(24)          # pdb_step_n: a captured graph
             st = bytes(b.get_state()); ct = b.get_contacts(); sg = b.get_state()
             live = b''.join(bytes(ct[i])[:32 * sg[i].numContacts] for i in range(n))
             res.append((st, live, rows, sum(1 for i in range(n) if sg[i].damageZoneLevel[4] > 0)))

@@ -41,6 +41,11 @@ if kind == 'touge':   # spread the cars around the lap, drive them with a mild c
         hl.pdb_teleport_to_spline(C.byref(P), trk, C.c_float((i % 4096) / 4096.0), C.byref(st[i]))
     b.set_state(st)
     a[:, 0] = 0.0; a[:, 1] = -0.5
+if kind in ('playground', 'nordring'):   # every car to its own random point of the lap (device teleports), driven by a mild constant action
+    lib.pdb_set_seed.argtypes = [C.c_void_p, C.c_void_p]; lib.pdb_reset_mode.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+    b.set_seed(np.arange(1, n + 1, dtype=np.uint32) * 7919)
+    b.reset(mode=2)
+    a[:, 0] *= 0.3; a[:, 1] = -0.5
 for _ in range(400): b.step_host(a)
 st = np.zeros((n, 32), dtype=np.uint64)
 lib.pdb_debug_stamps(b.h, st.ctypes.data_as(C.c_void_p))
