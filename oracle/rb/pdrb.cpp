@@ -589,9 +589,13 @@ static void solveContacts(World& w, float fps, int m, const int* rb0, const int*
     std::vector<int> state(nr);
     std::vector<float> x(nr, 0.0f), work(nr * nr), y(nr), di(nr);
     int iterations = 0;
+#ifndef PDRB_LCP_MAX_ITERATIONS
+#define PDRB_LCP_MAX_ITERATIONS 256   /* per stage; = the kernel's.  With 16 contacts (48 rows) 95 % of the solves take < 16 rounds, the tail
+                                         -- near-duplicate contact points, the single-flip fallback -- reaches a few hundred */
+#endif
     auto bpp = [&]() {
         int ninf = nr + 1, p = 3;
-        for (int it = 0; it < 64; ++it) {
+        for (int it = 0; it < PDRB_LCP_MAX_ITERATIONS; ++it) {
             ++iterations;
             for (int r = 0; r < nr; ++r) { if (state[r] == ST_LO) x[r] = lo[r]; else if (state[r] == ST_HI) x[r] = hi[r]; else if (state[r] != ST_FREE) x[r] = 0.0f; }
             for (int r = 0; r < nr; ++r) {

@@ -67,6 +67,9 @@ namespace pdb { void setError(const std::string& s); }
 #ifndef PDB_CONTACT_GRID
 #define PDB_CONTACT_GRID 32
 #endif
+#ifndef PDB_CONTACT_GRID_IDLE
+#define PDB_CONTACT_GRID_IDLE 8
+#endif
 struct pdb_batch {
     int device = 0;
     int n = 0;
@@ -193,7 +196,7 @@ static void launchTick(pdb_batch* b, hipStream_t st, int c0, int c1, pdb_step_ou
     if (cg <= 0) {
         const int held = b->hHint ? *(volatile int*)(b->hHint + q) : 0;
         cg = (2 * held + PDB_CPB - 1) / PDB_CPB;
-        if (cg < PDB_CONTACT_GRID) cg = PDB_CONTACT_GRID;
+        if (cg < (held > 0 ? PDB_CONTACT_GRID : PDB_CONTACT_GRID_IDLE)) cg = held > 0 ? PDB_CONTACT_GRID : PDB_CONTACT_GRID_IDLE;   // nobody touched anything lately: a handful of workgroups is launched, found empty and gone
         if (cg > 1024) cg = 1024;
     }
     int* HN = b->dHint ? b->dHint + q : nullptr;
