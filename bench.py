@@ -33,7 +33,7 @@ CARS_PER_GPU = 4096
 # algorithmic bytes per car-tick (DESIGN.md "Algorithmic bytes"): record read + record write + action + output row
 B_ALG = 2272 + 2272 + 8 + 104   # sizeof(pdb_dyn_state) in and out, float[2] action, pdb_step_out (checked against the ctypes mirrors in measure)
 HBM_PEAK_GBS = 8000.0
-PROFILE_TAG = 'r02'
+PROFILE_TAG = 'r03'
 
 
 def cpu_baseline(P, trk, S0, actions, seconds_target=15.0):
@@ -342,9 +342,9 @@ def measure(args, world, rank, local_rank, dist, want_cpu=False):
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic, "traffic_source": ("profiles/%s_pmc.json: (2*FETCH_SIZE + WRITE_SIZE)*1024 per launch, rocprofv3 --pmc passes of this command" % prof if traffic else None),
                          "kernel": "pdb_step_kernel", "kernel_avg_us": kernel_us, "alg_bytes_per_car_tick": B_ALG, "cars_per_launch": launch_cars,
-                         "concurrent_launches": conc, "device_achieved": achieved * conc, "device_frac": achieved * conc / HBM_PEAK_GBS,
+                         "concurrent_launches": conc, "device_achieved": B_ALG * n * args.steps / elapsed / 1e9, "device_frac": B_ALG * n * args.steps / elapsed / 1e9 / HBM_PEAK_GBS,   # whole device, from the wall time of the timed region
                          "valu_issue_busy_frac": valu_busy,   # the resource that actually bounds the kernel (profiles/*_pmc.json; definition in DESIGN.md section 3)
-                         "note": ("one launch = one partition (%d cars); %d partitions step concurrently on their own streams, so the device moves concurrent_launches x achieved" % (launch_cars, conc)) if conc > 1 else None},
+                         "note": ("one launch = one partition (%d cars); %d partitions step concurrently on their own streams, device_achieved = this GPU's algorithmic bytes over the wall time of the timed region" % (launch_cars, conc)) if conc > 1 else None},
         }
         if hasattr(lib, 'pdb_contact_pass_load'):
             res["contact_pass_cars"] = [int(lib.pdb_contact_pass_load(b.h, q)) for q in (list(range(args.partitions)) if split else [4])]   # cars the last contact passes held (diagnostic)

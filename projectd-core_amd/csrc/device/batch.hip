@@ -234,7 +234,7 @@ static int pushK(pdb_batch* b, hipStream_t st, bool async) {
         if (!b->partHas[p]) continue;
         DevConst& K = b->partK[p];
         fillConst(b->partParams[p], K, b->K.actionMode);
-        K.dt = b->K.dt; K.fps = b->K.fps; K.dtD = b->K.dtD; K.stuckTimeout = b->K.stuckTimeout; K.wantCarState = b->K.wantCarState; K.stamps = b->K.stamps;
+        K.dt = b->K.dt; K.fps = b->K.fps; K.dtD = b->K.dtD; K.stuckTimeout = b->K.stuckTimeout; K.wantCarState = b->K.wantCarState; K.stamps = b->K.stamps; K.stampCars = b->K.stampCars;
         K.envHitPenalty = b->K.envHitPenalty; K.envOffPenalty = b->K.envOffPenalty; K.envStuckPenalty = b->K.envStuckPenalty; K.envLowReward = b->K.envLowReward;
         K.envMode = b->K.envMode; K.envTermHit = b->K.envTermHit; K.envTermOff = b->K.envTermOff; K.envTermStuck = b->K.envTermStuck;
         K.envTeleportOnReset = b->K.envTeleportOnReset; K.envTeleportMode = b->K.envTeleportMode;
@@ -317,8 +317,9 @@ pdb_batch* pdb_create(int device, int n_cars, const pdb_car_params* params, cons
     }
 #ifdef PDB_STAMPS
     if (ok) {
-        ok = ok && hipMalloc(&b->dStamps, sizeof(unsigned long long) * 32 * (size_t)n_cars) == hipSuccess;
-        b->K.stamps = b->dStamps;
+        ok = ok && hipMalloc(&b->dStamps, sizeof(unsigned long long) * 64 * (size_t)n_cars) == hipSuccess;
+        ok = ok && hipMemset(b->dStamps, 0, sizeof(unsigned long long) * 64 * (size_t)n_cars) == hipSuccess;
+        b->K.stamps = b->dStamps; b->K.stampCars = n_cars;
         ok = ok && hipMemcpy(b->dK, &b->K, sizeof(DevConst), hipMemcpyHostToDevice) == hipSuccess;
     }
 #endif
@@ -765,7 +766,8 @@ int pdb_get_car_state(pdb_batch* b, int first, int count, pdb_car_state* out) {
 #ifdef PDB_STAMPS
 int pdb_debug_stamps(pdb_batch* b, unsigned long long* out) {
     HIPCHK(hipStreamSynchronize(b->stream));
-    HIPCHK(hipMemcpy(out, b->dStamps, sizeof(unsigned long long) * 32 * (size_t)b->n, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(out, b->dStamps, sizeof(unsigned long long) * 64 * (size_t)b->n, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemset(b->dStamps, 0, sizeof(unsigned long long) * 64 * (size_t)b->n));
     return PDB_OK;
 }
 #endif

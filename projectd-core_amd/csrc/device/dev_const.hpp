@@ -27,6 +27,7 @@ struct DevConst {
     int envMode, envTermHit, envTermOff, envTermStuck, envTeleportOnReset, envTeleportMode;
     int actionMode;
     int wantCarState;
-    unsigned long long* stamps;   // diagnostic build only (-DPDB_STAMPS): [car][16] shader-clock stamps
+    unsigned long long* stamps;   // diagnostic build only (-DPDB_STAMPS): [car][32] shader-clock stamps of the first pass, then [stampCars + car][32] of the contact pass
+    int stampCars, _padStamp;
 };
 

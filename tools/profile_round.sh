@@ -1,21 +1,21 @@
 #!/bin/bash
-# Run on the GPU box (through gpurun): bench line, rocprofv3 kernel stats, and the PMC passes that DESIGN.md /
+# Run on the GPU box (through gpurun; every command under its own timeout): bench line, rocprofv3 kernel stats, and the PMC passes that DESIGN.md /
 # bench.py's roofline block cite.  Usage: bash tools/profile_round.sh r01   (outputs under gpurun_out/<tag>/)
 set -u
-TAG=${1:-r02}
+TAG=${1:-r03}
 OUT=gpurun_out/$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
-python3 bench.py --steps 3000 --warmup 333 > $OUT/bench.json 2> $OUT/bench.err
+timeout 1500 python3 bench.py --steps 3000 --warmup 333 > $OUT/bench.json 2> $OUT/bench.err
 tail -1 $OUT/bench.json | cut -c1-300
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o run -- python3 bench.py --steps 300 --warmup 50 --no-cpu-baseline --no-extra > $OUT/stats.log 2>&1
-rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -o run -- python3 bench.py --steps 100 --warmup 20 --no-cpu-baseline --no-extra > $OUT/pmc_fetch.log 2>&1
-rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -o run -- python3 bench.py --steps 100 --warmup 20 --no-cpu-baseline --no-extra > $OUT/pmc_write.log 2>&1
-rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_SMEM SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY --output-format csv -d $OUT/pmc_sq1 -o run -- python3 bench.py --steps 100 --warmup 20 --no-cpu-baseline --no-extra > $OUT/pmc_sq1.log 2>&1
-rocprofv3 --pmc SQ_WAVES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_LDS_BANK_CONFLICT SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $OUT/pmc_sq2 -o run -- python3 bench.py --steps 100 --warmup 20 --no-cpu-baseline --no-extra > $OUT/pmc_sq2.log 2>&1
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o run -- python3 bench.py --steps 300 --warmup 50 --no-cpu-baseline --no-extra > $OUT/stats.log 2>&1
+timeout 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -o run -- python3 bench.py --steps 100 --warmup 20 --no-cpu-baseline --no-extra > $OUT/pmc_fetch.log 2>&1
+timeout 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -o run -- python3 bench.py --steps 100 --warmup 20 --no-cpu-baseline --no-extra > $OUT/pmc_write.log 2>&1
+timeout 300 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_SMEM SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY --output-format csv -d $OUT/pmc_sq1 -o run -- python3 bench.py --steps 100 --warmup 20 --no-cpu-baseline --no-extra > $OUT/pmc_sq1.log 2>&1
+timeout 300 rocprofv3 --pmc SQ_WAVES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_LDS_BANK_CONFLICT SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $OUT/pmc_sq2 -o run -- python3 bench.py --steps 100 --warmup 20 --no-cpu-baseline --no-extra > $OUT/pmc_sq2.log 2>&1
 # issue model: measured cycles per wave-instruction (tools/issue_rate.hip), plain and under the SQ counters
 if [ -x tools/issue_rate ]; then
-  tools/issue_rate > $OUT/issue_rate.txt 2>&1
-  rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY --output-format csv -d $OUT/pmc_issue -o run -- tools/issue_rate > $OUT/pmc_issue.log 2>&1
+  timeout 300 tools/issue_rate > $OUT/issue_rate.txt 2>&1
+  timeout 300 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY --output-format csv -d $OUT/pmc_issue -o run -- tools/issue_rate > $OUT/pmc_issue.log 2>&1
 fi
 python3 tools/summarise_profiles.py $TAG

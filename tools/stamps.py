@@ -47,8 +47,10 @@ if kind in ('playground', 'nordring'):   # every car to its own random point of 
     b.reset(mode=2)
     a[:, 0] *= 0.3; a[:, 1] = -0.5
 for _ in range(400): b.step_host(a)
-st = np.zeros((n, 32), dtype=np.uint64)
+st = np.zeros((2 * n, 32), dtype=np.uint64)
 lib.pdb_debug_stamps(b.h, st.ctypes.data_as(C.c_void_p))
+full = st[n:].astype(np.int64)     # the contact pass's stamps of the last tick (cars it held)
+st = st[:n]
 sti = st.astype(np.int64)
 CPB = 3
 first = sti[::CPB]                      # first car of each block also carries the pack wave's stamps (4, 14, 15)
@@ -65,3 +67,15 @@ for nm, k in (('pre-step + steering rods done', 4), ('tyres done', 24), ('suspen
 print('pack internals (car 0 of the block, wheel 0): pre-step end -> hub matrix %d | ray cast %d | contact + SCTM + forces %d | torque/lock %d | thermal %d ;; drive: tyres end -> before drivetrainStep %d | drivetrainStep %d' % (med(first[:,16]-first[:,4]), med(first[:,17]-first[:,16]), med(first[:,18]-first[:,17]), med(first[:,19]-first[:,18]), med(first[:,20]-first[:,19]), med(first[:,22]-first[:,24]), med(first[:,23]-first[:,22])))
 print('wave lifetime median %.0f clocks' % med(sti[:, 13] - t0))
 b.close()
+
+held = full[:, 0] != 0
+if held.any():
+    f = full[held]
+    print('contact pass: %d of %d cars in it on the last tick; median / 90th percentile / max shader clocks since the wave started the car:' % (held.sum(), n))
+    for nm, k in (('record loaded', 1), ('joint rows done, collision pass starts', 16), ('collision pass done', 17), ('A assembled', 8), ('LDL^T done', 3), ('forces ready (barrier 2)', 5),
+                  ('lambda of the unbounded rows', 9), ('integration done', 11), ('post scans done', 14), ('record stored', 13)):
+        d = f[:, k] - f[:, 0]
+        d = d[f[:, k] != 0]
+        if len(d): print('  %-48s %9.0f %9.0f %9.0f' % (nm, np.median(d), np.percentile(d, 90), d.max()))
+    cs = f[f[:, 19] != 0]
+    if len(cs): print('  contact solve (cars with live joints: %d): median %.0f, max %.0f clocks' % (len(cs), np.median(cs[:, 19] - cs[:, 18]), (cs[:, 19] - cs[:, 18]).max()))
