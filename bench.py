@@ -171,7 +171,6 @@ def measure(args, world, rank, local_rank, dist, want_cpu=False):
         part_st = [torch.cuda.ExternalStream(b.partition_stream(p), device=dev) for p in range(args.partitions)]
         part_rng = [b.partition_range(p) for p in range(args.partitions)]
         exch = sharding.PartitionExchange(part_rng, world, rank, dev, dist)
-        out2 = [out_t, torch.zeros_like(out_t)]
         if rank == 0:
             exch.load_actions(torch.from_numpy(all_actions).to(dev))
     if host_pipe:
@@ -211,10 +210,8 @@ def measure(args, world, rank, local_rank, dist, want_cpu=False):
                 f, c = part_rng[p]
                 with torch.cuda.stream(part_st[p]):
                     exch.scatter(p, act_t[f:f + c])
-                    exch.wait(p, t)                                  # the gather of tick t - 2 read this output block
-                    ob = out2[t & 1]
-                    b.step_partition(p, ob.data_ptr())
-                    exch.gather(p, ob[f:f + c], t)                   # asynchronous: overlaps the partition's next tick
+                    b.step_partition(p, out_t.data_ptr())
+                    exch.gather(p, out_t[f:f + c], wait=True)        # the partition's stream waits for it (the host does not): its next tick rewrites these rows
             return
         o = gather.slot(t)                  # the kernel writes tick t straight into its trajectory-ring slot
         if part_loops:     # every partition runs its own closed loop (kernel, then the policy on its rows) on its own stream
@@ -280,10 +277,7 @@ def measure(args, world, rank, local_rank, dist, want_cpu=False):
         b.wait_partitions()
         b.event_record(1)
         gather.finish()                       # outstanding gathers belong to the timed region
-        if part_exchange:
-            for p in range(args.partitions):
-                with torch.cuda.stream(part_st[p]):
-                    exch.wait(p, 0); exch.wait(p, 1)
+
         fence()
         elapsed = sharding.max_over_ranks(time.perf_counter() - t0, dev, dist, world)
         region_ms = b.event_elapsed_ms()

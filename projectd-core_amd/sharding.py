@@ -149,15 +149,19 @@ class PartitionExchange:
         else:
             self.dist.scatter(act_rows, list(self.scatter_src[p].unbind(0)) if self.rank == 0 else None, src=0, group=self.groups[p])
 
-    def gather(self, p, out_rows, slot=0):
-        """partition p's output rows of every rank -> gathered[slot & 1][p] (out_rows: the contiguous [c, 26] view of this rank's output
-        block of that tick).  Asynchronous: the partition's next tick is not held back by the collective -- ticks alternate between two
-        output blocks, and a block is only rewritten after wait(p, slot) has put the gather that still reads it in front of the writer."""
+    def gather(self, p, out_rows, slot=0, wait=True):
+        """partition p's output rows of every rank -> gathered2[slot & 1][p] (out_rows: the contiguous [c, 26] view of this rank's output
+        block of that tick).  wait=True: the caller's current stream (the partition's) waits for the collective -- stream-side, never the
+        host -- so the rows may be rewritten by the partition's next tick.  wait=False: asynchronous; the caller alternates between two
+        output blocks and calls wait(p, slot) before the block of that parity is written again.  (Measured on one rank, 8192 cars: the
+        asynchronous form costs ~10 us more host time per partition and tick than it saves on the stream -- the loop is bound by the
+        host's ~25 us per torch.distributed call -- so bench.py uses the waiting form.)"""
         r = slot & 1
-        self.work[r][p] = self.dist.all_gather_into_tensor(self.gathered2[r][p].view(-1, OUT_COLS), out_rows, group=self.groups[p], async_op=True)
+        w = self.dist.all_gather_into_tensor(self.gathered2[r][p].view(-1, OUT_COLS), out_rows, group=self.groups[p], async_op=not wait)
+        self.work[r][p] = None if wait else w
 
     def wait(self, p, slot):
-        """the caller's current stream waits for the gather of partition p issued with this slot parity (if one is outstanding)"""
+        """the caller's current stream waits for the asynchronous gather of partition p issued with this slot parity (if one is outstanding)"""
         r = slot & 1
         if self.work[r][p] is not None:
             self.work[r][p].wait()
