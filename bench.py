@@ -384,7 +384,7 @@ def parser():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--part-loop-min', type=int, default=8192, help='per-tick policies: from this many cars up every partition runs its own closed loop on its own stream')
     ap.add_argument('--no-extra', action='store_true', help='skip the `extra` block (the other configs measured in the same run)')
-    ap.add_argument('--partitions', type=int, default=3,
+    ap.add_argument('--partitions', type=int, default=3, choices=[1, 2, 3, 4],
                     help='free-running car ranges per GPU, one HIP stream each (pdb_set_partitions / pdb_step_ring; constant policy only -- a per-tick policy joins the ranges every tick); 1 = one launch per tick')
     ap.add_argument('--walls', action='store_true', help='touge workload: line both edges of the road with WALL surfaces (configs[4] shape: hull-vs-wall narrow phase next to the guard rails)')
     ap.add_argument('--spline-step', type=float, default=0.0, help='touge workload: metres between spline points (default 5 m = 891 points; 0.9 = 4.9 k points, the density of the reference tracks)')
