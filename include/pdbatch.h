@@ -109,6 +109,9 @@ int pdb_reset_device(pdb_batch* b, const uint8_t* device_mask, int mode);
  * `reset()` = teleport + step([0,0])), and that tick clears the byte.  Asking for the pointer arms the check in the step
  * kernels. */
 uint8_t* pdb_reset_mask_device(pdb_batch* b);
+/* env mode: clear the episode sums (cumulative reward, step count, pending reset) of the cars with device_mask[i] != 0 (NULL: all),
+ * on the device, asynchronous on pdb_stream -- the bookkeeping half of the env's reset() (projectd_env.py:216-227) */
+int pdb_clear_episodes(pdb_batch* b, const uint8_t* device_mask);
 /* seconds without a new track point before pdb_step_out.flags bit 2 (stuck) rises: projectd_env.py stuck_timeout, default 5 */
 int pdb_set_stuck_timeout(pdb_batch* b, double seconds);
 /* Env mode: the reward / termination / reset bookkeeping of pyprojectd/projectd_env.py:173-227 per car inside the tick (see

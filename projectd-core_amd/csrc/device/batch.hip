@@ -416,6 +416,13 @@ extern "C" __global__ void pdb_reset_kernel(pdb_dyn_state* __restrict__ states, 
     k33::teleportByModeDev(*Pp, T, mode >= 0 ? mode : rq - 1, states + i);
     if (mask && clear) mask[i] = 0;
 }
+// env mode's per-car episode sums (cumulative reward, step count, the pending-reset flag) cleared on the device: the env's reset()
+// without moving a record over PCIe (mask == nullptr: every car)
+extern "C" __global__ void pdb_clear_episodes_kernel(pdb_dyn_state* __restrict__ states, const uint8_t* __restrict__ mask, int n) {
+    const int i = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+    if (i >= n || (mask && !mask[i])) return;
+    states[i].envTotalReward = 0.0; states[i].envPending = 0; states[i].envStepId = 0;
+}
 static int resetLaunch(pdb_batch* b, uint8_t* dMask, int mode, int clear) {
     if (int rcj = joinParts(b)) return rcj;
     bool any = false;
@@ -448,6 +455,14 @@ int pdb_reset_device(pdb_batch* b, const uint8_t* device_mask, int mode) {
     if (!b || !device_mask || mode < 0 || mode > 2) { pdb::setError("pdb_reset_device: bad argument"); return PDB_ERR_ARG; }
     b->batchDirty = true;
     return resetLaunch(b, const_cast<uint8_t*>(device_mask), mode, 0);   // asynchronous on the batch's stream: no host round trip
+}
+int pdb_clear_episodes(pdb_batch* b, const uint8_t* device_mask) {
+    if (!b) { pdb::setError("null argument"); return PDB_ERR_ARG; }
+    if (int rcj = joinParts(b)) return rcj;
+    hipLaunchKernelGGL(pdb_clear_episodes_kernel, dim3((b->n + 255) / 256), dim3(256), 0, b->stream, b->dStates, device_mask, b->n);
+    HIPCHK(hipGetLastError());
+    b->batchDirty = true;
+    return PDB_OK;
 }
 uint8_t* pdb_reset_mask_device(pdb_batch* b) {
     if (!b) return nullptr;

@@ -186,6 +186,7 @@ def load_product(host_only=False):
         lib.pdb_step_partition.argtypes = [C.c_void_p, C.c_float, C.c_int, C.c_void_p]
         if 'PDB_LIB' not in os.environ or hasattr(lib, 'pdb_contact_pass_load'):   # (an older variant under the experiment hook lacks these)
             lib.pdb_contact_pass_load.argtypes = [C.c_void_p, C.c_int]
+            lib.pdb_clear_episodes.argtypes = [C.c_void_p, C.c_void_p]
             lib.pdb_host_actions.restype = C.c_void_p; lib.pdb_host_actions.argtypes = [C.c_void_p]
             lib.pdb_host_out.restype = C.c_void_p; lib.pdb_host_out.argtypes = [C.c_void_p]
             lib.pdb_step_host_partition.argtypes = [C.c_void_p, C.c_float, C.c_int]

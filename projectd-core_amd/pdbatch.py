@@ -175,6 +175,10 @@ class Batch:
         """the same with a uint8 mask that already lives on the device: asynchronous on the batch's stream, no host round trip"""
         self._chk(self.lib.pdb_reset_device(self.h, C.c_void_p(mask_ptr), mode))
 
+    def clear_episodes(self, mask_ptr=None):
+        """env mode: zero the episode sums of the masked cars (device uint8 mask; None: all) on the device, asynchronously"""
+        self._chk(self.lib.pdb_clear_episodes(self.h, C.c_void_p(mask_ptr) if mask_ptr else None))
+
     def reset_mask_ptr(self):
         """device array of n bytes: a car whose byte is 1 + mode is teleported at the top of its next tick, which clears the byte"""
         return self.lib.pdb_reset_mask_device(self.h)

@@ -29,6 +29,7 @@ class ProjectDTorchVecEnv:
         self.dev = torch.device('cuda:%d' % device)
         # setCarAutoTeleport (projectd_env.py:124): the teleport inside the tick that raises the flag
         lib = pc.load_product()
+        params = pc.CarParams.from_buffer_copy(bytes(params))   # the caller's block stays as it was
         if lib.pdb_set_auto_teleport(C.byref(params), int(cfg.teleport_on_hit), int(cfg.teleport_off_track), int(cfg.teleport_mode)) != 0:
             raise ValueError(lib.pdb_last_error().decode())
         self.batch = pdbatch.Batch(n, params, track_blob, device=device, action_mode=1)
@@ -48,11 +49,7 @@ class ProjectDTorchVecEnv:
             self.batch.reset(None, self.cfg.teleport_mode)
         self.act.zero_()
         self.batch.step_async()
-        self.batch.sync()
-        st = self.batch.get_state()
-        for s in st:
-            s.envTotalReward = 0.0; s.envPending = 0; s.envStepId = 0
-        self.batch.set_state(st)
+        self.batch.clear_episodes()      # on the device: no record crosses PCIe
         self.batch.set_env(self.cfg)
         return self.out[:, :E.OBS_DIM]
 
