@@ -1071,8 +1071,22 @@ static void autoClutchStep(Car& c, float dt) {
 static void engineStep(Car& c, float gasInput, float rpm) {
     const pdb_car_params& P = *c.P;
     pdb_dyn_state& S = c.S;
-    float gas = tclamp(curve(P.throttleCurve, gasInput * 100.0f) * 0.01f, 0.0f, 1.0f);
-    if (P.throttleCurve.n == 0) gas = gasInput;
+    // Engine::getThrottleResponseGas (Engine.cpp:344-366)
+    float gas;
+    if (P.throttleCurve.n && P.throttleCurveMax.n) {
+        const float fTrc = tclamp(curve(P.throttleCurve, gasInput * 100.0f) * 0.01f, 0.0f, 1.0f);
+        const float fTrcMax = tclamp(curve(P.throttleCurveMax, gasInput * 100.0f) * 0.01f, 0.0f, 1.0f);
+        const float fTrcScale = tclamp(rpm / P.throttleMaxRef, 0.0f, 1.0f);
+        gas = ((fTrcMax - fTrc) * fTrcScale) + fTrc;
+    } else if (P.throttleCurve.n) gas = tclamp(curve(P.throttleCurve, gasInput * 100.0f) * 0.01f, 0.0f, 1.0f);
+    else gas = gasInput;
+    if (P.gasCoastOffset > 0.0f) {   // [COAST_SETTINGS] (Engine.cpp:198-207)
+        float fGas1 = (rpm - (float)P.engMinimum) / (float)P.coastEntryRpm;
+        fGas1 = tclamp(fGas1, 0.0f, 1.0f);
+        float fGas2 = ((1.0f - (P.gasCoastOffset * fGas1)) * gas) + (P.gasCoastOffset * fGas1);
+        fGas2 = tclamp(fGas2, 0.0f, 1.0f);
+        gas = fGas2;
+    }
     const int iLimiter = P.engLimiter;
     if (iLimiter && (iLimiter * P.limiterMultiplier) < rpm) S.limiterOn = P.engLimiterCycles;
     if (S.limiterOn > 0) { gas = 0; S.limiterOn--; }
@@ -1409,6 +1423,13 @@ void Car::carStep(float dt) {
     // ---- stepComponents ----
     {   // BrakeSystem::step (BrakeSystem.cpp:82-149)
         float fFrontBias = Pm.frontBias;
+        if (Pm.ebbInternal) {   // EBBMode::Internal (:92-113): the front axle's share of the load, from the tyres' last loads
+            const float fLoadFront = S.tyre[1].load + S.tyre[0].load;
+            const float fLoadAWD = (S.tyre[3].load + S.tyre[2].load) + fLoadFront;
+            bool bFlag = false;
+            if (fLoadAWD != 0.0f) { if (S.speed * 3.6f > 10.0f) bFlag = true; }
+            fFrontBias = bFlag ? tclamp(((fLoadFront / fLoadAWD) * Pm.ebbFrontMultiplier), 0.0f, 1.0f) : Pm.frontBias;
+        }
         fFrontBias = tclamp(fFrontBias, Pm.biasMin, Pm.biasMax);
         const float fBrakeInput = tmax(controls.brake, 0.0f);
         const float fBrakeTorq = (Pm.brakePower * Pm.brakePowerMultiplier) * fBrakeInput;

@@ -71,6 +71,24 @@ def make_fwd_car(base, src='ks_toyota_ae86_drift', dst='pdb_fwd_ae86'):
     open(p, 'w', newline='').write(raw.replace('TYPE=RWD', 'TYPE=FWD'))
 
 
+def make_cold_car(base, src='ks_mazda_rx7_tuned', dst='pdb_cold_rx7'):
+    """Three branches no shipped car takes: [THROTTLE_RESPONSE] (a second throttle curve blended in by rpm, Engine.cpp:150-154,344-366),
+    [COAST_SETTINGS] (a throttle offset rising with rpm, Engine.cpp:61-67,198-207) and [EBB] (brake bias following the front axle's
+    share of the load, BrakeSystem.cpp:28-32,92-113).  The tuned RX-7 with the three sections added pins them."""
+    s = os.path.join(REF, 'content', 'cars', src, 'data'); d = os.path.join(base, 'content', 'cars', dst, 'data')
+    if os.path.isdir(d):
+        shutil.rmtree(d)
+    shutil.copytree(s, d)
+    os.system('chmod -R u+w "%s"' % d)
+    for fn, extra in (('engine.ini', ['', '[THROTTLE_RESPONSE]', 'RPM_REFERENCE=6000', 'LUT=(|0=0|20=35|50=72|80=93|100=100|)', '', '[COAST_SETTINGS]', 'LUT=(|0=0.0|1=0.08|2=0.15|)',
+                                      'DEFAULT=1', 'ACTIVATION_RPM=1500', '']),
+                      ('brakes.ini', ['', '[EBB]', 'FRONT_SHARE_MULTIPLIER=1.25', ''])):
+        p = os.path.join(d, fn)
+        raw = open(p, newline='').read()
+        eol = '\r\n' if '\r\n' in raw else '\n'
+        open(p, 'w', newline='').write(raw.rstrip('\r\n') + eol + eol.join(extra))
+
+
 def main():
     base = os.path.join(here, '_ref', 'base')
     os.makedirs(os.path.join(base, 'cfg'), exist_ok=True)
@@ -84,6 +102,7 @@ def main():
     make_multilink_car(base)
     make_heave_car(base)
     make_fwd_car(base)
+    make_cold_car(base)
     gen_track.gen_flat(os.path.join(base, 'content', 'tracks', 'flat'))
     gen_track.gen_touge(os.path.join(base, 'content', 'tracks', 'touge'))
     gen_track.gen_walled(os.path.join(base, 'content', 'tracks', 'walled'))

@@ -80,8 +80,11 @@ static const Scenario kScenarios[] = {
     {"akina", 3000, 300, 10, 0, 1, 1, 1, "ek_akina", 1, nullptr, 0, 0, 0, 0, 0, 0, 0},
     {"akina_tele", 3000, 300, 10, 0, 1, 1, 1, "ek_akina", 1, "gravygarage_street_ae86_readie", 0, 0, 600, 0, 1, 0, 0},
     {"nords", 3000, 300, 10, 0, 1, 1, 1, "ks_nordschleife", 1, "ks_toyota_supra_mkiv_drift", 0, 0, 0, 0, 0, 0, 0},
+    // branches no shipped car takes, on a derived car (oracle/make_base.py): [THROTTLE_RESPONSE], [COAST_SETTINGS], [EBB] -- the brake
+    // script (full and part throttle, a hard stop from speed, a hand-brake turn, trail braking)
+    {"cold", 2400, 200, 10, 1, 1, 1, 1, "flat", 0, "pdb_cold_rx7", 0, 0, 0, 0, 0, 0, 0},
 };
-static const int kNumScenarios = 38;
+static const int kNumScenarios = 39;
 static const float kTeleDist[4] = {0.13f, 0.41f, 0.77f, 0.95f};
 struct ScoreVar { const char* name; float value; };
 static const ScoreVar kScoringSetA[] = {
@@ -148,7 +151,7 @@ inline void scenarioControls(int sid, int tick, Ctl& c) {
     c.steer = 0; c.clutch = 0; c.brake = 0; c.handBrake = 0; c.gas = 0; c.requestedGearIndex = -1; c.gearUp = 0; c.gearDn = 0;
     const double t = (double)tick * (1.0 / 333.0);
     if (sid < 4 || sid == 7 || sid == 9 || sid == 14) { float a0, a1; scenarioAction(sid, tick, a0, a1); c.steer = a0; c.gas = envGas(a1); return; }
-    if (sid == 4) {
+    if (sid == 4 || sid == 38) {
         if (t < 3.0) { c.gas = 1.0f; }
         else if (t < 5.0) { c.brake = 0.8f; }
         else if (t < 6.0) { c.gas = 0.7f; c.steer = 0.3f; }

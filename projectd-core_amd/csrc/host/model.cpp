@@ -646,8 +646,13 @@ void buildCarModel(const std::string& basePathIn, const std::string& modelName, 
         P.handBrakeTorque = br.getFloat("DATA", "HANDBRAKE_TORQUE");
         P.brakePowerMultiplier = 1.0f;
         P.biasMin = 0.0f; P.biasMax = 1.0f;
-        if (br.hasSection("EBB") || br.hasSection("TEMPS_FRONT") || fileExists(dataPath + "steer_brake_controller.ini") || fileExists(dataPath + "ctrl_ebb.ini"))
-            throw std::runtime_error("pdb: EBB / brake temps / steer-brake controllers unsupported this round");
+        if (br.hasSection("TEMPS_FRONT") || fileExists(dataPath + "steer_brake_controller.ini") || fileExists(dataPath + "ctrl_ebb.ini"))
+            throw std::runtime_error("pdb: brake temps / steer-brake and EBB dynamic controllers unsupported this round");
+        if (br.hasSection("EBB")) {   // EBBMode::Internal (BrakeSystem.cpp:28-32): the bias follows the front axle's share of the load
+            P.ebbInternal = 1;
+            const float m = br.getFloat("EBB", "FRONT_SHARE_MULTIPLIER");
+            P.ebbFrontMultiplier = m > 1.1f ? m : 1.1f;
+        }
         Ini setup(dataPath + "setup.ini");
         if (setup.ready && setup.hasSection("FRONT_BIAS")) {
             P.biasMin = setup.getFloat("FRONT_BIAS", "MIN") * 0.01f;
@@ -675,7 +680,14 @@ void buildCarModel(const std::string& basePathIn, const std::string& modelName, 
         if (P.engLimiter) { P.rpmDamageThreshold = P.engLimiter * 1.05f; P.rpmDamageK = 10.0f; }
         int hz = eng.getInt("ENGINE_DATA", "LIMITER_HZ");
         P.engLimiterCycles = hz ? (1000 / hz / 3) : 50;
-        if (eng.hasSection("COAST_SETTINGS")) throw std::runtime_error("pdb: [COAST_SETTINGS] unsupported this round");
+        if (eng.hasSection("COAST_SETTINGS")) {   // Engine.cpp:61-67, setCoastSettings :394-399: the offset is the LUT's value at the DEFAULT index
+            pdb_curve off; memset(&off, 0, sizeof(off));
+            const std::string lutv = eng.getString("COAST_SETTINGS", "LUT");
+            if (lutv.find(".lut") != std::string::npos) curveLoad(off, dataPath + lutv); else curveParseInline(off, lutv);
+            const int id = eng.getInt("COAST_SETTINGS", "DEFAULT");
+            if (id >= 0 && id < off.n) P.gasCoastOffset = curveValue(off, (float)id);
+            P.coastEntryRpm = P.engMinimum + eng.getInt("COAST_SETTINGS", "ACTIVATION_RPM");
+        }
         // turbos (Engine.cpp:69-94): TURBO_0.. until a section is missing; cockpit-adjustable ones take the default adjustment
         bool adjustable = false;
         for (int id = 0; ; ++id) {
@@ -705,8 +717,12 @@ void buildCarModel(const std::string& basePathIn, const std::string& modelName, 
             }
         }
         if (eng.hasSection("OVERLAP") && eng.getFloat("OVERLAP", "GAIN") != 0.0f) throw std::runtime_error("pdb: [OVERLAP] unsupported this round");
-        if (eng.hasSection("THROTTLE_RESPONSE")) throw std::runtime_error("pdb: [THROTTLE_RESPONSE] unsupported this round");
         curveLoad(P.throttleCurve, dataPath + "throttle.lut");
+        if (eng.hasSection("THROTTLE_RESPONSE")) {   // Engine.cpp:150-154: a second curve, blended in by rpm / RPM_REFERENCE (getThrottleResponseGas :344-366)
+            P.throttleMaxRef = eng.getFloat("THROTTLE_RESPONSE", "RPM_REFERENCE");
+            const std::string lutv = eng.getString("THROTTLE_RESPONSE", "LUT");
+            if (lutv.find(".lut") != std::string::npos) curveLoad(P.throttleCurveMax, dataPath + lutv); else curveParseInline(P.throttleCurveMax, lutv);
+        }
         if (eng.hasSection("DAMAGE")) {
             P.rpmDamageThreshold = eng.getFloat("DAMAGE", "RPM_THRESHOLD");
             P.rpmDamageK = eng.getFloat("DAMAGE", "RPM_DAMAGE_K");
@@ -849,7 +865,7 @@ void buildCarModel(const std::string& basePathIn, const std::string& modelName, 
         auto sorted = [](const pdb_curve& c, const char* what) {
             for (int i = 1; i < c.n; ++i) if (c.x[i] < c.x[i - 1]) throw std::runtime_error(std::string("pdb: LUT with decreasing abscissae: ") + what);
         };
-        sorted(P.powerCurve, "power"); sorted(P.throttleCurve, "throttle"); sorted(P.upshiftProfile, "upshift"); sorted(P.downshiftProfile, "downshift");
+        sorted(P.powerCurve, "power"); sorted(P.throttleCurve, "throttle"); sorted(P.throttleCurveMax, "throttle response"); sorted(P.upshiftProfile, "upshift"); sorted(P.downshiftProfile, "downshift");
         sorted(P.blipProfile, "blip");
         for (int i = 0; i < 4; ++i) { sorted(P.tyre[i].performanceCurve, "tyre performance"); sorted(P.tyre[i].wearCurve, "tyre wear"); }
         for (int i = 0; i < P.numWings; ++i) { sorted(P.wings[i].lutAOA_CL, "wing CL"); sorted(P.wings[i].lutAOA_CD, "wing CD"); }
