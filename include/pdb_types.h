@@ -233,14 +233,14 @@ typedef struct pdb_car_params {
     pdb_collider collider;
     /* branches no shipped car takes (round 3; pinned on a derived car, oracle/make_base.py): a second throttle curve blended in by rpm
      * ([THROTTLE_RESPONSE], Engine.cpp:150-154,344-366), the coast offset of [COAST_SETTINGS] (Engine.cpp:61-67,198-207,394-399), the
-     * load-proportional brake bias of [EBB] (BrakeSystem.cpp:28-32,92-113) */
+     * load-proportional brake bias of [EBB] (BrakeSystem.cpp:28-32,92-113), the valve-overlap torque ripple of [OVERLAP] */
     pdb_curve throttleCurveMax;
     float throttleMaxRef;          /* THROTTLE_RESPONSE RPM_REFERENCE */
     float gasCoastOffset;          /* COAST_SETTINGS LUT at its DEFAULT index; 0 = off */
     int32_t coastEntryRpm;         /* engine minimum + ACTIVATION_RPM */
     int32_t ebbInternal;           /* brakes.ini has [EBB] */
     float ebbFrontMultiplier;      /* max(1.1, FRONT_SHARE_MULTIPLIER) */
-    int32_t _padCold;
+    float overlapFreq, overlapGain, overlapIdealRPM;   /* [OVERLAP] (Engine.cpp:96-101,300-307): a torque ripple below / above the ideal rpm; gain 0 = off */
 } pdb_car_params;
 
 /* ---------------------------------------------------------------------------------------------
@@ -398,7 +398,7 @@ typedef struct pdb_ray_rec {
 }
 /* sizes are part of the ABI (tests/test_abi.py reads these numbers) */
 static_assert(sizeof(pdb_car_state) == 664, "pdb_car_state must equal the reference CarState (pack 4)");
-static_assert(sizeof(pdb_car_params) == 12608, "pdb_car_params layout");
+static_assert(sizeof(pdb_car_params) == 12616, "pdb_car_params layout");
 static_assert(sizeof(pdb_dyn_state) == 2272, "pdb_dyn_state layout (multiple of 16 bytes)");
 static_assert(sizeof(pdb_step_out) == 104, "pdb_step_out layout");
 static_assert(sizeof(pdb_contact) == 32, "pdb_contact layout");

@@ -1128,6 +1128,10 @@ static void engineStep(Car& c, float gasInput, float rpm) {
     c.engOutTorque = fOutTorq;
     if (S.fuelPressure > 0.0f) {
         if (rpm >= (float)P.engMinimum) {
+            if (P.overlapGain != 0.0f) {   // [OVERLAP] (Engine.cpp:300-307)
+                const float fOverlap = m_sinf((float)S.physicsTime * 0.001f * P.overlapFreq * rpm * 0.0003333333333333333f) * 0.5f - 0.5f;
+                c.engOutTorque = (fOverlap * fabsf(rpm - P.overlapIdealRPM) * P.overlapGain) + fOutTorq;
+            }
         } else c.engOutTorque = tmax(15.0f, fOutTorq);
     }
     if (S.fuelPressure < 1.0f) c.engOutTorque = (c.engOutTorque - rpm * -0.01f) * S.fuelPressure + rpm * -0.01f;

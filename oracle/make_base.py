@@ -72,7 +72,7 @@ def make_fwd_car(base, src='ks_toyota_ae86_drift', dst='pdb_fwd_ae86'):
 
 
 def make_cold_car(base, src='ks_mazda_rx7_tuned', dst='pdb_cold_rx7'):
-    """Three branches no shipped car takes: [THROTTLE_RESPONSE] (a second throttle curve blended in by rpm, Engine.cpp:150-154,344-366),
+    """Four branches no shipped car takes: [OVERLAP] (a torque ripple away from the ideal rpm, Engine.cpp:96-101,300-307), [THROTTLE_RESPONSE] (a second throttle curve blended in by rpm, Engine.cpp:150-154,344-366),
     [COAST_SETTINGS] (a throttle offset rising with rpm, Engine.cpp:61-67,198-207) and [EBB] (brake bias following the front axle's
     share of the load, BrakeSystem.cpp:28-32,92-113).  The tuned RX-7 with the three sections added pins them."""
     s = os.path.join(REF, 'content', 'cars', src, 'data'); d = os.path.join(base, 'content', 'cars', dst, 'data')
@@ -81,7 +81,7 @@ def make_cold_car(base, src='ks_mazda_rx7_tuned', dst='pdb_cold_rx7'):
     shutil.copytree(s, d)
     os.system('chmod -R u+w "%s"' % d)
     for fn, extra in (('engine.ini', ['', '[THROTTLE_RESPONSE]', 'RPM_REFERENCE=6000', 'LUT=(|0=0|20=35|50=72|80=93|100=100|)', '', '[COAST_SETTINGS]', 'LUT=(|0=0.0|1=0.08|2=0.15|)',
-                                      'DEFAULT=1', 'ACTIVATION_RPM=1500', '']),
+                                      'DEFAULT=1', 'ACTIVATION_RPM=1500', '', '[OVERLAP]', 'FREQUENCY=1.3', 'GAIN=0.02', 'IDEAL_RPM=4200', '']),
                       ('brakes.ini', ['', '[EBB]', 'FRONT_SHARE_MULTIPLIER=1.25', ''])):
         p = os.path.join(d, fn)
         raw = open(p, newline='').read()

@@ -716,7 +716,9 @@ void buildCarModel(const std::string& basePathIn, const std::string& modelName, 
                 if (fileExists(dataPath + c1) || fileExists(dataPath + c2)) throw std::runtime_error("pdb: turbo dynamic controllers are not implemented");
             }
         }
-        if (eng.hasSection("OVERLAP") && eng.getFloat("OVERLAP", "GAIN") != 0.0f) throw std::runtime_error("pdb: [OVERLAP] unsupported this round");
+        if (eng.hasSection("OVERLAP")) {   // Engine.cpp:96-101
+            P.overlapFreq = eng.getFloat("OVERLAP", "FREQUENCY"); P.overlapGain = eng.getFloat("OVERLAP", "GAIN"); P.overlapIdealRPM = eng.getFloat("OVERLAP", "IDEAL_RPM");
+        }
         curveLoad(P.throttleCurve, dataPath + "throttle.lut");
         if (eng.hasSection("THROTTLE_RESPONSE")) {   // Engine.cpp:150-154: a second curve, blended in by rpm / RPM_REFERENCE (getThrottleResponseGas :344-366)
             P.throttleMaxRef = eng.getFloat("THROTTLE_RESPONSE", "RPM_REFERENCE");
