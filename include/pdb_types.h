@@ -307,7 +307,7 @@ typedef struct pdb_dyn_state {
  * tick and of the following even one (the group is emptied only when it is refilled, :228-243).  World coordinates.
  * kind 0: hull vs WALL (surface.mode 28692, mu 0.25, bounce 0.01, soft_cfm 1e-4); kind 1: belly box vs TRACK (mode 28700,
  * mu 0.1, soft_erp 0.714285731, soft_cfm 0.000952380942).  A car keeps its PDB_MAX_CONTACTS deepest contact points. */
-#define PDB_MAX_CONTACTS 16
+#define PDB_MAX_CONTACTS 32
 typedef struct pdb_contact {
     float pos[3];
     float depth;

@@ -125,7 +125,7 @@ static inline bool boxContact(const Pose& P, const float* centre, const float* h
 // hull (body-frame vertices, uint8 index triples) against one triangle: emit(normal, pos) per contact
 // one contact point = what a dContactGeom carries into dJointCreateContact (layout = pdb_contact, include/pdb_types.h)
 struct Contact { float pos[3]; float depth; float normal[3]; int kind; };   // kind 0: hull vs WALL (mode 28692), 1: box vs TRACK (mode 28700)
-enum { MAX_CONTACTS = 16, ITEM_BOX_CORNER = 1152, ITEM_BOX_EDGE = 1160, ID_STRIDE = 2048 };
+enum { MAX_CONTACTS = 32, ITEM_BOX_CORNER = 1152, ITEM_BOX_EDGE = 1160, ID_STRIDE = 2048 };
 static inline bool contactBefore(float da, unsigned ia, float db, unsigned ib) { return da > db || (da == db && ia < ib); }
 struct ContactSet {
     int n = 0;

@@ -508,6 +508,21 @@ static inline float sinc_ode(float x) {
 static inline float dot6c(const float* a, const float* b) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2] + a[3] * b[3] + a[4] * b[4] + a[5] * b[5]; }
 enum { ST_FREE = 0, ST_LO = 1, ST_HI = 2, ST_FIXED = 3, ST_OFF = 4 };
 
+// A = L diag(d) L^T of a symmetric positive definite 6x6 (lower triangle of A read; L unit lower, row-major)
+static inline void ldl6(const float* A, float* L, float* d, float* dinv) {
+    for (int j = 0; j < 6; ++j) {
+        float t[6];
+        float dj = A[j * 6 + j];
+        for (int k = 0; k < j; ++k) { t[k] = L[j * 6 + k] * d[k]; dj = fmaf(-L[j * 6 + k], t[k], dj); }
+        d[j] = dj; dinv[j] = 1.0f / dj;
+        for (int i = j + 1; i < 6; ++i) {
+            float vv = A[i * 6 + j];
+            for (int k = 0; k < j; ++k) vv = fmaf(-L[i * 6 + k], t[k], vv);
+            L[i * 6 + j] = vv * dinv[j];
+        }
+    }
+}
+
 static void solveContacts(World& w, float fps, int m, const int* rb0, const int* rb1, const float* JinvM, const float* L, const float* dinv,
                           const float* invIwB, const float* tmp1B, float* lambda, float* contactForce) {
     const int nc = (int)w.contacts.size();
@@ -574,61 +589,81 @@ static void solveContacts(World& w, float fps, int m, const int* rb0, const int*
         for (int i = 0; i < m; ++i) acc += G[i * 6 + a] * lambda[i];
         u[a] = tmp1B[a] + acc;
     }
-    // S (lower triangle), right-hand side
-    std::vector<float> S(nr * nr, 0.0f), bt(nr), KJ(nr * 6);
+    // ---- the contact rows in the body's 6-space ----
+    // K = Lk diag(dk) Lk^T (lower triangle of K as computed); Jh_r = J_r Lk; S = Jh diag(dk) Jh^T + diag(dd), dd = cfm/h.
+    float Lk[36], dk[6], dkinv[6];
+    ldl6(K, Lk, dk, dkinv);
+    std::vector<float> Jh(nr * 6), dd(nr), idd(nr), bt(nr);
     for (int r = 0; r < nr; ++r) {
         const float* J = &Jc[r * 6];
-        for (int a = 0; a < 6; ++a) KJ[r * 6 + a] = dot6c(&K[a * 6], J);
-        for (int s2 = 0; s2 <= r; ++s2) S[r * nr + s2] = dot6c(&KJ[r * 6], &Jc[s2 * 6]);
-        S[r * nr + r] += cfmc[r] * fps;
+        for (int a2 = 0; a2 < 6; ++a2) {
+            float acc = J[a2];
+            for (int b2 = a2 + 1; b2 < 6; ++b2) acc = fmaf(J[b2], Lk[b2 * 6 + a2], acc);
+            Jh[r * 6 + a2] = acc;
+        }
+        dd[r] = cfmc[r] * fps;
+        idd[r] = 1.0f / dd[r];
         float rr = cv[r] * fps;
         rr -= dot6c(J, u);
         bt[r] = rr;
     }
-    auto Sat = [&](int r, int s2) { return r >= s2 ? S[r * nr + s2] : S[s2 * nr + r]; };
     std::vector<int> state(nr);
-    std::vector<float> x(nr, 0.0f), work(nr * nr), y(nr), di(nr);
+    std::vector<float> x(nr, 0.0f);
     int iterations = 0;
 #ifndef PDRB_LCP_MAX_ITERATIONS
-#define PDRB_LCP_MAX_ITERATIONS 256   /* per stage; = the kernel's.  With 16 contacts (48 rows) 95 % of the solves take < 16 rounds, the tail
-                                         -- near-duplicate contact points, the single-flip fallback -- reaches a few hundred */
+#define PDRB_LCP_MAX_ITERATIONS 256   /* per stage; = the kernel's */
 #endif
+    // one quantity summed over the rows: contact c's three rows first ((t0 + t1) + t2, a row outside the mask gives 0), then
+    // the contacts as the leaves of a balanced binary tree over 64 slots (the kernel's lane = contact butterfly)
+    float leaf[64];
+    auto tree = [&]() { for (int n2 = 32; n2 >= 1; n2 >>= 1) for (int j = 0; j < n2; ++j) leaf[j] = leaf[2 * j] + leaf[2 * j + 1]; return leaf[0]; };
+    auto sum = [&](auto term) {
+        for (int c = 0; c < 64; ++c) { leaf[c] = 0.0f; if (c < nc) leaf[c] = (term(3 * c) + term(3 * c + 1)) + term(3 * c + 2); }
+        return tree();
+    };
     auto bpp = [&]() {
         int ninf = nr + 1, p = 3;
         for (int it = 0; it < PDRB_LCP_MAX_ITERATIONS; ++it) {
             ++iterations;
             for (int r = 0; r < nr; ++r) { if (state[r] == ST_LO) x[r] = lo[r]; else if (state[r] == ST_HI) x[r] = hi[r]; else if (state[r] != ST_FREE) x[r] = 0.0f; }
-            for (int r = 0; r < nr; ++r) {
-                if (state[r] != ST_FREE) continue;
-                float acc = bt[r];
-                for (int s2 = 0; s2 < nr; ++s2) if (state[s2] == ST_LO || state[s2] == ST_HI || state[s2] == ST_FIXED) acc = acc - Sat(r, s2) * x[s2];
-                y[r] = acc;
-                for (int s2 = 0; s2 <= r; ++s2) work[r * nr + s2] = S[r * nr + s2];
-            }
-            for (int k = 0; k < nr; ++k) {
-                if (state[k] != ST_FREE) continue;
-                const float id = 1.0f / work[k * nr + k];
-                di[k] = id;
-                for (int i = k + 1; i < nr; ++i) {
-                    if (state[i] != ST_FREE) continue;
-                    const float lik = work[i * nr + k] * id;
-                    for (int j = k + 1; j <= i; ++j) if (state[j] == ST_FREE) work[i * nr + j] = fmaf(-lik, work[j * nr + k], work[i * nr + j]);
+            // v = sum over the rows at a bound of Jh_r x_r;  N = sum over the free rows of Jh_r^T Jh_r / dd_r;  gb = sum over the free rows of Jh_r bt_r / dd_r
+            // the masks of the sums: a free row's 1/dd (else 0), a bounded row's x (else 0)
+            std::vector<float> fi(nr), xb(nr);
+            for (int r = 0; r < nr; ++r) { fi[r] = state[r] == ST_FREE ? idd[r] : 0.0f; xb[r] = (state[r] == ST_LO || state[r] == ST_HI) ? x[r] : 0.0f; }
+            float v[6], N[36], gb[6];
+            for (int a2 = 0; a2 < 6; ++a2) {
+                v[a2] = sum([&](int r) { return Jh[r * 6 + a2] * xb[r]; });
+                gb[a2] = sum([&](int r) { return (Jh[r * 6 + a2] * fi[r]) * bt[r]; });
+                for (int b2 = 0; b2 <= a2; ++b2) {
+                    N[a2 * 6 + b2] = sum([&](int r) { return (Jh[r * 6 + a2] * fi[r]) * Jh[r * 6 + b2]; });
+                    N[b2 * 6 + a2] = N[a2 * 6 + b2];
                 }
-                for (int i = k + 1; i < nr; ++i) if (state[i] == ST_FREE) work[i * nr + k] *= id;
             }
-            for (int k = 0; k < nr; ++k) { if (state[k] != ST_FREE) continue; for (int i = k + 1; i < nr; ++i) if (state[i] == ST_FREE) y[i] = fmaf(-work[i * nr + k], y[k], y[i]); }
-            for (int k = 0; k < nr; ++k) if (state[k] == ST_FREE) y[k] *= di[k];
-            for (int k = nr - 1; k >= 0; --k) { if (state[k] != ST_FREE) continue; for (int i = 0; i < k; ++i) if (state[i] == ST_FREE) y[i] = fmaf(-work[k * nr + i], y[k], y[i]); }
-            for (int r = 0; r < nr; ++r) if (state[r] == ST_FREE) x[r] = y[r];
+            // (diag(1/dk) + N) wh = gb - N vb, vb = dk v: the free rows' pull on the body, then the rows themselves
+            float vb[6], g[6], M[36], Lm[36], dm[6], dminv[6], wh[6], tot[6];
+            for (int a2 = 0; a2 < 6; ++a2) vb[a2] = dk[a2] * v[a2];
+            for (int a2 = 0; a2 < 6; ++a2) {
+                float acc = gb[a2];
+                for (int b2 = 0; b2 < 6; ++b2) acc = fmaf(-N[a2 * 6 + b2], vb[b2], acc);
+                g[a2] = acc;
+                for (int b2 = 0; b2 < 6; ++b2) M[a2 * 6 + b2] = N[a2 * 6 + b2];
+                M[a2 * 6 + a2] = N[a2 * 6 + a2] + dkinv[a2];
+            }
+            ldl6(M, Lm, dm, dminv);
+            for (int i = 0; i < 6; ++i) { float acc = g[i]; for (int k = 0; k < i; ++k) acc = fmaf(-Lm[i * 6 + k], wh[k], acc); wh[i] = acc; }
+            for (int i = 0; i < 6; ++i) wh[i] *= dminv[i];
+            for (int i = 5; i >= 0; --i) { float acc = wh[i]; for (int k = i + 1; k < 6; ++k) acc = fmaf(-Lm[k * 6 + i], wh[k], acc); wh[i] = acc; }
+            for (int a2 = 0; a2 < 6; ++a2) tot[a2] = vb[a2] + wh[a2];
             // infeasible rows and where they go
             int k = 0, last = -1;
             std::vector<int> to(nr, -1);
             for (int r = 0; r < nr; ++r) {
-                if (state[r] == ST_FREE) { if (x[r] < lo[r]) to[r] = ST_LO; else if (x[r] > hi[r]) to[r] = ST_HI; }
-                else if (state[r] == ST_LO || state[r] == ST_HI) {
-                    float acc = 0.0f;
-                    for (int s2 = 0; s2 < nr; ++s2) if (state[s2] != ST_OFF) acc += Sat(r, s2) * x[s2];
-                    const float wr = acc - bt[r];
+                const float jt = dot6c(&Jh[r * 6], tot);
+                if (state[r] == ST_FREE) {
+                    x[r] = (bt[r] - jt) * idd[r];
+                    if (x[r] < lo[r]) to[r] = ST_LO; else if (x[r] > hi[r]) to[r] = ST_HI;
+                } else if (state[r] == ST_LO || state[r] == ST_HI) {
+                    const float wr = (jt + dd[r] * x[r]) - bt[r];
                     if (state[r] == ST_LO ? (wr < 0.0f) : (wr > 0.0f)) to[r] = ST_FREE;
                 }
                 if (to[r] >= 0) { ++k; last = r; }
@@ -652,8 +687,7 @@ static void solveContacts(World& w, float fps, int m, const int* rb0, const int*
     // back to the unbounded rows and the body
     float yv[6];
     for (int a = 0; a < 6; ++a) {
-        float acc = 0.0f;
-        for (int r = 0; r < nr; ++r) acc += Jc[r * 6 + a] * x[r];
+        const float acc = sum([&](int r) { return Jc[r * 6 + a] * x[r]; });
         yv[a] = acc;
         contactForce[a] = acc;
     }

@@ -110,7 +110,7 @@ class DynState(C.Structure):
         [('gasUsage', C.c_float), ('locClutch', C.c_float), ('turboRotation', C.c_float * 3), ('simFrame', C.c_int32), ('damageChanged', C.c_int32),
          ('damageZoneLevel', C.c_float * 5), ('numContacts', C.c_int32), ('randState', C.c_int32), ('envPending', C.c_int32), ('envStepId', C.c_int32), ('_pad', C.c_int32 * 1)]
 assert C.sizeof(DynState) % 16 == 0
-MAX_CONTACTS = 16
+MAX_CONTACTS = 32
 class Contact(C.Structure):   # pdb_contact
     _fields_ = [('pos', C.c_float * 3), ('depth', C.c_float), ('normal', C.c_float * 3), ('kind', C.c_int32)]
 assert C.sizeof(Contact) == 32

@@ -27,8 +27,10 @@ def pytest_configure(config):
 
 @pytest.fixture(scope='session')
 def built():
-    import __graft_entry__ as g
-    g.build()
+    import __graft_entry__ as g, fcntl, tempfile
+    with open(os.path.join(tempfile.gettempdir(), 'pdbatch_build.lock'), 'w') as lock:   # pytest-xdist workers build one at a time
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        g.build()
     return True
 
 

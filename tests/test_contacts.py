@@ -148,7 +148,7 @@ def test_drive_invariants_on_the_walled_strip(oracle, hostlib, walled, steer, ga
         s0.body[b].pos[2] += shift; s0.body[b].lvel[2] = speed
     h = oracle.cpuref_create(C.byref(P), walled, len(walled), C.byref(s0))
     S = pc.DynState()
-    lam = (C.c_float * 48)(); lo = (C.c_float * 48)(); hi = (C.c_float * 48)(); it = C.c_int()
+    lam = (C.c_float * 96)(); lo = (C.c_float * 96)(); hi = (C.c_float * 96)(); it = C.c_int()
     contact_ticks = 0; e_prev = _kinetic(s0, P); e_before_hit = None; e_after_max = 0.0; first = None
     for t in range(2600):
         oracle.cpuref_step_env(h, steer, gas)
@@ -156,7 +156,7 @@ def test_drive_invariants_on_the_walled_strip(oracle, hostlib, walled, steer, ga
         e = _kinetic(S, P)
         if S.numContacts > 0:
             contact_ticks += 1
-            n = oracle.cpuref_last_contact_rows(h, lam, lo, hi, 48, C.byref(it))
+            n = oracle.cpuref_last_contact_rows(h, lam, lo, hi, 96, C.byref(it))
             assert n == 3 * S.numContacts and it.value <= 512
             L = np.array(lam[:n]); LO = np.array(lo[:n]); HI = np.array(hi[:n])
             assert np.all(L[0::3] >= 0.0)

@@ -23,6 +23,9 @@ acts = parity_util.make_actions(n, 7)
 hist = np.zeros(4096, dtype=np.int64)
 kinds = np.zeros(2, dtype=np.int64)
 S = pc.DynState()
+MAXR = 3 * pc.MAX_CONTACTS
+lam = (C.c_float * MAXR)(); lo = (C.c_float * MAXR)(); hi = (C.c_float * MAXR)(); itn = C.c_int()
+rounds = []
 for t in range(ticks):
     for i, h in enumerate(hs):
         orc.cpuref_step_env(h, float(acts[i, 0]), float(acts[i, 1]))
@@ -30,6 +33,8 @@ for t in range(ticks):
         if S.simFrame % 2 == 0:   # the frame just collided was odd
             c = orc.cpuref_contact_candidates(h)
             hist[min(c, 4095)] += 1
+        if S.numContacts > 0:
+            orc.cpuref_last_contact_rows(h, lam, lo, hi, MAXR, C.byref(itn)); rounds.append(itn.value)
 tot = hist[1:].sum()
 print('track %s, %d cars x %d ticks (%s): %d odd frames, %d with contact points' % (track, n, ticks, model, hist.sum(), tot))
 edges = [1, 2, 4, 7, 11, 17, 22, 33, 65, 129, 4096]
@@ -37,3 +42,6 @@ for a, b in zip(edges[:-1], edges[1:]):
     print('  %4d..%-4d candidates: %7d  (%.1f %% of frames in contact)' % (a, b - 1, hist[a:b].sum(), 100.0 * hist[a:b].sum() / max(tot, 1)))
 print('  max candidates: %d; frames above 10: %.1f %%, above 21: %.1f %%, above 32: %.1f %%' % (
     np.nonzero(hist)[0].max(), 100.0 * hist[11:].sum() / max(tot, 1), 100.0 * hist[22:].sum() / max(tot, 1), 100.0 * hist[33:].sum() / max(tot, 1)))
+if rounds:
+    r = np.sort(np.array(rounds))
+    print('  LCP rounds per solve (both stages, %d solves): median %d, p90 %d, p95 %d, p99 %d, max %d' % (len(r), r[len(r) // 2], r[int(len(r) * 0.9)], r[int(len(r) * 0.95)], r[int(len(r) * 0.99)], r[-1]))
