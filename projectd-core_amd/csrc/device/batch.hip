@@ -13,43 +13,83 @@
 #include "reset_core.hpp"   // Car::teleportByMode / Car::reset on a record: the host library's source, compiled for the device too
 
 // two LDS size classes of the same kernel source: 33 constraint rows (the strut / live-axle and the all-double-wishbone
-// cars; 8 KB of LDS per car, 6 workgroups per CU) and 40 rows (strut front + double wishbone rear: 38 rows; 5 per CU)
-#define PDB_KROWS 33
-#define PDB_KNS k33
-#define PDB_KMINWAVES 6
+// cars; 8 KB of LDS per car, 6 workgroups per CU) and 40 rows (strut front + double wishbone rear: 38 rows; 5 per CU).
+// Each class twice, so that the two passes can have workgroups of their own shape: PDB_FIRST_CPB / PDB_CONTACT_CPB cars per workgroup
+// (car waves + the pack wave).  Measured in round 3 on the playground: the contact pass with one car per workgroup (no car waits for
+// another at the workgroup's barriers) runs 393 / 628 us per launch against 188 / 333 us with three -- two-wave workgroups share
+// their SIMDs with each other, and this pass is a few long single-wave chains.
+#define PDB_FIRST_CPB 3
+#ifndef PDB_CONTACT_CPB
+#define PDB_CONTACT_CPB 3
+#endif
 #define PDB_KMINWAVES_C 2
+#define PDB_KROWS 33
+#define PDB_KMINWAVES 6
 #define PDB_KERNEL_EXACT pdb_step_kernel
 #define PDB_KERNEL_GUARDED pdb_step_kernel_generic
 #define PDB_KERNEL_EXACT_C pdb_contact_kernel
 #define PDB_KERNEL_GUARDED_C pdb_contact_kernel_generic
+#define PDB_KNS k33
+#define PDB_CPB PDB_FIRST_CPB
+#define PDB_FIRST_ONLY
 #include "step_kernel.hip.inc"
-#undef PDB_KROWS
+#undef PDB_FIRST_ONLY
+#undef PDB_CPB
+#undef PDB_BLOCK_THREADS
 #undef PDB_KNS
+#define PDB_KNS k33c
+#define PDB_CPB PDB_CONTACT_CPB
+#define PDB_CONTACT_ONLY
+#include "step_kernel.hip.inc"
+#undef PDB_CONTACT_ONLY
+#undef PDB_CPB
+#undef PDB_BLOCK_THREADS
+#undef PDB_KNS
+#undef PDB_KROWS
 #undef PDB_KMINWAVES
 #undef PDB_KERNEL_EXACT
 #undef PDB_KERNEL_GUARDED
 #undef PDB_KERNEL_EXACT_C
 #undef PDB_KERNEL_GUARDED_C
-#undef PDB_KMINWAVES_C
 #ifndef PDB_FAST_BUILD   /* development builds (make dev) compile the 33-row size class only */
 #define PDB_KROWS 40
-#define PDB_KNS k40
 #define PDB_KMINWAVES 5
-#define PDB_KMINWAVES_C 2
 #define PDB_KERNEL_EXACT pdb_step_kernel_wide40
 #define PDB_KERNEL_GUARDED pdb_step_kernel_wide
 #define PDB_KERNEL_EXACT_C pdb_contact_kernel_wide40
 #define PDB_KERNEL_GUARDED_C pdb_contact_kernel_wide
+#define PDB_KNS k40
+#define PDB_CPB PDB_FIRST_CPB
+#define PDB_FIRST_ONLY
 #include "step_kernel.hip.inc"
-#undef PDB_KROWS
+#undef PDB_FIRST_ONLY
+#undef PDB_CPB
+#undef PDB_BLOCK_THREADS
 #undef PDB_KNS
+#define PDB_KNS k40c
+#define PDB_CPB PDB_CONTACT_CPB
+#define PDB_CONTACT_ONLY
+#include "step_kernel.hip.inc"
+#undef PDB_CONTACT_ONLY
+#undef PDB_CPB
+#undef PDB_BLOCK_THREADS
+#undef PDB_KNS
+#undef PDB_KROWS
 #undef PDB_KMINWAVES
 #undef PDB_KERNEL_EXACT
 #undef PDB_KERNEL_GUARDED
 #undef PDB_KERNEL_EXACT_C
 #undef PDB_KERNEL_GUARDED_C
-#undef PDB_KMINWAVES_C
 #endif
+#undef PDB_KMINWAVES_C
+#ifndef PDB_FAST_BUILD
+static constexpr size_t kSnapStrideWide = k40::kSnapStride;
+static_assert(k40::kSnapStride >= k33::kSnapStride && k33::kSnapStride == k33c::kSnapStride && k40::kSnapStride == k40c::kSnapStride, "snapshot slots");
+#else
+static constexpr size_t kSnapStrideWide = k33::kSnapStride;
+#endif
+#define PDB_CPB PDB_FIRST_CPB   /* host side: the first pass's workgroup */
+#define PDB_BLOCK_THREADS (PDB_WAVE * (PDB_FIRST_CPB + 1))
 
 
 namespace pdb { void setError(const std::string& s); }
@@ -93,6 +133,7 @@ struct pdb_batch {
     DevConst partK[PDB_MAX_PARTS];
     pdb_car_params* dPartParams[PDB_MAX_PARTS] = {nullptr, nullptr, nullptr, nullptr};
     DevConst* dPartK[PDB_MAX_PARTS] = {nullptr, nullptr, nullptr, nullptr};
+    uint8_t* dSnap = nullptr;   // [n][snapshot slot]: what the first pass leaves for the contact pass of the same tick per handed-over car (its LDS block at the force barrier)
     int* dQueue[PDB_MAX_PARTS + 1] = {nullptr, nullptr, nullptr, nullptr, nullptr};   // RedoQueue per launch site: count, done, list[blocks]
     uint8_t* dResetScratch = nullptr;   // device copy of a host mask (pdb_reset)
     uint8_t* dResetMask = nullptr;   // [n]: 1 + teleport mode for cars to be reset at the top of their next tick (consumed and cleared by that tick)
@@ -182,6 +223,7 @@ static void launchTick(pdb_batch* b, hipStream_t st, int c0, int c1, pdb_step_ou
     pdb_car_state* CS = b->dCarStates ? b->dCarStates + c0 : nullptr;
     pdb_contact* CT = b->dContacts + (size_t)c0 * PDB_MAX_CONTACTS;
     void* Q = b->dQueue[q];
+    uint8_t* SN = b->dSnap + (size_t)c0 * (m <= 33 ? k33::kSnapStride : kSnapStrideWide);
     const bool own = q < PDB_MAX_PARTS && b->partHas[q];
     const pdb_car_params* DP = own ? b->dPartParams[q] : b->dParams;
     const DevConst* DK = own ? b->dPartK[q] : b->dK;
@@ -195,22 +237,22 @@ static void launchTick(pdb_batch* b, hipStream_t st, int c0, int c1, pdb_step_ou
     int cg = b->contactGrid;
     if (cg <= 0) {
         const int held = b->hHint ? *(volatile int*)(b->hHint + q) : 0;
-        cg = (2 * held + PDB_CPB - 1) / PDB_CPB;
+        cg = (2 * held + PDB_CONTACT_CPB - 1) / PDB_CONTACT_CPB;
         if (cg < (held > 0 ? PDB_CONTACT_GRID : PDB_CONTACT_GRID_IDLE)) cg = held > 0 ? PDB_CONTACT_GRID : PDB_CONTACT_GRID_IDLE;   // nobody touched anything lately: a handful of workgroups is launched, found empty and gone
-        if (cg > 1024) cg = 1024;
+        if (cg > 2048) cg = 2048;
     }
     int* HN = b->dHint ? b->dHint + q : nullptr;
-    const dim3 grid(nblk), block(PDB_BLOCK_THREADS), cgrid(nblk < cg ? nblk : cg);
+    const dim3 grid(nblk), block(PDB_BLOCK_THREADS), cblock(PDB_WAVE * (PDB_CONTACT_CPB + 1)), cgrid(((n + PDB_CONTACT_CPB - 1) / PDB_CONTACT_CPB) < cg ? ((n + PDB_CONTACT_CPB - 1) / PDB_CONTACT_CPB) : cg);
     if (m == 33) {
-        hipLaunchKernelGGL(k33::pdb_step_kernel, grid, block, 0, st, S, Aact, O, CS, DP, DK, b->dTrack, (k33::RedoQueue*)Q, RM, n);
-        if (contacts) hipLaunchKernelGGL(k33::pdb_contact_kernel, cgrid, block, 0, st, S, Aact, O, CS, DP, DK, b->dTrack, CT, (k33::RedoQueue*)Q, RM, n, HN);
+        hipLaunchKernelGGL(k33::pdb_step_kernel, grid, block, 0, st, S, Aact, O, CS, DP, DK, b->dTrack, (k33::RedoQueue*)Q, RM, n, SN);
+        if (contacts) hipLaunchKernelGGL(k33c::pdb_contact_kernel, cgrid, cblock, 0, st, S, Aact, O, CS, DP, DK, b->dTrack, CT, (k33c::RedoQueue*)Q, RM, n, HN, SN);
     } else if (m < 33) {
-        hipLaunchKernelGGL(k33::pdb_step_kernel_generic, grid, block, 0, st, S, Aact, O, CS, DP, DK, b->dTrack, (k33::RedoQueue*)Q, RM, n);
-        if (contacts) hipLaunchKernelGGL(k33::pdb_contact_kernel_generic, cgrid, block, 0, st, S, Aact, O, CS, DP, DK, b->dTrack, CT, (k33::RedoQueue*)Q, RM, n, HN);
+        hipLaunchKernelGGL(k33::pdb_step_kernel_generic, grid, block, 0, st, S, Aact, O, CS, DP, DK, b->dTrack, (k33::RedoQueue*)Q, RM, n, SN);
+        if (contacts) hipLaunchKernelGGL(k33c::pdb_contact_kernel_generic, cgrid, cblock, 0, st, S, Aact, O, CS, DP, DK, b->dTrack, CT, (k33c::RedoQueue*)Q, RM, n, HN, SN);
     } else {
 #ifndef PDB_FAST_BUILD
-        hipLaunchKernelGGL(k40::pdb_step_kernel_wide, grid, block, 0, st, S, Aact, O, CS, DP, DK, b->dTrack, (k40::RedoQueue*)Q, RM, n);
-        if (contacts) hipLaunchKernelGGL(k40::pdb_contact_kernel_wide, cgrid, block, 0, st, S, Aact, O, CS, DP, DK, b->dTrack, CT, (k40::RedoQueue*)Q, RM, n, HN);
+        hipLaunchKernelGGL(k40::pdb_step_kernel_wide, grid, block, 0, st, S, Aact, O, CS, DP, DK, b->dTrack, (k40::RedoQueue*)Q, RM, n, SN);
+        if (contacts) hipLaunchKernelGGL(k40c::pdb_contact_kernel_wide, cgrid, cblock, 0, st, S, Aact, O, CS, DP, DK, b->dTrack, CT, (k40c::RedoQueue*)Q, RM, n, HN, SN);
 #endif
     }
 }
@@ -298,8 +340,9 @@ pdb_batch* pdb_create(int device, int n_cars, const pdb_car_params* params, cons
     ok = ok && hipMemset(b->dContacts, 0, sizeof(pdb_contact) * PDB_MAX_CONTACTS * (size_t)n_cars) == hipSuccess;
     ok = ok && hipMalloc(&b->dResetMask, (size_t)n_cars) == hipSuccess;
     ok = ok && hipMemset(b->dResetMask, 0, (size_t)n_cars) == hipSuccess;
+    ok = ok && hipMalloc(&b->dSnap, kSnapStrideWide * (size_t)n_cars) == hipSuccess;
     for (int q = 0; q <= PDB_MAX_PARTS; ++q) {
-        const size_t qb = sizeof(int) * (size_t)(4 + n_cars);   // count, done, one entry per car
+        const size_t qb = sizeof(int) * (size_t)(4 + n_cars);   // count, done, countFull, pad, one entry per car
         ok = ok && hipMalloc(&b->dQueue[q], qb) == hipSuccess;
         ok = ok && hipMemset(b->dQueue[q], 0, qb) == hipSuccess;
     }
@@ -342,6 +385,7 @@ void pdb_destroy(pdb_batch* b) {
     if (b->hActions) (void)hipHostFree(b->hActions);
     if (b->hOut) (void)hipHostFree(b->hOut);
     for (int q = 0; q <= PDB_MAX_PARTS; ++q) (void)hipFree(b->dQueue[q]);
+    (void)hipFree(b->dSnap);
     for (int q = 0; q < PDB_MAX_PARTS; ++q) { (void)hipFree(b->dPartParams[q]); (void)hipFree(b->dPartK[q]); }
     if (b->ev0) (void)hipEventDestroy(b->ev0);
     if (b->ev1) (void)hipEventDestroy(b->ev1);

@@ -65,10 +65,13 @@ print('pack wave (median, relative to the block\'s first car wave start):')
 for nm, k in (('pre-step + steering rods done', 4), ('tyres done', 24), ('suspensions done', 30), ('drivetrain done', 15), ('tyre tail (thermal) done', 29), ('post: barrier passed', 25), ('post: locator done', 26), ('post: look-ahead done', 27), ('post: scoring done', 28)):
     print('  %-58s %8.0f' % (nm, med(first[:, k] - first[:, 0])))
 print('pack internals (car 0 of the block, wheel 0): pre-step end -> hub matrix %d | ray cast %d | contact + SCTM + forces %d | torque/lock %d | thermal %d ;; drive: tyres end -> before drivetrainStep %d | drivetrainStep %d' % (med(first[:,16]-first[:,4]), med(first[:,17]-first[:,16]), med(first[:,18]-first[:,17]), med(first[:,19]-first[:,18]), med(first[:,20]-first[:,19]), med(first[:,22]-first[:,24]), med(first[:,23]-first[:,22])))
-print('wave lifetime median %.0f clocks' % med(sti[:, 13] - t0))
+print('pack internals, 99th percentile / max: hub matrix %d/%d | ray cast %d/%d | contact + SCTM + forces %d/%d ;; tyres done %d/%d, drivetrain done %d/%d' % (
+    np.percentile(first[:,16]-first[:,4], 99), (first[:,16]-first[:,4]).max(), np.percentile(first[:,17]-first[:,16], 99), (first[:,17]-first[:,16]).max(), np.percentile(first[:,18]-first[:,17], 99), (first[:,18]-first[:,17]).max(),
+    np.percentile(first[:,24]-first[:,0], 99), (first[:,24]-first[:,0]).max(), np.percentile(first[:,15]-first[:,0], 99), (first[:,15]-first[:,0]).max()))
+print('wave lifetime median %.0f, 99th percentile %.0f, max %.0f clocks' % (med(sti[:, 13] - t0), np.percentile(sti[:, 13] - t0, 99), (sti[:, 13] - t0).max()))
 b.close()
 
-held = full[:, 0] != 0
+held = (full[:, 0] != 0) & (full[:, 13] > full[:, 13].max() - 4000000)   # rows of the last tick's pass (a car that left the pass keeps its old row)
 if held.any():
     f = full[held]
     print('contact pass: %d of %d cars in it on the last tick; median / 90th percentile / max shader clocks since the wave started the car:' % (held.sum(), n))
@@ -79,3 +82,37 @@ if held.any():
         if len(d): print('  %-48s %9.0f %9.0f %9.0f' % (nm, np.median(d), np.percentile(d, 90), d.max()))
     cs = f[f[:, 19] != 0]
     if len(cs): print('  contact solve (cars with live joints: %d): median %.0f, max %.0f clocks' % (len(cs), np.median(cs[:, 19] - cs[:, 18]), (cs[:, 19] - cs[:, 18]).max()))
+    pk = f[(f[:, 4] > f[:, 0]) & (f[:, 28] > f[:, 4]) & (f[:, 28] - f[:, 0] < 20000000) & (f[:, 24] > f[:, 4]) & (f[:, 15] > f[:, 24])]
+    if len(pk):
+        print('  pack wave of the contact pass (groups: %d), since the group\'s first car wave started:' % len(pk))
+        for nm, k in (('pre-step + steering rods done', 4), ('tyres done', 24), ('suspensions done', 30), ('drivetrain done', 15), ('tyre tail (thermal) done', 29), ('post: barrier passed', 25), ('post: scoring done', 28)):
+            d = pk[:, k] - pk[:, 0]
+            print('    %-44s %9.0f %9.0f %9.0f' % (nm, np.median(d), np.percentile(d, 90), d.max()))
+    cn = f[f[:, 20] != 0]
+    if len(cn):
+        u = cn.astype(np.uint64)
+        cols = {'turns': u[:, 20] >> 32, 'broad-phase survivors': u[:, 20] & 0xffffffff, 'dense turns': u[:, 21] >> 32, 'wall triangles one by one': u[:, 21] & 0xffffffff,
+                'road triangles (box)': u[:, 22] >> 32, 'pairs after the plane-side rejections': u[:, 22] & 0xffffffff, 'contact candidates': u[:, 23]}
+        coll = (cn[:, 17] - cn[:, 16]).astype(np.float64)
+        print('  collision pass counters (%d cars): median / 90th percentile / max, and the correlation with the pass\'s clocks' % len(cn))
+        for nm, v in cols.items():
+            v = v.astype(np.float64)
+            cc = np.corrcoef(v, coll)[0, 1] if v.std() > 0 else 0.0
+            print('    %-40s %8.0f %8.0f %8.0f   r = %.2f' % (nm, np.median(v), np.percentile(v, 90), v.max(), cc))
+        A = np.stack([np.ones(len(cn))] + [v.astype(np.float64) for v in cols.values()], axis=1)
+        coef = np.linalg.lstsq(A, coll, rcond=None)[0]
+        print('    least squares, clocks ~ ' + ' + '.join(['%.0f' % coef[0]] + ['%.0f x %s' % (c, nm) for c, nm in zip(coef[1:], cols.keys())]))
+    # the groups of the pass: its cars leave barrier 2 within a few clocks of each other
+    o = np.argsort(f[:, 5]); g = f[o]
+    brk = np.nonzero(np.diff(g[:, 5]) > 400)[0] + 1
+    grp = np.split(np.arange(len(g)), brk)
+    late = []; sizes = []
+    for ix in grp:
+        sizes.append(len(ix))
+        late.append((g[ix, 5].min() - g[ix, 3].max(), g[ix, 3].max() - g[ix, 0].min(), (g[ix, 0].max() - g[ix, 0].min())))
+    late = np.array(late, dtype=np.float64)
+    print('  groups by barrier-2 time: %d, sizes %s; barrier 2 release - last car\'s LDL^T done: median %.0f, 90th %.0f, max %.0f; last LDL^T done - first car start: median %.0f, 90th %.0f, max %.0f; spread of the cars\' starts: median %.0f, max %.0f' % (
+        len(grp), np.bincount(sizes)[:6], np.median(late[:, 0]), np.percentile(late[:, 0], 90), late[:, 0].max(), np.median(late[:, 1]), np.percentile(late[:, 1], 90), late[:, 1].max(), np.median(late[:, 2]), late[:, 2].max()))
+    t00 = f[:, 0].min()
+    print('  pass timeline (clocks since its first car started): car starts median %.0f, 90th %.0f, max %.0f; records stored median %.0f, max %.0f' % (
+        np.median(f[:, 0] - t00), np.percentile(f[:, 0] - t00, 90), (f[:, 0] - t00).max(), np.median(f[:, 13] - t00), (f[:, 13] - t00).max()))
