@@ -1,7 +1,7 @@
 #!/bin/bash
-# Diagnostic (GPU box): the contact pass with three cars per workgroup (libpdbatch_cpb3.so) against the shipped one, kernel stats of two playground legs
+# Diagnostic (GPU box): kernel stats of the playground legs (optionally against a library variant: ab_contact.sh libpdbatch_x.so)
 for leg in "--episodes" "--policy mlp"; do
-  for lib in "" "libpdbatch_cpb3.so"; do
+  for lib in "" $1; do
     bash tools/kstats.sh "pg_$(echo $leg | tr -d ' -')_$(basename ${lib:-shipped} .so)" "$lib" --workload playground $leg --cars 16384 --steps 100 --warmup 20 --settle 200
   done
 done

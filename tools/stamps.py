@@ -58,7 +58,7 @@ med = lambda x: float(np.median(x))
 t0 = sti[:, 0]
 print('cars %d (car wave, median shader clocks since wave start):' % n)
 for nm, k in (('record loaded, ERP set', 1), ('world inertia + non-steer joint rows done (barrier 1)', 2), ('steer rows done, A assembly starts', 7),
-              ('A assembled', 8), ('LDL^T done', 3), ('barrier 2 passed (forces ready)', 5), ('late bodies done, rhs starts', 6), ('lambda solved', 9),
+              ('barrier 2 passed (forces ready)', 5), ('late bodies done, rhs starts', 6), ('lambda solved', 9),
               ('integration done', 11), ('post scans done', 14), ('pack scoring done (barrier)', 12), ('record stored', 13)):
     print('  %-58s %8.0f' % (nm, med(sti[:, k] - t0)))
 print('pack wave (median, relative to the block\'s first car wave start):')
@@ -71,11 +71,11 @@ print('pack internals, 99th percentile / max: hub matrix %d/%d | ray cast %d/%d 
 print('wave lifetime median %.0f, 99th percentile %.0f, max %.0f clocks' % (med(sti[:, 13] - t0), np.percentile(sti[:, 13] - t0, 99), (sti[:, 13] - t0).max()))
 b.close()
 
-held = (full[:, 0] != 0) & (full[:, 13] > full[:, 13].max() - 4000000)   # rows of the last tick's pass (a car that left the pass keeps its old row)
+held = (full[:, 0] != 0) & (full[:, 13] > full[:, 13].max() - 1000000)   # rows of the last tick's pass (a car that left the pass keeps its old row; a tick here is over a million clocks)
 if held.any():
     f = full[held]
     print('contact pass: %d of %d cars in it on the last tick; median / 90th percentile / max shader clocks since the wave started the car:' % (held.sum(), n))
-    for nm, k in (('record loaded', 1), ('joint rows done, collision pass starts', 16), ('collision pass done', 17), ('A assembled', 8), ('LDL^T done', 3), ('forces ready (barrier 2)', 5),
+    for nm, k in (('record loaded', 1), ('joint rows done, collision pass starts', 16), ('collision pass done', 17), ('forces ready (barrier 2)', 5),
                   ('lambda of the unbounded rows', 9), ('integration done', 11), ('post scans done', 14), ('record stored', 13)):
         d = f[:, k] - f[:, 0]
         d = d[f[:, k] != 0]
@@ -102,17 +102,6 @@ if held.any():
         A = np.stack([np.ones(len(cn))] + [v.astype(np.float64) for v in cols.values()], axis=1)
         coef = np.linalg.lstsq(A, coll, rcond=None)[0]
         print('    least squares, clocks ~ ' + ' + '.join(['%.0f' % coef[0]] + ['%.0f x %s' % (c, nm) for c, nm in zip(coef[1:], cols.keys())]))
-    # the groups of the pass: its cars leave barrier 2 within a few clocks of each other
-    o = np.argsort(f[:, 5]); g = f[o]
-    brk = np.nonzero(np.diff(g[:, 5]) > 400)[0] + 1
-    grp = np.split(np.arange(len(g)), brk)
-    late = []; sizes = []
-    for ix in grp:
-        sizes.append(len(ix))
-        late.append((g[ix, 5].min() - g[ix, 3].max(), g[ix, 3].max() - g[ix, 0].min(), (g[ix, 0].max() - g[ix, 0].min())))
-    late = np.array(late, dtype=np.float64)
-    print('  groups by barrier-2 time: %d, sizes %s; barrier 2 release - last car\'s LDL^T done: median %.0f, 90th %.0f, max %.0f; last LDL^T done - first car start: median %.0f, 90th %.0f, max %.0f; spread of the cars\' starts: median %.0f, max %.0f' % (
-        len(grp), np.bincount(sizes)[:6], np.median(late[:, 0]), np.percentile(late[:, 0], 90), late[:, 0].max(), np.median(late[:, 1]), np.percentile(late[:, 1], 90), late[:, 1].max(), np.median(late[:, 2]), late[:, 2].max()))
     t00 = f[:, 0].min()
     print('  pass timeline (clocks since its first car started): car starts median %.0f, 90th %.0f, max %.0f; records stored median %.0f, max %.0f' % (
         np.median(f[:, 0] - t00), np.percentile(f[:, 0] - t00, 90), (f[:, 0] - t00).max(), np.median(f[:, 13] - t00), (f[:, 13] - t00).max()))
