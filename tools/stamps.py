@@ -1,4 +1,6 @@
-"""Diagnostic: per-phase shader-clock shares of pdb_step_kernel (libpdbatch_stamps.so, -DPDB_STAMPS)."""
+"""Diagnostic: per-phase shader-clock shares of pdb_step_kernel (libpdbatch_stamps.so, -DPDB_STAMPS).  One tick per launch with a host
+synchronisation in between: the device idles between launches, and phases that wait for memory read longer here than under the bench's
+continuous load (a round trip measured 9 us in this tool) -- read the compute phases and the shares, not the loads."""
 import ctypes as C, os, sys
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -75,7 +77,7 @@ held = (full[:, 0] != 0) & (full[:, 13] > full[:, 13].max() - 1000000)   # rows 
 if held.any():
     f = full[held]
     print('contact pass: %d of %d cars in it on the last tick; median / 90th percentile / max shader clocks since the wave started the car:' % (held.sum(), n))
-    for nm, k in (('record loaded', 1), ('joint rows done, collision pass starts', 16), ('collision pass done', 17), ('forces ready (barrier 2)', 5),
+    for nm, k in (('snapshot loads issued', 7), ('snapshot in LDS', 8), ('record loaded (workgroup barrier)', 1), ('joint rows done, collision pass starts', 16), ('collision pass done', 17), ('forces ready (barrier 2)', 5),
                   ('lambda of the unbounded rows', 9), ('integration done', 11), ('post scans done', 14), ('record stored', 13)):
         d = f[:, k] - f[:, 0]
         d = d[f[:, k] != 0]
