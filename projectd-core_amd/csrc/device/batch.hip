@@ -22,7 +22,9 @@
 #ifndef PDB_CONTACT_CPB
 #define PDB_CONTACT_CPB 3
 #endif
+#ifndef PDB_KMINWAVES_C
 #define PDB_KMINWAVES_C 2
+#endif
 #define PDB_KROWS 33
 #define PDB_KMINWAVES 6
 #define PDB_KERNEL_EXACT pdb_step_kernel
@@ -108,7 +110,7 @@ namespace pdb { void setError(const std::string& s); }
 #define PDB_CONTACT_GRID 32
 #endif
 #ifndef PDB_CONTACT_GRID_IDLE
-#define PDB_CONTACT_GRID_IDLE 8
+#define PDB_CONTACT_GRID_IDLE 1
 #endif
 struct pdb_batch {
     int device = 0;
