@@ -127,6 +127,18 @@ def test_gpu_matches_oracle_on_the_walled_strip(built, model):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize('grid', ['1', '3'])
+def test_contact_pass_results_do_not_depend_on_its_grid(built, grid, monkeypatch):
+    """the contact pass's workgroups take the queued cars in turn: with one workgroup (or three) for dozens of cars, every group after
+    the first runs in a workgroup that has already held other cars (stale LDS blocks, the pack wave's flag word, the staging block) --
+    same bits as the oracle"""
+    import parity_util
+    monkeypatch.setenv('PDB_CONTACT_GRID', grid)   # read when the batch is created
+    worst = parity_util.run_parity(n_cars=48, ticks=1400, seed=99, track='walled', model=AE86, check_every=7)
+    assert worst == 0.0, worst
+
+
+@pytest.mark.gpu
 def test_gpu_matches_oracle_on_the_wall_lined_road(built):
     """the synthetic mountain road with guard rails (WALL surfaces along both edges, configs[4] shape): 32 cars with constant
     actions run wide into the rails within a few seconds -- hull contacts on a curved, banked, hilly mesh, bit for bit"""

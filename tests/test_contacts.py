@@ -67,14 +67,18 @@ def test_friction_limits_follow_the_frictionless_normal_force(oracle):
 
 
 def test_lcp_solution_against_float64_active_set(oracle):
-    """many contacts at once on a tumbling body: the fp32 block-pivoting result satisfies the box LCP's conditions for the
+    """many contacts at once on a tumbling body: the fp32 solver's result satisfies the box LCP's conditions for the
     float64 rebuild of the same rows (normal stage and friction stage), within fp32 accuracy"""
     rng = np.random.RandomState(7)
     worst_iter = 0
-    for trial in range(40):
-        n = int(rng.randint(1, 11))
+    for trial in range(60):
+        # up to the cap of 32 contacts (96 rows); the later trials repeat contact points exactly, as two wall triangles sharing a pierced edge do --
+        # rows in exact pairs, the case block pivoting cycled on
+        n = int(rng.randint(1, 11)) if trial < 30 else int(rng.randint(11, 33))
         contacts = []
         for i in range(n):
+            if trial >= 45 and i >= 2 and rng.uniform() < 0.5:
+                contacts.append(contacts[int(rng.randint(0, i))]); continue
             nrm = np.array([rng.uniform(-0.3, 0.3), 1.0, rng.uniform(-0.3, 0.3)]); nrm /= np.linalg.norm(nrm)
             contacts.append((tuple(np.array([rng.uniform(-0.7, 0.7), 0.3 + rng.uniform(-0.02, 0.02), rng.uniform(-2, 2)], dtype=np.float32)),
                              tuple(nrm.astype(np.float32)), float(np.float32(rng.uniform(0, 0.03))), int(rng.randint(0, 2))))
@@ -116,7 +120,7 @@ def test_lcp_solution_against_float64_active_set(oracle):
                 assert w[i] > -2e-3 * scale, (trial, i)
             elif hi[i] > lo[i]:
                 assert w[i] < 2e-3 * scale, (trial, i)
-    assert worst_iter <= 64
+    assert worst_iter <= 40   # both stages together; the cap is 64 per stage
 
 
 @pytest.fixture(scope='module')
