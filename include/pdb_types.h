@@ -34,6 +34,17 @@ typedef struct pdb_curve {
     float y[PDB_MAX_CURVE];
 } pdb_curve;
 
+/* natural cubic spline through a LUT's points (Core/Curve.cpp:117-126 getCubicSplineValue -> Core/CubicSpline.cpp -> the tk::spline header the
+ * reference vendors, float arithmetic): f(x) = ((a_i h + b_i) h + c_i) h + y_i, h = x - x_i, i = the last point below x; quadratic continuation
+ * outside the points (left: b0, c0; right: b_{n-1}, c_{n-1}).  The coefficients are worked out once, by the loader.  n = 0: no curve. */
+#define PDB_MAX_SPLINE 16
+typedef struct pdb_spline {
+    int32_t n;
+    float b0, c0;
+    int32_t pad;
+    float x[PDB_MAX_SPLINE], y[PDB_MAX_SPLINE], a[PDB_MAX_SPLINE], b[PDB_MAX_SPLINE], c[PDB_MAX_SPLINE];
+} pdb_spline;
+
 /* Car/CarControls.h:9-20 */
 #pragma pack(push, 4)
 typedef struct pdb_controls {
@@ -140,6 +151,11 @@ typedef struct pdb_tyre {
     float surfaceTransfer, patchTransfer, patchCoreTransfer, internalCoreTransfer, coolFactorGain, camberSpreadK;
     pdb_curve performanceCurve;
     pdb_curve wearCurve;
+    /* load-sensitivity and camber LUTs that replace the closed forms when a compound carries them (Tyre.cpp:161-165,207-211; TyreModel.cpp:49-57,121-146):
+     * curveFlags bit 0 = DY_CURVE, bit 1 = DX_CURVE (both through the cubic spline), bit 2 = DCAMBER_LUT, bit 3 = DCAMBER_LUT_SMOOTH (spline instead
+     * of the piecewise-linear reading; the spline's x / y hold the LUT either way) */
+    int32_t curveFlags, curvePad;
+    pdb_spline dyLoadCurve, dxLoadCurve, dCamberCurve;
 } pdb_tyre;
 
 typedef struct pdb_wing {
@@ -398,7 +414,7 @@ typedef struct pdb_ray_rec {
 }
 /* sizes are part of the ABI (tests/test_abi.py reads these numbers) */
 static_assert(sizeof(pdb_car_state) == 664, "pdb_car_state must equal the reference CarState (pack 4)");
-static_assert(sizeof(pdb_car_params) == 12616, "pdb_car_params layout");
+static_assert(sizeof(pdb_car_params) == 16680, "pdb_car_params layout");
 static_assert(sizeof(pdb_dyn_state) == 2272, "pdb_dyn_state layout (multiple of 16 bytes)");
 static_assert(sizeof(pdb_step_out) == 104, "pdb_step_out layout");
 static_assert(sizeof(pdb_contact) == 32, "pdb_contact layout");

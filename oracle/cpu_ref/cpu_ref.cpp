@@ -469,8 +469,27 @@ static void axleStep(const pdb_susp& su, pdrb::World& w, TyreScratch& sc) {
 struct TMI { float load, slipAngleRAD, slipRatio, camberRAD, speed, u, cpLength, grain, blister, pressureRatio; bool useSimpleModel; };
 struct TMO { float Fy = 0, Fx = 0, Mz = 0, trail = 0, ndSlip = 0, Dy = 0, Dx = 0; };
 
-static float sctmStaticDX(const pdb_tyre& t, float load) { if (load != 0.0) return (m_powf(load, t.lsExpX) * t.lsMultX) / load; return 0; }
-static float sctmStaticDY(const pdb_tyre& t, float load) { if (load != 0.0f) return (m_powf(load, t.lsExpY) * t.lsMultY) / load; return 0; }
+// Curve::getCubicSplineValue (Core/Curve.cpp:117-126): the vendored tk::spline's operator() in float -- the last point below x (the first one for
+// anything left of the points), the cubic of that interval, quadratic continuation outside
+static float splineValue(const pdb_spline& s, float x) {
+    int lb = 0;
+    while (lb < s.n && s.x[lb] < x) ++lb;          // std::lower_bound
+    const int idx = lb - 1 > 0 ? lb - 1 : 0;
+    const float h = x - s.x[idx];
+    if (x < s.x[0]) return (s.b0 * h + s.c0) * h + s.y[0];
+    if (x > s.x[s.n - 1]) return (s.b[s.n - 1] * h + s.c[s.n - 1]) * h + s.y[s.n - 1];
+    return ((s.a[idx] * h + s.b[idx]) * h + s.c[idx]) * h + s.y[idx];
+}
+// Curve::getValue (Core/Curve.cpp:94-115) on a spline's points
+static float splineLinear(const pdb_spline& s, float ref) {
+    if (s.n <= 0) return 0.0f;
+    if (ref <= s.x[0]) return s.y[0];
+    for (int id = 1; id < s.n; ++id) if (ref <= s.x[id]) return (((s.y[id] - s.y[id - 1]) * (ref - s.x[id - 1])) / (s.x[id] - s.x[id - 1])) + s.y[id - 1];
+    return s.y[s.n - 1];
+}
+// SCTM::getStaticDX / getStaticDY (TyreModel.cpp:121-146)
+static float sctmStaticDX(const pdb_tyre& t, float load) { if (t.curveFlags & 2) return splineValue(t.dxLoadCurve, load); if (load != 0.0) return (m_powf(load, t.lsExpX) * t.lsMultX) / load; return 0; }
+static float sctmStaticDY(const pdb_tyre& t, float load) { if (t.curveFlags & 1) return splineValue(t.dyLoadCurve, load); if (load != 0.0f) return (m_powf(load, t.lsExpY) * t.lsMultY) / load; return 0; }
 static float sctmPureFY(const pdb_tyre& t, float asy, float /*D*/, float cf, float /*load*/, float slip) {
     const float v5 = (cf * 2.0f) * 0.0064f;
     const float v6 = 1.0f / (v5 / 3.0f);
@@ -498,7 +517,11 @@ static TMO sctmSolve(const pdb_tyre& t, const TMI& tmi) {
     float fCamberRadTmp = fabsf(fCamberRad);
     if ((fCamberRad < 0.0f || fUnk1 < 0.0f) && (fCamberRad > 0.0f || fUnk1 > 0.0f)) fCamberRadTmp = -fCamberRadTmp;
     fCamberRadTmp = -fCamberRadTmp;
-    {
+    if (t.curveFlags & 4) {   // DCAMBER_LUT (TyreModel.cpp:49-57)
+        const float fCamberDeg = fCamberRadTmp * 57.29578f;
+        if (t.curveFlags & 8) fUDy *= splineValue(t.dCamberCurve, fCamberDeg);
+        else fUDy *= splineLinear(t.dCamberCurve, fCamberDeg);
+    } else {
         float fCamberUnk = (fCamberRadTmp * t.dcamber0) - ((fCamberRadTmp * fCamberRadTmp) * t.dcamber1);
         if (fCamberUnk <= -1.0f) fCamberUnk = -0.8999999f;
         fUDy += (((fUDy / (fCamberUnk + 1.0f)) - fUDy) * t.dCamberBlend);

@@ -89,6 +89,33 @@ def make_cold_car(base, src='ks_mazda_rx7_tuned', dst='pdb_cold_rx7'):
         open(p, 'w', newline='').write(raw.rstrip('\r\n') + eol + eol.join(extra))
 
 
+def make_curves_car(base, src='ks_toyota_ae86_drift', dst='pdb_curves_ae86'):
+    """The LUT forms of the tyre's load sensitivity and camber factor, which no shipped car carries: DY_CURVE / DX_CURVE (Tyre.cpp:161-165 ->
+    SCTM::getStaticDY / getStaticDX, TyreModel.cpp:121-146) and DCAMBER_LUT (Tyre.cpp:207-211 -> TyreModel.cpp:49-57), read through the
+    natural cubic spline of Curve::getCubicSplineValue (Core/Curve.cpp:117-126) -- the front compound with DCAMBER_LUT_SMOOTH=1 (spline),
+    the rear one without (piecewise linear).  The AE86 with the keys added to its first compounds pins them."""
+    s = os.path.join(REF, 'content', 'cars', src, 'data'); d = os.path.join(base, 'content', 'cars', dst, 'data')
+    if os.path.isdir(d):
+        shutil.rmtree(d)
+    shutil.copytree(s, d)
+    os.system('chmod -R u+w "%s"' % d)
+    p = os.path.join(d, 'tyres.ini')
+    raw = open(p, newline='').read()
+    eol = '\r\n' if '\r\n' in raw else '\n'
+    add = {'[FRONT]': ['DY_CURVE=(|0=1.46|800=1.38|1600=1.30|2400=1.235|3300=1.18|4500=1.12|6000=1.07|8000=1.03|)',
+                       'DX_CURVE=(|0=1.52|1000=1.41|2000=1.33|3000=1.27|4500=1.20|6500=1.14|9000=1.09|)',
+                       'DCAMBER_LUT=(|-8=1.05|-5=1.062|-3=1.05|-1.5=1.03|0=1.0|1.5=0.965|3=0.93|6=0.85|)', 'DCAMBER_LUT_SMOOTH=1'],
+           '[REAR]': ['DY_CURVE=(|0=1.44|900=1.36|1800=1.285|2700=1.225|3600=1.175|5000=1.115|7000=1.06|)',
+                      'DX_CURVE=(|0=1.50|1200=1.39|2400=1.31|3600=1.245|5200=1.18|7500=1.12|)',
+                      'DCAMBER_LUT=(|-6=1.055|-3=1.045|0=1.0|3=0.935|6=0.86|)', 'DCAMBER_LUT_SMOOTH=0']}
+    out = []
+    for line in raw.split(eol):
+        out.append(line)
+        if line.strip() in add:
+            out.extend(add[line.strip()])
+    open(p, 'w', newline='').write(eol.join(out))
+
+
 def main():
     base = os.path.join(here, '_ref', 'base')
     os.makedirs(os.path.join(base, 'cfg'), exist_ok=True)
@@ -103,6 +130,7 @@ def main():
     make_heave_car(base)
     make_fwd_car(base)
     make_cold_car(base)
+    make_curves_car(base)
     gen_track.gen_flat(os.path.join(base, 'content', 'tracks', 'flat'))
     gen_track.gen_touge(os.path.join(base, 'content', 'tracks', 'touge'))
     gen_track.gen_walled(os.path.join(base, 'content', 'tracks', 'walled'))

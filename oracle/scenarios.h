@@ -83,8 +83,11 @@ static const Scenario kScenarios[] = {
     // branches no shipped car takes, on a derived car (oracle/make_base.py): [THROTTLE_RESPONSE], [COAST_SETTINGS], [EBB] -- the brake
     // script (full and part throttle, a hard stop from speed, a hand-brake turn, trail braking)
     {"cold", 2400, 200, 10, 1, 1, 1, 1, "flat", 0, "pdb_cold_rx7", 0, 0, 0, 0, 0, 0, 0},
+    // the tyre's LUT forms (DY_CURVE / DX_CURVE / DCAMBER_LUT through the cubic spline of Curve::getCubicSplineValue) on a derived car, driven
+    // round the mountain road: loads from nothing to twice the static one, camber of both signs
+    {"curves", 3000, 300, 10, 0, 1, 1, 1, "touge", 1, "pdb_curves_ae86", 0, 0, 0, 0, 0, 0, 0},
 };
-static const int kNumScenarios = 39;
+static const int kNumScenarios = 40;
 static const float kTeleDist[4] = {0.13f, 0.41f, 0.77f, 0.95f};
 struct ScoreVar { const char* name; float value; };
 static const ScoreVar kScoringSetA[] = {

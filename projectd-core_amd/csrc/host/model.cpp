@@ -51,6 +51,65 @@ static void mkDBall(std::vector<RawJoint>& out, const HBody* B, int b0, int b1, 
     out.push_back(j);
 }
 
+// Natural cubic spline through a LUT (what Curve::getCubicSplineValue evaluates, Core/Curve.cpp:117-126): the reference hands the points to the
+// tk::spline header it vendors (Core/tkspline.h, tkfloat = float): second derivative zero at both ends, the tridiagonal system for the b's solved
+// by an LU decomposition with rows scaled to a unit diagonal first, a and c from the b's, quadratic continuation past the ends.  Restated here for
+// the band width of one, in that header's order of operations and its mixture of float storage and double literals (1.0/3.0, 2.0/3.0, 3.0): the
+// coefficients have to come out with the same bits, because the values the tyre model reads from them do.
+static void splineBuild(pdb_spline& sp, const pdb_curve& cv) {
+    const int n = cv.n;
+    if (n < 3 || n > PDB_MAX_SPLINE) throw std::runtime_error("pdb: a cubic-spline tyre LUT needs 3.." + std::to_string(PDB_MAX_SPLINE) + " points");
+    for (int i = 0; i + 1 < n; ++i) if (!(cv.x[i] < cv.x[i + 1])) throw std::runtime_error("pdb: cubic-spline tyre LUT: references must increase");
+    memset(&sp, 0, sizeof(sp));
+    sp.n = n;
+    const float* x = cv.x; const float* y = cv.y;
+    std::vector<float> lo(n, 0.0f), di(n, 0.0f), up(n, 0.0f), rhs(n, 0.0f), sd(n, 0.0f);   // A(i,i-1), A(i,i), A(i,i+1), right-hand side, 1/diagonal
+    for (int i = 1; i < n - 1; ++i) {
+        lo[i] = (float)(1.0 / 3.0 * (double)(x[i] - x[i - 1]));
+        di[i] = (float)(2.0 / 3.0 * (double)(x[i + 1] - x[i - 1]));
+        up[i] = (float)(1.0 / 3.0 * (double)(x[i + 1] - x[i]));
+        rhs[i] = (y[i + 1] - y[i]) / (x[i + 1] - x[i]) - (y[i] - y[i - 1]) / (x[i] - x[i - 1]);
+    }
+    di[0] = 2.0f; up[0] = 0.0f; rhs[0] = 0.0f;                 // 2 b[0] = f'' = 0
+    di[n - 1] = 2.0f; lo[n - 1] = 0.0f; rhs[n - 1] = 0.0f;
+    // rows scaled to a unit diagonal
+    for (int i = 0; i < n; ++i) {
+        sd[i] = (float)(1.0 / (double)di[i]);
+        if (i > 0) lo[i] *= sd[i];
+        di[i] *= sd[i];
+        if (i < n - 1) up[i] *= sd[i];
+        di[i] = 1.0f;
+    }
+    // elimination
+    for (int k = 0; k + 1 < n; ++k) {
+        const float f = -lo[k + 1] / di[k];
+        lo[k + 1] = -f;
+        di[k + 1] = di[k + 1] + f * up[k];
+    }
+    // L y = b (with the scaling), R x = y
+    std::vector<float> yv(n), b(n);
+    for (int i = 0; i < n; ++i) {
+        float sum = 0.0f;
+        if (i > 0) sum += lo[i] * yv[i - 1];
+        yv[i] = (rhs[i] * sd[i]) - sum;
+    }
+    for (int i = n - 1; i >= 0; --i) {
+        float sum = 0.0f;
+        if (i < n - 1) sum += up[i] * b[i + 1];
+        b[i] = (yv[i] - sum) / di[i];
+    }
+    std::vector<float> a(n, 0.0f), c(n, 0.0f);
+    for (int i = 0; i < n - 1; ++i) {
+        a[i] = (float)(1.0 / 3.0 * (double)(b[i + 1] - b[i]) / (double)(x[i + 1] - x[i]));
+        c[i] = (float)((double)((y[i + 1] - y[i]) / (x[i + 1] - x[i])) - 1.0 / 3.0 * (2.0 * (double)b[i] + (double)b[i + 1]) * (double)(x[i + 1] - x[i]));
+    }
+    sp.b0 = b[0]; sp.c0 = c[0];
+    const float h = x[n - 1] - x[n - 2];
+    a[n - 1] = 0.0f;
+    c[n - 1] = (float)(3.0 * (double)a[n - 2] * (double)h * (double)h + 2.0 * (double)b[n - 2] * (double)h + (double)c[n - 2]);
+    for (int i = 0; i < n; ++i) { sp.x[i] = x[i]; sp.y[i] = y[i]; sp.a[i] = a[i]; sp.b[i] = b[i]; sp.c[i] = c[i]; }
+}
+
 static void loadTyre(pdb_tyre& t, pdb_car_params& P, const std::string& dataPath, int index) {
     Ini ini(dataPath + "tyres.ini");
     if (!ini.ready) throw std::runtime_error("pdb: tyres.ini not found in " + dataPath);
@@ -71,8 +130,23 @@ static void loadTyre(pdb_tyre& t, pdb_car_params& P, const std::string& dataPath
         const float sp = ini.getFloat("ADDITIONAL1", "CAMBER_TEMP_SPREAD_K");
         if (sp != 0.0f) t.camberSpreadK = sp;
     }
-    if (ini.hasKey(sec, "DY_CURVE") || ini.hasKey(sec, "DX_CURVE") || ini.hasKey(sec, "DCAMBER_LUT"))
-        throw std::runtime_error("pdb: DY_CURVE/DX_CURVE/DCAMBER_LUT cubic-spline tyre paths unsupported this round");
+    // DY_CURVE / DX_CURVE / DCAMBER_LUT (Tyre.cpp:161-165,207-211): LUTs read through a natural cubic spline (Curve::getCubicSplineValue)
+    t.curveFlags = 0;
+    {
+        auto lutOf = [&](const char* key, pdb_spline& sp) {
+            pdb_curve cv; memset(&cv, 0, sizeof(cv));
+            const std::string v = ini.getString(sec, key);
+            if (v.find(".lut") != std::string::npos) curveLoad(cv, dataPath + v); else curveParseInline(cv, v);   // INIReader::getCurve (INIReader.cpp:232-253)
+            if (cv.n > 0) splineBuild(sp, cv);
+            return cv.n > 0;
+        };
+        if (ini.hasKey(sec, "DY_CURVE") && lutOf("DY_CURVE", t.dyLoadCurve)) t.curveFlags |= 1;
+        if (ini.hasKey(sec, "DX_CURVE") && lutOf("DX_CURVE", t.dxLoadCurve)) t.curveFlags |= 2;
+        if (ini.hasKey(sec, "DCAMBER_LUT") && lutOf("DCAMBER_LUT", t.dCamberCurve)) {
+            t.curveFlags |= 4;
+            if (ini.getInt(sec, "DCAMBER_LUT_SMOOTH") != 0) t.curveFlags |= 8;
+        }
+    }
     float width = ini.getFloat(sec, "WIDTH"); (void)width;
     t.radius = ini.getFloat(sec, "RADIUS");
     t.rimRadius = ini.getFloat(sec, "RIM_RADIUS");

@@ -48,6 +48,8 @@ class Collider(C.Structure):
     _fields_ = [(n, C.c_int32) for n in ('enabled', 'hasBox', 'numVerts', 'numTris')] + \
         [('boxCentre', C.c_float * 3), ('boxHalf', C.c_float * 3), ('boundsLo', C.c_float * 3), ('boundsHi', C.c_float * 3),
          ('verts', (C.c_float * 3) * 128), ('tris', (C.c_uint8 * 3) * 192)]
+class Spline(C.Structure):
+    _fields_ = [('n', C.c_int32), ('b0', C.c_float), ('c0', C.c_float), ('pad', C.c_int32)] + [(k, C.c_float * 16) for k in ('x', 'y', 'a', 'b', 'c')]
 class Tyre(C.Structure):
     _fields_ = [(n, C.c_float) for n in ('radius', 'rimRadius', 'k', 'd', 'angularInertia', 'thermalFrictionK', 'thermalRollingK', 'thermalRollingSurfaceK',
                                          'radiusRaiseK', 'softnessIndex', 'Fz0', 'modelFz0', 'relaxationLength', 'rr0', 'rr1', 'rr_slip', 'pressureRef', 'pressureSpringGain',
@@ -56,7 +58,7 @@ class Tyre(C.Structure):
         [(n, C.c_float) for n in ('lsMultY', 'lsExpY', 'lsMultX', 'lsExpX', 'maxSlip0', 'maxSlip1', 'asy', 'falloffSpeed', 'speedSensitivity', 'camberGain',
                                   'dcamber0', 'dcamber1', 'cfXmult', 'pressureCfGain', 'brakeDXMod', 'dCamberBlend', 'combinedFactor',
                                   'surfaceTransfer', 'patchTransfer', 'patchCoreTransfer', 'internalCoreTransfer', 'coolFactorGain', 'camberSpreadK')] + \
-        [('performanceCurve', Curve), ('wearCurve', Curve)]
+        [('performanceCurve', Curve), ('wearCurve', Curve), ('curveFlags', C.c_int32), ('curvePad', C.c_int32), ('dyLoadCurve', Spline), ('dxLoadCurve', Spline), ('dCamberCurve', Spline)]
 class Wing(C.Structure):
     _fields_ = [('position', C.c_float * 3), ('area', C.c_float), ('cdGain', C.c_float), ('clGain', C.c_float), ('yawGain', C.c_float), ('angle', C.c_float),
                 ('isVertical', C.c_int32), ('lutAOA_CL', Curve), ('lutAOA_CD', Curve)]
