@@ -163,6 +163,7 @@ typedef struct pdb_wing {
     float area, cdGain, clGain, yawGain, angle;
     int32_t isVertical;
     pdb_curve lutAOA_CL, lutAOA_CD;
+    pdb_curve lutGH_CL, lutGH_CD;   /* ground-effect factors over the wing's height above the plane of the tyres' contact points (Wing.cpp:134-139,181-186); n = 0: none */
 } pdb_wing;
 
 typedef struct pdb_scoring {
@@ -257,6 +258,7 @@ typedef struct pdb_car_params {
     int32_t ebbInternal;           /* brakes.ini has [EBB] */
     float ebbFrontMultiplier;      /* max(1.1, FRONT_SHARE_MULTIPLIER) */
     float overlapFreq, overlapGain, overlapIdealRPM;   /* [OVERLAP] (Engine.cpp:96-101,300-307): a torque ripple below / above the ideal rpm; gain 0 = off */
+    int32_t wingGroundEffect;      /* some wing carries LUT_GH_CL / LUT_GH_CD (Wing.cpp:38-44): the wings then step after the tyres, on this tick's contact points (Car::getPointGroundHeight) */
 } pdb_car_params;
 
 /* ---------------------------------------------------------------------------------------------
@@ -414,7 +416,7 @@ typedef struct pdb_ray_rec {
 }
 /* sizes are part of the ABI (tests/test_abi.py reads these numbers) */
 static_assert(sizeof(pdb_car_state) == 664, "pdb_car_state must equal the reference CarState (pack 4)");
-static_assert(sizeof(pdb_car_params) == 16680, "pdb_car_params layout");
+static_assert(sizeof(pdb_car_params) == 19040, "pdb_car_params layout");
 static_assert(sizeof(pdb_dyn_state) == 2272, "pdb_dyn_state layout (multiple of 16 bytes)");
 static_assert(sizeof(pdb_step_out) == 104, "pdb_step_out layout");
 static_assert(sizeof(pdb_contact) == 32, "pdb_contact layout");

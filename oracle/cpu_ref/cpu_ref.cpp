@@ -979,6 +979,7 @@ static void wingStep(Car& c, int wi) {
     {   // addDrag
         const float off = wg.isVertical ? ws.yawAngle : ws.aoa;
         ws.cd = curve(wg.lutAOA_CD, (1.0f * angle) + off) * wg.cdGain;
+        if (wg.lutGH_CD.n) ws.cd *= curve(wg.lutGH_CD, ws.groundHeight);   // Wing.cpp:134-139
         const float fDot = lv.sqlen();
         const float fDrag = (((fDot * ws.cd) * c.P->airDensity) * wg.area) * 0.5f;
         ws.dragKG = fDrag * 0.10197838f;
@@ -993,6 +994,7 @@ static void wingStep(Car& c, int wi) {
             const float v8 = (m_sinf(fabsf(ws.yawAngle) * 0.017453f) * wg.yawGain) + 1.0f;
             ws.cl *= tclamp(v8, 0.0f, 1.0f);
         }
+        if (wg.lutGH_CL.n) ws.cl *= curve(wg.lutGH_CL, ws.groundHeight);   // Wing.cpp:181-186
         const float fDot = (fAxis * fAxis) + (lv.z * lv.z);
         const float fLift = (((fDot * ws.cl) * c.P->airDensity) * wg.area) * 0.5f;
         ws.liftKG = fLift * 0.10197838f;

@@ -116,6 +116,33 @@ def make_curves_car(base, src='ks_toyota_ae86_drift', dst='pdb_curves_ae86'):
     open(p, 'w', newline='').write(eol.join(out))
 
 
+def make_ground_effect_car(base, src='dthwsh_mazda_rx7_fc3s_sr20', dst='pdb_gh_fc3s'):
+    """Wings whose lift and drag coefficients follow their height above the plane of the tyres' contact points (LUT_GH_CL / LUT_GH_CD, Wing.cpp:38-44,
+    134-139,181-186; Car::getPointGroundHeight, Car.cpp:1380-1405): every shipped car leaves the two keys empty.  The FC3S with LUTs on its front wing
+    (both), its body (lift only) and its rear wing (drag only) pins them -- over the mountain road, where pitch and roll move the heights about."""
+    s = os.path.join(REF, 'content', 'cars', src, 'data'); d = os.path.join(base, 'content', 'cars', dst, 'data')
+    if os.path.isdir(d):
+        shutil.rmtree(d)
+    shutil.copytree(s, d)
+    os.system('chmod -R u+w "%s"' % d)
+    open(os.path.join(d, 'pdb_gh_cl.lut'), 'w').write('-0.05|1.75\n0.0|1.62\n0.04|1.44\n0.08|1.3\n0.15|1.17\n0.25|1.08\n0.4|1.02\n0.8|1.0\n')
+    open(os.path.join(d, 'pdb_gh_cd.lut'), 'w').write('-0.05|1.3\n0.0|1.24\n0.06|1.15\n0.15|1.07\n0.3|1.02\n0.8|1.0\n')
+    p = os.path.join(d, 'aero.ini')
+    raw = open(p, newline='').read()
+    eol = '\r\n' if '\r\n' in raw else '\n'
+    want = {'[WING_1]': {'LUT_GH_CL': 'pdb_gh_cl.lut', 'LUT_GH_CD': 'pdb_gh_cd.lut'}, '[WING_0]': {'LUT_GH_CL': 'pdb_gh_cl.lut'}, '[WING_2]': {'LUT_GH_CD': 'pdb_gh_cd.lut'}}
+    out = []; sec = None
+    for line in raw.split(eol):
+        t = line.strip()
+        if t.startswith('['):
+            sec = t
+        k = t.split('=')[0]
+        if sec in want and k in want[sec]:
+            line = '%s=%s' % (k, want[sec][k])
+        out.append(line)
+    open(p, 'w', newline='').write(eol.join(out))
+
+
 def main():
     base = os.path.join(here, '_ref', 'base')
     os.makedirs(os.path.join(base, 'cfg'), exist_ok=True)
@@ -131,6 +158,7 @@ def main():
     make_fwd_car(base)
     make_cold_car(base)
     make_curves_car(base)
+    make_ground_effect_car(base)
     gen_track.gen_flat(os.path.join(base, 'content', 'tracks', 'flat'))
     gen_track.gen_touge(os.path.join(base, 'content', 'tracks', 'touge'))
     gen_track.gen_walled(os.path.join(base, 'content', 'tracks', 'walled'))

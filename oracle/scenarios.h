@@ -86,8 +86,10 @@ static const Scenario kScenarios[] = {
     // the tyre's LUT forms (DY_CURVE / DX_CURVE / DCAMBER_LUT through the cubic spline of Curve::getCubicSplineValue) on a derived car, driven
     // round the mountain road: loads from nothing to twice the static one, camber of both signs
     {"curves", 3000, 300, 10, 0, 1, 1, 1, "touge", 1, "pdb_curves_ae86", 0, 0, 0, 0, 0, 0, 0},
+    // wings with ground-effect LUTs (LUT_GH_CL / LUT_GH_CD over Car::getPointGroundHeight) on a derived car, round the mountain road
+    {"groundfx", 3000, 300, 10, 0, 1, 1, 1, "touge", 1, "pdb_gh_fc3s", 0, 0, 0, 0, 0, 0, 0},
 };
-static const int kNumScenarios = 40;
+static const int kNumScenarios = 41;
 static const float kTeleDist[4] = {0.13f, 0.41f, 0.77f, 0.95f};
 struct ScoreVar { const char* name; float value; };
 static const ScoreVar kScoringSetA[] = {

@@ -699,8 +699,9 @@ void buildCarModel(const std::string& basePathIn, const std::string& modelName, 
                 curveLoad(W.lutAOA_CL, dataPath + aero.getString(secn, "LUT_AOA_CL"));
                 curveLoad(W.lutAOA_CD, dataPath + aero.getString(secn, "LUT_AOA_CD"));
                 const std::string ghcl = aero.getString(secn, "LUT_GH_CL"), ghcd = aero.getString(secn, "LUT_GH_CD");
-                if ((!ghcl.empty() && fileExists(dataPath + ghcl)) || (!ghcd.empty() && fileExists(dataPath + ghcd)))
-                    throw std::runtime_error("pdb: wing ground-effect LUTs unsupported this round");
+                if (!ghcl.empty() && fileExists(dataPath + ghcl)) curveLoad(W.lutGH_CL, dataPath + ghcl);   // Wing.cpp:38-44: loaded when the file is there
+                if (!ghcd.empty() && fileExists(dataPath + ghcd)) curveLoad(W.lutGH_CD, dataPath + ghcd);
+                if (W.lutGH_CL.n > 0 || W.lutGH_CD.n > 0) P.wingGroundEffect = 1;
                 W.cdGain = aero.getFloat(secn, "CD_GAIN");
                 W.clGain = aero.getFloat(secn, "CL_GAIN");
                 W.angle = aero.getFloat(secn, "ANGLE");
