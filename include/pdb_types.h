@@ -259,6 +259,9 @@ typedef struct pdb_car_params {
     float ebbFrontMultiplier;      /* max(1.1, FRONT_SHARE_MULTIPLIER) */
     float overlapFreq, overlapGain, overlapIdealRPM;   /* [OVERLAP] (Engine.cpp:96-101,300-307): a torque ripple below / above the ideal rpm; gain 0 = off */
     int32_t wingGroundEffect;      /* some wing carries LUT_GH_CL / LUT_GH_CD (Wing.cpp:38-44): the wings then step after the tyres, on this tick's contact points (Car::getPointGroundHeight) */
+    /* aero.ini without [WING_n] / [FIN_n]: AeroMap's own drag and lift from [DATA] (AeroMap.cpp:49-58,90-139); CDA is the class default 0.1, the lift acts
+     * at the base positions of suspensions 0 and 2 (Car.cpp:176-178) */
+    float aeroReferenceArea, aeroFrontShare, aeroCD, aeroCL, aeroCDX, aeroCDY, aeroCDA;
 } pdb_car_params;
 
 /* ---------------------------------------------------------------------------------------------
@@ -416,7 +419,7 @@ typedef struct pdb_ray_rec {
 }
 /* sizes are part of the ABI (tests/test_abi.py reads these numbers) */
 static_assert(sizeof(pdb_car_state) == 664, "pdb_car_state must equal the reference CarState (pack 4)");
-static_assert(sizeof(pdb_car_params) == 19040, "pdb_car_params layout");
+static_assert(sizeof(pdb_car_params) == 19064, "pdb_car_params layout");
 static_assert(sizeof(pdb_dyn_state) == 2272, "pdb_dyn_state layout (multiple of 16 bytes)");
 static_assert(sizeof(pdb_step_out) == 104, "pdb_step_out layout");
 static_assert(sizeof(pdb_contact) == 32, "pdb_contact layout");

@@ -944,6 +944,43 @@ static void tyreStep(Car& c, int i, float dt) {
 // ------------------------------------------------------------------------------------------------
 struct Plane { V3 normal; float d; Plane(const V3& p1, const V3& p2, const V3& p3) { const V3 a = p3 - p1, b = p2 - p1; normal = a.cross(b); d = -(p1 * normal); } };
 
+// AeroMap::addDrag / addLift (AeroMap.cpp:99-139)
+static void aeroDataStep(Car& c) {
+    const pdb_car_params& P = *c.P;
+    Body& body = c.w.bodies[PDB_BODY_CHASSIS];
+    const V3 lv = w2lN(body, getVelocity(body));
+    {
+        float fDot = lv.sqlen();
+        if (fDot != 0.0f) {
+            V3 vNorm = lv / sqrtf(fDot);
+            const float dynamicCD = (((fabsf(vNorm.x) * P.aeroCD) * P.aeroCDX) + P.aeroCD) + ((fabsf(vNorm.y) * P.aeroCD) * P.aeroCDY);
+            const float fDrag = ((dynamicCD * fDot) * P.airDensity) * P.aeroReferenceArea;
+            const V3 f = vNorm * -(fDrag * 0.5f);
+            const float zero[3] = {0, 0, 0};
+            body.addRelForceAtRelPos(&f.x, zero);
+            const V3 vAngVel(body.avel);
+            fDot = vAngVel.sqlen();
+            if (fDot != 0.0f) {
+                vNorm = vAngVel / sqrtf(fDot);
+                const V3 t = vNorm * -(fDot * P.aeroCDA);
+                body.addRelTorque(&t.x);
+            }
+        }
+    }
+    {
+        const float fZZ = lv.z * lv.z;
+        if (fZZ != 0.0f) {
+            const float fLift = (((fZZ * P.aeroCL) * P.airDensity) * P.aeroReferenceArea) * 0.5f;
+            const float fFrontLift = fLift * P.aeroFrontShare;
+            const V3 ff(0, -fFrontLift, 0);
+            body.addRelForceAtRelPos(&ff.x, P.susp[0].basePosition);
+            const float fRearLift = fLift * (1.0f - P.aeroFrontShare);
+            const V3 fr(0, -fRearLift, 0);
+            body.addRelForceAtRelPos(&fr.x, P.susp[2].basePosition);
+        }
+    }
+}
+
 static void wingStep(Car& c, int wi) {
     const pdb_car_params& P = *c.P;
     const pdb_wing& wg = P.wings[wi];
@@ -1478,6 +1515,7 @@ void Car::carStep(float dt) {
     }
     for (int i = 0; i < 4; ++i) tyreStep(*this, i, dt);
     for (int a = 0; a < 2; ++a) if (Pm.heave[a].k != 0.0f) heaveStep(Pm, Pm.heave[a], w, a * 2);   // Car.cpp:654-658
+    if (Pm.numWings == 0) aeroDataStep(*this);   // AeroMap::step (AeroMap.cpp:85-97): the map's own drag and lift when there are no wings
     for (int wi = 0; wi < Pm.numWings; ++wi) wingStep(*this, wi);
     {   // SteeringSystem::step (SteeringSystem.cpp:17-24) -> setSteerLengthOffset (SuspensionStrut.cpp:340-350)
         const float steer = -finalSteerAngleSignal * Pm.steerLinearRatio;

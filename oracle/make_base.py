@@ -143,6 +143,17 @@ def make_ground_effect_car(base, src='dthwsh_mazda_rx7_fc3s_sr20', dst='pdb_gh_f
     open(p, 'w', newline='').write(eol.join(out))
 
 
+def make_aerodata_car(base, src='ks_toyota_ae86_drift', dst='pdb_aerodata_ae86'):
+    """An aero.ini without wings: AeroMap's own drag (with its yaw / pitch sensitivities and the angular drag) and lift from [DATA]
+    (AeroMap.cpp:49-58,85-139) -- every shipped car has [WING_n] sections instead.  The AE86 with its aero.ini replaced pins the path."""
+    s = os.path.join(REF, 'content', 'cars', src, 'data'); d = os.path.join(base, 'content', 'cars', dst, 'data')
+    if os.path.isdir(d):
+        shutil.rmtree(d)
+    shutil.copytree(s, d)
+    os.system('chmod -R u+w "%s"' % d)
+    open(os.path.join(d, 'aero.ini'), 'w', newline='').write('\r\n'.join(['[HEADER]', 'VERSION=2', '', '[DATA]', 'REFERENCE_AREA=1.9', 'FRONT_SHARE=0.42', 'CD=0.36', 'CL=0.14', 'CDX=0.35', 'CDY=0.8', '']))
+
+
 def main():
     base = os.path.join(here, '_ref', 'base')
     os.makedirs(os.path.join(base, 'cfg'), exist_ok=True)
@@ -159,6 +170,7 @@ def main():
     make_cold_car(base)
     make_curves_car(base)
     make_ground_effect_car(base)
+    make_aerodata_car(base)
     gen_track.gen_flat(os.path.join(base, 'content', 'tracks', 'flat'))
     gen_track.gen_touge(os.path.join(base, 'content', 'tracks', 'touge'))
     gen_track.gen_walled(os.path.join(base, 'content', 'tracks', 'walled'))

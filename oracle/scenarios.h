@@ -88,8 +88,10 @@ static const Scenario kScenarios[] = {
     {"curves", 3000, 300, 10, 0, 1, 1, 1, "touge", 1, "pdb_curves_ae86", 0, 0, 0, 0, 0, 0, 0},
     // wings with ground-effect LUTs (LUT_GH_CL / LUT_GH_CD over Car::getPointGroundHeight) on a derived car, round the mountain road
     {"groundfx", 3000, 300, 10, 0, 1, 1, 1, "touge", 1, "pdb_gh_fc3s", 0, 0, 0, 0, 0, 0, 0},
+    // an aero.ini without wings: AeroMap's own drag and lift from [DATA] (derived car), round the mountain road
+    {"aerodata", 3000, 300, 10, 0, 1, 1, 1, "touge", 1, "pdb_aerodata_ae86", 0, 0, 0, 0, 0, 0, 0},
 };
-static const int kNumScenarios = 41;
+static const int kNumScenarios = 42;
 static const float kTeleDist[4] = {0.13f, 0.41f, 0.77f, 0.95f};
 struct ScoreVar { const char* name; float value; };
 static const ScoreVar kScoringSetA[] = {

@@ -707,7 +707,12 @@ void buildCarModel(const std::string& basePathIn, const std::string& modelName, 
                 W.angle = aero.getFloat(secn, "ANGLE");
                 if (aver >= 3) W.yawGain = aero.getFloat(secn, "YAW_CL_GAIN");
             }
-        if (n == 0) throw std::runtime_error("pdb: cars without [WING_n] (AeroMap [DATA] path) unsupported this round");
+        P.aeroReferenceArea = 1.0f; P.aeroFrontShare = 0.5f; P.aeroCD = 0.0f; P.aeroCL = 0.0f; P.aeroCDX = 0.0f; P.aeroCDY = 0.0f; P.aeroCDA = 0.1f;   // AeroMap.h:20-26
+        if (n == 0) {   // AeroMap.cpp:49-58: no wings at all -> the map's own coefficients
+            if (!aero.hasSection("DATA")) throw std::runtime_error("pdb: aero.ini has neither [WING_n] / [FIN_n] nor [DATA]");
+            P.aeroReferenceArea = aero.getFloat("DATA", "REFERENCE_AREA"); P.aeroFrontShare = aero.getFloat("DATA", "FRONT_SHARE");
+            P.aeroCD = aero.getFloat("DATA", "CD"); P.aeroCL = aero.getFloat("DATA", "CL"); P.aeroCDX = aero.getFloat("DATA", "CDX"); P.aeroCDY = aero.getFloat("DATA", "CDY");
+        }
         if (aero.hasSection("DYNAMIC_CONTROLLER_0")) throw std::runtime_error("pdb: wing dynamic controllers unsupported this round");
         P.numWings = n;
     }
