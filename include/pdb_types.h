@@ -34,6 +34,7 @@ typedef struct pdb_curve {
     float y[PDB_MAX_CURVE];
 } pdb_curve;
 
+#define PDB_MAX_WING_CTRL 4
 /* natural cubic spline through a LUT's points (Core/Curve.cpp:117-126 getCubicSplineValue -> Core/CubicSpline.cpp -> the tk::spline header the
  * reference vendors, float arithmetic): f(x) = ((a_i h + b_i) h + c_i) h + y_i, h = x - x_i, i = the last point below x; quadratic continuation
  * outside the points (left: b0, c0; right: b_{n-1}, c_{n-1}).  The coefficients are worked out once, by the loader.  n = 0: no curve. */
@@ -166,6 +167,15 @@ typedef struct pdb_wing {
     pdb_curve lutGH_CL, lutGH_CD;   /* ground-effect factors over the wing's height above the plane of the tyres' contact points (Wing.cpp:134-139,181-186); n = 0: none */
 } pdb_wing;
 
+typedef struct pdb_wing_ctrl {
+    int32_t wing;         /* index into wings[] (WING_n first, then FIN_n, as AeroMap builds its list) */
+    int32_t input;        /* WingControllerVariable: 1 BRAKE, 2 GAS, 3 LATG, 4 LONG, 5 STEER, 6 SPEED_KMH */
+    int32_t combinator;   /* 1 ADD, 2 MULT */
+    float filter;         /* ((1 - FILTER) * 1.3333334) * 333.33334 */
+    float upLimit, downLimit;
+    pdb_curve lut;
+} pdb_wing_ctrl;
+
 typedef struct pdb_scoring {
     float SmoothSteerSpeed, MinBonusSpeed, MaxBonusSpeed, StallRpm, DirectionThreshold, OutOfTrackThreshold,
         ApproachDistance, CriticalDistance, TravelBonus, TravelSplineBonus, DriftBonus, SpeedBonus, ThrottleBonus,
@@ -262,6 +272,10 @@ typedef struct pdb_car_params {
     /* aero.ini without [WING_n] / [FIN_n]: AeroMap's own drag and lift from [DATA] (AeroMap.cpp:49-58,90-139); CDA is the class default 0.1, the lift acts
      * at the base positions of suspensions 0 and 2 (Car.cpp:176-178) */
     float aeroReferenceArea, aeroFrontShare, aeroCD, aeroCL, aeroCDX, aeroCDY, aeroCDA;
+    /* aero.ini [DYNAMIC_CONTROLLER_n] (AeroMap.cpp:66-82, Car/WingDynamicController.cpp): a wing's angle = its ANGLE combined, controller by controller in
+     * section order, with a filtered LUT of a car signal and clamped to the controller's limits (Wing.cpp:105-124) */
+    int32_t numWingCtrl;
+    pdb_wing_ctrl wingCtrl[PDB_MAX_WING_CTRL];
 } pdb_car_params;
 
 /* ---------------------------------------------------------------------------------------------
@@ -321,6 +335,7 @@ typedef struct pdb_dyn_state {
                               * projectd_env.py:216-227); 2 = reset tick whose teleport the caller has already done */
     int32_t envStepId;       /* env mode: ticks since the episode's reset tick (projectd_env.py step_id) */
     int32_t _pad[1];         /* record size is a multiple of 16 bytes (coalesced 16-byte-per-lane copies) */
+    float wingCtrlOut[PDB_MAX_WING_CTRL];   /* WingDynamicController::outputAngle of the car's wing controllers (never reset: it outlives Car::reset, as in the reference) */
 } pdb_dyn_state;
 
 /* One contact joint between the chassis and the static world (what PhysicsEngineODE::onCollision hands to
@@ -419,8 +434,8 @@ typedef struct pdb_ray_rec {
 }
 /* sizes are part of the ABI (tests/test_abi.py reads these numbers) */
 static_assert(sizeof(pdb_car_state) == 664, "pdb_car_state must equal the reference CarState (pack 4)");
-static_assert(sizeof(pdb_car_params) == 19064, "pdb_car_params layout");
-static_assert(sizeof(pdb_dyn_state) == 2272, "pdb_dyn_state layout (multiple of 16 bytes)");
+static_assert(sizeof(pdb_car_params) == 19952, "pdb_car_params layout");
+static_assert(sizeof(pdb_dyn_state) == 2288, "pdb_dyn_state layout (multiple of 16 bytes)");
 static_assert(sizeof(pdb_step_out) == 104, "pdb_step_out layout");
 static_assert(sizeof(pdb_contact) == 32, "pdb_contact layout");
 static_assert(sizeof(pdb_ray_rec) == 48, "pdb_ray_rec layout");

@@ -944,6 +944,7 @@ static void tyreStep(Car& c, int i, float dt) {
 // ------------------------------------------------------------------------------------------------
 struct Plane { V3 normal; float d; Plane(const V3& p1, const V3& p2, const V3& p3) { const V3 a = p3 - p1, b = p2 - p1; normal = a.cross(b); d = -(p1 * normal); } };
 
+static inline float kmhOfSpeed(float ms) { return ms * 3.6f; }   // Speed::kmh
 // AeroMap::addDrag / addLift (AeroMap.cpp:99-139)
 static void aeroDataStep(Car& c) {
     const pdb_car_params& P = *c.P;
@@ -1008,7 +1009,27 @@ static void wingStep(Car& c, int wi) {
         if (dot2 != 0.0f) y2 = pt.y + ((pt * pl2.normal + pl2.d) / dot2);
         ws.groundHeight = ((pt.y - y2) + (pt.y - y1)) * 0.5f;
     }
-    const float angle = wg.angle;
+    // Wing::stepDynamicControllers (Wing.cpp:105-124) + WingDynamicController::step (WingDynamicController.cpp:64-75)
+    float angle = wg.angle;
+    for (int j = 0; j < P.numWingCtrl; ++j) {
+        const pdb_wing_ctrl& wc = P.wingCtrl[j];
+        if (wc.wing != wi) continue;
+        float in = 0.0f;
+        switch (wc.input) {
+            case 1: in = c.controls.brake; break;
+            case 2: in = c.controls.gas; break;
+            case 3: in = c.accG[0]; break;
+            case 4: in = c.accG[2]; break;
+            case 5: in = c.controls.steer; break;
+            case 6: in = kmhOfSpeed(c.S.speed); break;
+        }
+        float fAngle = curve(wc.lut, in);
+        const float out = c.S.wingCtrlOut[j];
+        if (fabsf(fAngle - out) >= 0.001f) fAngle = out + (fAngle - out) * tclamp(wc.filter * 0.003f, 0.0f, 1.0f);
+        c.S.wingCtrlOut[j] = fAngle;
+        if (wc.combinator == 1) angle += fAngle; else if (wc.combinator == 2) angle *= fAngle;
+        angle = tclamp(angle, wc.downLimit, wc.upLimit);
+    }
     if (vLocalVel.z == 0.0f) { ws.aoa = 0; ws.yawAngle = 0; ws.cd = 0; ws.cl = 0; return; }
     ws.aoa = m_atanf((1.0f / vLocalVel.z) * vLocalVel.y) * 57.29578f;
     ws.yawAngle = m_atanf((1.0f / vLocalVel.z) * vLocalVel.x) * 57.29578f;

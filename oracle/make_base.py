@@ -154,6 +154,29 @@ def make_aerodata_car(base, src='ks_toyota_ae86_drift', dst='pdb_aerodata_ae86')
     open(os.path.join(d, 'aero.ini'), 'w', newline='').write('\r\n'.join(['[HEADER]', 'VERSION=2', '', '[DATA]', 'REFERENCE_AREA=1.9', 'FRONT_SHARE=0.42', 'CD=0.36', 'CL=0.14', 'CDX=0.35', 'CDY=0.8', '']))
 
 
+def make_wingctrl_car(base, src='dthwsh_mazda_rx7_fc3s_sr20', dst='pdb_wingctrl_fc3s'):
+    """Wing dynamic controllers (aero.ini [DYNAMIC_CONTROLLER_n], AeroMap.cpp:66-82, Car/WingDynamicController.cpp, Wing.cpp:105-124): no shipped car has them.
+    The FC3S with four: the rear wing's angle rising with speed and, on top, with the brake pedal (an air brake); the front wing's scaled down with
+    lateral g; the body's nudged by the throttle -- ADD and MULT, filters, limits that bind."""
+    s = os.path.join(REF, 'content', 'cars', src, 'data'); d = os.path.join(base, 'content', 'cars', dst, 'data')
+    if os.path.isdir(d):
+        shutil.rmtree(d)
+    shutil.copytree(s, d)
+    os.system('chmod -R u+w "%s"' % d)
+    open(os.path.join(d, 'pdb_wc_speed.lut'), 'w').write('0|0\n40|1.5\n90|5\n150|9\n220|12\n')
+    open(os.path.join(d, 'pdb_wc_brake.lut'), 'w').write('0|0\n0.2|4\n1|22\n')
+    open(os.path.join(d, 'pdb_wc_latg.lut'), 'w').write('-2|0.55\n-0.5|0.9\n0|1\n0.5|0.9\n2|0.55\n')
+    open(os.path.join(d, 'pdb_wc_gas.lut'), 'w').write('0|-1\n0.5|0\n1|1.5\n')
+    p = os.path.join(d, 'aero.ini')
+    raw = open(p, newline='').read()
+    eol = '\r\n' if '\r\n' in raw else '\n'
+    extra = []
+    for i, (wing, inp, comb, lutf, filt, up, dn) in enumerate(((2, 'SPEED_KMH', 'ADD', 'pdb_wc_speed.lut', 0.97, 16, 0), (2, 'BRAKE', 'ADD', 'pdb_wc_brake.lut', 0.9, 30, 0),
+                                                                 (1, 'LATG', 'MULT', 'pdb_wc_latg.lut', 0.8, 10, -10), (0, 'GAS', 'ADD', 'pdb_wc_gas.lut', 0.5, 3, -0.5))):
+        extra += ['', '[DYNAMIC_CONTROLLER_%d]' % i, 'WING=%d' % wing, 'COMBINATOR=%s' % comb, 'INPUT=%s' % inp, 'LUT=%s' % lutf, 'FILTER=%g' % filt, 'UP_LIMIT=%g' % up, 'DOWN_LIMIT=%g' % dn]
+    open(p, 'w', newline='').write(raw.rstrip('\r\n') + eol + eol.join(extra) + eol)
+
+
 def main():
     base = os.path.join(here, '_ref', 'base')
     os.makedirs(os.path.join(base, 'cfg'), exist_ok=True)
@@ -171,6 +194,7 @@ def main():
     make_curves_car(base)
     make_ground_effect_car(base)
     make_aerodata_car(base)
+    make_wingctrl_car(base)
     gen_track.gen_flat(os.path.join(base, 'content', 'tracks', 'flat'))
     gen_track.gen_touge(os.path.join(base, 'content', 'tracks', 'touge'))
     gen_track.gen_walled(os.path.join(base, 'content', 'tracks', 'walled'))

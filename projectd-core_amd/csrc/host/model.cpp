@@ -713,7 +713,28 @@ void buildCarModel(const std::string& basePathIn, const std::string& modelName, 
             P.aeroReferenceArea = aero.getFloat("DATA", "REFERENCE_AREA"); P.aeroFrontShare = aero.getFloat("DATA", "FRONT_SHARE");
             P.aeroCD = aero.getFloat("DATA", "CD"); P.aeroCL = aero.getFloat("DATA", "CL"); P.aeroCDX = aero.getFloat("DATA", "CDX"); P.aeroCDY = aero.getFloat("DATA", "CDY");
         }
-        if (aero.hasSection("DYNAMIC_CONTROLLER_0")) throw std::runtime_error("pdb: wing dynamic controllers unsupported this round");
+        // [DYNAMIC_CONTROLLER_n] (AeroMap.cpp:66-82; WingDynamicController::init): a filtered LUT of a car signal added to / multiplied into a wing's angle
+        P.numWingCtrl = 0;
+        for (int id = 0;; ++id) {
+            char secn[40]; snprintf(secn, sizeof(secn), "DYNAMIC_CONTROLLER_%d", id);
+            if (!aero.hasSection(secn)) break;
+            const int iWing = aero.getInt(secn, "WING");
+            if (iWing < 0 || iWing >= n) continue;   // (the reference warns and goes on)
+            if (P.numWingCtrl >= PDB_MAX_WING_CTRL) throw std::runtime_error("pdb: more than " + std::to_string(PDB_MAX_WING_CTRL) + " wing dynamic controllers");
+            pdb_wing_ctrl& wc = P.wingCtrl[P.numWingCtrl++];
+            memset(&wc, 0, sizeof(wc));
+            wc.wing = iWing;
+            static const char* inputs[] = {"", "BRAKE", "GAS", "LATG", "LONG", "STEER", "SPEED_KMH", "SUS_TRAVEL_LR", "SUS_TRAVEL_RR"};
+            const std::string in = aero.getString(secn, "INPUT"), comb = aero.getString(secn, "COMBINATOR");
+            for (int k = 1; k <= 8; ++k) if (in == inputs[k]) wc.input = k;
+            wc.combinator = comb == "ADD" ? 1 : comb == "MULT" ? 2 : 0;
+            if (wc.input == 0 || wc.combinator == 0) throw std::runtime_error(std::string("pdb: ") + secn + ": unknown INPUT / COMBINATOR (the reference stops at its first step)");
+            if (wc.input >= 7) throw std::runtime_error(std::string("pdb: ") + secn + ": suspension-travel inputs of wing controllers unsupported");
+            curveLoad(wc.lut, dataPath + aero.getString(secn, "LUT"));
+            wc.filter = ((1.0f - aero.getFloat(secn, "FILTER")) * 1.3333334f) * 333.33334f;
+            wc.upLimit = aero.getFloat(secn, "UP_LIMIT");
+            wc.downLimit = aero.getFloat(secn, "DOWN_LIMIT");
+        }
         P.numWings = n;
     }
 
