@@ -35,6 +35,7 @@ typedef struct pdb_curve {
 } pdb_curve;
 
 #define PDB_MAX_WING_CTRL 4
+#define PDB_MAX_CTRL_STAGES 8
 /* natural cubic spline through a LUT's points (Core/Curve.cpp:117-126 getCubicSplineValue -> Core/CubicSpline.cpp -> the tk::spline header the
  * reference vendors, float arithmetic): f(x) = ((a_i h + b_i) h + c_i) h + y_i, h = x - x_i, i = the last point below x; quadratic continuation
  * outside the points (left: b0, c0; right: b_{n-1}, c_{n-1}).  The coefficients are worked out once, by the loader.  n = 0: no curve. */
@@ -176,6 +177,18 @@ typedef struct pdb_wing_ctrl {
     pdb_curve lut;
 } pdb_wing_ctrl;
 
+/* DynamicController (Car/DynamicController.cpp): a chain of stages, each a LUT of a car signal (or a constant) through a first-order filter, added to or
+ * multiplied into the running result and clamped when the stage has limits.  The car's controllers share the stage table; a stage's filtered value is a
+ * word of the record (pdb_dyn_state.ctrlValue). */
+typedef struct pdb_ctrl_stage {
+    int32_t input;        /* 1 BRAKE, 2 GAS, 3 LATG, 4 LONG, 5 STEER, 6 SPEED_KMH, 7 GEAR, 8 RPMS, 9 CONST */
+    int32_t combinator;   /* 1 ADD, 2 MULT */
+    float filter;         /* lagToLerpDeltaK(FILTER, 0.004, 0.003) */
+    float upLimit, downLimit, constValue;
+    pdb_curve lut;
+} pdb_ctrl_stage;
+typedef struct pdb_dyn_ctrl { int32_t first, count; } pdb_dyn_ctrl;   /* stages [first, first + count); count 0 = no controller */
+
 typedef struct pdb_scoring {
     float SmoothSteerSpeed, MinBonusSpeed, MaxBonusSpeed, StallRpm, DirectionThreshold, OutOfTrackThreshold,
         ApproachDistance, CriticalDistance, TravelBonus, TravelSplineBonus, DriftBonus, SpeedBonus, ThrottleBonus,
@@ -276,6 +289,11 @@ typedef struct pdb_car_params {
      * section order, with a filtered LUT of a car signal and clamped to the controller's limits (Wing.cpp:105-124) */
     int32_t numWingCtrl;
     pdb_wing_ctrl wingCtrl[PDB_MAX_WING_CTRL];
+    /* ctrl_single_lock.ini (Drivetrain.cpp:144-151,603-607: the differential's preload, power ramp 0), ctrl_turbo<n>.ini / ctrl_wastegate<n>.ini
+     * (Engine.cpp:124-143,368-376: a turbo's maxBoost / wastegate) */
+    pdb_dyn_ctrl ctrlDiffLock, ctrlTurboBoost[PDB_MAX_TURBOS], ctrlWastegate[PDB_MAX_TURBOS];
+    int32_t numCtrlStages, _padCtrl;
+    pdb_ctrl_stage ctrlStages[PDB_MAX_CTRL_STAGES];
 } pdb_car_params;
 
 /* ---------------------------------------------------------------------------------------------
@@ -335,6 +353,7 @@ typedef struct pdb_dyn_state {
                               * projectd_env.py:216-227); 2 = reset tick whose teleport the caller has already done */
     int32_t envStepId;       /* env mode: ticks since the episode's reset tick (projectd_env.py step_id) */
     int32_t _pad[1];         /* record size is a multiple of 16 bytes (coalesced 16-byte-per-lane copies) */
+    float ctrlValue[PDB_MAX_CTRL_STAGES];   /* DynamicControllerStage::currentValue of the car's controller stages (never reset, as in the reference) */
     float wingCtrlOut[PDB_MAX_WING_CTRL];   /* WingDynamicController::outputAngle of the car's wing controllers (never reset: it outlives Car::reset, as in the reference) */
 } pdb_dyn_state;
 
@@ -434,8 +453,8 @@ typedef struct pdb_ray_rec {
 }
 /* sizes are part of the ABI (tests/test_abi.py reads these numbers) */
 static_assert(sizeof(pdb_car_state) == 664, "pdb_car_state must equal the reference CarState (pack 4)");
-static_assert(sizeof(pdb_car_params) == 19952, "pdb_car_params layout");
-static_assert(sizeof(pdb_dyn_state) == 2288, "pdb_dyn_state layout (multiple of 16 bytes)");
+static_assert(sizeof(pdb_car_params) == 21776, "pdb_car_params layout");
+static_assert(sizeof(pdb_dyn_state) == 2320, "pdb_dyn_state layout (multiple of 16 bytes)");
 static_assert(sizeof(pdb_step_out) == 104, "pdb_step_out layout");
 static_assert(sizeof(pdb_contact) == 32, "pdb_contact layout");
 static_assert(sizeof(pdb_ray_rec) == 48, "pdb_ray_rec layout");

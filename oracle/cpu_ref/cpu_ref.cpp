@@ -1151,6 +1151,41 @@ static void autoClutchStep(Car& c, float dt) {
 }
 
 // Engine::step (Engine.cpp:193-342) -- no turbos, no coast generators, no overlap
+// DynamicController::eval / getInput (Car/DynamicController.cpp:117-166,168-255; the inputs the loader admits)
+static float dynCtrlEval(Car& c, const pdb_dyn_ctrl& dc) {
+    const pdb_car_params& P = *c.P;
+    pdb_dyn_state& S = c.S;
+    float fRes = 0;
+    for (int k = dc.first; k < dc.first + dc.count; ++k) {
+        const pdb_ctrl_stage& st = P.ctrlStages[k];
+        const float fCurValue = S.ctrlValue[k];
+        float fNewValue = 0;
+        if (st.input == 9) fNewValue = st.constValue;
+        else {
+            float in = 0.0f;
+            switch (st.input) {
+                case 1: in = c.controls.brake; break;
+                case 2: in = c.controls.gas; break;
+                case 3: in = c.accG[0]; break;
+                case 4: in = c.accG[2]; break;
+                case 5: in = c.controls.steer; break;
+                case 6: in = kmh(S.speed); break;
+                case 7: in = (float)(S.currentGear - 1); break;
+                case 8: in = engineRpm(c); break;
+            }
+            fNewValue = curve(st.lut, in);
+        }
+        if (fabsf(fNewValue - fCurValue) >= 0.001f) {
+            const float fFilter = tclamp(st.filter * 0.003f, 0.0f, 1.0f);
+            fNewValue = ((fNewValue - fCurValue) * fFilter) + fCurValue;
+        }
+        S.ctrlValue[k] = fNewValue;
+        if (st.combinator == 1) fRes += fNewValue; else fRes *= fNewValue;
+        if (st.downLimit != 0.0f || st.upLimit != 0.0f) fRes = tclamp(fRes, st.downLimit, st.upLimit);
+    }
+    return fRes;
+}
+
 static void engineStep(Car& c, float gasInput, float rpm) {
     const pdb_car_params& P = *c.P;
     pdb_dyn_state& S = c.S;
@@ -1183,7 +1218,10 @@ static void engineStep(Car& c, float gasInput, float rpm) {
     // stepTurbos (Engine.cpp:368-384) -> Turbo::step (Turbo.cpp:11-38) with the fixed 0.003 s step of the reference
     float turboBoost = 0;
     for (int t = 0; t < P.numTurbos; ++t) {
-        const pdb_turbo& tb = P.turbos[t];
+        pdb_turbo tb = P.turbos[t];
+        // Engine::stepTurbos' controllers (Engine.cpp:370-376): the turbo's maxBoost / wastegate of this tick
+        if (P.ctrlTurboBoost[t].count) tb.maxBoost = dynCtrlEval(c, P.ctrlTurboBoost[t]);
+        if (P.ctrlWastegate[t].count) tb.wastegate = dynCtrlEval(c, P.ctrlWastegate[t]);
         float rot = S.turboRotation[t];
         float fNewRotation = 0, fLag;
         if (rpm > 0.0f && fGas > 0.0f) fNewRotation = m_powf(tclamp(((fGas * rpm) / tb.rpmRef), 0.0f, 1.0f), tb.gamma);
@@ -1249,6 +1287,9 @@ static void drivetrainStep(Car& c, float dt) {
     c.locClutch = m_powf(c.controls.clutch, 1.5f);
     S.locClutch = (float)c.locClutch;   // exact: the value is a float
     c.currentClutchTorque = 0;
+    // Drivetrain::stepControllers (Drivetrain.cpp:587-608): ctrl_single_lock.ini drives the differential's preload, the power ramp is then 0
+    double diffPreLoad = P.diffPreLoad, diffPowerRamp = P.diffPowerRamp;
+    if (P.ctrlDiffLock.count) { diffPreLoad = dynCtrlEval(c, P.ctrlDiffLock); diffPowerRamp = 0; }
     // step2WD
     const int gr = S.gearReqRequest - 1;
     if ((!gr || gr == 1) && (S.gearReqTimeout < S.gearReqTimeAccumulator)) { S.currentGear = S.gearReqRequestedGear; S.gearReqRequest = 0; }
@@ -1322,8 +1363,8 @@ static void drivetrainStep(Car& c, float dt) {
         double fOutClutchTorq, fDiffLoad;
         if (fClutchTorq != 0.0) fOutClutchTorq = -fClutchTorq; else fOutClutchTorq = c.locClutch * outTorque;
         if (fOutClutchTorq <= 0.0) fDiffLoad = fabs(c.ratio * P.diffCoastRamp * fOutClutchTorq);
-        else fDiffLoad = fabs(c.ratio) * (P.diffPowerRamp * fOutClutchTorq);
-        const double fDiffTotalLoad = fDiffLoad + P.diffPreLoad;
+        else fDiffLoad = fabs(c.ratio) * (diffPowerRamp * fOutClutchTorq);
+        const double fDiffTotalLoad = fDiffLoad + diffPreLoad;
         if (fabs(S.outShaftLVel - S.driveVel) >= 0.1 || fabs(SR.feedbackTorque - SL.feedbackTorque) > fDiffTotalLoad) {
             const double fUnk1 = -((S.outShaftLVel - S.outShaftRVel) / (fabs(S.outShaftLVel - S.outShaftRVel) + 0.01) * fDiffTotalLoad);
             const double fDeltaV1 = dt * (fUnk1 / P.outShaftInertiaL * 0.5);

@@ -177,6 +177,44 @@ def make_wingctrl_car(base, src='dthwsh_mazda_rx7_fc3s_sr20', dst='pdb_wingctrl_
     open(p, 'w', newline='').write(raw.rstrip('\r\n') + eol + eol.join(extra) + eol)
 
 
+def make_dynctrl_car(base, src='ks_toyota_supra_mkiv_drift', dst='pdb_dynctrl_supra'):
+    """DynamicController files (Car/DynamicController.cpp) -- chains of filtered LUT stages over car signals: ctrl_wastegate0.ini (the first turbo's
+    wastegate from rpm, scaled by gear; Engine.cpp:124-143,368-376), ctrl_turbo1.ini (the second turbo's maxBoost: a constant scaled by the throttle),
+    ctrl_single_lock.ini (the differential's preload from speed and brake, the power ramp then 0; Drivetrain.cpp:144-151,603-607).  No shipped
+    car has any of them; the Supra with all three pins the evaluator and its three consumers."""
+    s = os.path.join(REF, 'content', 'cars', src, 'data'); d = os.path.join(base, 'content', 'cars', dst, 'data')
+    if os.path.isdir(d):
+        shutil.rmtree(d)
+    shutil.copytree(s, d)
+    os.system('chmod -R u+w "%s"' % d)
+    def ctrl(name, stages):
+        out = []
+        for i, st in enumerate(stages):
+            out += ['[CONTROLLER_%d]' % i] + ['%s=%s' % kv for kv in st] + ['']
+        open(os.path.join(d, name), 'w', newline='').write('\n'.join(out))
+    ctrl('ctrl_wastegate0.ini', [[('INPUT', 'RPMS'), ('COMBINATOR', 'ADD'), ('LUT', '(|0=0.6|2500=0.7|4500=1.0|6500=1.15|8000=0.9|)'), ('FILTER', '0.95'), ('UP_LIMIT', '1.1'), ('DOWN_LIMIT', '0.5')],
+                                 [('INPUT', 'GEAR'), ('COMBINATOR', 'MULT'), ('LUT', '(|0=0.8|1=0.85|2=0.95|3=1.0|5=1.05|)'), ('FILTER', '0.5'), ('UP_LIMIT', '0'), ('DOWN_LIMIT', '0')]])
+    ctrl('ctrl_turbo1.ini', [[('INPUT', 'CONST'), ('COMBINATOR', 'ADD'), ('CONST_VALUE', '1.25'), ('FILTER', '0.99'), ('UP_LIMIT', '0'), ('DOWN_LIMIT', '0')],
+                             [('INPUT', 'GAS'), ('COMBINATOR', 'MULT'), ('LUT', '(|0=0.7|0.5=0.9|1=1.0|)'), ('FILTER', '0.9'), ('UP_LIMIT', '1.3'), ('DOWN_LIMIT', '0.6')]])
+    lock = None
+    ctrl('ctrl_single_lock.ini', [[('INPUT', 'CONST'), ('COMBINATOR', 'ADD'), ('CONST_VALUE', '25'), ('FILTER', '0'), ('UP_LIMIT', '0'), ('DOWN_LIMIT', '0')],
+                                  [('INPUT', 'SPEED_KMH'), ('COMBINATOR', 'MULT'), ('LUT', '(|0=0.4|30=1.0|90=2.2|160=3.0|)'), ('FILTER', '0.8'), ('UP_LIMIT', '0'), ('DOWN_LIMIT', '0')],
+                                  [('INPUT', 'BRAKE'), ('COMBINATOR', 'ADD'), ('LUT', '(|0=0|1=40|)'), ('FILTER', '0.9'), ('UP_LIMIT', '90'), ('DOWN_LIMIT', '8')]])
+
+
+def make_dynctrl_ae86(base, src='ks_toyota_ae86_drift', dst='pdb_dynctrl_ae86'):
+    """A 33-row car with a controller file: the launcher must route it through the row-guarded kernels (the exact-size ones are compiled without the
+    controllers' call sites) -- tests/test_gpu_parity.py steps it against the oracle.  The differential's preload from speed and throttle."""
+    s = os.path.join(REF, 'content', 'cars', src, 'data'); d = os.path.join(base, 'content', 'cars', dst, 'data')
+    if os.path.isdir(d):
+        shutil.rmtree(d)
+    shutil.copytree(s, d)
+    os.system('chmod -R u+w "%s"' % d)
+    open(os.path.join(d, 'ctrl_single_lock.ini'), 'w', newline='').write('\n'.join([
+        '[CONTROLLER_0]', 'INPUT=SPEED_KMH', 'COMBINATOR=ADD', 'LUT=(|0=10|40=35|120=80|)', 'FILTER=0.9', 'UP_LIMIT=0', 'DOWN_LIMIT=0', '',
+        '[CONTROLLER_1]', 'INPUT=GAS', 'COMBINATOR=MULT', 'LUT=(|0=0.5|1=1.4|)', 'FILTER=0.7', 'UP_LIMIT=100', 'DOWN_LIMIT=5', '']))
+
+
 def main():
     base = os.path.join(here, '_ref', 'base')
     os.makedirs(os.path.join(base, 'cfg'), exist_ok=True)
@@ -195,6 +233,8 @@ def main():
     make_ground_effect_car(base)
     make_aerodata_car(base)
     make_wingctrl_car(base)
+    make_dynctrl_car(base)
+    make_dynctrl_ae86(base)
     gen_track.gen_flat(os.path.join(base, 'content', 'tracks', 'flat'))
     gen_track.gen_touge(os.path.join(base, 'content', 'tracks', 'touge'))
     gen_track.gen_walled(os.path.join(base, 'content', 'tracks', 'walled'))

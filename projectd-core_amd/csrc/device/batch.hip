@@ -245,10 +245,12 @@ static void launchTick(pdb_batch* b, hipStream_t st, int c0, int c1, pdb_step_ou
     }
     int* HN = b->dHint ? b->dHint + q : nullptr;
     const dim3 grid(nblk), block(PDB_BLOCK_THREADS), cblock(PDB_WAVE * (PDB_CONTACT_CPB + 1)), cgrid(((n + PDB_CONTACT_CPB - 1) / PDB_CONTACT_CPB) < cg ? ((n + PDB_CONTACT_CPB - 1) / PDB_CONTACT_CPB) : cg);
-    if (m == 33) {
+    // a car with DynamicController files goes through the row-guarded kernels: they are the ones compiled with the controllers' call sites
+    const bool ctrl = HP.numCtrlStages != 0;
+    if (m == 33 && !ctrl) {
         hipLaunchKernelGGL(k33::pdb_step_kernel, grid, block, 0, st, S, Aact, O, CS, DP, DK, b->dTrack, (k33::RedoQueue*)Q, RM, n, SN);
         if (contacts) hipLaunchKernelGGL(k33c::pdb_contact_kernel, cgrid, cblock, 0, st, S, Aact, O, CS, DP, DK, b->dTrack, CT, (k33c::RedoQueue*)Q, RM, n, HN, SN);
-    } else if (m < 33) {
+    } else if (m <= 33) {
         hipLaunchKernelGGL(k33::pdb_step_kernel_generic, grid, block, 0, st, S, Aact, O, CS, DP, DK, b->dTrack, (k33::RedoQueue*)Q, RM, n, SN);
         if (contacts) hipLaunchKernelGGL(k33c::pdb_contact_kernel_generic, cgrid, cblock, 0, st, S, Aact, O, CS, DP, DK, b->dTrack, CT, (k33c::RedoQueue*)Q, RM, n, HN, SN);
     } else {

@@ -51,6 +51,37 @@ static void mkDBall(std::vector<RawJoint>& out, const HBody* B, int b0, int b1, 
     out.push_back(j);
 }
 
+// DynamicController::init (Car/DynamicController.cpp:21-115): the stages of one controller file appended to the car's stage table
+static void dynCtrlLoad(pdb_car_params& P, pdb_dyn_ctrl& dc, const std::string& path) {
+    Ini ini(path);
+    dc.first = P.numCtrlStages; dc.count = 0;
+    static const char* known[] = {"", "BRAKE", "GAS", "LATG", "LONG", "STEER", "SPEED_KMH", "GEAR", "RPMS", "CONST"};
+    for (int id = 0;; ++id) {
+        char secn[32]; snprintf(secn, sizeof(secn), "CONTROLLER_%d", id);
+        if (!ini.hasSection(secn)) break;
+        const std::string in = ini.getString(secn, "INPUT"), comb = ini.getString(secn, "COMBINATOR");
+        int iv = 0;
+        for (int k = 1; k <= 9; ++k) if (in == known[k]) iv = k;
+        if (iv == 0) throw std::runtime_error("pdb: " + path + " " + secn + ": controller input " + in + " unsupported");
+        const int cm = comb == "ADD" ? 1 : comb == "MULT" ? 2 : 0;
+        if (cm == 0) continue;   // (the reference warns and skips the stage)
+        if (P.numCtrlStages >= PDB_MAX_CTRL_STAGES) throw std::runtime_error("pdb: more than " + std::to_string(PDB_MAX_CTRL_STAGES) + " dynamic-controller stages in the car");
+        pdb_ctrl_stage& st = P.ctrlStages[P.numCtrlStages++];
+        memset(&st, 0, sizeof(st));
+        st.input = iv; st.combinator = cm;
+        const float lag = ini.getFloat(secn, "FILTER"), orgdt = 0.004f, dt = 0.003f;
+        st.filter = (((1.0f / dt) * orgdt) * (1.0f - lag)) * (1.0f / dt);   // lagToLerpDeltaK (DynamicController.cpp:8)
+        st.upLimit = ini.getFloat(secn, "UP_LIMIT");
+        st.downLimit = ini.getFloat(secn, "DOWN_LIMIT");
+        if (iv == 9) st.constValue = ini.getFloat(secn, "CONST_VALUE");
+        else {
+            const std::string v = ini.getString(secn, "LUT");
+            if (v.find(".lut") != std::string::npos) curveLoad(st.lut, path.substr(0, path.find_last_of('/') + 1) + v); else curveParseInline(st.lut, v);
+        }
+        ++dc.count;
+    }
+}
+
 // Natural cubic spline through a LUT (what Curve::getCubicSplineValue evaluates, Core/Curve.cpp:117-126): the reference hands the points to the
 // tk::spline header it vendors (Core/tkspline.h, tkfloat = float): second derivative zero at both ends, the tridiagonal system for the b's solved
 // by an LU decomposition with rows scaled to a unit diagonal first, a and c from the b's, quadratic continuation past the ends.  Restated here for
@@ -814,7 +845,8 @@ void buildCarModel(const std::string& basePathIn, const std::string& modelName, 
         if (P.numTurbos > 0) {
             for (int id = 0; id < P.numTurbos; ++id) {
                 char c1[64], c2[64]; snprintf(c1, sizeof(c1), "ctrl_turbo%d.ini", id); snprintf(c2, sizeof(c2), "ctrl_wastegate%d.ini", id);
-                if (fileExists(dataPath + c1) || fileExists(dataPath + c2)) throw std::runtime_error("pdb: turbo dynamic controllers are not implemented");
+                if (fileExists(dataPath + c1)) dynCtrlLoad(P, P.ctrlTurboBoost[id], dataPath + c1);   // Engine.cpp:124-143
+                if (fileExists(dataPath + c2)) dynCtrlLoad(P, P.ctrlWastegate[id], dataPath + c2);
             }
         }
         if (eng.hasSection("OVERLAP")) {   // Engine.cpp:96-101
@@ -889,7 +921,7 @@ void buildCarModel(const std::string& basePathIn, const std::string& modelName, 
         const int tl = (P.tractionType == 0) ? 2 : 0;
         P.outShaftInertiaL = P.tyre[tl].angularInertia;
         P.outShaftInertiaR = P.tyre[tl + 1].angularInertia;
-        if (P.tractionType == 0 && fileExists(dataPath + "ctrl_single_lock.ini")) throw std::runtime_error("pdb: ctrl_single_lock.ini unsupported this round");
+        if (P.tractionType == 0 && fileExists(dataPath + "ctrl_single_lock.ini")) dynCtrlLoad(P, P.ctrlDiffLock, dataPath + "ctrl_single_lock.ini");   // Drivetrain.cpp:144-151
         // AutoClutch (AutoClutch.cpp:25-89)
         const std::string up = dt.getString("AUTOCLUTCH", "UPSHIFT_PROFILE"), dn = dt.getString("AUTOCLUTCH", "DOWNSHIFT_PROFILE");
         P.acUseOnChange = dt.getInt("AUTOCLUTCH", "USE_ON_CHANGES") != 0;

@@ -203,6 +203,15 @@ def test_full_controls_random(built):
         assert worst == 0.0
 
 
+@pytest.mark.parametrize('model', ['pdb_dynctrl_ae86', 'pdb_dynctrl_supra', 'pdb_wingctrl_fc3s'])
+def test_cars_with_dynamic_controllers(built, model):
+    """controller files (DynamicController: the differential's preload on a 33-row car -- which the launcher has to route through the row-guarded
+    kernels, the exact-size ones being compiled without the controllers' call sites -- and two turbos' wastegate / boost on a 26-row one) and wing
+    controllers on a 38-row one: 32 cars x 1200 ticks with random constant actions, every state word incl. the controllers' filtered values"""
+    worst = parity_util.run_parity(n_cars=32, ticks=1200, seed=22, resync=False, verbose=True, check_every=20, model=model)
+    assert worst == 0.0
+
+
 @pytest.mark.parametrize('model', ['ks_mazda_rx7_tuned', 'ks_toyota_supra_mkiv_drift', 'dthwsh_mazda_rx7_fc3s_sr20', 'gravygarage_street_ae86_readie', 'pdb_ml_supra', 'pdb_fwd_ae86'])
 def test_double_wishbone_turbo_cars(built, model):
     """the other four cars the reference ships: double wishbones on all four wheels (6 bodies, 21 joints, 26 rows -> the
