@@ -292,6 +292,9 @@ typedef struct pdb_car_params {
     /* ctrl_single_lock.ini (Drivetrain.cpp:144-151,603-607: the differential's preload, power ramp 0), ctrl_turbo<n>.ini / ctrl_wastegate<n>.ini
      * (Engine.cpp:124-143,368-376: a turbo's maxBoost / wastegate) */
     pdb_dyn_ctrl ctrlDiffLock, ctrlTurboBoost[PDB_MAX_TURBOS], ctrlWastegate[PDB_MAX_TURBOS];
+    /* ctrl_ebb.ini (BrakeSystem.cpp:64-69,90-93: the front brake bias of the tick; takes precedence over [EBB]), steer_brake_controller.ini
+     * (BrakeSystem.cpp:33-38,136-143: extra brake torque on the inner rear wheel) */
+    pdb_dyn_ctrl ctrlEbb, ctrlSteerBrake;
     int32_t numCtrlStages, _padCtrl;
     pdb_ctrl_stage ctrlStages[PDB_MAX_CTRL_STAGES];
 } pdb_car_params;
@@ -453,7 +456,7 @@ typedef struct pdb_ray_rec {
 }
 /* sizes are part of the ABI (tests/test_abi.py reads these numbers) */
 static_assert(sizeof(pdb_car_state) == 664, "pdb_car_state must equal the reference CarState (pack 4)");
-static_assert(sizeof(pdb_car_params) == 21776, "pdb_car_params layout");
+static_assert(sizeof(pdb_car_params) == 21792, "pdb_car_params layout");
 static_assert(sizeof(pdb_dyn_state) == 2320, "pdb_dyn_state layout (multiple of 16 bytes)");
 static_assert(sizeof(pdb_step_out) == 104, "pdb_step_out layout");
 static_assert(sizeof(pdb_contact) == 32, "pdb_contact layout");

@@ -1557,7 +1557,7 @@ void Car::carStep(float dt) {
             bool bFlag = false;
             if (fLoadAWD != 0.0f) { if (S.speed * 3.6f > 10.0f) bFlag = true; }
             fFrontBias = bFlag ? tclamp(((fLoadFront / fLoadAWD) * Pm.ebbFrontMultiplier), 0.0f, 1.0f) : Pm.frontBias;
-        }
+        } else if (Pm.ctrlEbb.count) fFrontBias = dynCtrlEval(*this, Pm.ctrlEbb);   // EBBMode::DynamicController (:90-93)
         fFrontBias = tclamp(fFrontBias, Pm.biasMin, Pm.biasMax);
         const float fBrakeInput = tmax(controls.brake, 0.0f);
         const float fBrakeTorq = (Pm.brakePower * Pm.brakePowerMultiplier) * fBrakeInput;
@@ -1568,6 +1568,10 @@ void Car::carStep(float dt) {
         ts[2].brakeTorque = fRear; ts[3].brakeTorque = fRear;
         ts[2].handBrakeTorque = controls.handBrake * Pm.handBrakeTorque;
         ts[3].handBrakeTorque = controls.handBrake * Pm.handBrakeTorque;
+        if (Pm.ctrlSteerBrake.count) {   // steerBrake (:136-143)
+            const float fSteerBrake = dynCtrlEval(*this, Pm.ctrlSteerBrake);
+            if (fSteerBrake >= 0.0f) ts[3].brakeTorque += fSteerBrake; else ts[2].brakeTorque -= fSteerBrake;
+        }
     }
     for (int i = 0; i < 4; ++i) {
         if (Pm.susp[i].type == PDB_SUSP_STRUT) strutStep(Pm.susp[i], w, ts[i]);

@@ -202,6 +202,23 @@ def make_dynctrl_car(base, src='ks_toyota_supra_mkiv_drift', dst='pdb_dynctrl_su
                                   [('INPUT', 'BRAKE'), ('COMBINATOR', 'ADD'), ('LUT', '(|0=0|1=40|)'), ('FILTER', '0.9'), ('UP_LIMIT', '90'), ('DOWN_LIMIT', '8')]])
 
 
+def make_brakectrl_car(base, src='ks_mazda_rx7_tuned', dst='pdb_brakectrl_rx7'):
+    """The brake system's two DynamicController files: ctrl_ebb.ini (the front bias of the tick: a constant shifted by the longitudinal g, limits;
+    BrakeSystem.cpp:64-69,90-93) and steer_brake_controller.ini (extra brake torque on the inner rear wheel from the steering input, faded in
+    with speed; BrakeSystem.cpp:33-38,136-143).  The tuned RX-7 with both, through the brake script."""
+    s = os.path.join(REF, 'content', 'cars', src, 'data'); d = os.path.join(base, 'content', 'cars', dst, 'data')
+    if os.path.isdir(d):
+        shutil.rmtree(d)
+    shutil.copytree(s, d)
+    os.system('chmod -R u+w "%s"' % d)
+    open(os.path.join(d, 'ctrl_ebb.ini'), 'w', newline='').write('\n'.join([
+        '[CONTROLLER_0]', 'INPUT=CONST', 'COMBINATOR=ADD', 'CONST_VALUE=0.62', 'FILTER=0', 'UP_LIMIT=0', 'DOWN_LIMIT=0', '',
+        '[CONTROLLER_1]', 'INPUT=LONG', 'COMBINATOR=ADD', 'LUT=(|-1.5=0.14|0=0|1=-0.06|)', 'FILTER=0.85', 'UP_LIMIT=0.8', 'DOWN_LIMIT=0.5', '']))
+    open(os.path.join(d, 'steer_brake_controller.ini'), 'w', newline='').write('\n'.join([
+        '[CONTROLLER_0]', 'INPUT=STEER', 'COMBINATOR=ADD', 'LUT=(|-1=-260|-0.1=0|0.1=0|1=260|)', 'FILTER=0.7', 'UP_LIMIT=0', 'DOWN_LIMIT=0', '',
+        '[CONTROLLER_1]', 'INPUT=SPEED_KMH', 'COMBINATOR=MULT', 'LUT=(|0=0|25=1|300=1|)', 'FILTER=0.5', 'UP_LIMIT=200', 'DOWN_LIMIT=-200', '']))
+
+
 def make_dynctrl_ae86(base, src='ks_toyota_ae86_drift', dst='pdb_dynctrl_ae86'):
     """A 33-row car with a controller file: the launcher must route it through the row-guarded kernels (the exact-size ones are compiled without the
     controllers' call sites) -- tests/test_gpu_parity.py steps it against the oracle.  The differential's preload from speed and throttle."""
@@ -235,6 +252,7 @@ def main():
     make_wingctrl_car(base)
     make_dynctrl_car(base)
     make_dynctrl_ae86(base)
+    make_brakectrl_car(base)
     gen_track.gen_flat(os.path.join(base, 'content', 'tracks', 'flat'))
     gen_track.gen_touge(os.path.join(base, 'content', 'tracks', 'touge'))
     gen_track.gen_walled(os.path.join(base, 'content', 'tracks', 'walled'))

@@ -778,12 +778,20 @@ void buildCarModel(const std::string& basePathIn, const std::string& modelName, 
         P.handBrakeTorque = br.getFloat("DATA", "HANDBRAKE_TORQUE");
         P.brakePowerMultiplier = 1.0f;
         P.biasMin = 0.0f; P.biasMax = 1.0f;
-        if (br.hasSection("TEMPS_FRONT") || fileExists(dataPath + "steer_brake_controller.ini") || fileExists(dataPath + "ctrl_ebb.ini"))
-            throw std::runtime_error("pdb: brake temps / steer-brake and EBB dynamic controllers unsupported this round");
+        if (br.hasSection("TEMPS_FRONT") && br.hasSection("TEMPS_REAR")) throw std::runtime_error("pdb: brake disc temperatures ([TEMPS_FRONT] / [TEMPS_REAR]) unsupported");
+        if (fileExists(dataPath + "steer_brake_controller.ini")) {   // BrakeSystem.cpp:33-38
+            dynCtrlLoad(P, P.ctrlSteerBrake, dataPath + "steer_brake_controller.ini");
+            if (P.ctrlSteerBrake.count == 0) throw std::runtime_error("pdb: steer_brake_controller.ini has no usable stage");
+        }
         if (br.hasSection("EBB")) {   // EBBMode::Internal (BrakeSystem.cpp:28-32): the bias follows the front axle's share of the load
             P.ebbInternal = 1;
             const float m = br.getFloat("EBB", "FRONT_SHARE_MULTIPLIER");
             P.ebbFrontMultiplier = m > 1.1f ? m : 1.1f;
+        }
+        if (fileExists(dataPath + "ctrl_ebb.ini")) {   // EBBMode::DynamicController (BrakeSystem.cpp:64-69): takes the place of the internal mode
+            dynCtrlLoad(P, P.ctrlEbb, dataPath + "ctrl_ebb.ini");
+            if (P.ctrlEbb.count == 0) throw std::runtime_error("pdb: ctrl_ebb.ini has no usable stage");
+            P.ebbInternal = 0;
         }
         Ini setup(dataPath + "setup.ini");
         if (setup.ready && setup.hasSection("FRONT_BIAS")) {
