@@ -89,7 +89,7 @@ def measure(args, world, rank, local_rank, dist, want_cpu=False):
     n = args.cars
     policy = args.policy or ('feedback' if (args.workload != 'flat' or args.episodes) else 'constant')
     assert B_ALG == 2 * C.sizeof(pc.DynState) + 8 + C.sizeof(pc.StepOut), 'B_ALG is stale: update it with the record layout'
-    P = pdbatch.packed_params()
+    P = pdbatch.packed_params(os.environ['PDB_BENCH_CAR'] + '.env') if os.environ.get('PDB_BENCH_CAR') else pdbatch.packed_params()   # (diagnostic: another packed car; the bench line is the AE86)
     if args.no_body_contacts:
         P.collider.enabled = 0
     gen_args = {}

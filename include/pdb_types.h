@@ -295,6 +295,8 @@ typedef struct pdb_car_params {
     /* ctrl_ebb.ini (BrakeSystem.cpp:64-69,90-93: the front brake bias of the tick; takes precedence over [EBB]), steer_brake_controller.ini
      * (BrakeSystem.cpp:33-38,136-143: extra brake torque on the inner rear wheel) */
     pdb_dyn_ctrl ctrlEbb, ctrlSteerBrake;
+    /* ctrl_arb_front.ini / ctrl_arb_rear.ini (Car.cpp:158-167, AntirollBar.cpp:19-22): the bar's rate of the tick; the bars step after the drivetrain */
+    pdb_dyn_ctrl ctrlArb[2];
     int32_t numCtrlStages, _padCtrl;
     pdb_ctrl_stage ctrlStages[PDB_MAX_CTRL_STAGES];
 } pdb_car_params;
@@ -456,7 +458,7 @@ typedef struct pdb_ray_rec {
 }
 /* sizes are part of the ABI (tests/test_abi.py reads these numbers) */
 static_assert(sizeof(pdb_car_state) == 664, "pdb_car_state must equal the reference CarState (pack 4)");
-static_assert(sizeof(pdb_car_params) == 21792, "pdb_car_params layout");
+static_assert(sizeof(pdb_car_params) == 21808, "pdb_car_params layout");
 static_assert(sizeof(pdb_dyn_state) == 2320, "pdb_dyn_state layout (multiple of 16 bytes)");
 static_assert(sizeof(pdb_step_out) == 104, "pdb_step_out layout");
 static_assert(sizeof(pdb_contact) == 32, "pdb_contact layout");

@@ -1666,7 +1666,8 @@ void Car::carStep(float dt) {
     drivetrainStep(*this, dt);
     // AntirollBar::step (AntirollBar.cpp:19-46)
     for (int a = 0; a < 2; ++a) {
-        const float k = Pm.arbK[a];
+        float k = Pm.arbK[a];
+        if (Pm.ctrlArb[a].count) k = dynCtrlEval(*this, Pm.ctrlArb[a]);   // if (ctrl.ready) k = ctrl.eval() (AntirollBar.cpp:21-22)
         if (k > 0.0f) {
             const M44 mb = worldMatrix(body);
             const V3 vBodyM2(mb.m[4], mb.m[5], mb.m[6]);

@@ -205,7 +205,7 @@ def make_dynctrl_car(base, src='ks_toyota_supra_mkiv_drift', dst='pdb_dynctrl_su
 def make_brakectrl_car(base, src='ks_mazda_rx7_tuned', dst='pdb_brakectrl_rx7'):
     """The brake system's two DynamicController files: ctrl_ebb.ini (the front bias of the tick: a constant shifted by the longitudinal g, limits;
     BrakeSystem.cpp:64-69,90-93) and steer_brake_controller.ini (extra brake torque on the inner rear wheel from the steering input, faded in
-    with speed; BrakeSystem.cpp:33-38,136-143).  The tuned RX-7 with both, through the brake script."""
+    with speed; BrakeSystem.cpp:33-38,136-143) -- and the anti-roll bars' ctrl_arb_front.ini / ctrl_arb_rear.ini.  The tuned RX-7 with all four, through the brake script."""
     s = os.path.join(REF, 'content', 'cars', src, 'data'); d = os.path.join(base, 'content', 'cars', dst, 'data')
     if os.path.isdir(d):
         shutil.rmtree(d)
@@ -217,6 +217,13 @@ def make_brakectrl_car(base, src='ks_mazda_rx7_tuned', dst='pdb_brakectrl_rx7'):
     open(os.path.join(d, 'steer_brake_controller.ini'), 'w', newline='').write('\n'.join([
         '[CONTROLLER_0]', 'INPUT=STEER', 'COMBINATOR=ADD', 'LUT=(|-1=-260|-0.1=0|0.1=0|1=260|)', 'FILTER=0.7', 'UP_LIMIT=0', 'DOWN_LIMIT=0', '',
         '[CONTROLLER_1]', 'INPUT=SPEED_KMH', 'COMBINATOR=MULT', 'LUT=(|0=0|25=1|300=1|)', 'FILTER=0.5', 'UP_LIMIT=200', 'DOWN_LIMIT=-200', '']))
+    # the anti-roll bars' rates from controller files (Car.cpp:158-167, AntirollBar.cpp:19-22; the bars step after the drivetrain: the rear one reads this tick's rpm and gear)
+    open(os.path.join(d, 'ctrl_arb_front.ini'), 'w', newline='').write('\n'.join([
+        '[CONTROLLER_0]', 'INPUT=SPEED_KMH', 'COMBINATOR=ADD', 'LUT=(|0=18000|60=30000|160=52000|)', 'FILTER=0.9', 'UP_LIMIT=0', 'DOWN_LIMIT=0', '',
+        '[CONTROLLER_1]', 'INPUT=LATG', 'COMBINATOR=MULT', 'LUT=(|-1.5=1.3|0=1|1.5=1.3|)', 'FILTER=0.6', 'UP_LIMIT=60000', 'DOWN_LIMIT=10000', '']))
+    open(os.path.join(d, 'ctrl_arb_rear.ini'), 'w', newline='').write('\n'.join([
+        '[CONTROLLER_0]', 'INPUT=RPMS', 'COMBINATOR=ADD', 'LUT=(|0=9000|3000=14000|7000=26000|)', 'FILTER=0.8', 'UP_LIMIT=0', 'DOWN_LIMIT=0', '',
+        '[CONTROLLER_1]', 'INPUT=GEAR', 'COMBINATOR=MULT', 'LUT=(|0=1.2|1=1.1|3=1.0|5=0.9|)', 'FILTER=0.3', 'UP_LIMIT=0', 'DOWN_LIMIT=0', '']))
 
 
 def make_dynctrl_ae86(base, src='ks_toyota_ae86_drift', dst='pdb_dynctrl_ae86'):

@@ -28,6 +28,8 @@
 #define PDB_KROWS 33
 #define PDB_KMINWAVES 6
 #define PDB_KERNEL_EXACT pdb_step_kernel
+#define PDB_KSLOT0_EXACT true    /* the class's first kernel pair: exactly 33 rows, no run-time row guards */
+#define PDB_KSLOT0_CTRL false
 #define PDB_KERNEL_GUARDED pdb_step_kernel_generic
 #define PDB_KERNEL_EXACT_C pdb_contact_kernel
 #define PDB_KERNEL_GUARDED_C pdb_contact_kernel_generic
@@ -50,15 +52,19 @@
 #undef PDB_KROWS
 #undef PDB_KMINWAVES
 #undef PDB_KERNEL_EXACT
+#undef PDB_KSLOT0_EXACT
+#undef PDB_KSLOT0_CTRL
 #undef PDB_KERNEL_GUARDED
 #undef PDB_KERNEL_EXACT_C
 #undef PDB_KERNEL_GUARDED_C
 #ifndef PDB_FAST_BUILD   /* development builds (make dev) compile the 33-row size class only */
 #define PDB_KROWS 40
 #define PDB_KMINWAVES 5
-#define PDB_KERNEL_EXACT pdb_step_kernel_wide40
+#define PDB_KERNEL_EXACT pdb_step_kernel_ctrl
+#define PDB_KSLOT0_EXACT false   /* the 40-row class's first kernel pair: row-guarded like the second, compiled with the DynamicController call sites (any car with controller files) */
+#define PDB_KSLOT0_CTRL true
 #define PDB_KERNEL_GUARDED pdb_step_kernel_wide
-#define PDB_KERNEL_EXACT_C pdb_contact_kernel_wide40
+#define PDB_KERNEL_EXACT_C pdb_contact_kernel_ctrl
 #define PDB_KERNEL_GUARDED_C pdb_contact_kernel_wide
 #define PDB_KNS k40
 #define PDB_CPB PDB_FIRST_CPB
@@ -79,6 +85,8 @@
 #undef PDB_KROWS
 #undef PDB_KMINWAVES
 #undef PDB_KERNEL_EXACT
+#undef PDB_KSLOT0_EXACT
+#undef PDB_KSLOT0_CTRL
 #undef PDB_KERNEL_GUARDED
 #undef PDB_KERNEL_EXACT_C
 #undef PDB_KERNEL_GUARDED_C
@@ -225,11 +233,11 @@ static void launchTick(pdb_batch* b, hipStream_t st, int c0, int c1, pdb_step_ou
     pdb_car_state* CS = b->dCarStates ? b->dCarStates + c0 : nullptr;
     pdb_contact* CT = b->dContacts + (size_t)c0 * PDB_MAX_CONTACTS;
     void* Q = b->dQueue[q];
-    uint8_t* SN = b->dSnap + (size_t)c0 * (m <= 33 ? k33::kSnapStride : kSnapStrideWide);
     const bool own = q < PDB_MAX_PARTS && b->partHas[q];
     const pdb_car_params* DP = own ? b->dPartParams[q] : b->dParams;
     const DevConst* DK = own ? b->dPartK[q] : b->dK;
     const pdb_car_params& HP = own ? b->partParams[q] : b->params;
+    uint8_t* SN = b->dSnap + (size_t)c0 * ((m <= 33 && HP.numCtrlStages == 0) ? k33::kSnapStride : kSnapStrideWide);
     uint8_t* RM = b->resetMaskArmed ? b->dResetMask + c0 : nullptr;
     const int n = c1 - c0;
     // the contact pass also serves episode resets asked for through the reset mask and the in-tick auto-teleport
@@ -245,12 +253,17 @@ static void launchTick(pdb_batch* b, hipStream_t st, int c0, int c1, pdb_step_ou
     }
     int* HN = b->dHint ? b->dHint + q : nullptr;
     const dim3 grid(nblk), block(PDB_BLOCK_THREADS), cblock(PDB_WAVE * (PDB_CONTACT_CPB + 1)), cgrid(((n + PDB_CONTACT_CPB - 1) / PDB_CONTACT_CPB) < cg ? ((n + PDB_CONTACT_CPB - 1) / PDB_CONTACT_CPB) : cg);
-    // a car with DynamicController files goes through the row-guarded kernels: they are the ones compiled with the controllers' call sites
+    // a car with DynamicController files goes through the kernel pair compiled with the controllers' call sites (40-row class, row-guarded: any car)
     const bool ctrl = HP.numCtrlStages != 0;
-    if (m == 33 && !ctrl) {
+    if (ctrl) {
+#ifndef PDB_FAST_BUILD
+        hipLaunchKernelGGL(k40::pdb_step_kernel_ctrl, grid, block, 0, st, S, Aact, O, CS, DP, DK, b->dTrack, (k40::RedoQueue*)Q, RM, n, SN);
+        if (contacts) hipLaunchKernelGGL(k40c::pdb_contact_kernel_ctrl, cgrid, cblock, 0, st, S, Aact, O, CS, DP, DK, b->dTrack, CT, (k40c::RedoQueue*)Q, RM, n, HN, SN);
+#endif
+    } else if (m == 33) {
         hipLaunchKernelGGL(k33::pdb_step_kernel, grid, block, 0, st, S, Aact, O, CS, DP, DK, b->dTrack, (k33::RedoQueue*)Q, RM, n, SN);
         if (contacts) hipLaunchKernelGGL(k33c::pdb_contact_kernel, cgrid, cblock, 0, st, S, Aact, O, CS, DP, DK, b->dTrack, CT, (k33c::RedoQueue*)Q, RM, n, HN, SN);
-    } else if (m <= 33) {
+    } else if (m < 33) {
         hipLaunchKernelGGL(k33::pdb_step_kernel_generic, grid, block, 0, st, S, Aact, O, CS, DP, DK, b->dTrack, (k33::RedoQueue*)Q, RM, n, SN);
         if (contacts) hipLaunchKernelGGL(k33c::pdb_contact_kernel_generic, cgrid, cblock, 0, st, S, Aact, O, CS, DP, DK, b->dTrack, CT, (k33c::RedoQueue*)Q, RM, n, HN, SN);
     } else {

@@ -708,6 +708,8 @@ void buildCarModel(const std::string& basePathIn, const std::string& modelName, 
     buildPatchConn(P);
     P.arbK[0] = sus.getFloat("ARB", "FRONT");
     P.arbK[1] = sus.getFloat("ARB", "REAR");
+    if (fileExists(dataPath + "ctrl_arb_front.ini")) dynCtrlLoad(P, P.ctrlArb[0], dataPath + "ctrl_arb_front.ini");   // Car.cpp:158-167
+    if (fileExists(dataPath + "ctrl_arb_rear.ini")) dynCtrlLoad(P, P.ctrlArb[1], dataPath + "ctrl_arb_rear.ini");
     P.waterTmass = 20.0f; P.waterCoolSpeedK = 0.002f;
 
     // ---- aero (AeroMap.cpp:15-81, Wing.cpp:19-69) ----

@@ -94,7 +94,7 @@ class CarParams(C.Structure):
         [('upshiftProfile', Curve), ('downshiftProfile', Curve), ('blipProfile', Curve), ('blipPerformTime', C.c_double), ('asChangeUpRpm', C.c_int32), ('asChangeDnRpm', C.c_int32),
          ('asSlipThreshold', C.c_float), ('asGasCutoffTime', C.c_float), ('smoothSteer', C.c_int32), ('patchConnCount', C.c_int8 * 36), ('patchConn', (C.c_int8 * 4) * 36),
          ('scoring', Scoring), ('collider', Collider), ('throttleCurveMax', Curve), ('throttleMaxRef', C.c_float), ('gasCoastOffset', C.c_float),
-         ('coastEntryRpm', C.c_int32), ('ebbInternal', C.c_int32), ('ebbFrontMultiplier', C.c_float), ('overlapFreq', C.c_float), ('overlapGain', C.c_float), ('overlapIdealRPM', C.c_float), ('wingGroundEffect', C.c_int32)] + [(k, C.c_float) for k in ('aeroReferenceArea', 'aeroFrontShare', 'aeroCD', 'aeroCL', 'aeroCDX', 'aeroCDY', 'aeroCDA')] + [('numWingCtrl', C.c_int32), ('wingCtrl', WingCtrl * 4), ('ctrlDiffLock', DynCtrl), ('ctrlTurboBoost', DynCtrl * 3), ('ctrlWastegate', DynCtrl * 3), ('ctrlEbb', DynCtrl), ('ctrlSteerBrake', DynCtrl), ('numCtrlStages', C.c_int32), ('_padCtrl', C.c_int32), ('ctrlStages', CtrlStage * 8)]
+         ('coastEntryRpm', C.c_int32), ('ebbInternal', C.c_int32), ('ebbFrontMultiplier', C.c_float), ('overlapFreq', C.c_float), ('overlapGain', C.c_float), ('overlapIdealRPM', C.c_float), ('wingGroundEffect', C.c_int32)] + [(k, C.c_float) for k in ('aeroReferenceArea', 'aeroFrontShare', 'aeroCD', 'aeroCL', 'aeroCDX', 'aeroCDY', 'aeroCDA')] + [('numWingCtrl', C.c_int32), ('wingCtrl', WingCtrl * 4), ('ctrlDiffLock', DynCtrl), ('ctrlTurboBoost', DynCtrl * 3), ('ctrlWastegate', DynCtrl * 3), ('ctrlEbb', DynCtrl), ('ctrlSteerBrake', DynCtrl), ('ctrlArb', DynCtrl * 2), ('numCtrlStages', C.c_int32), ('_padCtrl', C.c_int32), ('ctrlStages', CtrlStage * 8)]
 class BodyState(C.Structure):
     _fields_ = [('pos', C.c_float * 3), ('q', C.c_float * 4), ('R', C.c_float * 9), ('lvel', C.c_float * 3), ('avel', C.c_float * 3)]
 class TyreState(C.Structure):

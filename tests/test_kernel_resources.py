@@ -29,11 +29,11 @@ def test_first_pass_kernels_keep_six_workgroups_per_cu():
     # the contact pass holds few workgroups (the cars that touch something): it trades occupancy for registers and LDS -- two
     # workgroups per CU (256 VGPRs, no vector spills worth the name) and the collision staging block in LDS (64 KB is the limit of a
     # statically allocated workgroup)
-    for name in ('pdb_contact_kernel', 'pdb_contact_kernel_generic', 'pdb_contact_kernel_wide', 'pdb_contact_kernel_wide40'):
+    for name in ('pdb_contact_kernel', 'pdb_contact_kernel_generic', 'pdb_contact_kernel_wide', 'pdb_contact_kernel_ctrl'):
         assert k[name]['vgprs'] <= 256 and k[name]['occupancy'] >= 2, (name, k[name])
         assert k[name]['lds'] <= 65536 and k[name]['scratch'] <= 128, (name, k[name])
     # scratch of the first pass: the cold teleport block's frame (round 2: 72 bytes).  A hot-path spill shows up as a larger frame first.
     for name in ('pdb_step_kernel', 'pdb_step_kernel_generic'):
         assert k[name]['scratch'] <= 96, (name, k[name])
-    for name in ('pdb_step_kernel_wide', 'pdb_step_kernel_wide40'):   # 40-row cars: five workgroups (96 VGPRs, 29.9 KB)
+    for name in ('pdb_step_kernel_wide', 'pdb_step_kernel_ctrl'):   # 40-row cars: five workgroups (96 VGPRs, 29.9 KB)
         assert k[name]['vgprs'] <= 96 and k[name]['lds'] <= 32000, (name, k[name])
