@@ -181,7 +181,8 @@ typedef struct pdb_wing_ctrl {
  * multiplied into the running result and clamped when the stage has limits.  The car's controllers share the stage table; a stage's filtered value is a
  * word of the record (pdb_dyn_state.ctrlValue). */
 typedef struct pdb_ctrl_stage {
-    int32_t input;        /* 1 BRAKE, 2 GAS, 3 LATG, 4 LONG, 5 STEER, 6 SPEED_KMH, 7 GEAR, 8 RPMS, 9 CONST */
+    int32_t input;        /* 1 BRAKE, 2 GAS, 3 LATG, 4 LONG, 5 STEER, 6 SPEED_KMH, 7 GEAR, 8 RPMS, 9 CONST, 10 SLIPRATIO_MAX, 11 SLIPRATIO_AVG, 12 / 13 SLIPANGLE_FRONT / REAR_AVG,
+                           * 14 / 15 SLIPANGLE_FRONT / REAR_MAX, 16 OVERSTEER_FACTOR, 17 REAR_SPEED_RATIO, 18 STEER_DEG, 19 WHEEL_STEER_DEG, 20 / 21 LOAD_SPREAD_LF / RF */
     int32_t combinator;   /* 1 ADD, 2 MULT */
     float filter;         /* lagToLerpDeltaK(FILTER, 0.004, 0.003) */
     float upLimit, downLimit, constValue;

@@ -1172,6 +1172,24 @@ static float dynCtrlEval(Car& c, const pdb_dyn_ctrl& dc) {
                 case 6: in = kmh(S.speed); break;
                 case 7: in = (float)(S.currentGear - 1); break;
                 case 8: in = engineRpm(c); break;
+                default: {   // the tyres' status as it stands when the consumer steps (DynamicController.cpp:191-253)
+                    const pdb_tyre_state* t = S.tyre;
+                    const int d0 = P.tractionType == 0 ? 2 : 0;   // the driven axle (RWD / FWD)
+                    switch (st.input) {
+                        case 10: in = tmax(t[d0].slipRatio, t[d0 + 1].slipRatio); break;
+                        case 11: in = (t[d0].slipRatio + t[d0 + 1].slipRatio) * 0.5f; break;
+                        case 12: in = ((t[0].slipAngleRAD + t[1].slipAngleRAD) * 57.29578f) * 0.5f; break;
+                        case 13: in = ((t[2].slipAngleRAD + t[3].slipAngleRAD) * 57.29578f) * 0.5f; break;
+                        case 14: in = tmax<float>(fabsf(t[0].slipAngleRAD), fabsf(t[1].slipAngleRAD)) * 57.29578f; break;
+                        case 15: in = tmax<float>(fabsf(t[2].slipAngleRAD), fabsf(t[3].slipAngleRAD)) * 57.29578f; break;
+                        case 16: in = ((fabsf(t[2].slipAngleRAD) + fabsf(t[3].slipAngleRAD) * 0.5f) - (fabsf(t[0].slipAngleRAD) + fabsf(t[1].slipAngleRAD) * 0.5f)) * 57.29578f; break;
+                        case 17: { const float front = (t[1].angularVelocity + t[0].angularVelocity) * 0.5f; in = front != 0.0f ? ((t[3].angularVelocity + t[2].angularVelocity) * 0.5f) / front : 0.0f; } break;
+                        case 18: in = P.steerLock * c.controls.steer; break;
+                        case 19: in = c.finalSteerAngleSignal; break;
+                        case 20: in = t[0].load / (t[0].load + t[1].load); break;
+                        case 21: in = t[1].load / (float)(t[1].load + t[0].load); break;
+                    }
+                } break;
             }
             fNewValue = curve(st.lut, in);
         }

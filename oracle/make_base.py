@@ -226,6 +226,32 @@ def make_brakectrl_car(base, src='ks_mazda_rx7_tuned', dst='pdb_brakectrl_rx7'):
         '[CONTROLLER_1]', 'INPUT=GEAR', 'COMBINATOR=MULT', 'LUT=(|0=1.2|1=1.1|3=1.0|5=0.9|)', 'FILTER=0.3', 'UP_LIMIT=0', 'DOWN_LIMIT=0', '']))
 
 
+def make_ctrl_inputs_cars(base, src='ks_toyota_ae86_drift'):
+    """The controller inputs that read the tyres' status (DynamicController.cpp:191-253), on two derived AE86s (eight stages per car): A -- the front
+    anti-roll bar's rate from the driven axle's slip ratios and the axles' mean slip angles (stepped after the tyres and the drivetrain of the tick), the
+    EBB's front bias from the front load spread and the steering angles (stepped before them: last tick's status); B -- the rear bar's rate from the
+    largest slip angles, the oversteer factor and the rear / front wheel-speed ratio."""
+    def car(dst, files):
+        s = os.path.join(REF, 'content', 'cars', src, 'data'); d = os.path.join(base, 'content', 'cars', dst, 'data')
+        if os.path.isdir(d):
+            shutil.rmtree(d)
+        shutil.copytree(s, d)
+        os.system('chmod -R u+w "%s"' % d)
+        for name, stages in files.items():
+            out = []
+            for i, (inp, comb, lutv, filt, up, dn) in enumerate(stages):
+                out += ['[CONTROLLER_%d]' % i, 'INPUT=%s' % inp, 'COMBINATOR=%s' % comb, 'LUT=%s' % lutv, 'FILTER=%g' % filt, 'UP_LIMIT=%g' % up, 'DOWN_LIMIT=%g' % dn, '']
+            open(os.path.join(d, name), 'w', newline='').write('\n'.join(out))
+    car('pdb_ctrlin_a_ae86', {
+        'ctrl_arb_front.ini': [('SLIPRATIO_MAX', 'ADD', '(|-1=30000|0=20000|0.3=26000|2=36000|)', 0.7, 0, 0), ('SLIPRATIO_AVG', 'ADD', '(|-1=-4000|0=0|1=5000|)', 0.5, 0, 0),
+                               ('SLIPANGLE_FRONT_AVG', 'ADD', '(|-20=3000|0=0|20=3000|)', 0.8, 0, 0), ('SLIPANGLE_REAR_AVG', 'ADD', '(|-30=-5000|0=0|30=-5000|)', 0.6, 45000, 12000)],
+        'ctrl_ebb.ini': [('LOAD_SPREAD_LF', 'ADD', '(|0=0.3|0.5=0.6|1=0.3|)', 0.2, 0, 0), ('LOAD_SPREAD_RF', 'ADD', '(|0=0.1|0.5=0.0|1=0.1|)', 0.4, 0, 0),
+                         ('STEER_DEG', 'ADD', '(|-500=0.05|0=0|500=0.05|)', 0.9, 0, 0), ('WHEEL_STEER_DEG', 'ADD', '(|-1=-0.04|0=0|1=0.04|)', 0.3, 0.78, 0.5)]})
+    car('pdb_ctrlin_b_ae86', {
+        'ctrl_arb_rear.ini': [('SLIPANGLE_FRONT_MAX', 'ADD', '(|0=9000|10=12000|40=15000|)', 0.85, 0, 0), ('SLIPANGLE_REAR_MAX', 'ADD', '(|0=0|15=4000|60=9000|)', 0.6, 0, 0),
+                              ('OVERSTEER_FACTOR', 'ADD', '(|-30=2500|0=0|30=-3000|)', 0.75, 0, 0), ('REAR_SPEED_RATIO', 'MULT', '(|0=0.8|1=1.0|1.5=1.25|3=1.4|)', 0.5, 30000, 4000)]})
+
+
 def make_dynctrl_ae86(base, src='ks_toyota_ae86_drift', dst='pdb_dynctrl_ae86'):
     """A 33-row car with a controller file: the launcher must route it through the row-guarded kernels (the exact-size ones are compiled without the
     controllers' call sites) -- tests/test_gpu_parity.py steps it against the oracle.  The differential's preload from speed and throttle."""
@@ -260,6 +286,7 @@ def main():
     make_dynctrl_car(base)
     make_dynctrl_ae86(base)
     make_brakectrl_car(base)
+    make_ctrl_inputs_cars(base)
     gen_track.gen_flat(os.path.join(base, 'content', 'tracks', 'flat'))
     gen_track.gen_touge(os.path.join(base, 'content', 'tracks', 'touge'))
     gen_track.gen_walled(os.path.join(base, 'content', 'tracks', 'walled'))

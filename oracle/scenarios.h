@@ -96,8 +96,11 @@ static const Scenario kScenarios[] = {
     {"dynctrl", 2400, 200, 10, 1, 1, 1, 1, "flat", 0, "pdb_dynctrl_supra", 0, 0, 0, 0, 0, 0, 0},
     // the brake system's controller files (ctrl_ebb.ini: the front bias; steer_brake_controller.ini: torque on the inner rear wheel) -- the brake script
     {"brakectrl", 2400, 200, 10, 1, 1, 1, 1, "flat", 0, "pdb_brakectrl_rx7", 0, 0, 0, 0, 0, 0, 0},
+    // the controller inputs that read the tyres' status (slip ratios and angles, oversteer factor, wheel-speed ratio, load spread, steering angles), on two derived cars
+    {"ctrlin_a", 2400, 200, 10, 1, 1, 1, 1, "flat", 0, "pdb_ctrlin_a_ae86", 0, 0, 0, 0, 0, 0, 0},
+    {"ctrlin_b", 2400, 200, 10, 1, 1, 1, 1, "flat", 0, "pdb_ctrlin_b_ae86", 0, 0, 0, 0, 0, 0, 0},
 };
-static const int kNumScenarios = 45;
+static const int kNumScenarios = 47;
 static const float kTeleDist[4] = {0.13f, 0.41f, 0.77f, 0.95f};
 struct ScoreVar { const char* name; float value; };
 static const ScoreVar kScoringSetA[] = {
@@ -164,7 +167,7 @@ inline void scenarioControls(int sid, int tick, Ctl& c) {
     c.steer = 0; c.clutch = 0; c.brake = 0; c.handBrake = 0; c.gas = 0; c.requestedGearIndex = -1; c.gearUp = 0; c.gearDn = 0;
     const double t = (double)tick * (1.0 / 333.0);
     if (sid < 4 || sid == 7 || sid == 9 || sid == 14) { float a0, a1; scenarioAction(sid, tick, a0, a1); c.steer = a0; c.gas = envGas(a1); return; }
-    if (sid == 4 || sid == 38 || sid == 42 || sid == 43 || sid == 44) {
+    if (sid == 4 || sid == 38 || (sid >= 42 && sid <= 46)) {
         if (t < 3.0) { c.gas = 1.0f; }
         else if (t < 5.0) { c.brake = 0.8f; }
         else if (t < 6.0) { c.gas = 0.7f; c.steer = 0.3f; }

@@ -55,13 +55,15 @@ static void mkDBall(std::vector<RawJoint>& out, const HBody* B, int b0, int b1, 
 static void dynCtrlLoad(pdb_car_params& P, pdb_dyn_ctrl& dc, const std::string& path) {
     Ini ini(path);
     dc.first = P.numCtrlStages; dc.count = 0;
-    static const char* known[] = {"", "BRAKE", "GAS", "LATG", "LONG", "STEER", "SPEED_KMH", "GEAR", "RPMS", "CONST"};
+    static const char* known[] = {"", "BRAKE", "GAS", "LATG", "LONG", "STEER", "SPEED_KMH", "GEAR", "RPMS", "CONST", "SLIPRATIO_MAX", "SLIPRATIO_AVG", "SLIPANGLE_FRONT_AVG",
+                                  "SLIPANGLE_REAR_AVG", "SLIPANGLE_FRONT_MAX", "SLIPANGLE_REAR_MAX", "OVERSTEER_FACTOR", "REAR_SPEED_RATIO", "STEER_DEG", "WHEEL_STEER_DEG",
+                                  "LOAD_SPREAD_LF", "LOAD_SPREAD_RF"};   // (the suspension-travel inputs are not: the travel is not part of the record)
     for (int id = 0;; ++id) {
         char secn[32]; snprintf(secn, sizeof(secn), "CONTROLLER_%d", id);
         if (!ini.hasSection(secn)) break;
         const std::string in = ini.getString(secn, "INPUT"), comb = ini.getString(secn, "COMBINATOR");
         int iv = 0;
-        for (int k = 1; k <= 9; ++k) if (in == known[k]) iv = k;
+        for (int k = 1; k <= 21; ++k) if (in == known[k]) iv = k;
         if (iv == 0) throw std::runtime_error("pdb: " + path + " " + secn + ": controller input " + in + " unsupported");
         const int cm = comb == "ADD" ? 1 : comb == "MULT" ? 2 : 0;
         if (cm == 0) continue;   // (the reference warns and skips the stage)
