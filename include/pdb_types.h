@@ -188,7 +188,8 @@ typedef struct pdb_ctrl_stage {
     float upLimit, downLimit, constValue;
     pdb_curve lut;
 } pdb_ctrl_stage;
-typedef struct pdb_dyn_ctrl { int32_t first, count; } pdb_dyn_ctrl;   /* stages [first, first + count); count 0 = no controller */
+typedef struct pdb_dyn_ctrl { int32_t first, count; } pdb_dyn_ctrl;
+typedef struct pdb_brake_disc { float torqueK, coolTransfer, coolSpeedFactor; pdb_curve perfCurve; } pdb_brake_disc;   /* stages [first, first + count); count 0 = no controller */
 
 typedef struct pdb_scoring {
     float SmoothSteerSpeed, MinBonusSpeed, MaxBonusSpeed, StallRpm, DirectionThreshold, OutOfTrackThreshold,
@@ -296,6 +297,10 @@ typedef struct pdb_car_params {
     /* ctrl_ebb.ini (BrakeSystem.cpp:64-69,90-93: the front brake bias of the tick; takes precedence over [EBB]), steer_brake_controller.ini
      * (BrakeSystem.cpp:33-38,136-143: extra brake torque on the inner rear wheel) */
     pdb_dyn_ctrl ctrlEbb, ctrlSteerBrake;
+    /* brakes.ini [TEMPS_FRONT] + [TEMPS_REAR] (BrakeSystem.cpp:40-52,151-169): each disc's temperature follows the work done on it and the air stream,
+     * and scales its brake torque through PERF_CURVE */
+    int32_t hasBrakeTemps, _padBrake;
+    pdb_brake_disc discs[4];
     /* ctrl_arb_front.ini / ctrl_arb_rear.ini (Car.cpp:158-167, AntirollBar.cpp:19-22): the bar's rate of the tick; the bars step after the drivetrain */
     pdb_dyn_ctrl ctrlArb[2];
     int32_t numCtrlStages, _padCtrl;
@@ -359,6 +364,7 @@ typedef struct pdb_dyn_state {
                               * projectd_env.py:216-227); 2 = reset tick whose teleport the caller has already done */
     int32_t envStepId;       /* env mode: ticks since the episode's reset tick (projectd_env.py step_id) */
     int32_t _pad[1];         /* record size is a multiple of 16 bytes (coalesced 16-byte-per-lane copies) */
+    float brakeDiscT[4];     /* BrakeDisc::t (BrakeSystem.cpp:151-169): 0 at creation, the ambient temperature after Car::reset */
     float ctrlValue[PDB_MAX_CTRL_STAGES];   /* DynamicControllerStage::currentValue of the car's controller stages (never reset, as in the reference) */
     float wingCtrlOut[PDB_MAX_WING_CTRL];   /* WingDynamicController::outputAngle of the car's wing controllers (never reset: it outlives Car::reset, as in the reference) */
 } pdb_dyn_state;
@@ -459,8 +465,8 @@ typedef struct pdb_ray_rec {
 }
 /* sizes are part of the ABI (tests/test_abi.py reads these numbers) */
 static_assert(sizeof(pdb_car_state) == 664, "pdb_car_state must equal the reference CarState (pack 4)");
-static_assert(sizeof(pdb_car_params) == 21808, "pdb_car_params layout");
-static_assert(sizeof(pdb_dyn_state) == 2320, "pdb_dyn_state layout (multiple of 16 bytes)");
+static_assert(sizeof(pdb_car_params) == 22648, "pdb_car_params layout");
+static_assert(sizeof(pdb_dyn_state) == 2336, "pdb_dyn_state layout (multiple of 16 bytes)");
 static_assert(sizeof(pdb_step_out) == 104, "pdb_step_out layout");
 static_assert(sizeof(pdb_contact) == 32, "pdb_contact layout");
 static_assert(sizeof(pdb_ray_rec) == 48, "pdb_ray_rec layout");

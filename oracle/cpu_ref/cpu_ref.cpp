@@ -1590,6 +1590,18 @@ void Car::carStep(float dt) {
             const float fSteerBrake = dynCtrlEval(*this, Pm.ctrlSteerBrake);
             if (fSteerBrake >= 0.0f) ts[3].brakeTorque += fSteerBrake; else ts[2].brakeTorque -= fSteerBrake;
         }
+        if (Pm.hasBrakeTemps) {   // BrakeSystem::stepTemps (:151-169)
+            const float fAmbientTemp = Pm.ambientTemperature, fSpeed = kmh(S.speed);
+            for (int i = 0; i < 4; ++i) {
+                const pdb_brake_disc& d = Pm.discs[i];
+                float t = S.brakeDiscT[i];
+                ts[i].brakeTorque = curve(d.perfCurve, t) * ts[i].brakeTorque;
+                const float fCool = ((fSpeed * d.coolSpeedFactor) + 1.0f) * d.coolTransfer;
+                t += (((fAmbientTemp - t) * fCool) * dt);
+                t += (((fabsf(S.tyre[i].angularVelocity) * (ts[i].brakeTorque * d.torqueK)) * 0.001f) * dt);
+                S.brakeDiscT[i] = t;
+            }
+        }
     }
     for (int i = 0; i < 4; ++i) {
         if (Pm.susp[i].type == PDB_SUSP_STRUT) strutStep(Pm.susp[i], w, ts[i]);

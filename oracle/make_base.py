@@ -226,6 +226,23 @@ def make_brakectrl_car(base, src='ks_mazda_rx7_tuned', dst='pdb_brakectrl_rx7'):
         '[CONTROLLER_1]', 'INPUT=GEAR', 'COMBINATOR=MULT', 'LUT=(|0=1.2|1=1.1|3=1.0|5=0.9|)', 'FILTER=0.3', 'UP_LIMIT=0', 'DOWN_LIMIT=0', '']))
 
 
+def make_braketemp_car(base, src='ks_mazda_rx7_tuned', dst='pdb_braketemp_rx7'):
+    """Brake disc temperatures (brakes.ini [TEMPS_FRONT] + [TEMPS_REAR], BrakeSystem.cpp:40-52,151-169: the reference names the F40, which it does not
+    ship): each disc heats with the work done on it, cools with the air stream and scales its torque through PERF_CURVE; Car::reset puts the discs at
+    the ambient temperature.  The tuned RX-7 with both sections, through the brake script with a reset in mid-run."""
+    s = os.path.join(REF, 'content', 'cars', src, 'data'); d = os.path.join(base, 'content', 'cars', dst, 'data')
+    if os.path.isdir(d):
+        shutil.rmtree(d)
+    shutil.copytree(s, d)
+    os.system('chmod -R u+w "%s"' % d)
+    p = os.path.join(d, 'brakes.ini')
+    raw = open(p, newline='').read()
+    eol = '\r\n' if '\r\n' in raw else '\n'
+    extra = ['', '[TEMPS_FRONT]', 'COOL_TRANSFER=0.004', 'COOL_SPEED_FACTOR=0.006', 'TORQUE_K=0.9', 'PERF_CURVE=(|0=0.7|60=0.85|200=1.0|500=1.0|800=0.55|)', '',
+             '[TEMPS_REAR]', 'COOL_TRANSFER=0.003', 'COOL_SPEED_FACTOR=0.004', 'TORQUE_K=0.7', 'PERF_CURVE=(|0=0.8|100=1.0|450=1.0|700=0.6|)', '']
+    open(p, 'w', newline='').write(raw.rstrip('\r\n') + eol + eol.join(extra))
+
+
 def make_ctrl_inputs_cars(base, src='ks_toyota_ae86_drift'):
     """The controller inputs that read the tyres' status (DynamicController.cpp:191-253), on two derived AE86s (eight stages per car): A -- the front
     anti-roll bar's rate from the driven axle's slip ratios and the axles' mean slip angles (stepped after the tyres and the drivetrain of the tick), the
@@ -287,6 +304,7 @@ def main():
     make_dynctrl_ae86(base)
     make_brakectrl_car(base)
     make_ctrl_inputs_cars(base)
+    make_braketemp_car(base)
     gen_track.gen_flat(os.path.join(base, 'content', 'tracks', 'flat'))
     gen_track.gen_touge(os.path.join(base, 'content', 'tracks', 'touge'))
     gen_track.gen_walled(os.path.join(base, 'content', 'tracks', 'walled'))

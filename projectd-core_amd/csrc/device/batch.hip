@@ -237,7 +237,7 @@ static void launchTick(pdb_batch* b, hipStream_t st, int c0, int c1, pdb_step_ou
     const pdb_car_params* DP = own ? b->dPartParams[q] : b->dParams;
     const DevConst* DK = own ? b->dPartK[q] : b->dK;
     const pdb_car_params& HP = own ? b->partParams[q] : b->params;
-    uint8_t* SN = b->dSnap + (size_t)c0 * ((m <= 33 && HP.numCtrlStages == 0) ? k33::kSnapStride : kSnapStrideWide);
+    uint8_t* SN = b->dSnap + (size_t)c0 * ((m <= 33 && HP.numCtrlStages == 0 && HP.hasBrakeTemps == 0) ? k33::kSnapStride : kSnapStrideWide);
     uint8_t* RM = b->resetMaskArmed ? b->dResetMask + c0 : nullptr;
     const int n = c1 - c0;
     // the contact pass also serves episode resets asked for through the reset mask and the in-tick auto-teleport
@@ -254,7 +254,7 @@ static void launchTick(pdb_batch* b, hipStream_t st, int c0, int c1, pdb_step_ou
     int* HN = b->dHint ? b->dHint + q : nullptr;
     const dim3 grid(nblk), block(PDB_BLOCK_THREADS), cblock(PDB_WAVE * (PDB_CONTACT_CPB + 1)), cgrid(((n + PDB_CONTACT_CPB - 1) / PDB_CONTACT_CPB) < cg ? ((n + PDB_CONTACT_CPB - 1) / PDB_CONTACT_CPB) : cg);
     // a car with DynamicController files goes through the kernel pair compiled with the controllers' call sites (40-row class, row-guarded: any car)
-    const bool ctrl = HP.numCtrlStages != 0;
+    const bool ctrl = HP.numCtrlStages != 0 || HP.hasBrakeTemps != 0;
     if (ctrl) {
 #ifndef PDB_FAST_BUILD
         hipLaunchKernelGGL(k40::pdb_step_kernel_ctrl, grid, block, 0, st, S, Aact, O, CS, DP, DK, b->dTrack, (k40::RedoQueue*)Q, RM, n, SN);

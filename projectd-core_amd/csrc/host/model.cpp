@@ -782,7 +782,16 @@ void buildCarModel(const std::string& basePathIn, const std::string& modelName, 
         P.handBrakeTorque = br.getFloat("DATA", "HANDBRAKE_TORQUE");
         P.brakePowerMultiplier = 1.0f;
         P.biasMin = 0.0f; P.biasMax = 1.0f;
-        if (br.hasSection("TEMPS_FRONT") && br.hasSection("TEMPS_REAR")) throw std::runtime_error("pdb: brake disc temperatures ([TEMPS_FRONT] / [TEMPS_REAR]) unsupported");
+        if (br.hasSection("TEMPS_FRONT") && br.hasSection("TEMPS_REAR")) {   // BrakeSystem.cpp:40-52
+            P.hasBrakeTemps = 1;
+            for (int id = 0; id < 4; ++id) {
+                const char* sec = id < 2 ? "TEMPS_FRONT" : "TEMPS_REAR";
+                pdb_brake_disc& d = P.discs[id];
+                const std::string v = br.getString(sec, "PERF_CURVE");
+                if (v.find(".lut") != std::string::npos) curveLoad(d.perfCurve, dataPath + v); else curveParseInline(d.perfCurve, v);
+                d.torqueK = br.getFloat(sec, "TORQUE_K"); d.coolTransfer = br.getFloat(sec, "COOL_TRANSFER"); d.coolSpeedFactor = br.getFloat(sec, "COOL_SPEED_FACTOR");
+            }
+        }
         if (fileExists(dataPath + "steer_brake_controller.ini")) {   // BrakeSystem.cpp:33-38
             dynCtrlLoad(P, P.ctrlSteerBrake, dataPath + "steer_brake_controller.ini");
             if (P.ctrlSteerBrake.count == 0) throw std::runtime_error("pdb: steer_brake_controller.ini has no usable stage");

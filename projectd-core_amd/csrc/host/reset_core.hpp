@@ -110,6 +110,7 @@ PDB_HD inline void teleportToSplineT(const pdb_car_params& P, int numFat, const 
         bodyPos[1] += (P.baseCarHeight + 0.0f + 0.01f);
         // Car::reset()
         S.waterT = 60.0f;
+        for (int i = 0; i < 4; ++i) S.brakeDiscT[i] = P.ambientTemperature;   // BrakeSystem::reset (BrakeSystem.cpp:73-80)
         S.fuel = P.fuel;
         S.collisionFlag = 0; S.oldCollisionFlag = 0; S.outOfTrackFlag = 0;
         S.lastTrackPointTimestamp = (float)S.physicsTime;

@@ -63,6 +63,8 @@ class WingCtrl(C.Structure):
     _fields_ = [('wing', C.c_int32), ('input', C.c_int32), ('combinator', C.c_int32), ('filter', C.c_float), ('upLimit', C.c_float), ('downLimit', C.c_float), ('lut', Curve)]
 class CtrlStage(C.Structure):
     _fields_ = [('input', C.c_int32), ('combinator', C.c_int32), ('filter', C.c_float), ('upLimit', C.c_float), ('downLimit', C.c_float), ('constValue', C.c_float), ('lut', Curve)]
+class BrakeDisc(C.Structure):
+    _fields_ = [('torqueK', C.c_float), ('coolTransfer', C.c_float), ('coolSpeedFactor', C.c_float), ('perfCurve', Curve)]
 class DynCtrl(C.Structure):
     _fields_ = [('first', C.c_int32), ('count', C.c_int32)]
 class Wing(C.Structure):
@@ -94,7 +96,7 @@ class CarParams(C.Structure):
         [('upshiftProfile', Curve), ('downshiftProfile', Curve), ('blipProfile', Curve), ('blipPerformTime', C.c_double), ('asChangeUpRpm', C.c_int32), ('asChangeDnRpm', C.c_int32),
          ('asSlipThreshold', C.c_float), ('asGasCutoffTime', C.c_float), ('smoothSteer', C.c_int32), ('patchConnCount', C.c_int8 * 36), ('patchConn', (C.c_int8 * 4) * 36),
          ('scoring', Scoring), ('collider', Collider), ('throttleCurveMax', Curve), ('throttleMaxRef', C.c_float), ('gasCoastOffset', C.c_float),
-         ('coastEntryRpm', C.c_int32), ('ebbInternal', C.c_int32), ('ebbFrontMultiplier', C.c_float), ('overlapFreq', C.c_float), ('overlapGain', C.c_float), ('overlapIdealRPM', C.c_float), ('wingGroundEffect', C.c_int32)] + [(k, C.c_float) for k in ('aeroReferenceArea', 'aeroFrontShare', 'aeroCD', 'aeroCL', 'aeroCDX', 'aeroCDY', 'aeroCDA')] + [('numWingCtrl', C.c_int32), ('wingCtrl', WingCtrl * 4), ('ctrlDiffLock', DynCtrl), ('ctrlTurboBoost', DynCtrl * 3), ('ctrlWastegate', DynCtrl * 3), ('ctrlEbb', DynCtrl), ('ctrlSteerBrake', DynCtrl), ('ctrlArb', DynCtrl * 2), ('numCtrlStages', C.c_int32), ('_padCtrl', C.c_int32), ('ctrlStages', CtrlStage * 8)]
+         ('coastEntryRpm', C.c_int32), ('ebbInternal', C.c_int32), ('ebbFrontMultiplier', C.c_float), ('overlapFreq', C.c_float), ('overlapGain', C.c_float), ('overlapIdealRPM', C.c_float), ('wingGroundEffect', C.c_int32)] + [(k, C.c_float) for k in ('aeroReferenceArea', 'aeroFrontShare', 'aeroCD', 'aeroCL', 'aeroCDX', 'aeroCDY', 'aeroCDA')] + [('numWingCtrl', C.c_int32), ('wingCtrl', WingCtrl * 4), ('ctrlDiffLock', DynCtrl), ('ctrlTurboBoost', DynCtrl * 3), ('ctrlWastegate', DynCtrl * 3), ('ctrlEbb', DynCtrl), ('ctrlSteerBrake', DynCtrl), ('hasBrakeTemps', C.c_int32), ('_padBrake', C.c_int32), ('discs', BrakeDisc * 4), ('ctrlArb', DynCtrl * 2), ('numCtrlStages', C.c_int32), ('_padCtrl', C.c_int32), ('ctrlStages', CtrlStage * 8)]
 class BodyState(C.Structure):
     _fields_ = [('pos', C.c_float * 3), ('q', C.c_float * 4), ('R', C.c_float * 9), ('lvel', C.c_float * 3), ('avel', C.c_float * 3)]
 class TyreState(C.Structure):
@@ -116,7 +118,7 @@ class DynState(C.Structure):
         [(n, C.c_int32) for n in ('oldPointId', 'oldSplinePointId', 'drifting', 'driftExtreme', 'driftInvalid', 'driftComboCounter', 'collisionFlag', 'oldCollisionFlag',
                                   'outOfTrackFlag')] + \
         [('gasUsage', C.c_float), ('locClutch', C.c_float), ('turboRotation', C.c_float * 3), ('simFrame', C.c_int32), ('damageChanged', C.c_int32),
-         ('damageZoneLevel', C.c_float * 5), ('numContacts', C.c_int32), ('randState', C.c_int32), ('envPending', C.c_int32), ('envStepId', C.c_int32), ('_pad', C.c_int32 * 1), ('ctrlValue', C.c_float * 8), ('wingCtrlOut', C.c_float * 4)]
+         ('damageZoneLevel', C.c_float * 5), ('numContacts', C.c_int32), ('randState', C.c_int32), ('envPending', C.c_int32), ('envStepId', C.c_int32), ('_pad', C.c_int32 * 1), ('brakeDiscT', C.c_float * 4), ('ctrlValue', C.c_float * 8), ('wingCtrlOut', C.c_float * 4)]
 assert C.sizeof(DynState) % 16 == 0
 MAX_CONTACTS = 32
 class Contact(C.Structure):   # pdb_contact
