@@ -169,6 +169,7 @@ struct pdb_batch {
     float* hActions = nullptr;          // page-locked host mirrors (pdb_host_actions / pdb_host_out): the pipelined host-policy loop
     pdb_step_out* hOut = nullptr;
     int contactGrid = 0;   // workgroups of the contact pass: 0 = adaptive (from the queue lengths the last passes saw); PDB_CONTACT_GRID in the environment fixes it (diagnostic)
+    bool capturing = false;   // launches being recorded into a graph: the contact pass's grid is then frozen, so it is not sized for an idle pass
     int* hHint = nullptr;  // page-locked, device-visible: per launch site, the number of cars the last contact pass held (written by its last workgroup; read here without waiting)
     int* dHint = nullptr;
 };
@@ -249,6 +250,7 @@ static void launchTick(pdb_batch* b, hipStream_t st, int c0, int c1, pdb_step_ou
         const int held = b->hHint ? *(volatile int*)(b->hHint + q) : 0;
         cg = (2 * held + PDB_CONTACT_CPB - 1) / PDB_CONTACT_CPB;
         if (cg < (held > 0 ? PDB_CONTACT_GRID : PDB_CONTACT_GRID_IDLE)) cg = held > 0 ? PDB_CONTACT_GRID : PDB_CONTACT_GRID_IDLE;   // nobody touched anything lately: a handful of workgroups is launched, found empty and gone
+        if (b->capturing && cg < PDB_CONTACT_GRID) cg = PDB_CONTACT_GRID;   // a replayed graph cannot follow the load
         if (cg > 2048) cg = 2048;
     }
     int* HN = b->dHint ? b->dHint + q : nullptr;
@@ -629,8 +631,10 @@ int pdb_step_n(pdb_batch* b, float dt, int n) {
         if (b->graphExec) { (void)hipGraphExecDestroy(b->graphExec); b->graphExec = nullptr; }
         hipGraph_t g = nullptr;
         HIPCHK(hipStreamBeginCapture(b->stream, hipStreamCaptureModeThreadLocal));
+        b->capturing = true;
         for (int i = 0; i < n; ++i)
             launchWhole(b, b->stream, b->dOutActive);
+        b->capturing = false;
         HIPCHK(hipStreamEndCapture(b->stream, &g));
         HIPCHK(hipGraphInstantiate(&b->graphExec, g, nullptr, nullptr, 0));
         (void)hipGraphDestroy(g);
