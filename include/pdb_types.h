@@ -170,7 +170,7 @@ typedef struct pdb_wing {
 
 typedef struct pdb_wing_ctrl {
     int32_t wing;         /* index into wings[] (WING_n first, then FIN_n, as AeroMap builds its list) */
-    int32_t input;        /* WingControllerVariable: 1 BRAKE, 2 GAS, 3 LATG, 4 LONG, 5 STEER, 6 SPEED_KMH */
+    int32_t input;        /* WingControllerVariable: 1 BRAKE, 2 GAS, 3 LATG, 4 LONG, 5 STEER, 6 SPEED_KMH, 7 / 8 SUS_TRAVEL_LR / RR (such a wing steps after the suspensions of the tick) */
     int32_t combinator;   /* 1 ADD, 2 MULT */
     float filter;         /* ((1 - FILTER) * 1.3333334) * 333.33334 */
     float upLimit, downLimit;
@@ -182,7 +182,8 @@ typedef struct pdb_wing_ctrl {
  * word of the record (pdb_dyn_state.ctrlValue). */
 typedef struct pdb_ctrl_stage {
     int32_t input;        /* 1 BRAKE, 2 GAS, 3 LATG, 4 LONG, 5 STEER, 6 SPEED_KMH, 7 GEAR, 8 RPMS, 9 CONST, 10 SLIPRATIO_MAX, 11 SLIPRATIO_AVG, 12 / 13 SLIPANGLE_FRONT / REAR_AVG,
-                           * 14 / 15 SLIPANGLE_FRONT / REAR_MAX, 16 OVERSTEER_FACTOR, 17 REAR_SPEED_RATIO, 18 STEER_DEG, 19 WHEEL_STEER_DEG, 20 / 21 LOAD_SPREAD_LF / RF */
+                           * 14 / 15 SLIPANGLE_FRONT / REAR_MAX, 16 OVERSTEER_FACTOR, 17 REAR_SPEED_RATIO, 18 STEER_DEG, 19 WHEEL_STEER_DEG, 20 / 21 LOAD_SPREAD_LF / RF,
+                           * 22 AVG_TRAVEL_REAR, 23 / 24 SUS_TRAVEL_LR / RR */
     int32_t combinator;   /* 1 ADD, 2 MULT */
     float filter;         /* lagToLerpDeltaK(FILTER, 0.004, 0.003) */
     float upLimit, downLimit, constValue;
@@ -364,6 +365,7 @@ typedef struct pdb_dyn_state {
                               * projectd_env.py:216-227); 2 = reset tick whose teleport the caller has already done */
     int32_t envStepId;       /* env mode: ticks since the episode's reset tick (projectd_env.py step_id) */
     int32_t _pad[1];         /* record size is a multiple of 16 bytes (coalesced 16-byte-per-lane copies) */
+    float suspTravel[4];     /* ISuspension status.travel of the last suspension step (read by controllers: the brake system's before this tick's step, the others after it) */
     float brakeDiscT[4];     /* BrakeDisc::t (BrakeSystem.cpp:151-169): 0 at creation, the ambient temperature after Car::reset */
     float ctrlValue[PDB_MAX_CTRL_STAGES];   /* DynamicControllerStage::currentValue of the car's controller stages (never reset, as in the reference) */
     float wingCtrlOut[PDB_MAX_WING_CTRL];   /* WingDynamicController::outputAngle of the car's wing controllers (never reset: it outlives Car::reset, as in the reference) */
@@ -466,7 +468,7 @@ typedef struct pdb_ray_rec {
 /* sizes are part of the ABI (tests/test_abi.py reads these numbers) */
 static_assert(sizeof(pdb_car_state) == 664, "pdb_car_state must equal the reference CarState (pack 4)");
 static_assert(sizeof(pdb_car_params) == 22648, "pdb_car_params layout");
-static_assert(sizeof(pdb_dyn_state) == 2336, "pdb_dyn_state layout (multiple of 16 bytes)");
+static_assert(sizeof(pdb_dyn_state) == 2352, "pdb_dyn_state layout (multiple of 16 bytes)");
 static_assert(sizeof(pdb_step_out) == 104, "pdb_step_out layout");
 static_assert(sizeof(pdb_contact) == 32, "pdb_contact layout");
 static_assert(sizeof(pdb_ray_rec) == 48, "pdb_ray_rec layout");

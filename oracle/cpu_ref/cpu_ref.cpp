@@ -1022,6 +1022,8 @@ static void wingStep(Car& c, int wi) {
             case 4: in = c.accG[2]; break;
             case 5: in = c.controls.steer; break;
             case 6: in = kmhOfSpeed(c.S.speed); break;
+            case 7: in = c.S.suspTravel[2]; break;
+            case 8: in = c.S.suspTravel[3]; break;
         }
         float fAngle = curve(wc.lut, in);
         const float out = c.S.wingCtrlOut[j];
@@ -1188,6 +1190,9 @@ static float dynCtrlEval(Car& c, const pdb_dyn_ctrl& dc) {
                         case 19: in = c.finalSteerAngleSignal; break;
                         case 20: in = t[0].load / (t[0].load + t[1].load); break;
                         case 21: in = t[1].load / (float)(t[1].load + t[0].load); break;
+                        case 22: in = (S.suspTravel[2] + S.suspTravel[3]) * 0.5f * 1000.0f; break;
+                        case 23: in = S.suspTravel[2] * 1000.0f; break;
+                        case 24: in = S.suspTravel[3] * 1000.0f; break;
                     }
                 } break;
             }
@@ -1608,6 +1613,7 @@ void Car::carStep(float dt) {
         else if (Pm.susp[i].type == PDB_SUSP_DW) dwStep(Pm.susp[i], w, ts[i]);
         else if (Pm.susp[i].type == PDB_SUSP_ML) mlStep(Pm.susp[i], w, ts[i]);
         else axleStep(Pm.susp[i], w, ts[i]);
+        S.suspTravel[i] = ts[i].travel;   // ISuspension status.travel: part of the record (controllers read it, the brake system's a tick later)
     }
     for (int i = 0; i < 4; ++i) tyreStep(*this, i, dt);
     for (int a = 0; a < 2; ++a) if (Pm.heave[a].k != 0.0f) heaveStep(Pm, Pm.heave[a], w, a * 2);   // Car.cpp:654-658

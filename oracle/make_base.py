@@ -177,6 +177,28 @@ def make_wingctrl_car(base, src='dthwsh_mazda_rx7_fc3s_sr20', dst='pdb_wingctrl_
     open(p, 'w', newline='').write(raw.rstrip('\r\n') + eol + eol.join(extra) + eol)
 
 
+def make_wingctrl2_car(base, src='dthwsh_mazda_rx7_fc3s_sr20', dst='pdb_wingctrl2_fc3s'):
+    """The wing controllers' other four inputs (WingDynamicController.cpp:77-107): the rear suspensions' travel (metres; such a wing steps after the
+    suspensions of the tick), the longitudinal g and the steering input."""
+    s = os.path.join(REF, 'content', 'cars', src, 'data'); d = os.path.join(base, 'content', 'cars', dst, 'data')
+    if os.path.isdir(d):
+        shutil.rmtree(d)
+    shutil.copytree(s, d)
+    os.system('chmod -R u+w "%s"' % d)
+    open(os.path.join(d, 'pdb_wc_travl.lut'), 'w').write('-0.05|-2\n0|0\n0.06|5\n')
+    open(os.path.join(d, 'pdb_wc_travr.lut'), 'w').write('-0.05|0.8\n0|1\n0.06|1.3\n')
+    open(os.path.join(d, 'pdb_wc_long.lut'), 'w').write('-1.5|6\n0|0\n1|-2\n')
+    open(os.path.join(d, 'pdb_wc_steer.lut'), 'w').write('-1|1.5\n0|0\n1|1.5\n')
+    p = os.path.join(d, 'aero.ini')
+    raw = open(p, newline='').read()
+    eol = '\r\n' if '\r\n' in raw else '\n'
+    extra = []
+    for i, (wing, inp, comb, lutf, filt, up, dn) in enumerate(((2, 'SUS_TRAVEL_LR', 'ADD', 'pdb_wc_travl.lut', 0.9, 14, -3), (2, 'SUS_TRAVEL_RR', 'MULT', 'pdb_wc_travr.lut', 0.7, 16, -4),
+                                                                 (1, 'LONG', 'ADD', 'pdb_wc_long.lut', 0.85, 8, -4), (0, 'STEER', 'ADD', 'pdb_wc_steer.lut', 0.6, 4, -1))):
+        extra += ['', '[DYNAMIC_CONTROLLER_%d]' % i, 'WING=%d' % wing, 'COMBINATOR=%s' % comb, 'INPUT=%s' % inp, 'LUT=%s' % lutf, 'FILTER=%g' % filt, 'UP_LIMIT=%g' % up, 'DOWN_LIMIT=%g' % dn]
+    open(p, 'w', newline='').write(raw.rstrip('\r\n') + eol + eol.join(extra) + eol)
+
+
 def make_dynctrl_car(base, src='ks_toyota_supra_mkiv_drift', dst='pdb_dynctrl_supra'):
     """DynamicController files (Car/DynamicController.cpp) -- chains of filtered LUT stages over car signals: ctrl_wastegate0.ini (the first turbo's
     wastegate from rpm, scaled by gear; Engine.cpp:124-143,368-376), ctrl_turbo1.ini (the second turbo's maxBoost: a constant scaled by the throttle),
@@ -266,7 +288,10 @@ def make_ctrl_inputs_cars(base, src='ks_toyota_ae86_drift'):
                          ('STEER_DEG', 'ADD', '(|-500=0.05|0=0|500=0.05|)', 0.9, 0, 0), ('WHEEL_STEER_DEG', 'ADD', '(|-1=-0.04|0=0|1=0.04|)', 0.3, 0.78, 0.5)]})
     car('pdb_ctrlin_b_ae86', {
         'ctrl_arb_rear.ini': [('SLIPANGLE_FRONT_MAX', 'ADD', '(|0=9000|10=12000|40=15000|)', 0.85, 0, 0), ('SLIPANGLE_REAR_MAX', 'ADD', '(|0=0|15=4000|60=9000|)', 0.6, 0, 0),
-                              ('OVERSTEER_FACTOR', 'ADD', '(|-30=2500|0=0|30=-3000|)', 0.75, 0, 0), ('REAR_SPEED_RATIO', 'MULT', '(|0=0.8|1=1.0|1.5=1.25|3=1.4|)', 0.5, 30000, 4000)]})
+                              ('OVERSTEER_FACTOR', 'ADD', '(|-30=2500|0=0|30=-3000|)', 0.75, 0, 0), ('REAR_SPEED_RATIO', 'MULT', '(|0=0.8|1=1.0|1.5=1.25|3=1.4|)', 0.5, 30000, 4000)],
+        # the suspension-travel inputs (millimetres), read by the brake system before this tick's suspension step
+        'ctrl_ebb.ini': [('AVG_TRAVEL_REAR', 'ADD', '(|-40=0.7|0=0.62|60=0.55|)', 0.6, 0, 0), ('SUS_TRAVEL_LR', 'ADD', '(|-40=0.03|0=0|60=-0.03|)', 0.3, 0, 0),
+                         ('SUS_TRAVEL_RR', 'ADD', '(|-40=-0.02|0=0|60=0.04|)', 0.8, 0.8, 0.45)]})
 
 
 def make_dynctrl_ae86(base, src='ks_toyota_ae86_drift', dst='pdb_dynctrl_ae86'):
@@ -300,6 +325,7 @@ def main():
     make_ground_effect_car(base)
     make_aerodata_car(base)
     make_wingctrl_car(base)
+    make_wingctrl2_car(base)
     make_dynctrl_car(base)
     make_dynctrl_ae86(base)
     make_brakectrl_car(base)

@@ -101,8 +101,10 @@ static const Scenario kScenarios[] = {
     {"ctrlin_b", 2400, 200, 10, 1, 1, 1, 1, "flat", 0, "pdb_ctrlin_b_ae86", 0, 0, 0, 0, 0, 0, 0},
     // brake disc temperatures ([TEMPS_FRONT] / [TEMPS_REAR]) on a derived car: the brake script, with a reset to the start in mid-run (the discs go to the ambient temperature)
     {"braketemp", 2400, 200, 10, 1, 1, 1, 1, "flat", 0, "pdb_braketemp_rx7", 0, 0, 1300, 0, 0, 0, 0},
+    // the wing controllers' other inputs (rear suspension travel, longitudinal g, steer) on a derived car -- the brake script
+    {"wingctrl2", 2400, 200, 10, 1, 1, 1, 1, "flat", 0, "pdb_wingctrl2_fc3s", 0, 0, 0, 0, 0, 0, 0},
 };
-static const int kNumScenarios = 48;
+static const int kNumScenarios = 49;
 static const float kTeleDist[4] = {0.13f, 0.41f, 0.77f, 0.95f};
 struct ScoreVar { const char* name; float value; };
 static const ScoreVar kScoringSetA[] = {
@@ -169,7 +171,7 @@ inline void scenarioControls(int sid, int tick, Ctl& c) {
     c.steer = 0; c.clutch = 0; c.brake = 0; c.handBrake = 0; c.gas = 0; c.requestedGearIndex = -1; c.gearUp = 0; c.gearDn = 0;
     const double t = (double)tick * (1.0 / 333.0);
     if (sid < 4 || sid == 7 || sid == 9 || sid == 14) { float a0, a1; scenarioAction(sid, tick, a0, a1); c.steer = a0; c.gas = envGas(a1); return; }
-    if (sid == 4 || sid == 38 || (sid >= 42 && sid <= 47)) {
+    if (sid == 4 || sid == 38 || (sid >= 42 && sid <= 48)) {
         if (t < 3.0) { c.gas = 1.0f; }
         else if (t < 5.0) { c.brake = 0.8f; }
         else if (t < 6.0) { c.gas = 0.7f; c.steer = 0.3f; }

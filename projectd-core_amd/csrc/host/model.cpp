@@ -57,13 +57,13 @@ static void dynCtrlLoad(pdb_car_params& P, pdb_dyn_ctrl& dc, const std::string& 
     dc.first = P.numCtrlStages; dc.count = 0;
     static const char* known[] = {"", "BRAKE", "GAS", "LATG", "LONG", "STEER", "SPEED_KMH", "GEAR", "RPMS", "CONST", "SLIPRATIO_MAX", "SLIPRATIO_AVG", "SLIPANGLE_FRONT_AVG",
                                   "SLIPANGLE_REAR_AVG", "SLIPANGLE_FRONT_MAX", "SLIPANGLE_REAR_MAX", "OVERSTEER_FACTOR", "REAR_SPEED_RATIO", "STEER_DEG", "WHEEL_STEER_DEG",
-                                  "LOAD_SPREAD_LF", "LOAD_SPREAD_RF"};   // (the suspension-travel inputs are not: the travel is not part of the record)
+                                  "LOAD_SPREAD_LF", "LOAD_SPREAD_RF", "AVG_TRAVEL_REAR", "SUS_TRAVEL_LR", "SUS_TRAVEL_RR"};
     for (int id = 0;; ++id) {
         char secn[32]; snprintf(secn, sizeof(secn), "CONTROLLER_%d", id);
         if (!ini.hasSection(secn)) break;
         const std::string in = ini.getString(secn, "INPUT"), comb = ini.getString(secn, "COMBINATOR");
         int iv = 0;
-        for (int k = 1; k <= 21; ++k) if (in == known[k]) iv = k;
+        for (int k = 1; k <= 24; ++k) if (in == known[k]) iv = k;
         if (iv == 0) throw std::runtime_error("pdb: " + path + " " + secn + ": controller input " + in + " unsupported");
         const int cm = comb == "ADD" ? 1 : comb == "MULT" ? 2 : 0;
         if (cm == 0) continue;   // (the reference warns and skips the stage)
@@ -764,7 +764,7 @@ void buildCarModel(const std::string& basePathIn, const std::string& modelName, 
             for (int k = 1; k <= 8; ++k) if (in == inputs[k]) wc.input = k;
             wc.combinator = comb == "ADD" ? 1 : comb == "MULT" ? 2 : 0;
             if (wc.input == 0 || wc.combinator == 0) throw std::runtime_error(std::string("pdb: ") + secn + ": unknown INPUT / COMBINATOR (the reference stops at its first step)");
-            if (wc.input >= 7) throw std::runtime_error(std::string("pdb: ") + secn + ": suspension-travel inputs of wing controllers unsupported");
+            if (wc.input >= 7) P.wingGroundEffect = 1;   // reads this tick's suspension travel: the wings then step after the force barrier, like those with ground-effect LUTs
             curveLoad(wc.lut, dataPath + aero.getString(secn, "LUT"));
             wc.filter = ((1.0f - aero.getFloat(secn, "FILTER")) * 1.3333334f) * 333.33334f;
             wc.upLimit = aero.getFloat(secn, "UP_LIMIT");

@@ -118,7 +118,7 @@ class DynState(C.Structure):
         [(n, C.c_int32) for n in ('oldPointId', 'oldSplinePointId', 'drifting', 'driftExtreme', 'driftInvalid', 'driftComboCounter', 'collisionFlag', 'oldCollisionFlag',
                                   'outOfTrackFlag')] + \
         [('gasUsage', C.c_float), ('locClutch', C.c_float), ('turboRotation', C.c_float * 3), ('simFrame', C.c_int32), ('damageChanged', C.c_int32),
-         ('damageZoneLevel', C.c_float * 5), ('numContacts', C.c_int32), ('randState', C.c_int32), ('envPending', C.c_int32), ('envStepId', C.c_int32), ('_pad', C.c_int32 * 1), ('brakeDiscT', C.c_float * 4), ('ctrlValue', C.c_float * 8), ('wingCtrlOut', C.c_float * 4)]
+         ('damageZoneLevel', C.c_float * 5), ('numContacts', C.c_int32), ('randState', C.c_int32), ('envPending', C.c_int32), ('envStepId', C.c_int32), ('_pad', C.c_int32 * 1), ('suspTravel', C.c_float * 4), ('brakeDiscT', C.c_float * 4), ('ctrlValue', C.c_float * 8), ('wingCtrlOut', C.c_float * 4)]
 assert C.sizeof(DynState) % 16 == 0
 MAX_CONTACTS = 32
 class Contact(C.Structure):   # pdb_contact

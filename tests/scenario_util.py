@@ -1,4 +1,4 @@
-"""The 48 scripted scenarios of oracle/scenarios.h (the reference-TU goldens' scripts) as a set-up + driver usable from any
+"""The 49 scripted scenarios of oracle/scenarios.h (the reference-TU goldens' scripts) as a set-up + driver usable from any
 test: car block, track blob, initial state the way tests/test_oracle_golden.py prepares them, and a tick-by-tick driver that
 steps the CPU oracle and -- optionally -- a GPU batch through the same script (actions, mid-run resets / teleports, the boost)."""
 import ctypes as C, os, sys
