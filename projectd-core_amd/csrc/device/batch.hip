@@ -169,6 +169,8 @@ struct pdb_batch {
     float* hActions = nullptr;          // page-locked host mirrors (pdb_host_actions / pdb_host_out): the pipelined host-policy loop
     pdb_step_out* hOut = nullptr;
     int contactGrid = 0;   // workgroups of the contact pass: 0 = adaptive (from the queue lengths the last passes saw); PDB_CONTACT_GRID in the environment fixes it (diagnostic)
+    int burst[PDB_MAX_PARTS + 1] = {0, 0, 0, 0, 0};   // per launch site: ticks for which the contact pass is launched wide whatever the hint says (after a reset: cars just put down
+                                                        // tend to go through the pass once, all of them in the same tick)
     bool capturing = false;   // launches being recorded into a graph: the contact pass's grid is then frozen, so it is not sized for an idle pass
     int* hHint = nullptr;  // page-locked, device-visible: per launch site, the number of cars the last contact pass held (written by its last workgroup; read here without waiting)
     int* dHint = nullptr;
@@ -251,6 +253,7 @@ static void launchTick(pdb_batch* b, hipStream_t st, int c0, int c1, pdb_step_ou
         cg = (2 * held + PDB_CONTACT_CPB - 1) / PDB_CONTACT_CPB;
         if (cg < (held > 0 ? PDB_CONTACT_GRID : PDB_CONTACT_GRID_IDLE)) cg = held > 0 ? PDB_CONTACT_GRID : PDB_CONTACT_GRID_IDLE;   // nobody touched anything lately: a handful of workgroups is launched, found empty and gone
         if (b->capturing && cg < PDB_CONTACT_GRID) cg = PDB_CONTACT_GRID;   // a replayed graph cannot follow the load
+        if (!b->capturing && b->burst[q] > 0) { --b->burst[q]; if (cg < 512) cg = 512; }
         if (cg > 2048) cg = 2048;
     }
     int* HN = b->dHint ? b->dHint + q : nullptr;
@@ -488,6 +491,7 @@ extern "C" __global__ void pdb_clear_episodes_kernel(pdb_dyn_state* __restrict__
 }
 static int resetLaunch(pdb_batch* b, uint8_t* dMask, int mode, int clear) {
     if (int rcj = joinParts(b)) return rcj;
+    for (int q = 0; q <= PDB_MAX_PARTS; ++q) b->burst[q] = 2;
     bool any = false;
     for (int p = 0; p < b->parts; ++p) any = any || b->partHas[p];
     if (!any) hipLaunchKernelGGL(pdb_reset_kernel, dim3((b->n + 63) / 64), dim3(64), 0, b->stream, b->dStates, dMask, b->dParams, b->dTrack, b->n, mode, clear);
