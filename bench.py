@@ -33,7 +33,7 @@ CARS_PER_GPU = 4096
 # algorithmic bytes per car-tick (DESIGN.md "Algorithmic bytes"): record read + record write + action + output row
 B_ALG = 2352 + 2352 + 8 + 104   # sizeof(pdb_dyn_state) in and out, float[2] action, pdb_step_out (checked against the ctypes mirrors in measure)
 HBM_PEAK_GBS = 8000.0
-PROFILE_TAG = 'r03'
+PROFILE_TAG = 'r04'
 
 
 def cpu_baseline(P, trk, S0, actions, seconds_target=15.0):
@@ -97,7 +97,8 @@ def measure(args, world, rank, local_rank, dist, want_cpu=False):
         gen_args['step'] = args.spline_step
     if args.walls:
         gen_args['walls'] = True
-    trk = pdbatch.synthetic_track(args.workload, **gen_args)
+    is_ref = args.workload in pdbatch.REFERENCE_TRACKS   # one of the reference's own tracks, packed in the build container (tools/pack_tracks.py)
+    trk = pdbatch.reference_track(args.workload) if is_ref else pdbatch.synthetic_track(args.workload, **gen_args)
     lib = pc.load_product()
     S0 = pc.DynState()
     assert lib.pdb_initial_state(C.byref(P), trk, C.byref(S0)) == 0
@@ -108,7 +109,7 @@ def measure(args, world, rank, local_rank, dist, want_cpu=False):
     stream = torch.cuda.current_stream()
     b.set_stream(stream.cuda_stream)
     b.upload_actions(actions)
-    if args.workload in ('playground', 'nordring'):   # reference-scale meshes: every car to its own random point of the lap, on the device
+    if args.workload in ('playground', 'nordring') or is_ref:   # reference-scale meshes: every car to its own random point of the lap, on the device
         b.set_seed(np.arange(first, first + n, dtype=np.uint32) * 2654435761 % 4294967291 + 1)   # Car::teleportByMode(Random) draws from the car's own rand()
         b.reset(mode=2)
     if args.workload == 'touge':   # spread the cars around the lap (host-side teleports, once)
@@ -132,6 +133,19 @@ def measure(args, world, rank, local_rank, dist, want_cpu=False):
         w3 = (torch.randn(256, 2, generator=g) / 16.0).to(dev); b3 = torch.tensor([0.0, 0.5], device=dev)
         import projectd_env
         obs_scale = (1.0 / torch.from_numpy(projectd_env.obs_bounds(projectd_env.EnvConfig())[1])).to(dev)
+    if policy == 'scripted':   # gas = 0.6 + 0.4 sin(2 pi t / 7 s + phi_i), phi_i from seed 2345 by GLOBAL car id; steer = a P-law on
+        # lookAhead[0] (the road's bend 10 m ahead; bodyVsTrack is a cosine and carries no sign) + the side probes' centring + yaw damping, clipped to +-1
+        phi = torch.from_numpy(np.random.RandomState(2345).uniform(0.0, 2.0 * np.pi, n * world).astype(np.float32)[first:last]).to(dev)
+        sw = np.zeros((24, 1), np.float32)
+        sw[12, 0] = -1.0; sw[21, 0] = 0.03; sw[20, 0] = -0.03; sw[4, 0] = 0.15
+        sc_w = torch.from_numpy(sw).to(dev)
+    if policy in ('host_mlp',):   # the SAC-sized actor on the HOST (24 -> 256 -> 256 -> 2, fixed random weights, seed 4567), torch on the CPU cores
+        g = torch.Generator(device='cpu'); g.manual_seed(4567)
+        hw1 = torch.randn(24, 256, generator=g) / 24 ** 0.5; hb1 = torch.zeros(256)
+        hw2 = torch.randn(256, 256, generator=g) / 16.0; hb2 = torch.zeros(256)
+        hw3 = torch.randn(256, 2, generator=g) / 16.0; hb3 = torch.tensor([0.0, 0.5])
+        import projectd_env
+        h_scale = 1.0 / torch.from_numpy(projectd_env.obs_bounds(projectd_env.EnvConfig())[1])
     if policy == 'feedback':
         fw = np.zeros((24, 2), np.float32)
         fw[21, 0] = 0.03; fw[20, 0] = -0.03; fw[19, 0] = 0.015; fw[18, 0] = -0.015; fw[4, 0] = 0.15; fw[2, 1] = -0.3
@@ -143,9 +157,27 @@ def measure(args, world, rank, local_rank, dist, want_cpu=False):
     # the env is the same launches as a tick of the bare stepper
     if args.episodes:
         import projectd_env as E
-        b.set_env(E.EnvConfig())
+        b.set_env(E.EnvConfig(teleport_mode=args.teleport_mode))
 
-    def policy_step(o, a):
+    def host_policy(o, a):
+        """obs rows [m, 24] -> action rows [m, 2], on the host, in place"""
+        if policy == 'host_mlp':
+            x = torch.from_numpy(o) * h_scale
+            h2 = torch.relu(torch.relu(x @ hw1 + hb1) @ hw2 + hb2)
+            torch.tanh(h2 @ hw3 + hb3, out=torch.from_numpy(a))
+        else:   # the probe-feedback law in numpy
+            np.clip(0.03 * (o[:, 21] - o[:, 20]) + 0.015 * (o[:, 19] - o[:, 18]) + 0.15 * o[:, 4], -1.0, 1.0, out=a[:, 0])
+            np.clip(0.3 * (12.0 - o[:, 2]), -1.0, 1.0, out=a[:, 1])
+
+    def policy_step(o, a, t=0, f=0):
+        if policy == 'scripted':
+            c = a.shape[0]
+            torch.mm(o[:, :24], sc_w, out=a[:, 0:1])
+            a[:, 0].clamp_(-1.0, 1.0)
+            # env action -> gas is linscale(a1, -1, 1, 0.1, 1.0) (projectd_env.py:160): a1 = (gas - 0.1) / 0.45 - 1
+            torch.sin(phi[f:f + c] + (2.0 * np.pi / 7.0) * (t / 333.0), out=a[:, 1])
+            a[:, 1].mul_(0.4 / 0.45).add_(0.5 / 0.45 - 1.0)
+            return
         if policy == 'feedback':   # oracle/scenarios.h scenarioFeedback (a linear law of the observation, clamped) as one addmm + one clamp
             torch.addmm(fb_b, o[:, :24], fb_w, out=a)
             a.clamp_(-1.0, 1.0)
@@ -160,8 +192,8 @@ def measure(args, world, rank, local_rank, dist, want_cpu=False):
     use_ring = policy == 'constant' and args.partitions > 1 and not do_scatter
     # a per-tick policy: per-partition closed loops, unless a gather has to see whole ticks (N > 1)
     # and only where a tick is long enough to hide the doubled number of (small) policy launches: the host enqueues ~10 per partition and tick
-    part_loops = policy not in ('constant', 'host', 'host_sync') and args.partitions > 1 and not gather.active and n >= args.part_loop_min
-    host_pipe = policy == 'host' and args.partitions > 1
+    part_loops = policy not in ('constant', 'host', 'host_sync', 'host_mlp') and args.partitions > 1 and not gather.active and n >= args.part_loop_min
+    host_pipe = policy in ('host', 'host_mlp') and args.partitions > 1
     # configs[3] as worded (a gather and an action scatter EVERY tick) over free-running partitions: one set of collectives per partition
     part_exchange = do_scatter and args.partitions > 1 and policy == 'constant' and n >= args.part_loop_min and (dist is not None) and (world == 1 or dist.get_backend() == 'nccl')
     split = use_ring or part_loops or host_pipe or part_exchange   # the cars step as free-running partitions
@@ -186,24 +218,20 @@ def measure(args, world, rank, local_rank, dist, want_cpu=False):
 
     def tick():
         t = tick_id[0]; tick_id[0] = t + 1
-        if policy == 'host' and host_pipe:   # configs[4] as SURVEY 8d words it, pipelined over the partitions: while the host works out
+        if host_pipe:   # configs[4] as SURVEY 8d words it, pipelined over the partitions: while the host works out
             # partition p's actions from the rows that have just come down, the other partitions' ticks and copies are in flight
             for p in range(args.partitions):
                 f, c = part_rng[p]
                 if host_primed[p]:
                     b.wait_host_partition(p)
-                    o = h_out['obs'][f:f + c]; a = h_act[f:f + c]
-                    np.clip(0.03 * (o[:, 21] - o[:, 20]) + 0.015 * (o[:, 19] - o[:, 18]) + 0.15 * o[:, 4], -1.0, 1.0, out=a[:, 0])
-                    np.clip(0.3 * (12.0 - o[:, 2]), -1.0, 1.0, out=a[:, 1])
+                    host_policy(h_out['obs'][f:f + c], h_act[f:f + c])
                 b.step_host_partition(p)
                 host_primed[p] = True
             return
-        if policy in ('host', 'host_sync'):   # the same loop as one synchronous round trip per tick (pdb_step_host): actions up, the tick,
+        if policy in ('host', 'host_sync', 'host_mlp'):   # the same loop as one synchronous round trip per tick (pdb_step_host): actions up, the tick,
             # observations down, then the host computes the next actions (the probe-feedback law in numpy)
             o = b.step_host(host_act[0])['obs']
-            a = host_act[0]
-            a[:, 0] = np.clip(0.03 * (o[:, 21] - o[:, 20]) + 0.015 * (o[:, 19] - o[:, 18]) + 0.15 * o[:, 4], -1.0, 1.0)
-            a[:, 1] = np.clip(0.3 * (12.0 - o[:, 2]), -1.0, 1.0)
+            host_policy(np.ascontiguousarray(o), host_act[0])
             return
         if part_exchange:   # per partition, on its own stream: actions from the learner, the tick, outputs to the learner
             for p in range(args.partitions):
@@ -219,13 +247,13 @@ def measure(args, world, rank, local_rank, dist, want_cpu=False):
                 f, c = part_rng[p]
                 with torch.cuda.stream(part_st[p]):
                     b.step_partition(p, o.data_ptr())
-                    policy_step(o[f:f + c], act_t[f:f + c])
+                    policy_step(o[f:f + c], act_t[f:f + c], t, f)
             return
         if do_scatter:
             act_t.copy_(sharding.scatter_actions(scatter_src, n, world, rank, dev, dist))
         b.set_out_device_ptr(o.data_ptr())
         b.step_async()
-        policy_step(o, act_t)
+        policy_step(o, act_t, t, 0)
         gather.after_tick(t)
 
     def run(nsteps):
@@ -314,6 +342,15 @@ def measure(args, world, rank, local_rank, dist, want_cpu=False):
               (n, {'playground': "synthetic paddock of the reference's driftplayground scale: barriers, tyre stacks, cones, islands as separate WALL meshes",
                    'nordring': "synthetic open ribbon of the reference's ks_nordschleife scale with guard rails"}[args.workload],
                hdr.numSurfaces, hdr.numTris, hdr.numFat, len(trk) / 1e6, policy)) if args.workload in ('playground', 'nordring') else \
+             ("%s: %d cars/GPU, AE86, the reference's %s (%d surfaces, %d triangles, %d spline points, %.1f MB track blob), policy=%s, dt=1/333 s" %
+              ("configs[2]" if args.workload == 'ek_akina' else "configs[4]", n,
+               {'ek_akina': "ek_akina spline (shipped) with the road generated around it as a ribbon (its surfaces.bin is a missing blob)",
+                'ks_nordschleife': "ks_nordschleife spline (shipped) with the road generated around it as a ribbon",
+                'ks_nordschleife_walls': "ks_nordschleife spline (shipped) with the road and guard rails (WALL surfaces) generated around it"}.get(args.workload, args.workload + " as shipped (surfaces.bin, spline.bin, spline.cache)"),
+               hdr.numSurfaces, hdr.numTris, hdr.numFat, len(trk) / 1e6,
+               {'host': "probe-feedback law in numpy on the HOST, pipelined over the partitions (actions up / observations down every tick)",
+                'host_mlp': "SAC-sized 24-256-256-2 MLP with fixed random weights evaluated by torch on the HOST's cores, pipelined over the partitions (actions up / observations down every tick)",
+                'scripted': "gas = 0.6 + 0.4 sin(2 pi t / 7 s + phi_i), P-steer on lookAhead[0] + side probes, on the GPU"}.get(policy, policy))) if is_ref else \
              ("configs[1]: %d cars/GPU, AE86, flat-plane track, %s, dt=1/333 s" % (n, "per-car constant random actions" if policy == "constant" else "policy=" + policy)) if args.workload == 'flat' else \
              ("configs[2] shape: %d cars/GPU, AE86, synthetic closed mountain road (%s%s), policy=%s on the GPU, dt=1/333 s" %
               (n, "spline point every %.1f m" % args.spline_step if args.spline_step else "1782 triangles, 891 spline points", ", guard rails (WALL surfaces) along both edges" if args.walls else "", policy))
@@ -342,7 +379,7 @@ def measure(args, world, rank, local_rank, dist, want_cpu=False):
         }
         if hasattr(lib, 'pdb_contact_pass_load'):
             res["contact_pass_cars"] = [int(lib.pdb_contact_pass_load(b.h, q)) for q in (list(range(args.partitions)) if split else [4])]   # cars the last contact passes held (diagnostic)
-        if args.episodes:   # how often episodes end in this workload: counted over 300 more ticks, outside the timed region
+        if args.episodes and not policy.startswith('host'):   # how often episodes end in this workload: counted over 300 more ticks, outside the timed region
             ends = torch.zeros((), dtype=torch.int64, device=dev)
             for _ in range(300):
                 tick()
@@ -367,6 +404,14 @@ EXTRA = [   # (key, argv) -- the other BASELINE configs' shapes, each measured b
     ("configs4_playground_16384_episodes", ['--workload', 'playground', '--cars', '16384', '--episodes', '--steps', '300', '--warmup', '50', '--settle', '200']),
     ("configs4_nordring_16384_mlp", ['--workload', 'nordring', '--cars', '16384', '--policy', 'mlp', '--steps', '300', '--warmup', '50', '--settle', '200']),
     ("configs4_nordring_16384_feedback", ['--workload', 'nordring', '--cars', '16384', '--steps', '300', '--warmup', '50', '--settle', '200']),
+    # the reference's own tracks: configs[2] on the Akina ribbon with SURVEY 8d's scripted gas / P-steer (env loop: a car that leaves the
+    # road is put back at a random point of the lap); configs[4] as worded -- the policy on the HOST, pipelined -- at the 8192-car shard size
+    ("configs2_akina_16384_scripted", ['--workload', 'ek_akina', '--cars', '16384', '--policy', 'scripted', '--episodes', '--teleport-mode', '2', '--steps', '300', '--warmup', '50', '--settle', '200']),
+    ("configs4_nordschleife_8192_host_policy", ['--workload', 'ks_nordschleife_walls', '--cars', '8192', '--policy', 'host', '--episodes', '--teleport-mode', '2', '--steps', '200', '--warmup', '30', '--settle', '100']),
+    ("configs4_nordschleife_8192_host_mlp", ['--workload', 'ks_nordschleife_walls', '--cars', '8192', '--policy', 'host_mlp', '--episodes', '--teleport-mode', '2', '--steps', '100', '--warmup', '20', '--settle', '100']),
+    ("configs4_driftplayground_8192_host_policy", ['--workload', 'driftplayground', '--cars', '8192', '--policy', 'host', '--episodes', '--teleport-mode', '2', '--steps', '200', '--warmup', '30', '--settle', '100']),
+    ("configs4_driftplayground_8192_host_mlp", ['--workload', 'driftplayground', '--cars', '8192', '--policy', 'host_mlp', '--episodes', '--teleport-mode', '2', '--steps', '100', '--warmup', '20', '--settle', '100']),
+    ("configs4_driftplayground_16384_mlp", ['--workload', 'driftplayground', '--cars', '16384', '--policy', 'mlp', '--episodes', '--teleport-mode', '2', '--steps', '300', '--warmup', '50', '--settle', '200']),
     ("episodes_4096", ['--workload', 'touge', '--walls', '--cars', '4096', '--episodes', '--steps', '600', '--warmup', '100', '--settle', '200']),
     ("episodes_4096_reset_free", ['--workload', 'touge', '--walls', '--cars', '4096', '--policy', 'feedback', '--steps', '600', '--warmup', '100', '--settle', '200']),
     ("episodes_16384", ['--workload', 'touge', '--walls', '--cars', '16384', '--episodes', '--steps', '300', '--warmup', '50', '--settle', '200']),
@@ -389,7 +434,7 @@ def parser():
     ap.add_argument('--walls', action='store_true', help='touge workload: line both edges of the road with WALL surfaces (configs[4] shape: hull-vs-wall narrow phase next to the guard rails)')
     ap.add_argument('--spline-step', type=float, default=0.0, help='touge workload: metres between spline points (default 5 m = 891 points; 0.9 = 4.9 k points, the density of the reference tracks)')
     ap.add_argument('--no-body-contacts', action='store_true', help='diagnostic A/B: switch the collision pass off in the car block (never the bench line)')
-    ap.add_argument('--policy', choices=['constant', 'feedback', 'mlp', 'random', 'host', 'host_sync'], default=None,
+    ap.add_argument('--policy', choices=['constant', 'feedback', 'mlp', 'random', 'host', 'host_sync', 'host_mlp', 'scripted'], default=None,
                     help='where actions come from each tick: constant (configs[1]), feedback (probe controller on the GPU, default for touge), '
                          'mlp (configs[4] shape: a SAC-sized 24-256-256-2 tanh MLP with fixed random weights, evaluated with torch on the GPU from the observation block), random, '
                          'host (the feedback law in numpy on the HOST, actions up / observations down every tick, pipelined over the partitions), host_sync (the same through the synchronous pdb_step_host)')
@@ -398,7 +443,8 @@ def parser():
     ap.add_argument('--scatter-actions', action='store_true', help='with a gather: rank 0 scatters the [N,2] action block back every tick (configs[3] as SURVEY 8d words it)')
     ap.add_argument('--force-gather', action='store_true', help='run the observation all-gather even with one rank (exercises the RCCL + side-stream path on a single GPU)')
     ap.add_argument('--backend', default='nccl', help='torch.distributed backend for N > 1 (nccl = RCCL; gloo only to exercise the multi-rank path on a single-GPU box)')
-    ap.add_argument('--workload', choices=['flat', 'touge', 'playground', 'nordring'], default='flat',
+    ap.add_argument('--teleport-mode', type=int, default=0, choices=[0, 1, 2], help='--episodes: where a reset puts the car (projectd_env.py teleport_mode: 0 start, 1 nearest, 2 random point of the lap)')
+    ap.add_argument('--workload', choices=['flat', 'touge', 'playground', 'nordring', 'driftplayground', 'ebisu_touge', 'yamanashi_short', 'euphoria_hillside_park', 'ek_akina', 'ks_nordschleife', 'ks_nordschleife_walls'], default='flat',
                     help='flat = BASELINE configs[1] (the bench line); touge = configs[2] shape: closed hilly road, cars spread around the lap, probe-feedback steering computed on the GPU each tick')
     return ap
 
@@ -467,7 +513,10 @@ def main():
                         d2.init_process_group(args.backend, init_method='env://')
                 r = measure(a, 1, 0, 0, d2)
                 extra[key] = {"value": r["value"], "ms_per_step": r["ms_per_step"], "steps": r["steps"], "repeats": r["repeats"], "workload": r["config"]["workload"],
-                              "partitions": r["config"]["partitions"], "collective": r["config"]["collective"], "kernel_avg_us": r["roofline"]["kernel_avg_us"]}
+                              "partitions": r["config"]["partitions"], "collective": r["config"]["collective"], "kernel_avg_us": r["roofline"]["kernel_avg_us"],
+                              "roofline": {k: r["roofline"][k] for k in ("bound", "achieved", "peak", "unit", "frac", "kernel", "kernel_avg_us", "cars_per_launch", "concurrent_launches", "device_achieved", "device_frac")}}
+                if "contact_pass_cars" in r:
+                    extra[key]["contact_pass_cars"] = r["contact_pass_cars"]
                 if "episode_ends_per_tick" in r:
                     extra[key]["episode_ends_per_tick"] = r["episode_ends_per_tick"]
             except Exception as e:   # an extra line must never cost the headline

@@ -239,3 +239,33 @@ def build_track(lib, base, name, recompute_fat_points=False):
     data = C.string_at(blob, n.value)
     lib.pdb_free(blob)
     return data
+
+
+# ---- packed tracks: the product's track blob, compressed, for machines without the reference's content/ directory (tools/pack_tracks.py)
+TRACK_PACK_DIR = os.path.join(PKG, 'data', 'tracks')
+_PACK_MAGIC = b'PDTZ0001'
+
+def track_pack_path(name):
+    return os.path.join(TRACK_PACK_DIR, name + '.pdtrack.z')
+
+def write_track_pack(path, blob):
+    import zlib, struct
+    tmp = path + '.tmp%d' % os.getpid()
+    with open(tmp, 'wb') as f:
+        f.write(_PACK_MAGIC + struct.pack('<QI', len(blob), zlib.crc32(blob)) + zlib.compress(blob, 6))
+    os.replace(tmp, path)
+
+def load_track_pack(name):
+    """the blob pdb_build_track gave for this track in the build container; RuntimeError when the pack is absent"""
+    import zlib, struct
+    path = track_pack_path(name)
+    if not os.path.exists(path):
+        raise RuntimeError('%s not packed (build container: python tools/pack_tracks.py)' % path)
+    raw = open(path, 'rb').read()
+    if raw[:8] != _PACK_MAGIC:
+        raise RuntimeError('%s: not a track pack' % path)
+    n, crc = struct.unpack('<QI', raw[8:20])
+    blob = zlib.decompress(raw[20:])
+    if len(blob) != n or zlib.crc32(blob) != crc:
+        raise RuntimeError('%s: damaged track pack' % path)
+    return blob

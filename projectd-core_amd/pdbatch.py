@@ -228,3 +228,16 @@ def synthetic_track(kind='flat', **gen_args):
     if gen_args:
         synthetic_tracks.GENERATORS[kind](os.path.join(d, 'content', 'tracks', kind), **gen_args)
     return pc.build_track(lib, d, kind)
+
+
+REFERENCE_TRACKS = ('driftplayground', 'ebisu_touge', 'yamanashi_short', 'euphoria_hillside_park', 'ek_akina', 'ks_nordschleife',
+                    'ks_nordschleife_walls')
+
+
+def reference_track(name='driftplayground'):
+    """blob of one of the reference's own tracks (projectd_env.py:23 defaults to driftplayground), from its packed form
+    (data/tracks/<name>.pdtrack.z, written in the build container by tools/pack_tracks.py: the four meshes through Sim/Track.cpp's
+    build, ek_akina / ks_nordschleife as a ribbon around their shipped spline; ks_nordschleife_walls =
+    that ribbon with guard rails along both edges)"""
+    assert name in REFERENCE_TRACKS, name
+    return pc.load_track_pack(name)

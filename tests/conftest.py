@@ -63,10 +63,11 @@ def env_params():
     return P
 
 
-def car_params(model):
-    """packed env-configured block of one of the supported cars (projectd-core_amd/data, tools/pack_cars.py)"""
+def car_params(model, kind='env'):
+    """packed env-configured block of one of the supported cars (projectd-core_amd/data, tools/pack_cars.py);
+    kind='tuned': model is a scenario's name, the block carries that scenario's setCarTune list as well"""
     P = pc.CarParams()
-    data = open(os.path.join(ROOT, 'projectd-core_amd', 'data', model + '.env.pdcar'), 'rb').read()
+    data = open(os.path.join(ROOT, 'projectd-core_amd', 'data', model + '.' + kind + '.pdcar'), 'rb').read()
     assert len(data) == C.sizeof(P)
     C.memmove(C.byref(P), data, len(data))
     return P

@@ -7,7 +7,7 @@ import pdb_ctypes as pc
 from conftest import car_params
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-REF_CONTENT = '/root/reference/content'
+REF_CONTENT = os.environ.get('PDB_REF_CONTENT', '/root/reference/content')   # (the override lets a test hide it, as on the GPU box)
 
 
 class Skip(Exception):
@@ -25,7 +25,10 @@ def track_blob(hostlib, track, base_dir):
         gen(os.path.join(base_dir, 'content', 'tracks', track))
         return pc.build_track(hostlib, base_dir, track)
     if not os.path.isdir(os.path.join(REF_CONTENT, 'tracks', track)):
-        raise Skip('reference content not present')
+        try:    # a machine without the reference's content: the blob packed in the build container (tools/pack_tracks.py)
+            return pc.load_track_pack(track)
+        except RuntimeError as e:
+            raise Skip(str(e))
     if track in RIBBON_TRACKS:
         synthetic_tracks.ribbon_track_from(os.path.join(REF_CONTENT, 'tracks', track), os.path.join(base_dir, 'content', 'tracks', track))
         return pc.build_track(hostlib, base_dir, track)
@@ -43,12 +46,15 @@ def setup(orc, hostlib, sid, base_dir):
     nm = C.c_char_p(); val = C.c_float()
     if orc.cpuref_scenario_tune(sid, 0, C.byref(nm), C.byref(val)):
         if not os.path.isdir(os.path.join(REF_CONTENT, 'cars')):
-            raise Skip('reference content not present')
-        P = pc.env_params(hostlib, '/root/reference', model)
-        i = 0
-        while orc.cpuref_scenario_tune(sid, i, C.byref(nm), C.byref(val)):
-            hostlib.pdb_set_car_tune(C.byref(P), b'/root/reference', model.encode(), nm.value, val.value, 0)
-            i += 1
+            # the cars' setup.ini is absent: the block as tools/pack_cars.py left it after the env's tunes and this scenario's list
+            # (tests/test_loader.py holds the packed block against this very loop in the build container)
+            P = car_params(name, kind='tuned')
+        else:
+            P = pc.env_params(hostlib, '/root/reference', model)
+            i = 0
+            while orc.cpuref_scenario_tune(sid, i, C.byref(nm), C.byref(val)):
+                hostlib.pdb_set_car_tune(C.byref(P), b'/root/reference', model.encode(), nm.value, val.value, 0)
+                i += 1
     i = 0
     while orc.cpuref_scenario_scoring(sid, i, C.byref(nm), C.byref(val)):
         assert hostlib.pdb_set_scoring_var(C.byref(P), nm.value, val.value) == 0

@@ -158,7 +158,7 @@ def test_gpu_matches_oracle_on_the_wall_lined_road(built):
 # synthetic_tracks.gen_playground / gen_nordring build tracks of the same scale from closed-form geometry.
 def _scale_run(track, model, n_cars, ticks, seed):
     import parity_util, pdbatch
-    blob = pdbatch.synthetic_track(track)
+    blob = pdbatch.reference_track(track) if track in pdbatch.REFERENCE_TRACKS else pdbatch.synthetic_track(track)
     h = pc.TrackHeader.from_buffer_copy(blob[:C.sizeof(pc.TrackHeader)])
     seen = {'flag': 0, 'dmg': 0, 'cars': set(), 'contacts': 0}
 
@@ -193,3 +193,24 @@ def test_gpu_matches_oracle_on_the_13k_point_walled_ribbon(built):
     assert h.numFat == 13323 and h.numTris >= 79000
     assert worst == 0.0, worst
     assert len(seen['cars']) >= 6 and seen['contacts'] > 40, seen     # sampled every 8th tick
+
+
+# ---- the reference's OWN tracks, packed in the build container (tools/pack_tracks.py -> projectd-core_amd/data/tracks/)
+@pytest.mark.gpu
+def test_gpu_matches_oracle_on_driftplayground(built):
+    """the env's default track (projectd_env.py:23; 510 surfaces, 112 411 triangles, 490 WALL meshes, Sim/Track.cpp:97-272):
+    32 AE86s put down along the lap with their own constant actions for 1800 ticks -- within seconds they are in the barriers and
+    tyre stacks; every state scalar and every live contact joint bit for bit"""
+    h, worst, seen = _scale_run('driftplayground', AE86, 32, 1800, 11)
+    assert h.numSurfaces == 510 and h.numTris == 112411
+    assert worst == 0.0, worst
+    assert len(seen['cars']) >= 8 and seen['contacts'] > 40, seen    # sampled every 8th tick
+
+
+@pytest.mark.gpu
+def test_gpu_matches_oracle_on_the_nordschleife_ribbon(built):
+    """ks_nordschleife's shipped spline (13 323 points) with the road and the guard rails generated around it: 24 Supras x 1600 ticks"""
+    h, worst, seen = _scale_run('ks_nordschleife_walls', 'ks_toyota_supra_mkiv_drift', 24, 1600, 5)
+    assert h.numFat == 13323
+    assert worst == 0.0, worst
+    assert len(seen['cars']) >= 4 and seen['contacts'] > 20, seen

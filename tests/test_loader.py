@@ -1,7 +1,7 @@
 """Host logic behind the boundary: car-model / track builders, tunes, scoring vars, reset poses (csrc/host/*).
 Tests that need the reference's shipped car data run only where /root/reference exists (the build container);
 the packed AE86 block they check (projectd-core_amd/data/*.pdcar) is what travels to the GPU box."""
-import ctypes as C, os, struct
+import ctypes as C, os, struct, sys
 import numpy as np
 import pytest
 import pdb_ctypes as pc
@@ -25,6 +25,49 @@ def test_packed_ae86_block_is_reproducible(hostlib):
     D = pc.CarParams()
     assert hostlib.pdb_build_car_model(REF.encode(), AE86.encode(), C.byref(D)) == 0
     assert bytes(D) == open(os.path.join(ROOT, 'projectd-core_amd', 'data', AE86 + '.default.pdcar'), 'rb').read()
+
+
+@needs_ref
+def test_tuned_scenario_blocks_are_reproducible(hostlib, oracle):
+    """<scenario>.tuned.pdcar (what the tunes* scenarios start from on a machine without the cars' setup.ini) = the env block +
+    the scenario's setCarTune list through pdb_set_car_tune, exactly as tests/scenario_util.setup applies it here"""
+    seen = 0
+    for sid in range(oracle.cpuref_num_scenarios()):
+        nm = C.c_char_p(); val = C.c_float()
+        if not oracle.cpuref_scenario_tune(sid, 0, C.byref(nm), C.byref(val)):
+            continue
+        name = oracle.cpuref_scenario_name(sid).decode(); model = oracle.cpuref_scenario_car(sid).decode()
+        P = pc.env_params(hostlib, REF, model)
+        i = 0
+        while oracle.cpuref_scenario_tune(sid, i, C.byref(nm), C.byref(val)):
+            hostlib.pdb_set_car_tune(C.byref(P), REF.encode(), model.encode(), nm.value, val.value, 0)
+            i += 1
+        assert bytes(P) == open(os.path.join(ROOT, 'projectd-core_amd', 'data', name + '.tuned.pdcar'), 'rb').read(), name
+        seen += 1
+    assert seen == 3
+
+
+@needs_ref
+def test_track_packs_hold_the_blobs_the_loader_builds(hostlib, built):
+    """projectd-core_amd/data/tracks/*.pdtrack.z (git-ignored build output of __graft_entry__.build(), tools/pack_tracks.py): the
+    reference's six tracks as the product's blob, for the GPU box; each pack decompresses to what pdb_build_track gives here"""
+    sys.path.insert(0, os.path.join(ROOT, 'tools'))
+    import pack_tracks, tempfile, synthetic_tracks
+    scratch = synthetic_tracks.make_base(tempfile.mkdtemp(prefix='pdb_packtest_'), tracks=())
+    for name in pack_tracks.MESH_TRACKS + pack_tracks.RIBBON_TRACKS + pack_tracks.WALLED_RIBBONS:
+        assert pc.load_track_pack(name) == pack_tracks.build_blob(hostlib, name, scratch), name
+
+
+@needs_ref
+def test_scenarios_set_up_identically_without_the_reference_content(hostlib, oracle, base_dir, monkeypatch):
+    """what the GPU box sees (no /root/reference: packed tracks, packed tuned blocks) is byte for byte what the build container sees"""
+    import scenario_util as SU
+    for sid in range(oracle.cpuref_num_scenarios()):
+        monkeypatch.setattr(SU, 'REF_CONTENT', REF + '/content')
+        here = SU.setup(oracle, hostlib, sid, base_dir)
+        monkeypatch.setattr(SU, 'REF_CONTENT', '/nonexistent/content')
+        there = SU.setup(oracle, hostlib, sid, base_dir)
+        assert bytes(here['P']) == bytes(there['P']) and here['blob'] == there['blob'] and bytes(here['S0']) == bytes(there['S0']), here['name']
 
 
 @needs_ref

@@ -20,3 +20,20 @@ for REFB, m in models:
     E = pc.env_params(lib, REFB, m)
     open(os.path.join(out, m + '.env.pdcar'), 'wb').write(bytes(E))
     print('%-36s bodies %d joints %d rows %d turbos %d gears %d' % (m, P.numBodies, P.numJoints, P.numRows, P.numTurbos, P.numGears))
+
+# the scenarios that end their set-up with a list of setCarTune calls (oracle/scenarios.h: tuneSet): the block as it stands after the
+# env's own tunes and that list, <scenario>.tuned.pdcar -- what tests/scenario_util.setup starts from where the cars' setup.ini is absent
+sys.path.insert(0, os.path.join(ROOT, 'tests'))
+import oracle_ctypes
+orc = oracle_ctypes.load_oracle()
+for sid in range(orc.cpuref_num_scenarios()):
+    nm = C.c_char_p(); val = C.c_float()
+    if orc.cpuref_scenario_tune(sid, 0, C.byref(nm), C.byref(val)):
+        name = orc.cpuref_scenario_name(sid).decode(); model = orc.cpuref_scenario_car(sid).decode()
+        P = pc.env_params(lib, REF, model)
+        i = 0
+        while orc.cpuref_scenario_tune(sid, i, C.byref(nm), C.byref(val)):
+            lib.pdb_set_car_tune(C.byref(P), REF.encode(), model.encode(), nm.value, val.value, 0)
+            i += 1
+        open(os.path.join(out, name + '.tuned.pdcar'), 'wb').write(bytes(P))
+        print('%-36s %s + %d tunes' % (name + '.tuned', model, i))
