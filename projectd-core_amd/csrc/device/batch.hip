@@ -104,6 +104,7 @@ static constexpr size_t kSnapStrideWide = k33::kSnapStride;
 
 namespace pdb { void setError(const std::string& s); }
 
+#define LAUNCHCHK(b) do { HIPCHK(hipGetLastError()); if ((b)->launchRefused) return PDB_ERR_HIP; } while (0)
 #define HIPCHK(expr)                                                                                 \
     do {                                                                                             \
         hipError_t _e = (expr);                                                                      \
@@ -171,6 +172,7 @@ struct pdb_batch {
     int contactGrid = 0;   // workgroups of the contact pass: 0 = adaptive (from the queue lengths the last passes saw); PDB_CONTACT_GRID in the environment fixes it (diagnostic)
     int burst[PDB_MAX_PARTS + 1] = {0, 0, 0, 0, 0};   // per launch site: ticks for which the contact pass is launched wide whatever the hint says (after a reset: cars just put down
                                                         // tend to go through the pass once, all of them in the same tick)
+    bool launchRefused = false;   // a tick could not be launched (no memory for the hand-over snapshots): the entry point that asked returns PDB_ERR_HIP
     bool capturing = false;   // launches being recorded into a graph: the contact pass's grid is then frozen, so it is not sized for an idle pass
     int* hHint = nullptr;  // page-locked, device-visible: per launch site, the number of cars the last contact pass held (written by its last workgroup; read here without waiting)
     int* dHint = nullptr;
@@ -228,7 +230,17 @@ static void fillConst(const pdb_car_params& P, DevConst& K, int actionMode) {
 // contact pass over the blocks the first pass queued (cars with live contact joints or fresh contacts; a small fixed grid that
 // finds an empty queue on almost every tick).  `q` = which of the batch's queues this launch site uses (one per partition
 // stream, one for the batch's own stream: launches that can be in flight together never share a queue).
+// The hand-over snapshots (about 10 KB per car, four times the record) exist only once a contact pass can run: body colliders on, the
+// reset mask armed or the in-tick auto-teleport set.  Allocated on first need, outside any graph capture (pdb_step_n calls this before it records).
+static bool passNeeded(const pdb_batch* b, const pdb_car_params& HP) { return HP.collider.enabled != 0 || b->resetMaskArmed || HP.autoTeleport != 0; }
+static void ensureSnap(pdb_batch* b) {
+    if (b->dSnap) return;
+    bool need = passNeeded(b, b->params);
+    for (int p = 0; p < PDB_MAX_PARTS; ++p) need = need || (b->partHas[p] && passNeeded(b, b->partParams[p]));
+    if (need && hipMalloc(&b->dSnap, kSnapStrideWide * (size_t)b->n) != hipSuccess) { b->dSnap = nullptr; pdb::setError("pdbatch: out of device memory for the contact pass's hand-over snapshots"); }
+}
 static void launchTick(pdb_batch* b, hipStream_t st, int c0, int c1, pdb_step_out* out, int q) {
+    ensureSnap(b);
     const int nblk = (c1 - c0 + PDB_CPB - 1) / PDB_CPB, m = b->params.numRows;
     pdb_dyn_state* S = b->dStates + c0;
     const float* Aact = b->dActions + (size_t)c0 * b->actionStride;
@@ -240,11 +252,14 @@ static void launchTick(pdb_batch* b, hipStream_t st, int c0, int c1, pdb_step_ou
     const pdb_car_params* DP = own ? b->dPartParams[q] : b->dParams;
     const DevConst* DK = own ? b->dPartK[q] : b->dK;
     const pdb_car_params& HP = own ? b->partParams[q] : b->params;
-    uint8_t* SN = b->dSnap + (size_t)c0 * ((m <= 33 && HP.numCtrlStages == 0 && HP.hasBrakeTemps == 0) ? k33::kSnapStride : kSnapStrideWide);
+    // every launch's snapshot region starts at the ALLOCATION's stride (partitions may carry car blocks of different kernel classes: with the
+    // launch's own, narrower stride a later partition's region would begin inside an earlier, wider one's); the kernel indexes its slots with its own stride inside it
+    uint8_t* SN = b->dSnap + (size_t)c0 * kSnapStrideWide;
     uint8_t* RM = b->resetMaskArmed ? b->dResetMask + c0 : nullptr;
     const int n = c1 - c0;
     // the contact pass also serves episode resets asked for through the reset mask and the in-tick auto-teleport
-    const bool contacts = HP.collider.enabled != 0 || b->resetMaskArmed || HP.autoTeleport != 0;
+    const bool contacts = passNeeded(b, HP);
+    if (contacts && !b->dSnap) { b->launchRefused = true; return; }   // (ensureSnap left the message) never a first pass whose queued cars nobody finishes
     // the contact pass's grid: enough workgroups for twice the cars its last pass held (a stale number, read without waiting: it only
     // sizes the grid -- workgroups take the queued cars in turn whatever their number), at least PDB_CONTACT_GRID, at most what is resident at once
     int cg = b->contactGrid;
@@ -316,7 +331,7 @@ static int launch(pdb_batch* b, float dt, bool wantCarState) {
         if (int rck = pushK(b, b->stream, true)) return rck;
     }
     launchWhole(b, b->stream, b->dOutActive);
-    HIPCHK(hipGetLastError());
+    LAUNCHCHK(b);
     return PDB_OK;
 }
 
@@ -336,6 +351,9 @@ pdb_batch* pdb_create(int device, int n_cars, const pdb_car_params* params, cons
             pdb::setError("pdb_create: not a track blob of this version (build it with pdb_build_track)"); return nullptr;
         }
     }
+#ifdef PDB_FAST_BUILD   // the development build carries the 33-row class only: refuse what it cannot step rather than return PDB_OK without a launch
+    if (params->numRows > 33 || params->numCtrlStages != 0 || params->hasBrakeTemps != 0) { pdb::setError("pdb_create: this development build (PDB_FAST_BUILD) holds only the 33-row kernels without controllers"); return nullptr; }
+#endif
     int count = 0;
     if (hipGetDeviceCount(&count) != hipSuccess || count <= 0 || device < 0 || device >= count) {
         pdb::setError("pdb_create: no usable HIP device (there is no CPU fallback)");
@@ -362,7 +380,6 @@ pdb_batch* pdb_create(int device, int n_cars, const pdb_car_params* params, cons
     ok = ok && hipMemset(b->dContacts, 0, sizeof(pdb_contact) * PDB_MAX_CONTACTS * (size_t)n_cars) == hipSuccess;
     ok = ok && hipMalloc(&b->dResetMask, (size_t)n_cars) == hipSuccess;
     ok = ok && hipMemset(b->dResetMask, 0, (size_t)n_cars) == hipSuccess;
-    ok = ok && hipMalloc(&b->dSnap, kSnapStrideWide * (size_t)n_cars) == hipSuccess;
     for (int q = 0; q <= PDB_MAX_PARTS; ++q) {
         const size_t qb = sizeof(int) * (size_t)(4 + n_cars);   // count, done, countFull, pad, one entry per car
         ok = ok && hipMalloc(&b->dQueue[q], qb) == hipSuccess;
@@ -501,7 +518,7 @@ static int resetLaunch(pdb_batch* b, uint8_t* dMask, int mode, int clear) {
         hipLaunchKernelGGL(pdb_reset_kernel, dim3((c1 - c0 + 63) / 64), dim3(64), 0, b->stream, b->dStates + c0, dMask ? dMask + c0 : nullptr,
                            b->partHas[p] ? b->dPartParams[p] : b->dParams, b->dTrack, c1 - c0, mode, clear);
     }
-    HIPCHK(hipGetLastError());
+    LAUNCHCHK(b);
     return PDB_OK;
 }
 int pdb_reset_mode(pdb_batch* b, const uint8_t* mask, int mode) {
@@ -527,7 +544,7 @@ int pdb_clear_episodes(pdb_batch* b, const uint8_t* device_mask) {
     if (!b) { pdb::setError("null argument"); return PDB_ERR_ARG; }
     if (int rcj = joinParts(b)) return rcj;
     hipLaunchKernelGGL(pdb_clear_episodes_kernel, dim3((b->n + 255) / 256), dim3(256), 0, b->stream, b->dStates, device_mask, b->n);
-    HIPCHK(hipGetLastError());
+    LAUNCHCHK(b);
     b->batchDirty = true;
     return PDB_OK;
 }
@@ -551,10 +568,17 @@ int pdb_set_partition_params(pdb_batch* b, int part, const pdb_car_params* param
     if (int rcj = joinParts(b)) return rcj;
     for (int p = 0; p < PDB_MAX_PARTS; ++p) if (b->partStream[p]) HIPCHK(hipStreamSynchronize(b->partStream[p]));
     HIPCHK(hipStreamSynchronize(b->stream));
-    if (!params) { b->partHas[part] = false; return PDB_OK; }
+    if (!params) {
+        b->partHas[part] = false;
+        if (b->graphExec) { (void)hipGraphExecDestroy(b->graphExec); b->graphExec = nullptr; }   // the captured launches carry the partitions' own blocks
+        return PDB_OK;
+    }
     const pdb_car_params& A = b->params;
     bool same = params->numBodies == A.numBodies && params->numJoints == A.numJoints && params->numRows == A.numRows;
     for (int j = 0; same && j < A.numJoints; ++j) same = params->joints[j].type == A.joints[j].type && params->joints[j].b0 == A.joints[j].b0 && params->joints[j].b1 == A.joints[j].b1;
+#ifdef PDB_FAST_BUILD
+    if (params->numCtrlStages != 0 || params->hasBrakeTemps != 0) { pdb::setError("pdb_set_partition_params: this development build (PDB_FAST_BUILD) holds no controller kernels"); return PDB_ERR_ARG; }
+#endif
     if (!same) { pdb::setError("pdb_set_partition_params: the block's rigid-body topology differs from the batch's (one kernel variant per batch)"); return PDB_ERR_ARG; }
     if (!b->dPartParams[part]) { HIPCHK(hipMalloc(&b->dPartParams[part], sizeof(pdb_car_params))); HIPCHK(hipMalloc(&b->dPartK[part], sizeof(DevConst))); }
     b->partParams[part] = *params;
@@ -623,7 +647,7 @@ int pdb_step_n(pdb_batch* b, float dt, int n) {
     if (b->stream == nullptr) {   // the legacy default stream (a caller's pdb_set_stream) cannot be captured: n plain launches
         HIPCHK(hipEventRecord(b->ev0, b->stream));
         for (int i = 0; i < n; ++i) launchWhole(b, b->stream, b->dOutActive);
-        HIPCHK(hipGetLastError());
+        LAUNCHCHK(b);
         HIPCHK(hipEventRecord(b->ev1, b->stream));
         HIPCHK(hipEventSynchronize(b->ev1));
         float ms0 = 0;
@@ -634,6 +658,7 @@ int pdb_step_n(pdb_batch* b, float dt, int n) {
     if (!b->graphExec || b->graphTicks != n || b->graphDt != dt) {
         if (b->graphExec) { (void)hipGraphExecDestroy(b->graphExec); b->graphExec = nullptr; }
         hipGraph_t g = nullptr;
+        ensureSnap(b);
         HIPCHK(hipStreamBeginCapture(b->stream, hipStreamCaptureModeThreadLocal));
         b->capturing = true;
         for (int i = 0; i < n; ++i)
@@ -719,7 +744,7 @@ int pdb_step_ring(pdb_batch* b, float dt, int n_ticks, pdb_step_out* ring, int r
             launchTick(b, forked ? b->partStream[p] : b->stream, c0, c1, out, forked ? p : PDB_MAX_PARTS);
         }
     }
-    HIPCHK(hipGetLastError());
+    LAUNCHCHK(b);
     for (int p = 0; p < np; ++p) {
         const int c0 = forked ? partFirst(b, p) : 0, c1 = forked ? partFirst(b, p + 1) : b->n;
         if (c1 <= c0) continue;
@@ -749,7 +774,7 @@ int pdb_step_partition(pdb_batch* b, float dt, int part, pdb_step_out* out) {
     if (b->partMark) { for (int p = 0; p < b->parts; ++p) HIPCHK(hipEventRecord(b->partStart[p], b->partStream[p])); b->partMark = false; }
     pdb_step_out* o = out ? out : b->dOutActive;
     launchTick(b, st, c0, c1, o, part);
-    HIPCHK(hipGetLastError());
+    LAUNCHCHK(b);
     HIPCHK(hipEventRecord(b->partEnd[part], st));
     b->partDirty = true;
     return PDB_OK;

@@ -82,6 +82,9 @@ static void dynCtrlLoad(pdb_car_params& P, pdb_dyn_ctrl& dc, const std::string& 
         }
         ++dc.count;
     }
+    // a present file without one usable stage: the reference's controller object exists and eval() gives 0 every tick (e.g. diffPreLoad = 0 and
+    // diffPowerRamp = 0, Drivetrain.cpp:603-607), while the kernels gate their call sites on count != 0 -- refused rather than stepped differently
+    if (dc.count == 0) throw std::runtime_error("pdb: " + path + ": no usable [CONTROLLER_n] stage (the reference would evaluate it to 0 every tick; not supported)");
 }
 
 // Natural cubic spline through a LUT (what Curve::getCubicSplineValue evaluates, Core/Curve.cpp:117-126): the reference hands the points to the

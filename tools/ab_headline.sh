@@ -1,5 +1,5 @@
 #!/bin/bash
-# Diagnostic (GPU box): the bench line with library variants (PDB_LIB: files under projectd-core_amd/, e.g. libpdbatch_r2.so = the round-2
+# Diagnostic (GPU box): the bench line with library variants (PDB_LIB: paths relative to projectd-core_amd/, e.g. ../tools/variants/libpdbatch_r3.so = the round-3
 # final library built from commit ed498b4) against the in-tree one, alternating, same box.  usage: ab_headline.sh [variant.so ...]
 H="--no-cpu-baseline --no-extra --steps 3000 --warmup 333"
 line() { lib=$1; shift; label=$1; shift; if [ -n "$lib" ]; then export PDB_LIB=$lib; else unset PDB_LIB; fi

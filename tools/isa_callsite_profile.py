@@ -11,11 +11,13 @@ import collections, json, os, re, subprocess, sys, tempfile
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 LLVM = '/opt/rocm/lib/llvm/bin'
 kern = sys.argv[1] if len(sys.argv) > 1 else 'pdb_step_kernel'
-only_scratch = len(sys.argv) > 2 and sys.argv[2] == 'scratch'
-tmp = tempfile.mkdtemp(prefix='pdb_isa_')
+only_scratch = len(sys.argv) > 2 and sys.argv[2] in ('scratch', 'scratchlist')
+list_scratch = len(sys.argv) > 2 and sys.argv[2] == 'scratchlist'   # every scratch instruction with its address and inline stack
+tmp = os.environ.get('PDB_ISA_TMP') or tempfile.mkdtemp(prefix='pdb_isa_')   # PDB_ISA_TMP: keep / reuse the -g object between runs
 csrc = os.path.join(ROOT, 'projectd-core_amd', 'csrc')
 obj, co = os.path.join(tmp, 'k.o'), os.path.join(tmp, 'k.co')
-subprocess.check_call(['/opt/rocm/bin/hipcc', '--offload-arch=gfx950', '-std=c++17', '-O3', '-ffp-contract=off', '-fno-fast-math', '-fPIC', '-g', '-DPDB_FAST_BUILD',
+if not os.path.exists(obj):
+  subprocess.check_call(['/opt/rocm/bin/hipcc', '--offload-arch=gfx950', '-std=c++17', '-O3', '-ffp-contract=off', '-fno-fast-math', '-fPIC', '-g', '-DPDB_FAST_BUILD', '-mllvm', '-disable-machine-licm',
                        '-I' + os.path.join(ROOT, 'include'), '-I' + os.path.join(csrc, 'host'), '-I' + os.path.join(csrc, 'device'),
                        '--cuda-device-only', '-c', os.path.join(csrc, 'device', 'batch.hip'), '-o', obj])
 subprocess.check_call([LLVM + '/clang-offload-bundler', '--unbundle', '--type=o', '--input=' + obj, '--targets=hipv4-amdgcn-amd-amdhsa--gfx950', '--output=' + co])
@@ -29,13 +31,16 @@ for l in dis.split('\n'):
     if inside:
         m = re.match(r'^\s+([a-z_0-9]+)\s.*// ([0-9A-F]+):', l)
         if m and (not only_scratch or m.group(1).startswith('scratch_')):
-            ins.append((int(m.group(2), 16), m.group(1)))
+            ins.append((int(m.group(2), 16), m.group(1) + (' ' + l.split('//')[0].split(None, 1)[1].strip() if only_scratch else '')))
 sym = subprocess.run([LLVM + '/llvm-symbolizer', '--obj=' + co, '--inlines', '--output-style=JSON'], input='\n'.join('0x%x' % a for a, _ in ins),
                      capture_output=True, text=True).stdout
 recs = [json.loads(l) for l in sym.strip().split('\n')]
 src = open(os.path.join(csrc, 'device', 'step_kernel.hip.inc')).read().split('\n')
 short = lambda fn: (re.search(r'(?:k\d+::)?(\w+)(?:<[^>]*>)?\(', fn) or re.search(r'(\w+)', fn)).group(1)
 tot, valu, callee = collections.Counter(), collections.Counter(), {}
+if list_scratch:
+    for (a, op), r in zip(ins, recs):
+        print('%6x %-22s %s' % (a, op, ' <- '.join('%s:%d' % (short(f['FunctionName']), f['Line']) for f in r['Symbol'])))
 for (a, op), r in zip(ins, recs):
     fr = r['Symbol']
     idx = next((i for i, f in enumerate(fr) if 'stepBody' in f['FunctionName']), None)
