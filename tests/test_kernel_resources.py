@@ -37,3 +37,32 @@ def test_first_pass_kernels_keep_six_workgroups_per_cu():
         assert k[name]['scratch'] <= 96, (name, k[name])
     for name in ('pdb_step_kernel_wide', 'pdb_step_kernel_ctrl'):   # 40-row cars: five workgroups (96 VGPRs, 29.9 KB)
         assert k[name]['vgprs'] <= 96 and k[name]['lds'] <= 32000, (name, k[name])
+
+
+COLD_BLOCKS = ('teleportByModeT', 'wingStepGroundEffect')   # the env's reset tick (inlined teleport) and the wings of a car with ground-effect LUTs
+
+
+def test_no_scratch_instruction_on_the_first_pass_hot_path():
+    """The frame size cannot tell a spill in the cold teleport block from one on the path every car takes (round 3 had 21 scratch stores and
+    32 loads in the tyre chain and the collision broad phase behind an 80-byte frame).  Here the 33-row first-pass kernel is compiled with debug
+    info (same flags otherwise), disassembled, and EVERY scratch_ instruction is attributed through its inline stack: each has to sit inside one
+    of the cold blocks.  (tools/isa_callsite_profile.py; the -g object is cached under /tmp by the sources' hash: about a minute when they change.)"""
+    import hashlib, subprocess, sys, tempfile
+    root = os.path.join(HERE, '..')
+    dev = os.path.join(root, 'projectd-core_amd', 'csrc')
+    h = hashlib.sha256()
+    for dp, dn, fn in sorted(os.walk(dev)):
+        for f in sorted(fn):
+            if f.endswith(('.hip', '.inc', '.hpp', '.h')):
+                h.update(open(os.path.join(dp, f), 'rb').read())
+    for f in ('pdb_types.h', 'pdbatch.h'):
+        h.update(open(os.path.join(root, 'include', f), 'rb').read())
+    cache = os.path.join(tempfile.gettempdir(), 'pdb_isa_' + h.hexdigest()[:16])
+    os.makedirs(cache, exist_ok=True)
+    r = subprocess.run([sys.executable, os.path.join(root, 'tools', 'isa_callsite_profile.py'), 'pdb_step_kernel', 'scratchlist'],
+                       env=dict(os.environ, PDB_ISA_TMP=cache), capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.split('\n') if re.match(r'^\s*[0-9a-f]+ scratch_', l)]
+    assert lines, 'the cold teleport block is known to spill: no scratch instruction at all means the listing broke'
+    hot = [l for l in lines if not any(c in l for c in COLD_BLOCKS)]
+    assert not hot, 'scratch traffic on the hot path of pdb_step_kernel:\n' + '\n'.join(hot[:20])
