@@ -196,14 +196,22 @@ def measure(args, world, rank, local_rank, dist, want_cpu=False):
     part_loops = policy not in ('constant', 'host', 'host_sync', 'host_mlp') and args.partitions > 1 and not gather.active and n >= args.part_loop_min
     host_pipe = policy in ('host', 'host_mlp') and args.partitions > 1
     # configs[3] as worded (a gather and an action scatter EVERY tick) over free-running partitions: one set of collectives per partition
-    part_exchange = do_scatter and args.partitions > 1 and policy == 'constant' and n >= args.part_loop_min and (dist is not None) and (world == 1 or dist.get_backend() == 'nccl')
+    part_exchange = do_scatter and args.partitions > 1 and policy == 'constant' and n >= args.part_loop_min and (dist is not None)
     split = use_ring or part_loops or host_pipe or part_exchange   # the cars step as free-running partitions
     if split:
         b.set_partitions(args.partitions)
+    lib_exchange = False
     if part_exchange:
         part_st = [torch.cuda.ExternalStream(b.partition_stream(p), device=dev) for p in range(args.partitions)]
         part_rng = [b.partition_range(p) for p in range(args.partitions)]
-        exch = sharding.PartitionExchange(part_rng, world, rank, dev, dist)
+        if not args.torch_exchange and (world == 1 or dist.get_backend() == 'nccl'):
+            try:     # the three steps issued by the library through its own RCCL communicators (collective: every rank succeeds or none)
+                exch = sharding.LibraryExchange(b, part_rng, world, rank, dev, dist)
+                lib_exchange = True
+            except RuntimeError as e:
+                sys.stderr.write('bench: %s; per-partition exchange through torch.distributed instead\n' % e)
+        if not lib_exchange:
+            exch = sharding.PartitionExchange(part_rng, world, rank, dev, dist)
         if rank == 0:
             exch.load_actions(torch.from_numpy(all_actions).to(dev))
     if host_pipe:
@@ -234,7 +242,11 @@ def measure(args, world, rank, local_rank, dist, want_cpu=False):
             o = b.step_host(host_act[0])['obs']
             host_policy(np.ascontiguousarray(o), host_act[0])
             return
-        if part_exchange:   # per partition, on its own stream: actions from the learner, the tick, outputs to the learner
+        if part_exchange and lib_exchange:   # per partition, on its own stream: actions from the learner, the tick, outputs to the learner -- three enqueues inside the library
+            for p in range(args.partitions):
+                exch.step(p)
+            return
+        if part_exchange:   # the same through torch.distributed (gloo, or --torch-exchange)
             for p in range(args.partitions):
                 f, c = part_rng[p]
                 with torch.cuda.stream(part_st[p]):
@@ -367,7 +379,7 @@ def measure(args, world, rank, local_rank, dist, want_cpu=False):
             "dtype": "f32 (+f64 drivetrain)", "data": "synthetic",
             "repeats": len(regions), "timed_region_s": total,
             "config": {"workload": wl, "cars_per_gpu": n, "partitions": (args.partitions if split else 1), "settle_ticks": args.settle,
-                       "collective": ("per partition and tick, on the partition's own stream and RCCL communicator: scatter of its [n,2] action rows from rank 0 -> tick -> all-gather of its [n,26] output rows (the partitions are never joined)" if part_exchange else
+                       "collective": (("per partition and tick, on the partition's own stream and RCCL communicator: scatter of its [n,2] action rows from rank 0 -> tick -> all-gather of its [n,26] output rows (the partitions are never joined); issued by %s" % ("the library (pdb_step_exchange_partition: three enqueues from C per partition and tick)" if lib_exchange else "torch.distributed (six calls per tick)")) if part_exchange else
                                       "RCCL all-gather of %d-tick trajectory rings [k,N,26] obs/reward/flags on a side stream, kernel writes the ring in place%s" %
                                       (args.gather_ticks, "; actions scattered from rank 0 every tick" if args.scatter_actions else "")) if (world > 1 or args.force_gather) else "none",
                        "parity": "bit-exact vs CPU oracle (tests/, -m gpu); rigid-body solver and contact generation unpinned (ODE absent from the reference tree)"},
@@ -398,6 +410,7 @@ EXTRA = [   # (key, argv) -- the other BASELINE configs' shapes, each measured b
     ("configs4_shape_16384_walls_mlp", ['--workload', 'touge', '--cars', '16384', '--walls', '--policy', 'mlp', '--steps', '300', '--warmup', '50', '--settle', '200']),
     ("configs3_shard_8192", ['--cars', '8192', '--steps', '600', '--warmup', '100']),
     ("configs3_shard_8192_gather_k1_scatter", ['--cars', '8192', '--steps', '300', '--warmup', '50', '--force-gather', '--gather-ticks', '1', '--scatter-actions']),
+    ("configs3_shard_8192_gather_k1_scatter_torch", ['--cars', '8192', '--steps', '300', '--warmup', '50', '--force-gather', '--gather-ticks', '1', '--scatter-actions', '--torch-exchange']),
     ("configs3_shard_8192_gather_k32", ['--cars', '8192', '--steps', '600', '--warmup', '100', '--force-gather', '--gather-ticks', '32']),
     ("configs4_shape_16384_walls_host_policy", ['--workload', 'touge', '--cars', '16384', '--walls', '--policy', 'host', '--steps', '200', '--warmup', '30', '--settle', '100']),
     ("configs4_shape_16384_walls_host_policy_sync", ['--workload', 'touge', '--cars', '16384', '--walls', '--policy', 'host_sync', '--steps', '200', '--warmup', '30', '--settle', '100']),
@@ -442,6 +455,7 @@ def parser():
     ap.add_argument('--episodes', action='store_true', help='run the env loop: terminations with penalties like projectd_env.py, resets through the device reset mask')
     ap.add_argument('--gather-ticks', type=int, default=32, help='ticks per trajectory ring gathered to the learner (N > 1): 1 = plain per-tick gather')
     ap.add_argument('--scatter-actions', action='store_true', help='with a gather: rank 0 scatters the [N,2] action block back every tick (configs[3] as SURVEY 8d words it)')
+    ap.add_argument('--torch-exchange', action='store_true', help='the per-partition exchange (--scatter-actions with --gather-ticks 1) through torch.distributed instead of the library\'s own RCCL communicators (A/B)')
     ap.add_argument('--force-gather', action='store_true', help='run the observation all-gather even with one rank (exercises the RCCL + side-stream path on a single GPU)')
     ap.add_argument('--backend', default='nccl', help='torch.distributed backend for N > 1 (nccl = RCCL; gloo only to exercise the multi-rank path on a single-GPU box)')
     ap.add_argument('--teleport-mode', type=int, default=0, choices=[0, 1, 2], help='--episodes: where a reset puts the car (projectd_env.py teleport_mode: 0 start, 1 nearest, 2 random point of the lap)')
@@ -525,6 +539,18 @@ def main():
         res["extra"] = extra
     if world > 1 and not args.scatter_actions and not args.no_extra:   # the other collective variant SURVEY 8d words (a gather + an action scatter every tick), same process, same rule
         a2 = parser().parse_args(sys.argv[1:] + ['--gather-ticks', '1', '--scatter-actions', '--no-cpu-baseline', '--no-extra'])
+        # this optional second measurement must never cost the headline already measured: if it does not come back (a rank that failed alone
+        # leaves the others inside a collective), rank 0 prints the line it has and every rank leaves
+        import threading
+
+        def _give_up():
+            if rank == 0:
+                res.setdefault("extra", {})["configs3_gather_k1_scatter"] = {"error": "did not finish within 240 s"}
+                json_out.write(json.dumps(res) + '\n'); json_out.flush()
+            os._exit(0)
+        watchdog = threading.Timer(240.0, _give_up)
+        watchdog.daemon = True
+        watchdog.start()
         try:
             r2 = measure(a2, world, rank, local_rank, dist)
             if rank == 0:
@@ -533,6 +559,7 @@ def main():
         except Exception as e:
             if rank == 0:
                 res.setdefault("extra", {})["configs3_gather_k1_scatter"] = {"error": repr(e)[:200]}
+        watchdog.cancel()
     if rank == 0:
         json_out.write(json.dumps(res) + '\n')
         json_out.flush()

@@ -157,6 +157,20 @@ int pdb_wait_partitions(pdb_batch* b, void* hip_stream);
  * on pdb_partition_stream). */
 int pdb_step_partition(pdb_batch* b, float dt, int part, pdb_step_out* out);
 void* pdb_partition_stream(pdb_batch* b, int part);
+/* The learner exchange of a sharded job (one process per GPU, contiguous car blocks; no counterpart in the reference, whose envs are
+ * separate processes under stable-baselines' SubprocVecEnv) issued by the library itself: every partition has its own RCCL communicator, and
+ * pdb_step_exchange_partition enqueues on the partition's stream
+ *     rank 0's action rows for this partition -> every rank's action block  |  one tick of the partition  |  all-gather of its output rows,
+ * three enqueues from C, nothing of the host's in between, the partitions never joined.  RCCL is taken from the process at run time (the one
+ * torch uses, if torch is loaded); without it these return PDB_ERR_NO_DEVICE and nothing else is affected.
+ *   pdb_comm_unique_id: rank 0 calls it once per partition and hands the 128-byte ids to every rank (any transport: a torch.distributed
+ *     broadcast, a file); pdb_comm_init(b, world, rank, ids, n_ids >= partitions) is collective over the ranks, after pdb_set_partitions.
+ *   scatter_src (rank 0 only, device memory): float[world][cars of the partition][action stride] -- rank r's rows at index r;
+ *   gathered (every rank, device memory): pdb_step_out[world][cars of the partition], valid once the partition's stream has passed the call. */
+int pdb_comm_unique_id(void* id128);
+int pdb_comm_init(pdb_batch* b, int world, int rank, const void* ids, int n_ids);
+int pdb_comm_destroy(pdb_batch* b);
+int pdb_step_exchange_partition(pdb_batch* b, float dt, int part, const float* scatter_src, pdb_step_out* gathered);
 /* A policy that lives on the HOST (BASELINE configs[4]; the reference's loop: projectd_env.py:157-171 under stable-baselines),
  * pipelined over the partitions instead of one synchronous round trip per tick (pdb_step_host): the library owns page-locked
  * host mirrors of the action block (pdb_host_actions: float[N][stride]) and of the output block (pdb_host_out: pdb_step_out[N]).

@@ -104,6 +104,8 @@ static constexpr size_t kSnapStrideWide = k33::kSnapStride;
 
 namespace pdb { void setError(const std::string& s); }
 
+#include <dlfcn.h>
+#include <rccl/rccl.h>   // types and prototypes only: the library is taken at run time (rcclApi), never linked
 #define LAUNCHCHK(b) do { HIPCHK(hipGetLastError()); if ((b)->launchRefused) return PDB_ERR_HIP; } while (0)
 #define HIPCHK(expr)                                                                                 \
     do {                                                                                             \
@@ -174,10 +176,14 @@ struct pdb_batch {
                                                         // tend to go through the pass once, all of them in the same tick)
     bool launchRefused = false;   // a tick could not be launched (no memory for the hand-over snapshots): the entry point that asked returns PDB_ERR_HIP
     bool capturing = false;   // launches being recorded into a graph: the contact pass's grid is then frozen, so it is not sized for an idle pass
+    // the per-tick exchange with the learner issued by the library itself (pdb_comm_init / pdb_step_exchange_partition): one RCCL communicator per partition
+    ncclComm_t comm[PDB_MAX_PARTS] = {nullptr, nullptr, nullptr, nullptr};
+    int commWorld = 0, commRank = 0;
     int* hHint = nullptr;  // page-locked, device-visible: per launch site, the number of cars the last contact pass held (written by its last workgroup; read here without waiting)
     int* dHint = nullptr;
 };
 static int partFirst(const pdb_batch* b, int p);
+static void commFree(pdb_batch* b);
 // Every entry point that works through the batch's stream first lets that stream wait for the partitions' kernels still in
 // flight (pdb_step_ring with join == 0): state reads, resets and plain launches are always ordered after them.
 static int joinParts(pdb_batch* b) {
@@ -417,6 +423,7 @@ pdb_batch* pdb_create(int device, int n_cars, const pdb_car_params* params, cons
 void pdb_destroy(pdb_batch* b) {
     if (!b) return;
     (void)hipSetDevice(b->device);
+    commFree(b);
     if (b->graphExec) (void)hipGraphExecDestroy(b->graphExec);
     if (b->stream) (void)hipStreamSynchronize(b->stream);
     (void)hipFree(b->dStates); (void)hipFree(b->dActions); (void)hipFree(b->dOut); (void)hipFree(b->dCarStates); (void)hipFree(b->dParams); (void)hipFree(b->dK); (void)hipFree(b->dTrack); (void)hipFree(b->dContacts); (void)hipFree(b->dResetMask); (void)hipFree(b->dResetScratch);
@@ -809,6 +816,89 @@ void* pdb_partition_stream(pdb_batch* b, int part) { return (b && part >= 0 && p
 int pdb_partition_range(pdb_batch* b, int part, int* first, int* count) {
     if (!b || part < 0 || part >= b->parts || !first || !count) { pdb::setError("pdb_partition_range: bad argument"); return PDB_ERR_ARG; }
     *first = partFirst(b, part); *count = partFirst(b, part + 1) - partFirst(b, part);
+    return PDB_OK;
+}
+// ---- the learner exchange of SURVEY 8e issued by the library: per partition and tick, on the partition's own stream and its own RCCL
+// communicator, scatter of the partition's action rows from rank 0 -> the partition's tick -> all-gather of its output rows.  Three enqueues
+// from C per partition and tick, nothing of the host's in between (through torch.distributed the same three steps cost six calls of ~25 us each,
+// more than the tick takes on the GPU).  RCCL is taken from the process at run time (dlopen by soname: in a torch process that is the RCCL torch
+// itself uses, otherwise /opt/rocm's), so the library carries no link-time dependency on it and loads on machines without it.
+struct RcclApi {
+    void* lib = nullptr; bool tried = false;
+    decltype(&ncclGetUniqueId) getUniqueId = nullptr; decltype(&ncclCommInitRank) commInitRank = nullptr; decltype(&ncclCommDestroy) commDestroy = nullptr;
+    decltype(&ncclAllGather) allGather = nullptr; decltype(&ncclSend) send = nullptr; decltype(&ncclRecv) recv = nullptr;
+    decltype(&ncclGroupStart) groupStart = nullptr; decltype(&ncclGroupEnd) groupEnd = nullptr; decltype(&ncclGetErrorString) errorString = nullptr;
+};
+static RcclApi* rcclApi() {
+    static RcclApi api;
+    if (api.tried) return api.lib ? &api : nullptr;
+    api.tried = true;
+    void* h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+    if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+    if (!h) { pdb::setError(std::string("pdb_comm: RCCL not found in this process (") + dlerror() + ")"); return nullptr; }
+    bool ok = true;
+    auto sym = [&](const char* n) { void* p = dlsym(h, n); if (!p) ok = false; return p; };
+    api.getUniqueId = (decltype(api.getUniqueId))sym("ncclGetUniqueId"); api.commInitRank = (decltype(api.commInitRank))sym("ncclCommInitRank");
+    api.commDestroy = (decltype(api.commDestroy))sym("ncclCommDestroy"); api.allGather = (decltype(api.allGather))sym("ncclAllGather");
+    api.send = (decltype(api.send))sym("ncclSend"); api.recv = (decltype(api.recv))sym("ncclRecv");
+    api.groupStart = (decltype(api.groupStart))sym("ncclGroupStart"); api.groupEnd = (decltype(api.groupEnd))sym("ncclGroupEnd");
+    api.errorString = (decltype(api.errorString))sym("ncclGetErrorString");
+    if (!ok) { pdb::setError("pdb_comm: the RCCL in this process lacks an entry point"); return nullptr; }
+    api.lib = h;
+    return &api;
+}
+#define NCCLCHK(api, expr) do { ncclResult_t _r = (expr); if (_r != ncclSuccess) { pdb::setError(std::string("RCCL: ") + (api)->errorString(_r) + " at " #expr); return PDB_ERR_HIP; } } while (0)
+int pdb_comm_unique_id(void* id128) {
+    if (!id128) { pdb::setError("pdb_comm_unique_id: null argument"); return PDB_ERR_ARG; }
+    RcclApi* R = rcclApi(); if (!R) return PDB_ERR_NO_DEVICE;
+    static_assert(sizeof(ncclUniqueId) == 128, "id size");
+    ncclUniqueId id; NCCLCHK(R, R->getUniqueId(&id));
+    memcpy(id128, &id, sizeof(id));
+    return PDB_OK;
+}
+static void commFree(pdb_batch* b) {
+    RcclApi* R = rcclApi();
+    for (int p = 0; p < PDB_MAX_PARTS; ++p) { if (b->comm[p] && R) (void)R->commDestroy(b->comm[p]); b->comm[p] = nullptr; }
+    b->commWorld = 0;
+}
+int pdb_comm_init(pdb_batch* b, int world, int rank, const void* ids, int n_ids) {
+    if (!b || world < 1 || rank < 0 || rank >= world || !ids || n_ids < b->parts || b->parts < 2) { pdb::setError("pdb_comm_init: bad argument (pdb_set_partitions first; one 128-byte id per partition, the same on every rank)"); return PDB_ERR_ARG; }
+    RcclApi* R = rcclApi(); if (!R) return PDB_ERR_NO_DEVICE;
+    commFree(b);
+    HIPCHK(hipSetDevice(b->device));
+    for (int p = 0; p < b->parts; ++p) {   // every rank creates the partitions' communicators in the same order
+        ncclUniqueId id; memcpy(&id, (const uint8_t*)ids + (size_t)p * sizeof(id), sizeof(id));
+        NCCLCHK(R, R->commInitRank(&b->comm[p], world, id, rank));
+    }
+    b->commWorld = world; b->commRank = rank;
+    return PDB_OK;
+}
+int pdb_comm_destroy(pdb_batch* b) { if (!b) { pdb::setError("null argument"); return PDB_ERR_ARG; } commFree(b); return PDB_OK; }
+// scatter_src (rank 0 only; device memory): float[world][cars of the partition][action stride], rank r's rows of this partition at index r.
+// gathered (device memory, every rank): pdb_step_out[world][cars of the partition].  Both are read / written on the partition's stream.
+int pdb_step_exchange_partition(pdb_batch* b, float dt, int part, const float* scatter_src, pdb_step_out* gathered) {
+    if (!b || part < 0 || part >= b->parts || b->parts < 2 || !b->partStream[part] || !gathered) { pdb::setError("pdb_step_exchange_partition: bad argument"); return PDB_ERR_ARG; }
+    if (!b->comm[part]) { pdb::setError("pdb_step_exchange_partition: pdb_comm_init first"); return PDB_ERR_ARG; }
+    if (b->commRank == 0 && !scatter_src) { pdb::setError("pdb_step_exchange_partition: rank 0 passes the learner's action rows"); return PDB_ERR_ARG; }
+    RcclApi* R = rcclApi(); if (!R) return PDB_ERR_NO_DEVICE;
+    const int c0 = partFirst(b, part), c1 = partFirst(b, part + 1), c = c1 - c0;
+    if (c <= 0) return PDB_OK;
+    hipStream_t st = b->partStream[part];
+    float* mine = b->dActions + (size_t)c0 * b->actionStride;
+    const size_t rowFloats = (size_t)c * b->actionStride;
+    if (b->commRank == 0) {   // the learner's rows for its own cars stay on the device; the other ranks' go out point to point
+        HIPCHK(hipMemcpyAsync(mine, scatter_src, rowFloats * sizeof(float), hipMemcpyDeviceToDevice, st));
+        if (b->commWorld > 1) {
+            NCCLCHK(R, R->groupStart());
+            for (int r = 1; r < b->commWorld; ++r) NCCLCHK(R, R->send(scatter_src + (size_t)r * rowFloats, rowFloats, ncclFloat, r, b->comm[part], st));
+            NCCLCHK(R, R->groupEnd());
+        }
+    } else NCCLCHK(R, R->recv(mine, rowFloats, ncclFloat, 0, b->comm[part], st));
+    int rc = pdb_step_partition(b, dt, part, nullptr);
+    if (rc != PDB_OK) return rc;
+    static_assert(sizeof(pdb_step_out) % 4 == 0, "rows as floats");
+    NCCLCHK(R, R->allGather(b->dOutActive + c0, gathered, (size_t)c * (sizeof(pdb_step_out) / 4), ncclFloat, b->comm[part], st));
+    HIPCHK(hipEventRecord(b->partEnd[part], st));   // the partition's end now includes the gather
     return PDB_OK;
 }
 int pdb_wait_partitions(pdb_batch* b, void* hip_stream) {

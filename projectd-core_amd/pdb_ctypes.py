@@ -203,6 +203,11 @@ def load_product(host_only=False):
             lib.pdb_step_host_partition.argtypes = [C.c_void_p, C.c_float, C.c_int]
             lib.pdb_wait_host_partition.argtypes = [C.c_void_p, C.c_int]
         lib.pdb_partition_stream.restype = C.c_void_p; lib.pdb_partition_stream.argtypes = [C.c_void_p, C.c_int]
+        if hasattr(lib, 'pdb_comm_init'):
+            lib.pdb_comm_unique_id.argtypes = [C.c_void_p]
+            lib.pdb_comm_init.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int]
+            lib.pdb_comm_destroy.argtypes = [C.c_void_p]
+            lib.pdb_step_exchange_partition.argtypes = [C.c_void_p, C.c_float, C.c_int, C.c_void_p, C.c_void_p]
         lib.pdb_partition_range.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
         lib.pdb_partition_mark.argtypes = [C.c_void_p]
         lib.pdb_partition_elapsed_ms.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]

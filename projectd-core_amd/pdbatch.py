@@ -90,6 +90,22 @@ class Batch:
     def wait_host_partition(self, part):
         self._chk(self.lib.pdb_wait_host_partition(self.h, part))
 
+    def comm_unique_ids(self, parts):
+        """rank 0: one 128-byte RCCL id per partition (bytes, to be handed to every rank)"""
+        buf = (C.c_uint8 * (128 * parts))()
+        for p in range(parts):
+            self._chk(self.lib.pdb_comm_unique_id(C.byref(buf, 128 * p)))
+        return bytes(buf)
+
+    def comm_init(self, world, rank, ids):
+        """collective over the ranks, after set_partitions: the partitions' RCCL communicators inside the library"""
+        buf = (C.c_uint8 * len(ids)).from_buffer_copy(ids)
+        self._chk(self.lib.pdb_comm_init(self.h, world, rank, buf, len(ids) // 128))
+
+    def step_exchange_partition(self, part, scatter_src_ptr, gathered_ptr):
+        """on the partition's stream: the learner's action rows in, one tick, the output rows of every rank out (device pointers)"""
+        self._chk(self.lib.pdb_step_exchange_partition(self.h, C.c_float(SIM_DT), part, C.c_void_p(scatter_src_ptr), C.c_void_p(gathered_ptr)))
+
     def partition_stream(self, part):
         return self.lib.pdb_partition_stream(self.h, part)
 

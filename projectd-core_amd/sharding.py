@@ -142,10 +142,19 @@ class PartitionExchange:
         for p, (f, c) in enumerate(self.ranges):
             self.scatter_src[p].copy_(a[:, f:f + c])
 
+    def _via_host(self, t):
+        # gloo moves host memory: device rows go through the host, synchronously (the single-GPU test of the multi-rank path; RCCL takes them as they are)
+        return t.is_cuda and self.world > 1 and self.dist.get_backend(self.groups[0]) == 'gloo'
+
     def scatter(self, p, act_rows):
         """this rank's action rows of partition p <- the learner's (act_rows: the [c, 2] view of the batch's action block)"""
         if self.world == 1:
             act_rows.copy_(self.scatter_src[p][0])
+        elif self._via_host(act_rows):
+            import torch
+            host = torch.empty(act_rows.shape, dtype=act_rows.dtype)
+            self.dist.scatter(host, [x.cpu() for x in self.scatter_src[p].unbind(0)] if self.rank == 0 else None, src=0, group=self.groups[p])
+            act_rows.copy_(host)
         else:
             self.dist.scatter(act_rows, list(self.scatter_src[p].unbind(0)) if self.rank == 0 else None, src=0, group=self.groups[p])
 
@@ -157,6 +166,14 @@ class PartitionExchange:
         asynchronous form costs ~10 us more host time per partition and tick than it saves on the stream -- the loop is bound by the
         host's ~25 us per torch.distributed call -- so bench.py uses the waiting form.)"""
         r = slot & 1
+        if self.world > 1 and self._via_host(out_rows):
+            import torch
+            torch.cuda.current_stream().synchronize()      # the partition's tick has written the rows
+            host = torch.empty((self.world * out_rows.shape[0], OUT_COLS), dtype=out_rows.dtype)
+            self.dist.all_gather_into_tensor(host, out_rows.cpu(), group=self.groups[p])
+            self.gathered2[r][p].view(-1, OUT_COLS).copy_(host)
+            self.work[r][p] = None
+            return
         w = self.dist.all_gather_into_tensor(self.gathered2[r][p].view(-1, OUT_COLS), out_rows, group=self.groups[p], async_op=not wait)
         self.work[r][p] = None if wait else w
 
@@ -166,6 +183,52 @@ class PartitionExchange:
         if self.work[r][p] is not None:
             self.work[r][p].wait()
             self.work[r][p] = None
+
+
+class LibraryExchange:
+    """PartitionExchange's three steps per partition and tick -- the learner's action rows in, the partition's tick, its output rows of every
+    rank out -- issued by the LIBRARY on the partition's stream through its own RCCL communicators (pdb_comm_init /
+    pdb_step_exchange_partition): three enqueues from C, no torch.distributed call in the loop.  The 128-byte communicator ids travel over the
+    torch process group once, at construction (which is collective).  Raises RuntimeError on every rank if any rank cannot set it up (no RCCL in
+    the process, two ranks on one GPU, ...): the caller falls back to PartitionExchange."""
+
+    def __init__(self, batch, part_ranges, world, rank, device, dist, action_stride=2):
+        import torch
+        self.batch, self.world, self.rank, self.ranges = batch, world, rank, list(part_ranges)
+        ok, err, ids = 1, None, None
+        try:
+            if rank == 0:
+                ids = batch.comm_unique_ids(len(self.ranges))
+        except RuntimeError as e:
+            ok, err = 0, e
+        if world > 1:
+            box = [ids if ok else None]
+            dist.broadcast_object_list(box, src=0)
+            ids = box[0]
+            ok = 0 if ids is None else ok
+        if ok:
+            try:
+                batch.comm_init(world, rank, ids)
+            except RuntimeError as e:
+                ok, err = 0, e
+        if world > 1:   # agree before anybody enters a collective the others will not
+            flag = torch.tensor([ok], dtype=torch.int32, device=(device if dist.get_backend() == 'nccl' else 'cpu'))
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            ok = int(flag.item())
+        if not ok:
+            raise RuntimeError('LibraryExchange unavailable: %s' % (err if err is not None else 'another rank could not set it up'))
+        self.gathered = [torch.empty((world, c, OUT_COLS), dtype=torch.float32, device=device) for (f, c) in self.ranges]
+        self.scatter_src = [torch.zeros((world, c, action_stride), dtype=torch.float32, device=device) for (f, c) in self.ranges] if rank == 0 else None
+
+    def load_actions(self, all_actions):
+        """learner: all_actions [world * n_local, stride] (global car order) -> the per-partition scatter sources"""
+        a = all_actions.reshape(self.world, -1, all_actions.shape[-1])
+        for p, (f, c) in enumerate(self.ranges):
+            self.scatter_src[p].copy_(a[:, f:f + c])
+
+    def step(self, p):
+        """enqueue partition p's scatter -> tick -> gather on its stream (nothing waited for)"""
+        self.batch.step_exchange_partition(p, self.scatter_src[p].data_ptr() if self.rank == 0 else 0, self.gathered[p].data_ptr())
 
 
 def scatter_actions(all_actions, n_local, world, rank, device, dist=None):

@@ -66,3 +66,34 @@ def test_gather_over_ranks_equals_single_process(built, oracle, world):
     ref = ring.reshape(8, world, n_global // world, 26).transpose(1, 0, 2, 3)      # rank-major like the gathered tensor
     assert np.array_equal(got.view(np.int32), np.ascontiguousarray(ref).view(np.int32))
     assert np.any(ref[..., :24] != 0)
+
+
+@pytest.mark.timeout(600)
+@pytest.mark.parametrize('world', [2, 4])
+def test_partition_exchange_over_ranks_equals_single_process(built, oracle, world):
+    """sharding.PartitionExchange with world > 1 (it had never run): every tick the learner's actions -- different every tick -- are
+    scattered per partition, the partition steps, its output rows are all-gathered; what rank 0 holds after every tick equals a single process
+    stepping all cars with those actions, bit for bit"""
+    import _sharding_worker as w
+    import pdbatch, oracle_ctypes
+    n_global, ticks = 16, 30
+    port = _free_port()
+    with tempfile.TemporaryDirectory() as d:
+        out = os.path.join(d, 'hist.npy')
+        env = dict(os.environ, OMP_NUM_THREADS='1')
+        procs = [subprocess.Popen([sys.executable, os.path.join(HERE, '_sharding_worker.py'), 'exchange', str(r), str(world), str(port), str(n_global), str(ticks), out], env=env)
+                 for r in range(world)]
+        rcs = [p.wait(timeout=540) for p in procs]
+        assert rcs == [0] * world
+        got = np.load(out)                                   # [ticks, world, n_local, 26]
+    P = pdbatch.packed_params(); trk = pdbatch.synthetic_track('flat')
+    lib = pc.load_product(host_only=True); orc = oracle_ctypes.load_oracle(True)
+    S0 = pc.DynState(); assert lib.pdb_initial_state(C.byref(P), trk, C.byref(S0)) == 0
+    hs = [orc.cpuref_create(C.byref(P), trk, len(trk), C.byref(S0)) for _ in range(n_global)]
+    ref = np.zeros((ticks, n_global, 26), np.float32)
+    for t in range(ticks):
+        ref[t] = w.step_block(orc, hs, w.exchange_actions(t, n_global))
+    for h in hs:
+        orc.cpuref_destroy(h)
+    assert np.array_equal(got.reshape(ticks, n_global, 26).view(np.int32), ref.view(np.int32))
+    assert np.any(ref[..., :24] != 0)
