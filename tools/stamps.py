@@ -8,7 +8,7 @@ sys.path.insert(0, os.path.join(ROOT, 'tests')); sys.path.insert(0, os.path.join
 import pdb_ctypes as pc, parity_util as pu, pdbatch
 pc_load = pc.load_product
 def load_stamps():
-    lib = pc._load(os.path.join(pc.ROOT, 'tools', 'variants', 'libpdbatch_stamps.so'))
+    lib = pc._load(os.path.join(pc.ROOT, 'tools', 'variants', os.environ.get('PDB_STAMPS_LIB', 'libpdbatch_stamps.so')))
     return lib
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
 orig = pc.load_product
@@ -17,7 +17,7 @@ def patched(host_only=False):
     lib = orig.__wrapped__() if hasattr(orig, '__wrapped__') else None
     return lib
 # build a Batch on the stamps library
-lib = C.CDLL(os.path.join(pc.ROOT, 'tools', 'variants', 'libpdbatch_stamps.so'))
+lib = C.CDLL(os.path.join(pc.ROOT, 'tools', 'variants', os.environ.get('PDB_STAMPS_LIB', 'libpdbatch_stamps.so')))
 import types
 def lp(host_only=False):
     l = lib
