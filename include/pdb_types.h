@@ -393,6 +393,20 @@ typedef struct pdb_step_out {
                                * bit5 fault: the chassis pose or velocity is not finite (the car needs a reset) */
 } pdb_step_out;
 
+/* Per-lane setup and reward weights: what the reference gives every simulator of its own (PyProjectD.cpp:328-365 setCarTune / setScoringVar on that
+ * env's car; projectd_env.py:127-132 applies eight tunes and twenty-one scoring variables per env) as a 144-byte row per car of a batch, so that a
+ * batch can randomise the setup lane by lane.  The row holds the RESOLVED parameter values -- the fields of pdb_car_params those calls write
+ * (Car/SetupManager.cpp: FRONT_BIAS, DIFF_POWER, DIFF_COAST, FINAL_RATIO, PRESSURE_LF/RF/LR/RR; Car/ScoringSystem.cpp:37-101) -- taken from a car
+ * block that has been through pdb_set_car_tune / pdb_set_scoring_var (pdb_lane_tune_from_params).  valid = 0: the lane uses its block's values. */
+typedef struct pdb_lane_tune {
+    double finalRatio, diffPowerRamp, diffCoastRamp;
+    float frontBias;
+    float pressureStatic[4];
+    pdb_scoring scoring;
+    int32_t valid;
+    int32_t _pad[3];
+} pdb_lane_tune;
+
 /* Env mode: the reward / termination / reset bookkeeping of pyprojectd/projectd_env.py:173-227, per car, inside the tick --
  * reward = stepReward minus the penalties of the rules that fired, terminate on hit / off track / stuck / cumulative reward below
  * low_reward; the tick after a termination is the env's reset(): teleport by teleport_mode (if teleport_on_reset) at its top, the
@@ -471,6 +485,7 @@ static_assert(sizeof(pdb_car_params) == 22648, "pdb_car_params layout");
 static_assert(sizeof(pdb_dyn_state) == 2352, "pdb_dyn_state layout (multiple of 16 bytes)");
 static_assert(sizeof(pdb_step_out) == 104, "pdb_step_out layout");
 static_assert(sizeof(pdb_contact) == 32, "pdb_contact layout");
+static_assert(sizeof(pdb_lane_tune) == 144, "pdb_lane_tune layout (a multiple of 16 bytes: it rides in the car's LDS block)");
 static_assert(sizeof(pdb_ray_rec) == 48, "pdb_ray_rec layout");
 #endif
 #endif

@@ -147,6 +147,12 @@ int pdb_contact_pass_load(pdb_batch* b, int site);
  * e.g. to randomise the setup over the cars of a batch.  The partition's cars step, reset and teleport with it, through every
  * step entry point (the whole-batch ones then issue one launch per partition range). */
 int pdb_set_partition_params(pdb_batch* b, int part, const pdb_car_params* params);
+/* Per-LANE setup and reward weights (pdb_lane_tune, include/pdb_types.h): the reference's setCarTune / setScoringVar are per simulator, i.e. per env
+ * (PyProjectD.cpp:328-365); here a lane's row overrides the eight tunes of projectd_env.py:127-130 and the scoring variables of its car block.
+ * pdb_lane_tune_from_params (host library too) reads the row out of a block that went through pdb_set_car_tune / pdb_set_scoring_var;
+ * pdb_set_lane_tunes(b, first, count, rows) installs rows for the cars [first, first + count) (rows == NULL: those lanes back to their block). */
+int pdb_lane_tune_from_params(const pdb_car_params* params, pdb_lane_tune* row);
+int pdb_set_lane_tunes(pdb_batch* b, int first, int count, const pdb_lane_tune* rows);
 int pdb_step_ring(pdb_batch* b, float dt, int n_ticks, pdb_step_out* ring, int ring_slots, int first_slot, int join);
 int pdb_wait_partitions(pdb_batch* b, void* hip_stream);
 /* Per-partition loops: pdb_step_partition enqueues one tick of one part on that part's stream (pdb_partition_stream), nothing

@@ -18,7 +18,9 @@
 // (car waves + the pack wave).  Measured in round 3 on the playground: the contact pass with one car per workgroup (no car waits for
 // another at the workgroup's barriers) runs 393 / 628 us per launch against 188 / 333 us with three -- two-wave workgroups share
 // their SIMDs with each other, and this pass is a few long single-wave chains.
+#ifndef PDB_FIRST_CPB
 #define PDB_FIRST_CPB 3
+#endif
 #ifndef PDB_CONTACT_CPB
 #define PDB_CONTACT_CPB 3
 #endif
@@ -151,6 +153,7 @@ struct pdb_batch {
     uint8_t* dResetScratch = nullptr;   // device copy of a host mask (pdb_reset)
     uint8_t* dResetMask = nullptr;   // [n]: 1 + teleport mode for cars to be reset at the top of their next tick (consumed and cleared by that tick)
     bool resetMaskArmed = false;     // pdb_reset_mask_device was asked for: the step kernels look at the mask
+    pdb_lane_tune* dLaneTunes = nullptr;   // [n] per-lane tunes and reward weights (pdb_set_lane_tunes), allocated on first use; rows with valid == 0 fall back to the block
     pdb_contact* dContacts = nullptr;   // [n][PDB_MAX_CONTACTS]: each car's live contact joints (the first pdb_dyn_state.numContacts of its row)
     hipEvent_t ev0 = nullptr, ev1 = nullptr, tev0 = nullptr, tev1 = nullptr;
     bool ownStream = true;
@@ -184,6 +187,7 @@ struct pdb_batch {
 };
 static int partFirst(const pdb_batch* b, int p);
 static void commFree(pdb_batch* b);
+static void wideContactPasses(pdb_batch* b);
 // Every entry point that works through the batch's stream first lets that stream wait for the partitions' kernels still in
 // flight (pdb_step_ring with join == 0): state reads, resets and plain launches are always ordered after them.
 static int joinParts(pdb_batch* b) {
@@ -227,6 +231,8 @@ static void fillConst(const pdb_car_params& P, DevConst& K, int actionMode) {
         K.invMass[b] = (b < P.numBodies) ? 1.0f / P.bodies[b].mass : 0.0f;
         for (int k = 0; k < 3; ++k) K.invInertia[b][k] = (b < P.numBodies) ? 1.0f / P.bodies[b].inertia[k] : 0.0f;
     }
+    (void)pdb_lane_tune_from_params(&P, &K.laneDefault);
+    K.laneTunes = nullptr;
     K.actionMode = actionMode;
     K.wantCarState = 0;
     K.stuckTimeout = 5.0;   // projectd_env.py:47
@@ -319,6 +325,7 @@ static int pushK(pdb_batch* b, hipStream_t st, bool async) {
         if (!b->partHas[p]) continue;
         DevConst& K = b->partK[p];
         fillConst(b->partParams[p], K, b->K.actionMode);
+        K.laneTunes = b->K.laneTunes;
         K.dt = b->K.dt; K.fps = b->K.fps; K.dtD = b->K.dtD; K.stuckTimeout = b->K.stuckTimeout; K.wantCarState = b->K.wantCarState; K.stamps = b->K.stamps; K.stampCars = b->K.stampCars;
         K.envHitPenalty = b->K.envHitPenalty; K.envOffPenalty = b->K.envOffPenalty; K.envStuckPenalty = b->K.envStuckPenalty; K.envLowReward = b->K.envLowReward;
         K.envMode = b->K.envMode; K.envTermHit = b->K.envTermHit; K.envTermOff = b->K.envTermOff; K.envTermStuck = b->K.envTermStuck;
@@ -432,6 +439,7 @@ void pdb_destroy(pdb_batch* b) {
     if (b->hOut) (void)hipHostFree(b->hOut);
     for (int q = 0; q <= PDB_MAX_PARTS; ++q) (void)hipFree(b->dQueue[q]);
     (void)hipFree(b->dSnap);
+    (void)hipFree(b->dLaneTunes);
     for (int q = 0; q < PDB_MAX_PARTS; ++q) { (void)hipFree(b->dPartParams[q]); (void)hipFree(b->dPartK[q]); }
     if (b->ev0) (void)hipEventDestroy(b->ev0);
     if (b->ev1) (void)hipEventDestroy(b->ev1);
@@ -452,6 +460,7 @@ int pdb_num_cars(const pdb_batch* b) { return b ? b->n : 0; }
 int pdb_set_state_all(pdb_batch* b, const pdb_dyn_state* state) {
     if (!b || !state) { pdb::setError("null argument"); return PDB_ERR_ARG; }
     if (int rcj = joinParts(b)) return rcj;
+    wideContactPasses(b);
     std::vector<pdb_dyn_state> tmp((size_t)b->n, *state);
     HIPCHK(hipMemcpyAsync(b->dStates, tmp.data(), sizeof(pdb_dyn_state) * (size_t)b->n, hipMemcpyHostToDevice, b->stream));
     HIPCHK(hipStreamSynchronize(b->stream));
@@ -460,6 +469,7 @@ int pdb_set_state_all(pdb_batch* b, const pdb_dyn_state* state) {
 int pdb_set_state(pdb_batch* b, int first, int count, const pdb_dyn_state* states) {
     if (!b || !states || first < 0 || count < 0 || first + count > b->n) { pdb::setError("bad range"); return PDB_ERR_ARG; }
     if (int rcj = joinParts(b)) return rcj;
+    wideContactPasses(b);
     HIPCHK(hipMemcpyAsync(b->dStates + first, states, sizeof(pdb_dyn_state) * (size_t)count, hipMemcpyHostToDevice, b->stream));
     HIPCHK(hipStreamSynchronize(b->stream));
     return PDB_OK;
@@ -482,6 +492,7 @@ int pdb_get_contacts(pdb_batch* b, int first, int count, pdb_contact* out) {
 int pdb_set_contacts(pdb_batch* b, int first, int count, const pdb_contact* in) {
     if (!b || !in || first < 0 || count < 0 || first + count > b->n) { pdb::setError("bad range"); return PDB_ERR_ARG; }
     if (int rcj = joinParts(b)) return rcj;
+    wideContactPasses(b);
     HIPCHK(hipMemcpyAsync(b->dContacts + (size_t)first * PDB_MAX_CONTACTS, in, sizeof(pdb_contact) * PDB_MAX_CONTACTS * (size_t)count, hipMemcpyHostToDevice, b->stream));
     HIPCHK(hipStreamSynchronize(b->stream));
     return PDB_OK;
@@ -513,9 +524,15 @@ extern "C" __global__ void pdb_clear_episodes_kernel(pdb_dyn_state* __restrict__
     if (i >= n || (mask && !mask[i])) return;
     states[i].envTotalReward = 0.0; states[i].envPending = 0; states[i].envStepId = 0;
 }
+// After anything that puts cars down or rewrites their records (resets, teleports through the mask, pdb_set_state, pdb_set_contacts): the contact pass is
+// launched wide for the next PDB_BURST_TICKS ticks of every launch site, whatever the hint says.  Cars just put down go through the pass -- all of them
+// in the same ticks -- and the hint is both late (written at a pass's END) and read early (the host enqueues ticks ahead): with two wide ticks the
+// third and fourth pass after a 16384-car reset still ran 20 ms each in ONE workgroup (profiles/r04: tools/contact_trace.py), eight cover the lag.
+#define PDB_BURST_TICKS 8
+static void wideContactPasses(pdb_batch* b) { for (int q = 0; q <= PDB_MAX_PARTS; ++q) b->burst[q] = PDB_BURST_TICKS; }
 static int resetLaunch(pdb_batch* b, uint8_t* dMask, int mode, int clear) {
     if (int rcj = joinParts(b)) return rcj;
-    for (int q = 0; q <= PDB_MAX_PARTS; ++q) b->burst[q] = 2;
+    wideContactPasses(b);
     bool any = false;
     for (int p = 0; p < b->parts; ++p) any = any || b->partHas[p];
     if (!any) hipLaunchKernelGGL(pdb_reset_kernel, dim3((b->n + 63) / 64), dim3(64), 0, b->stream, b->dStates, dMask, b->dParams, b->dTrack, b->n, mode, clear);
@@ -593,6 +610,25 @@ int pdb_set_partition_params(pdb_batch* b, int part, const pdb_car_params* param
     HIPCHK(hipMemcpy(b->dPartParams[part], params, sizeof(pdb_car_params), hipMemcpyHostToDevice));
     if (b->graphExec) { (void)hipGraphExecDestroy(b->graphExec); b->graphExec = nullptr; }
     return pushK(b, b->stream, false);
+}
+int pdb_set_lane_tunes(pdb_batch* b, int first, int count, const pdb_lane_tune* rows) {
+    if (!b || first < 0 || count < 0 || first + count > b->n) { pdb::setError("pdb_set_lane_tunes: bad range"); return PDB_ERR_ARG; }
+    if (int rcj = joinParts(b)) return rcj;
+    for (int p = 0; p < PDB_MAX_PARTS; ++p) if (b->partStream[p]) HIPCHK(hipStreamSynchronize(b->partStream[p]));
+    HIPCHK(hipStreamSynchronize(b->stream));
+    if (!b->dLaneTunes) {
+        if (!rows) return PDB_OK;   // nothing installed, nothing to take back
+        HIPCHK(hipMalloc(&b->dLaneTunes, sizeof(pdb_lane_tune) * (size_t)b->n));
+        HIPCHK(hipMemset(b->dLaneTunes, 0, sizeof(pdb_lane_tune) * (size_t)b->n));   // valid = 0 everywhere
+        b->K.laneTunes = b->dLaneTunes;
+        if (int rck = pushK(b, b->stream, false)) return rck;
+    }
+    if (count == 0) return PDB_OK;
+    if (rows) {
+        for (int i = 0; i < count; ++i) if (rows[i].valid != 0 && rows[i].valid != 1) { pdb::setError("pdb_set_lane_tunes: a row's valid field is neither 0 nor 1 (fill rows with pdb_lane_tune_from_params)"); return PDB_ERR_ARG; }
+        HIPCHK(hipMemcpy(b->dLaneTunes + first, rows, sizeof(pdb_lane_tune) * (size_t)count, hipMemcpyHostToDevice));
+    } else HIPCHK(hipMemset(b->dLaneTunes + first, 0, sizeof(pdb_lane_tune) * (size_t)count));
+    return PDB_OK;
 }
 int pdb_set_env(pdb_batch* b, const pdb_env_config* cfg) {
     if (!b || !cfg || cfg->teleport_mode < 0 || cfg->teleport_mode > 2) { pdb::setError("pdb_set_env: bad argument"); return PDB_ERR_ARG; }

@@ -27,6 +27,8 @@ struct DevConst {
     int envMode, envTermHit, envTermOff, envTermStuck, envTeleportOnReset, envTeleportMode;
     int actionMode;
     int wantCarState;
+    pdb_lane_tune laneDefault;            // the car block's own values of the per-lane tunes (a lane without a valid row reads these)
+    const pdb_lane_tune* laneTunes;       // [cars of the batch] or null: pdb_set_lane_tunes
     unsigned long long* stamps;   // diagnostic build only (-DPDB_STAMPS): [car][32] shader-clock stamps of the first pass, then [stampCars + car][32] of the contact pass
     int stampCars, _padStamp;
 };

@@ -38,6 +38,16 @@ int pdb_set_scoring_var(pdb_car_params* params, const char* name, float value) {
     if (!pdb::setScoringVar(*params, name, value)) { pdb::setError(std::string("unknown scoring var ") + name); return PDB_ERR_ARG; }
     return PDB_OK;
 }
+int pdb_lane_tune_from_params(const pdb_car_params* params, pdb_lane_tune* row) {
+    if (!params || !row) { pdb::setError("null argument"); return PDB_ERR_ARG; }
+    memset(row, 0, sizeof(*row));
+    row->finalRatio = params->finalRatio; row->diffPowerRamp = params->diffPowerRamp; row->diffCoastRamp = params->diffCoastRamp;
+    row->frontBias = params->frontBias;
+    for (int i = 0; i < 4; ++i) row->pressureStatic[i] = params->tyre[i].pressureStatic;
+    row->scoring = params->scoring;
+    row->valid = 1;
+    return PDB_OK;
+}
 float pdb_get_scoring_var(const pdb_car_params* params, const char* name) {
     float w = 0;
     if (params && name) pdb::getScoringVar(*params, name, w);

@@ -128,6 +128,10 @@ class EnvConfig(C.Structure):   # pdb_env_config
     _fields_ = [('enabled', C.c_int32), ('terminate_on_hit', C.c_int32), ('terminate_off_track', C.c_int32), ('terminate_when_stuck', C.c_int32),
                 ('hit_penalty', C.c_double), ('off_track_penalty', C.c_double), ('stuck_penalty', C.c_double), ('low_reward', C.c_double),
                 ('teleport_on_reset', C.c_int32), ('teleport_mode', C.c_int32)]
+class LaneTune(C.Structure):   # pdb_lane_tune
+    _fields_ = [('finalRatio', C.c_double), ('diffPowerRamp', C.c_double), ('diffCoastRamp', C.c_double), ('frontBias', C.c_float), ('pressureStatic', C.c_float * 4),
+                ('scoring', Scoring), ('valid', C.c_int32), ('_pad', C.c_int32 * 3)]
+assert C.sizeof(LaneTune) == 144
 class Surface(C.Structure):   # pdb_surface
     _fields_ = [(n, C.c_float) for n in ('gripMod', 'damping', 'sinHeight', 'sinLength', 'granularity', 'dirtAdditiveK')] + \
                [(n, C.c_int32) for n in ('collisionCategory', 'isValidTrack', 'triStart', 'triCount', 'sectorID', '_pad')]
@@ -161,6 +165,7 @@ def load_product(host_only=False):
     lib.pdb_teleport_to_spline.argtypes = [C.c_void_p, C.c_void_p, C.c_float, C.c_void_p]
     lib.pdb_teleport_by_mode.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
     lib.pdb_set_auto_teleport.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int]
+    lib.pdb_lane_tune_from_params.argtypes = [C.c_void_p, C.c_void_p]
     if not host_only:
         lib.pdb_create.restype = C.c_void_p
         lib.pdb_create.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_uint64, C.c_int]
@@ -179,6 +184,8 @@ def load_product(host_only=False):
         lib.pdb_set_seed.argtypes = [C.c_void_p, C.c_void_p]
         lib.pdb_set_env.argtypes = [C.c_void_p, C.c_void_p]
         lib.pdb_set_partition_params.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+        if hasattr(lib, 'pdb_set_lane_tunes'):
+            lib.pdb_set_lane_tunes.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]
         lib.pdb_actions_device.restype = C.c_void_p; lib.pdb_actions_device.argtypes = [C.c_void_p]
         lib.pdb_out_device.restype = C.c_void_p; lib.pdb_out_device.argtypes = [C.c_void_p]
         lib.pdb_set_out_device.argtypes = [C.c_void_p, C.c_void_p]

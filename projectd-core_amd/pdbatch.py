@@ -199,6 +199,16 @@ class Batch:
         """device array of n bytes: a car whose byte is 1 + mode is teleported at the top of its next tick, which clears the byte"""
         return self.lib.pdb_reset_mask_device(self.h)
 
+    def set_lane_tunes(self, blocks, first=0):
+        """per-lane setup and reward weights (PyProjectD.cpp:328-365 is per simulator = per env): lane first + i takes the eight env tunes
+        (FRONT_BIAS, DIFF_POWER, DIFF_COAST, FINAL_RATIO, PRESSURE_*) and the scoring variables of blocks[i], a pdb_car_params that went
+        through pdb_set_car_tune / pdb_set_scoring_var (None: that lane back to the batch's own block)"""
+        rows = (pc.LaneTune * len(blocks))()
+        for i, P in enumerate(blocks):
+            if P is not None:
+                self._chk(self.lib.pdb_lane_tune_from_params(C.byref(P), C.byref(rows[i])))
+        self._chk(self.lib.pdb_set_lane_tunes(self.h, first, len(blocks), rows))
+
     def set_env(self, cfg=None, **kw):
         """env mode (pdb_set_env): the reward / termination / reset rules of projectd_env.py:173-227 inside the tick.  cfg: an object with
         the reference env's attribute names (projectd_env.EnvConfig), or keyword overrides; set_env(enabled=False) switches it off."""

@@ -104,11 +104,13 @@ def make_actions(n, seed, lo=-0.3, hi=0.3):
 
 
 def run_parity(n_cars=8, ticks=200, seed=1234, resync=False, verbose=False, check_every=1, actions_fn=None, model='ks_toyota_ae86_drift', track='flat',
-               on_tick=None, params_fn=None, spread=None, threads=None):
+               on_tick=None, params_fn=None, spread=None, threads=None, lane_params_fn=None):
     """Step `n_cars` cars for `ticks` ticks on the GPU (through the C ABI) and in the CPU oracle, from the same
     initial state.  resync=True re-injects the oracle state into the GPU before every tick (single-tick parity).
     spread=(lo, hi): car i starts from teleportCarToSpline(lo + (hi - lo) * i / n_cars) (the product's host function, for both
     sides) instead of the start pose.  threads: step the oracle's cars on that many host threads (the calls release the GIL).
+    lane_params_fn(i, Pi): edit car i's own copy of the block (the eight env tunes, the scoring variables); the oracle steps car i with it, the
+    GPU batch is created with the common block and gets the copies through set_lane_tunes (pdb_set_lane_tunes).
     Returns the worst relative deviation over all cars, ticks and float fields; raises on integer mismatches."""
     import pdbatch
     P = pdbatch.packed_params(model + '.env')
@@ -119,15 +121,21 @@ def run_parity(n_cars=8, ticks=200, seed=1234, resync=False, verbose=False, chec
     S0 = pc.DynState()
     assert lib.pdb_initial_state(C.byref(P), trk, C.byref(S0)) == 0
     b = pdbatch.Batch(n_cars, P, trk, device=0, action_mode=1)
+    Pl = [P] * n_cars
+    if lane_params_fn is not None:
+        Pl = []
+        for i in range(n_cars):
+            Pi = pc.CarParams.from_buffer_copy(bytes(P)); lane_params_fn(i, Pi); Pl.append(Pi)
+        b.set_lane_tunes(Pl)
     if spread is None:
-        hs = [orc.cpuref_create(C.byref(P), trk, len(trk), C.byref(S0)) for _ in range(n_cars)]
+        hs = [orc.cpuref_create(C.byref(Pl[i]), trk, len(trk), C.byref(S0)) for i in range(n_cars)]
     else:
         init = (pc.DynState * n_cars)()
         for i in range(n_cars):
             C.memmove(C.byref(init[i]), C.byref(S0), C.sizeof(S0))
             assert lib.pdb_teleport_to_spline(C.byref(P), trk, C.c_float(spread[0] + (spread[1] - spread[0]) * i / n_cars), C.byref(init[i])) == 0
         b.set_state(init)
-        hs = [orc.cpuref_create(C.byref(P), trk, len(trk), C.byref(init[i])) for i in range(n_cars)]
+        hs = [orc.cpuref_create(C.byref(Pl[i]), trk, len(trk), C.byref(init[i])) for i in range(n_cars)]
     pool = None
     if threads and threads > 1 and not P.autoTeleport:
         from concurrent.futures import ThreadPoolExecutor

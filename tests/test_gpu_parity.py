@@ -619,3 +619,72 @@ def test_rings_partitions_and_graph_replay_with_contacts(built, track, model, ti
         assert r[0] == res[0][0] and r[1] == res[0][1]
         for a, c in zip(r[2], res[0][2]):
             assert np.array_equal(a.view(np.int32), c.view(np.int32))
+
+
+def _randomised_lane(i, P):
+    """a different setup and different reward weights for every lane: the fields the env's eight tunes write (projectd_env.py:127-130,
+    Car/SetupManager.cpp) and every scoring variable (projectd_env.py:54-94, Car/ScoringSystem.cpp:37-101)"""
+    r = np.random.RandomState(1000 + i)
+    P.frontBias = float(np.float32(r.uniform(0.45, 0.75)))
+    P.diffPowerRamp = float(r.uniform(0.05, 0.9)); P.diffCoastRamp = float(r.uniform(0.05, 0.9))
+    P.finalRatio = float(r.uniform(3.6, 5.4))
+    for w in range(4):
+        P.tyre[w].pressureStatic = float(np.float32(r.uniform(22.0, 34.0)))
+    for k in pc.SCORING_VARS:
+        setattr(P.scoring, k, float(np.float32(getattr(P.scoring, k) * r.uniform(0.5, 1.5) + r.uniform(0.0, 0.3))))
+    P.scoring.OutOfTrackThreshold = float(np.float32(r.uniform(0.4, 0.6)))
+    P.scoring.SmoothSteerSpeed = float(np.float32(r.uniform(4.0, 14.0)))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('track,model', [('touge', 'ks_toyota_ae86_drift'), ('walled', 'ks_toyota_supra_mkiv_drift')])
+def test_every_lane_with_its_own_tunes_and_reward_weights(built, track, model):
+    """pdb_set_lane_tunes: 24 lanes, each with its own FRONT_BIAS / DIFF_POWER / DIFF_COAST / FINAL_RATIO / tyre pressures and its own 21 scoring
+    variables (the reference gives every env's simulator its own, PyProjectD.cpp:328-365); the oracle steps every car with its own block -- every
+    state scalar, reward sums included, bit for bit; and the lanes do differ"""
+    import parity_util
+    seen = {}
+
+    def on_tick(t, i, sg, sc):
+        if t >= 1500:
+            seen[i] = (sg.totalReward, sg.tyre[0].pressureDynamic, sg.driveVel)
+    worst = parity_util.run_parity(n_cars=24, ticks=1600, seed=17, track=track, model=model, check_every=10, lane_params_fn=_randomised_lane,
+                                   spread=(0.0, 0.9) if track == 'touge' else None, threads=8)
+    assert worst == 0.0, worst
+    assert len({v[1] for v in seen.values()}) >= 20 and len({v[0] for v in seen.values()}) >= 20, seen
+
+
+@pytest.mark.gpu
+def test_lane_tunes_can_be_taken_back_and_follow_the_partitions(built):
+    """rows with valid = 0 (never set, or set back with None) read the lane's own block -- the partition's, where it has one; free-running
+    partitions and the whole-batch launch agree"""
+    import pdbatch, parity_util
+    P = pdbatch.packed_params(); trk = pdbatch.synthetic_track('flat')
+    n = 12
+    acts = parity_util.make_actions(n, 5)
+
+    def run(setup):
+        b = pdbatch.Batch(n, P, trk, device=0, action_mode=1)
+        setup(b)
+        for _ in range(300):
+            b.step_host(acts)
+        st = bytes(b.get_state()); b.close()
+        return st
+    plain = run(lambda b: None)
+    Q = pc.CarParams.from_buffer_copy(bytes(P)); _randomised_lane(3, Q)
+
+    def set_then_back(b):
+        b.set_lane_tunes([Q] * n)
+        b.set_lane_tunes([None] * n)
+    assert run(set_then_back) == plain
+    tuned = run(lambda b: b.set_lane_tunes([Q] * 6, first=3))
+    assert tuned != plain
+    sz = C.sizeof(pc.DynState)
+    assert tuned[:3 * sz] == plain[:3 * sz] and tuned[9 * sz:] == plain[9 * sz:]      # the other lanes are untouched
+    whole = run(lambda b: (b.set_lane_tunes([Q] * n),))
+    own = pdbatch.Batch(n, Q, trk, device=0, action_mode=1)
+    for _ in range(300):
+        own.step_host(acts)
+    st_own = bytes(own.get_state()); own.close()
+    strip = lambda raw: b''.join(raw[i * sz:(i + 1) * sz] for i in range(n))
+    assert strip(whole) == strip(st_own)                                              # a row = that lane stepped with the tuned block

@@ -71,6 +71,36 @@ def test_scenarios_set_up_identically_without_the_reference_content(hostlib, ora
 
 
 @needs_ref
+def test_lane_tune_rows_cover_what_the_env_tunes_and_scoring_vars_write(hostlib):
+    """pdb_lane_tune (the per-lane override row) holds exactly the fields of the car block that projectd_env.py's eight setCarTune calls and its
+    setScoringVar calls change: a block tuned through pdb_set_car_tune / pdb_set_scoring_var differs from the untuned one ONLY inside those fields,
+    and the row read out of it carries the new values"""
+    base = pc.env_params(hostlib, REF)
+    tuned = pc.CarParams.from_buffer_copy(bytes(base))
+    vals = {'FRONT_BIAS': 62.0, 'DIFF_POWER': 45.0, 'DIFF_COAST': 20.0, 'FINAL_RATIO': 4.3, 'PRESSURE_LF': 31.0, 'PRESSURE_RF': 30.0, 'PRESSURE_LR': 26.0, 'PRESSURE_RR': 25.0}
+    assert set(vals) == set(pc.ENV_TUNES)
+    for k, v in vals.items():
+        assert hostlib.pdb_set_car_tune(C.byref(tuned), REF.encode(), AE86.encode(), k.encode(), v, 0) == 0
+    for j, k in enumerate(pc.ENV_SCORING):
+        assert hostlib.pdb_set_scoring_var(C.byref(tuned), k.encode(), 0.25 + j) == 0
+    covered = set()
+    for name, size in (('finalRatio', 8), ('diffPowerRamp', 8), ('diffCoastRamp', 8), ('frontBias', 4), ('scoring', C.sizeof(pc.Scoring))):
+        off = getattr(pc.CarParams, name).offset
+        covered.update(range(off, off + size))
+    for w in range(4):
+        off = pc.CarParams.tyre.offset + w * C.sizeof(pc.Tyre) + pc.Tyre.pressureStatic.offset
+        covered.update(range(off, off + 4))
+    a, b = bytes(base), bytes(tuned)
+    diff = {i for i in range(len(a)) if a[i] != b[i]}
+    assert diff and diff <= covered, sorted(diff - covered)[:8]
+    row = pc.LaneTune()
+    assert hostlib.pdb_lane_tune_from_params(C.byref(tuned), C.byref(row)) == 0
+    assert row.valid == 1 and row.finalRatio == tuned.finalRatio == 4.3 and abs(row.frontBias - 0.62) < 1e-6
+    assert [row.pressureStatic[w] for w in range(4)] == [31.0, 30.0, 26.0, 25.0]
+    assert bytes(row.scoring) == bytes(tuned.scoring) and row.scoring.StallPenalty == 0.25 + len(pc.ENV_SCORING) - 1
+
+
+@needs_ref
 def test_ae86_topology(hostlib):
     """7 bodies, 16 joints, 33 constraint rows; RWD, 5 forward gears + R + N"""
     P = pc.CarParams()
