@@ -95,7 +95,7 @@ def test_lane_tune_rows_cover_what_the_env_tunes_and_scoring_vars_write(hostlib)
     assert diff and diff <= covered, sorted(diff - covered)[:8]
     row = pc.LaneTune()
     assert hostlib.pdb_lane_tune_from_params(C.byref(tuned), C.byref(row)) == 0
-    assert row.valid == 1 and row.finalRatio == tuned.finalRatio == 4.3 and abs(row.frontBias - 0.62) < 1e-6
+    assert row.valid == 1 and row.finalRatio == tuned.finalRatio == float(np.float32(4.3)) and abs(row.frontBias - 0.62) < 1e-6
     assert [row.pressureStatic[w] for w in range(4)] == [31.0, 30.0, 26.0, 25.0]
     assert bytes(row.scoring) == bytes(tuned.scoring) and row.scoring.StallPenalty == 0.25 + len(pc.ENV_SCORING) - 1
 
