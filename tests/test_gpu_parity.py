@@ -648,7 +648,7 @@ def test_every_lane_with_its_own_tunes_and_reward_weights(built, track, model):
     def on_tick(t, i, sg, sc):
         if t >= 1500:
             seen[i] = (sg.totalReward, sg.tyre[0].pressureDynamic, sg.driveVel)
-    worst = parity_util.run_parity(n_cars=24, ticks=1600, seed=17, track=track, model=model, check_every=10, lane_params_fn=_randomised_lane,
+    worst = parity_util.run_parity(n_cars=24, ticks=1600, seed=17, track=track, model=model, check_every=10, lane_params_fn=_randomised_lane, on_tick=on_tick,
                                    spread=(0.0, 0.9) if track == 'touge' else None, threads=8)
     assert worst == 0.0, worst
     assert len({v[1] for v in seen.values()}) >= 20 and len({v[0] for v in seen.values()}) >= 20, seen
