@@ -2,7 +2,7 @@
 # Run on the GPU box (through gpurun; every command under its own timeout): bench line, rocprofv3 kernel stats, and the PMC passes that DESIGN.md /
 # bench.py's roofline block cite.  Usage: bash tools/profile_round.sh r01   (outputs under gpurun_out/<tag>/)
 set -u
-TAG=${1:-r03}
+TAG=${1:-r04}
 OUT=gpurun_out/$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
