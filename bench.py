@@ -516,7 +516,8 @@ def main():
     is_headline = world == 1 and not args.no_extra and args.workload == 'flat' and args.cars == CARS_PER_GPU and not args.episodes and not args.force_gather
     if is_headline:
         extra = {}
-        for key, argv in EXTRA:
+        only = [k for k in os.environ.get('PDB_BENCH_EXTRA', '').split(',') if k]   # diagnostic: a subset of the legs, in the order given
+        for key, argv in ([(k, dict(EXTRA)[k]) for k in only] if only else EXTRA):
             a = parser().parse_args(argv + ['--no-cpu-baseline', '--no-extra'])
             d2 = None
             try:

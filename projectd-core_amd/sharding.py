@@ -4,6 +4,7 @@ reference's RL loop implies: gather of the [N/P, 26] observation/reward/flag blo
 actions (RCCL over xGMI on the GPU box; the same code runs on gloo/CPU tensors in tests/test_sharding.py).
 The output blocks are gathered as k-tick trajectory rings (TrajectoryGather) so that the collective overlaps compute.
 Per-car inputs are keyed by the GLOBAL car index so results do not depend on the number of ranks."""
+import os
 import numpy as np
 
 OUT_COLS = 26   # pdb_step_out: obs[24], reward, flags (include/pdb_types.h)
@@ -195,6 +196,11 @@ class LibraryExchange:
     def __init__(self, batch, part_ranges, world, rank, device, dist, action_stride=2):
         import torch
         self.batch, self.world, self.rank, self.ranges = batch, world, rank, list(part_ranges)
+        if dist is not None and dist.is_initialized() and dist.get_backend() == 'nccl' and os.environ.get('PDB_EXCHANGE_NO_PREWARM') is None:
+            # torch's own RCCL communicator first: created AFTER the library's (at the first torch collective) it left every later kernel of the process
+            # 25 % slower, for good (measured: tools/exchange_residue2.py)
+            dist.all_reduce(torch.zeros(1, device=device))
+            torch.cuda.synchronize()
         ok, err, ids = 1, None, None
         try:
             if rank == 0:
