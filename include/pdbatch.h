@@ -206,6 +206,11 @@ int pdb_event_record(pdb_batch* b, int which);
 /* waits for the end event and returns the elapsed milliseconds between the two events */
 int pdb_event_elapsed_ms(pdb_batch* b, float* ms);
 int pdb_sync(pdb_batch* b);
+/* pdb_step_host for a SUBSET of the cars: those whose hold byte (hold[n], host memory) is non-zero sit the tick out -- record, contact joints and
+ * output row untouched; `out` receives every row (the held cars' rows as they were).  No counterpart in the reference, where every env is its own
+ * simulator and resets on its own (projectd_env.py:216-227); a vector env uses it to run the reset tick of the lanes whose episode has just ended
+ * before its step returns (stable-baselines3's convention), while every other lane waits. */
+int pdb_step_host_held(pdb_batch* b, const float* actions, float dt, const uint8_t* hold, pdb_step_out* out);
 /* convenience: upload actions, one tick, download outputs */
 int pdb_step_host(pdb_batch* b, const float* actions, float dt, pdb_step_out* out);
 int pdb_get_car_state(pdb_batch* b, int first, int count, pdb_car_state* out);

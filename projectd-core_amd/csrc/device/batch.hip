@@ -153,6 +153,7 @@ struct pdb_batch {
     uint8_t* dResetScratch = nullptr;   // device copy of a host mask (pdb_reset)
     uint8_t* dResetMask = nullptr;   // [n]: 1 + teleport mode for cars to be reset at the top of their next tick (consumed and cleared by that tick)
     bool resetMaskArmed = false;     // pdb_reset_mask_device was asked for: the step kernels look at the mask
+    unsigned char* dHold = nullptr;   // [n] hold mask of pdb_step_host_held, allocated on first use
     pdb_lane_tune* dLaneTunes = nullptr;   // [n] per-lane tunes and reward weights (pdb_set_lane_tunes), allocated on first use; rows with valid == 0 fall back to the block
     pdb_contact* dContacts = nullptr;   // [n][PDB_MAX_CONTACTS]: each car's live contact joints (the first pdb_dyn_state.numContacts of its row)
     hipEvent_t ev0 = nullptr, ev1 = nullptr, tev0 = nullptr, tev1 = nullptr;
@@ -326,6 +327,7 @@ static int pushK(pdb_batch* b, hipStream_t st, bool async) {
         DevConst& K = b->partK[p];
         fillConst(b->partParams[p], K, b->K.actionMode);
         K.laneTunes = b->K.laneTunes;
+        K.holdMask = b->K.holdMask;
         K.dt = b->K.dt; K.fps = b->K.fps; K.dtD = b->K.dtD; K.stuckTimeout = b->K.stuckTimeout; K.wantCarState = b->K.wantCarState; K.stamps = b->K.stamps; K.stampCars = b->K.stampCars;
         K.envHitPenalty = b->K.envHitPenalty; K.envOffPenalty = b->K.envOffPenalty; K.envStuckPenalty = b->K.envStuckPenalty; K.envLowReward = b->K.envLowReward;
         K.envMode = b->K.envMode; K.envTermHit = b->K.envTermHit; K.envTermOff = b->K.envTermOff; K.envTermStuck = b->K.envTermStuck;
@@ -440,6 +442,7 @@ void pdb_destroy(pdb_batch* b) {
     for (int q = 0; q <= PDB_MAX_PARTS; ++q) (void)hipFree(b->dQueue[q]);
     (void)hipFree(b->dSnap);
     (void)hipFree(b->dLaneTunes);
+    (void)hipFree(b->dHold);
     for (int q = 0; q < PDB_MAX_PARTS; ++q) { (void)hipFree(b->dPartParams[q]); (void)hipFree(b->dPartK[q]); }
     if (b->ev0) (void)hipEventDestroy(b->ev0);
     if (b->ev1) (void)hipEventDestroy(b->ev1);
@@ -988,6 +991,27 @@ int pdb_step_host(pdb_batch* b, const float* actions, float dt, pdb_step_out* ou
     if (out) HIPCHK(hipMemcpyAsync(out, b->dOutActive, sizeof(pdb_step_out) * (size_t)b->n, hipMemcpyDeviceToHost, b->stream));
     HIPCHK(hipStreamSynchronize(b->stream));
     return PDB_OK;
+}
+
+// One tick of the cars whose hold byte is zero; the others sit the launch out (record, contact joints, output row untouched).  The vector env's
+// same-step reset (projectd_sb3.py): the lanes whose episode ended in the step just taken run their reset tick -- teleport + step([0, 0]),
+// projectd_env.py:216-227 -- before the step returns, while every other lane is held.  Workgroups whose cars are all held leave at once, so the
+// launch costs what the few cars that move cost.
+int pdb_step_host_held(pdb_batch* b, const float* actions, float dt, const uint8_t* hold, pdb_step_out* out) {
+    if (!b || !actions || !hold) { pdb::setError("null argument"); return PDB_ERR_ARG; }
+    if (int rcj = joinParts(b)) return rcj;
+    if (!b->dHold) HIPCHK(hipMalloc(&b->dHold, (size_t)b->n));
+    HIPCHK(hipMemcpyAsync(b->dHold, hold, (size_t)b->n, hipMemcpyHostToDevice, b->stream));
+    HIPCHK(hipMemcpyAsync(b->dActions, actions, sizeof(float) * b->actionStride * (size_t)b->n, hipMemcpyHostToDevice, b->stream));
+    HIPCHK(hipStreamSynchronize(b->stream));   // nothing in flight reads the constants block while the mask is switched on ...
+    b->K.holdMask = b->dHold;
+    if (int rck = pushK(b, b->stream, false)) return rck;
+    int rc = launch(b, dt, true);
+    if (rc == PDB_OK && out) HIPCHK(hipMemcpyAsync(out, b->dOutActive, sizeof(pdb_step_out) * (size_t)b->n, hipMemcpyDeviceToHost, b->stream));
+    HIPCHK(hipStreamSynchronize(b->stream));   // ... and off again
+    b->K.holdMask = nullptr;
+    if (int rck = pushK(b, b->stream, false)) return rck;
+    return rc;
 }
 
 int pdb_get_car_state(pdb_batch* b, int first, int count, pdb_car_state* out) {

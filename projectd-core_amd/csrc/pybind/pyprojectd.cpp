@@ -265,6 +265,15 @@ py::array_t<float> stepBatch(int id, py::array_t<float, py::array::c_style | py:
     memcpy(r.mutable_data(), B->out.data(), sizeof(pdb_step_out) * (size_t)B->n);
     return r;
 }
+// one tick of the lanes whose hold byte is zero; the others sit it out (pdb_step_host_held).  Returns every lane's row: the held lanes' as they were
+py::array_t<float> stepBatchHeld(int id, py::array_t<float, py::array::c_style | py::array::forcecast> actions, py::array_t<uint8_t, py::array::c_style | py::array::forcecast> hold, double dt) {
+    Batch* B = getBatch(id);
+    if (!B || actions.size() != (py::ssize_t)B->n * 2 || hold.size() != (py::ssize_t)B->n) return py::array_t<float>();
+    if (pdb_step_host_held(B->b, actions.data(), (float)dt, hold.data(), B->out.data()) != PDB_OK) { logf("EXCEPTION: %s", pdb_last_error()); return py::array_t<float>(); }
+    py::array_t<float> r({(py::ssize_t)B->n, (py::ssize_t)26});
+    memcpy(r.mutable_data(), B->out.data(), sizeof(pdb_step_out) * (size_t)B->n);
+    return r;
+}
 void resetBatch(int id, py::object mask, int mode) {   // teleportCarByMode(mode) for the masked lanes
     Batch* B = getBatch(id);
     if (!B) return;
@@ -404,6 +413,7 @@ PYBIND11_MODULE(PyProjectD, m) {
     m.def("destroyBatch", &destroyBatch, "");
     m.def("setBatchLaneTune", &setBatchLaneTune, "", py::arg("batchId"), py::arg("lane"), py::arg("simId"));
     m.def("stepBatch", &stepBatch, "", py::arg("batchId"), py::arg("actions"), py::arg("dt") = 1.0 / 333.0);
+    m.def("stepBatchHeld", &stepBatchHeld, "", py::arg("batchId"), py::arg("actions"), py::arg("hold"), py::arg("dt") = 1.0 / 333.0);
     m.def("resetBatch", &resetBatch, "", py::arg("batchId"), py::arg("mask") = py::none(), py::arg("mode") = 0);
     m.def("setBatchStuckTimeout", &setBatchStuckTimeout, "");
     m.def("setBatchEnv", &setBatchEnv, "");

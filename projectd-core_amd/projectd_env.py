@@ -102,11 +102,16 @@ def _configure_simulator(cfg, base_dir):
 
 
 class ProjectDVecEnv:
-    def __init__(self, num_envs, base_dir=None, device=0, auto_reset=True, **settings):
+    def __init__(self, num_envs, base_dir=None, device=0, auto_reset=True, same_step_reset=False, **settings):
+        """same_step_reset (with auto_reset): a lane whose episode ends in a step() takes its reset tick -- teleport + step([0, 0]),
+        projectd_env.py:216-227 -- before that step() returns, every other lane held (pdb_step_host_held): the step returns done = True, the terminal
+        reward, and the NEW episode's first observation; the terminal observation is in info['terminal_observation'] (a dict lane -> obs).  This is
+        stable-baselines3's VecEnv convention.  Default False: the reset tick is the lane's next step (gymnasium's AutoresetMode.NEXT_STEP), at no cost."""
         base_dir = base_dir or default_base_dir()
         self.cfg = EnvConfig(**settings)
         self.num_envs = int(num_envs)
         self.auto_reset = auto_reset
+        self.same_step_reset = bool(same_step_reset and auto_reset)
         self.sim, self.car = _configure_simulator(self.cfg, base_dir)
         self.batch = pd.createBatch(self.sim, self.num_envs, device)
         if self.batch < 0:
@@ -156,6 +161,8 @@ class ProjectDVecEnv:
             self.total_reward += reward; self.total_reward[fresh] = 0.0
             self.step_id += 1; self.step_id[fresh] = 0
             info = {'episode_reward': self.total_reward.copy()} if terminated.any() else {}
+            if self.same_step_reset and terminated.any():
+                obs = self._reset_tick_now(terminated, obs, info)
             return obs, reward.astype(np.float32), terminated, np.zeros(self.num_envs, dtype=bool), info
         fresh = self.pending_reset.copy()
         a[fresh] = 0.0
@@ -185,6 +192,21 @@ class ProjectDVecEnv:
                 pd.resetBatch(self.batch, terminated.astype(np.uint8), int(cfg.teleport_mode))
             self.pending_reset |= terminated
         return obs, reward.astype(np.float32), terminated, truncated, info
+
+    def _reset_tick_now(self, done, obs, info):
+        """same-step reset (kernel env mode): the done lanes' reset tick right away, everybody else held; their rows of `obs` become the new episodes'
+        first observations, the terminal ones go to info['terminal_observation']"""
+        info['terminal_observation'] = {int(i): obs[i].copy() for i in np.nonzero(done)[0]}
+        out = pd.stepBatchHeld(self.batch, np.zeros((self.num_envs, 2), np.float32), (~done).astype(np.uint8), SIM_DT)
+        if out.shape != (self.num_envs, 26):
+            raise RuntimeError('stepBatchHeld failed')
+        fresh = (out[:, 25].view(np.int32) & 16) != 0
+        if not np.array_equal(fresh & done, done):
+            raise RuntimeError('a lane that ended its episode did not take its reset tick')
+        obs = obs.copy(); obs[done] = out[done, :OBS_DIM]
+        self.total_reward[done] = 0.0; self.step_id[done] = 0
+        self.last_reset_tick = np.zeros(self.num_envs, dtype=bool)   # nobody's NEXT step is a reset tick
+        return obs
 
     def reset(self, mask=None):
         """Reset every lane (mask None) -- teleport + one zero-action tick, returns the first observations -- or schedule

@@ -8,12 +8,15 @@ pyprojectd/hyperparams/sac.yml: `normalize: {norm_obs: True, norm_reward: False}
   RunningObsNorm      SB3 VecNormalize's observation normalisation (RunningMeanStd update, clip 10, epsilon 1e-8) for use without
                       SB3; `wrap_normalize(env)` returns SB3's VecNormalize when available, else this.
 
-Episode ends: the kernel's env mode resets a terminated lane on its NEXT step (gymnasium's AutoresetMode.NEXT_STEP: that step
-returns the new episode's first observation with reward 0 and done False).  SB3 expects the reset observation in the same step
-as done=True; so on a step where lanes finish, step_wait() returns, for those lanes, done=True, the terminal observation in
-infos[i]["terminal_observation"], and as observation the terminal one again -- and marks the lane: its next transition is the
-reset tick, flagged infos[i]["reset_tick"] = True (reward 0, done False) for a buffer that wants to drop it.  Time limits
-(max_episode_steps 80000) end an episode with infos[i]["TimeLimit.truncated"] = True."""
+Episode ends follow SB3's convention (same-step reset, the default here): on the step where a lane's episode ends, step_wait() returns for it
+done = True, the terminal reward, the terminal observation in infos[i]["terminal_observation"] and, as observation, the NEW episode's first one --
+the lane's reset tick (teleport + step([0, 0]), reference projectd_env.py:216-227) is run before the step returns, with every other lane held
+(pdb_step_host_held: one more launch in which only the workgroups of the lanes that reset do anything).  Time limits (max_episode_steps 80000)
+end an episode the same way, with infos[i]["TimeLimit.truncated"] = True.  Every stored transition is a real one; VecNormalize sees each
+observation once.
+same_step_reset=False keeps the kernel's free next-step form (gymnasium's AutoresetMode.NEXT_STEP): the step after an episode end is the lane's
+reset tick -- it returns the new episode's first observation with reward 0 and done False and is flagged infos[i]["reset_tick"] = True for a
+buffer that wants to drop it; on the step that ends the episode the observation returned is the terminal one."""
 import numpy as np
 import projectd_env as E
 
@@ -37,8 +40,9 @@ def _box(low, high):
 
 
 class ProjectDSB3VecEnv(_Base):
-    def __init__(self, num_envs, base_dir=None, device=0, max_episode_steps=MAX_EPISODE_STEPS, **settings):
-        self.impl = E.ProjectDVecEnv(num_envs, base_dir, device=device, auto_reset=True, **settings)
+    def __init__(self, num_envs, base_dir=None, device=0, max_episode_steps=MAX_EPISODE_STEPS, same_step_reset=True, **settings):
+        self.impl = E.ProjectDVecEnv(num_envs, base_dir, device=device, auto_reset=True, same_step_reset=same_step_reset, **settings)
+        self.same_step_reset = bool(same_step_reset)
         lo, hi = E.obs_bounds(self.impl.cfg)
         obs_space, act_space = _box(lo, hi), _box(np.array([-1, -1], np.float32), np.array([1, 1], np.float32))
         if _Base is not object:
@@ -59,13 +63,18 @@ class ProjectDSB3VecEnv(_Base):
     def step_wait(self):
         obs, reward, terminated, truncated, info = self.impl.step(self._actions)
         too_long = (self.impl.step_id >= self.max_episode_steps) & ~terminated
+        terminal = dict(info.get('terminal_observation', {}))   # same-step mode: the lanes that terminated have taken their reset tick already
         if too_long.any():
-            self.impl.reset(too_long)   # teleport now, reset tick on the lanes' next step
+            self.impl.reset(too_long)   # teleport now; the reset tick on the lanes' next step -- or, same-step, right away
+            if self.same_step_reset:
+                extra = {}
+                obs = self.impl._reset_tick_now(too_long, obs, extra)
+                terminal.update(extra['terminal_observation'])
         done = terminated | too_long
         reset_tick = self.impl.last_reset_tick if hasattr(self.impl, 'last_reset_tick') else np.zeros(self.num_envs, bool)
         infos = [{} for _ in range(self.num_envs)]
         for i in np.nonzero(done)[0]:
-            infos[i]['terminal_observation'] = obs[i].copy()
+            infos[i]['terminal_observation'] = terminal[int(i)] if int(i) in terminal else obs[i].copy()
             infos[i]['TimeLimit.truncated'] = bool(too_long[i])
         for i in np.nonzero(reset_tick)[0]:
             infos[i]['reset_tick'] = True

@@ -114,10 +114,10 @@ def test_gym_and_gymnasium_envs_step_like_the_plain_env(stubs, base):
 
 @pytest.mark.gpu
 def test_sb3_vec_env_episode_protocol(stubs, base):
-    """done / terminal_observation / reset_tick / TimeLimit.truncated on the batch, with the observation normaliser on top"""
+    """next-step form (same_step_reset=False): done / terminal_observation / reset_tick / TimeLimit.truncated on the batch, with the observation normaliser on top"""
     import projectd_sb3
     n = 16
-    env = projectd_sb3.ProjectDSB3VecEnv(n, track_name='flat', stuck_timeout=0.3, max_episode_steps=100000, terminate_low_reward=-1e9)
+    env = projectd_sb3.ProjectDSB3VecEnv(n, track_name='flat', stuck_timeout=0.3, max_episode_steps=100000, terminate_low_reward=-1e9, same_step_reset=False)
     venv = projectd_sb3.wrap_normalize(env)
     obs = venv.reset()
     assert obs.shape == (n, 24) and obs.dtype == np.float32
@@ -144,3 +144,58 @@ def test_sb3_vec_env_episode_protocol(stubs, base):
     assert env.env_is_wrapped(object) == [False] * n and env.get_attr('track_name') == ['flat'] * n
     env.seed(11)
     venv.close()
+
+
+def _lane_actions(lane, k):
+    """the action lane `lane` gives on its k-th real (non-reset) step"""
+    return np.array([0.35 * np.sin(0.7 * lane + 0.013 * k), 0.2 + 0.7 * np.cos(0.31 * lane + 0.004 * k)], np.float32)
+
+
+@pytest.mark.gpu
+def test_same_step_reset_is_the_next_step_stream_with_the_reset_ticks_folded_in(stubs, base):
+    """stable-baselines3's convention (the SB3 adapter's default, pdb_step_host_held): on the step where a lane's episode ends the observation returned
+    is the NEW episode's first one, the terminal one goes to infos[i]['terminal_observation'], and no lane ever spends a step on a reset tick.  Lane by
+    lane the stream equals the next-step env's (itself held against the oracle, tests/test_pyprojectd_api.py) with every reset-tick transition folded
+    into the step before it -- observations, rewards, dones, bit for bit -- while the lanes that did not end an episode are untouched by the extra launch.
+    Episodes end by the stuck rule, by leaving the road and by the time limit."""
+    import projectd_sb3
+    n = 12
+    kw = dict(track_name='flat', stuck_timeout=0.4, terminate_low_reward=-1e9, max_episode_steps=140)
+    A = projectd_sb3.ProjectDSB3VecEnv(n, same_step_reset=False, **kw)     # next-step: the reference stream
+    B = projectd_sb3.ProjectDSB3VecEnv(n, same_step_reset=True, **kw)
+    oa = A.reset(); ob = B.reset()
+    assert np.array_equal(oa, ob)
+    ka = np.zeros(n, int); kb = np.zeros(n, int)                 # real steps taken per lane
+    # per lane: A's transitions with the reset ticks folded in, as a queue B's are checked against
+    want = [[] for _ in range(n)]
+    open_done = [None] * n                                        # A: a done transition waiting for its reset tick's observation
+    got_done = np.zeros(n, int); got_trunc = np.zeros(n, int)
+    slow = np.arange(n) % 3 == 0                                  # these lanes creep (stuck rule); the others drive, some off the road
+    for t in range(700):
+        acts = np.stack([_lane_actions(i, ka[i]) for i in range(n)]); acts[slow, 1] = -1.0
+        o, r, d, infos = A.step(acts)
+        for i in range(n):
+            if infos[i].get('reset_tick'):                        # the reset tick: its observation completes the transition before it
+                assert open_done[i] is not None and r[i] == 0.0 and not d[i]
+                tr = open_done[i]; open_done[i] = None
+                want[i].append((o[i].copy(), tr[1], True, tr[0], tr[2]))
+                continue
+            ka[i] += 1
+            if d[i]:
+                assert np.array_equal(infos[i]['terminal_observation'], o[i])
+                open_done[i] = (o[i].copy(), r[i], bool(infos[i]['TimeLimit.truncated']))
+            else:
+                want[i].append((o[i].copy(), r[i], False, None, False))
+    for t in range(560):
+        acts = np.stack([_lane_actions(i, kb[i]) for i in range(n)]); acts[slow, 1] = -1.0
+        o, r, d, infos = B.step(acts)
+        kb += 1
+        for i in range(n):
+            assert 'reset_tick' not in infos[i]
+            wo, wr, wd, wterm, wtrunc = want[i].pop(0)
+            assert d[i] == wd and r[i] == wr and np.array_equal(o[i], wo), (t, i)
+            if d[i]:
+                assert np.array_equal(infos[i]['terminal_observation'], wterm) and infos[i]['TimeLimit.truncated'] == wtrunc
+                got_done[i] += 1; got_trunc[i] += int(wtrunc)
+    assert got_done.min() >= 2 and got_trunc.sum() >= 3 and (got_done - got_trunc).sum() >= 6, (got_done, got_trunc)
+    A.close(); B.close()
