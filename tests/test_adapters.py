@@ -158,9 +158,15 @@ def test_same_step_reset_is_the_next_step_stream_with_the_reset_ticks_folded_in(
     lane the stream equals the next-step env's (itself held against the oracle, tests/test_pyprojectd_api.py) with every reset-tick transition folded
     into the step before it -- observations, rewards, dones, bit for bit -- while the lanes that did not end an episode are untouched by the extra launch.
     Episodes end by the stuck rule, by leaving the road and by the time limit."""
+    got_done = np.zeros(12, int); got_trunc = np.zeros(12, int)
+    for limit in (140, 60):     # the stuck rule fires after 0.4 s = 133 steps: first it ends the episodes, then the time limit does
+        d1, t1 = _same_step_against_next_step(12, dict(track_name='flat', stuck_timeout=0.4, terminate_low_reward=-1e9, max_episode_steps=limit))
+        got_done += d1; got_trunc += t1
+    assert got_done.min() >= 6 and got_trunc.min() >= 3 and (got_done - got_trunc).min() >= 3, (got_done, got_trunc)
+
+
+def _same_step_against_next_step(n, kw):
     import projectd_sb3
-    n = 12
-    kw = dict(track_name='flat', stuck_timeout=0.4, terminate_low_reward=-1e9, max_episode_steps=140)
     A = projectd_sb3.ProjectDSB3VecEnv(n, same_step_reset=False, **kw)     # next-step: the reference stream
     B = projectd_sb3.ProjectDSB3VecEnv(n, same_step_reset=True, **kw)
     oa = A.reset(); ob = B.reset()
@@ -197,5 +203,5 @@ def test_same_step_reset_is_the_next_step_stream_with_the_reset_ticks_folded_in(
             if d[i]:
                 assert np.array_equal(infos[i]['terminal_observation'], wterm) and infos[i]['TimeLimit.truncated'] == wtrunc
                 got_done[i] += 1; got_trunc[i] += int(wtrunc)
-    assert got_done.min() >= 2 and got_trunc.sum() >= 3 and (got_done - got_trunc).sum() >= 6, (got_done, got_trunc)
     A.close(); B.close()
+    return got_done, got_trunc
