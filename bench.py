@@ -204,7 +204,9 @@ def measure(args, world, rank, local_rank, dist, want_cpu=False):
     if part_exchange:
         part_st = [torch.cuda.ExternalStream(b.partition_stream(p), device=dev) for p in range(args.partitions)]
         part_rng = [b.partition_range(p) for p in range(args.partitions)]
-        if not args.torch_exchange and (world == 1 or dist.get_backend() == 'nccl'):
+        # the library's own RCCL path has only ever run with ONE rank (two ranks cannot share the build's single GPU under RCCL): with more ranks it is opt-in,
+        # so that an untried code path can never cost the driver's multi-GPU line; torch's PartitionExchange (held on gloo at world sizes 2 and 4) is the default there
+        if not args.torch_exchange and (world == 1 or (args.library_exchange and dist.get_backend() == 'nccl')):
             try:     # the three steps issued by the library through its own RCCL communicators (collective: every rank succeeds or none)
                 exch = sharding.LibraryExchange(b, part_rng, world, rank, dev, dist)
                 lib_exchange = True
@@ -455,6 +457,7 @@ def parser():
     ap.add_argument('--episodes', action='store_true', help='run the env loop: terminations with penalties like projectd_env.py, resets through the device reset mask')
     ap.add_argument('--gather-ticks', type=int, default=32, help='ticks per trajectory ring gathered to the learner (N > 1): 1 = plain per-tick gather')
     ap.add_argument('--scatter-actions', action='store_true', help='with a gather: rank 0 scatters the [N,2] action block back every tick (configs[3] as SURVEY 8d words it)')
+    ap.add_argument('--library-exchange', action='store_true', help='N > 1: the per-partition exchange through the library\'s own RCCL communicators (pdb_step_exchange_partition); default with one rank, opt-in with more')
     ap.add_argument('--torch-exchange', action='store_true', help='the per-partition exchange (--scatter-actions with --gather-ticks 1) through torch.distributed instead of the library\'s own RCCL communicators (A/B)')
     ap.add_argument('--force-gather', action='store_true', help='run the observation all-gather even with one rank (exercises the RCCL + side-stream path on a single GPU)')
     ap.add_argument('--backend', default='nccl', help='torch.distributed backend for N > 1 (nccl = RCCL; gloo only to exercise the multi-rank path on a single-GPU box)')
