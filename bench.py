@@ -136,9 +136,6 @@ def measure(args, world, rank, local_rank, dist, want_cpu=False):
     if policy == 'scripted':   # gas = 0.6 + 0.4 sin(2 pi t / 7 s + phi_i), phi_i from seed 2345 by GLOBAL car id; steer = a P-law on
         # lookAhead[0] (the road's bend 10 m ahead; bodyVsTrack is a cosine and carries no sign) + the side probes' centring + yaw damping, clipped to +-1
         phi = torch.from_numpy(np.random.RandomState(2345).uniform(0.0, 2.0 * np.pi, n * world).astype(np.float32)[first:last]).to(dev)
-        sw = np.zeros((24, 1), np.float32)
-        sw[12, 0] = -1.0; sw[21, 0] = 0.03; sw[20, 0] = -0.03; sw[4, 0] = 0.15
-        sc_w = torch.from_numpy(sw).to(dev)
     if policy in ('host_mlp',):   # the SAC-sized actor on the HOST (24 -> 256 -> 256 -> 2, fixed random weights, seed 4567), torch on the CPU cores
         g = torch.Generator(device='cpu'); g.manual_seed(4567)
         hw1 = torch.randn(24, 256, generator=g) / 24 ** 0.5; hb1 = torch.zeros(256)
@@ -173,7 +170,8 @@ def measure(args, world, rank, local_rank, dist, want_cpu=False):
     def policy_step(o, a, t=0, f=0):
         if policy == 'scripted':
             c = a.shape[0]
-            torch.mm(o[:, :24], sc_w, out=a[:, 0:1])
+            # four columns by hand (no GEMM dispatch for a [c, 24] x [24, 1] product)
+            torch.add(o[:, 21], o[:, 20], alpha=-1.0, out=a[:, 0]).mul_(0.03).add_(o[:, 12], alpha=-1.0).add_(o[:, 4], alpha=0.15)
             a[:, 0].clamp_(-1.0, 1.0)
             # env action -> gas is linscale(a1, -1, 1, 0.1, 1.0) (projectd_env.py:160): a1 = (gas - 0.1) / 0.45 - 1
             torch.sin(phi[f:f + c] + (2.0 * np.pi / 7.0) * (t / 333.0), out=a[:, 1])
