@@ -10,34 +10,58 @@ import oracle_ctypes
 _DT = np.dtype(pc.DynState)
 
 
-def state_vectors(st):
-    """Flatten one DynState into (float vector, int vector, names) for comparison."""
-    arr = np.frombuffer(bytes(st), dtype=_DT)[0]
-    fl, it, fn, inn = [], [], [], []
-    def walk(prefix, v, dt):
+def _leaves():
+    """(name, byte offset, numpy scalar dtype) of every leaf of pdb_dyn_state, padding fields skipped, in declaration order"""
+    out = []
+
+    def walk(prefix, dt, off):
         if dt.names:
             for n in dt.names:
                 if n.startswith('_pad'):
                     continue
-                walk(prefix + '.' + n if prefix else n, v[n], dt[n])
+                walk(prefix + '.' + n if prefix else n, dt.fields[n][0], off + dt.fields[n][1])
         elif dt.subdtype:
             base, shape = dt.subdtype
-            vv = np.asarray(v).reshape(-1) if not base.names else None
-            if base.names:
-                flat = np.asarray(v).reshape(-1)
-                for i in range(flat.shape[0]):
-                    walk('%s[%d]' % (prefix, i), flat[i], base)
-            else:
-                for i, x in enumerate(vv):
-                    (fl if base.kind == 'f' else it).append(float(x) if base.kind == 'f' else int(x))
-                    (fn if base.kind == 'f' else inn).append('%s[%d]' % (prefix, i))
+            cnt = int(np.prod(shape))
+            for i in range(cnt):
+                walk('%s[%d]' % (prefix, i), base, off + i * base.itemsize)
         else:
-            if dt.kind == 'f':
-                fl.append(float(v)); fn.append(prefix)
-            else:
-                it.append(int(v)); inn.append(prefix)
-    walk('', arr, _DT)
-    return np.array(fl), np.array(it, dtype=np.int64), fn, inn
+            out.append((prefix, off, dt))
+    walk('', _DT, 0)
+    return out
+
+
+_LAYOUT = None
+
+
+def _layout():
+    """per scalar type: the leaves' offsets (in units of the type) and their places in the float / integer vectors -- worked out once"""
+    global _LAYOUT
+    if _LAYOUT is None:
+        fn, inn, groups = [], [], {}
+        for name, off, dt in _leaves():
+            isf = dt.kind == 'f'
+            pos = len(fn) if isf else len(inn)
+            (fn if isf else inn).append(name)
+            assert off % dt.itemsize == 0
+            g = groups.setdefault((dt.str, isf), ([], []))
+            g[0].append(off // dt.itemsize); g[1].append(pos)
+        _LAYOUT = (fn, inn, [(np.dtype(k[0]), k[1], np.array(v[0]), np.array(v[1])) for k, v in groups.items()])
+    return _LAYOUT
+
+
+def state_vectors(st):
+    """Flatten one DynState into (float vector, int vector, names) for comparison."""
+    fn, inn, groups = _layout()
+    raw = bytes(st)
+    fl = np.zeros(len(fn)); it = np.zeros(len(inn), dtype=np.int64)
+    for dt, isf, idx, pos in groups:
+        v = np.frombuffer(raw, dtype=dt)[idx]
+        if isf:
+            fl[pos] = v
+        else:
+            it[pos] = v
+    return fl, it, fn, inn
 
 
 # per-field scale floor for the relative error: max(|ref|, 1e-3 * scale) (SURVEY.md section 8d)
