@@ -290,6 +290,26 @@ def test_bench_multi_rank_path_on_one_gpu(built):
     assert 'all-gather' in d['config']['collective']
 
 
+@pytest.mark.gpu
+def test_bench_per_partition_exchange_with_two_ranks_on_one_gpu(built):
+    """configs[3] as SURVEY 8d words it -- a gather and an action scatter EVERY tick -- over free-running partitions, each with its own process
+    group (sharding.PartitionExchange), with two ranks: over gloo, sharing the box's one GPU, the device rows going through the host.  What the
+    driver's 8-GPU launch runs over RCCL, minus the transport."""
+    import json, subprocess, socket
+    s = socket.socket(); s.bind(('127.0.0.1', 0)); port = s.getsockname()[1]; s.close()
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1', '--master-port', str(port),
+           os.path.join(root, 'bench.py'), '--gpus', '2', '--steps', '30', '--warmup', '10', '--settle', '20', '--cars', '384', '--part-loop-min', '128', '--backend', 'gloo',
+           '--gather-ticks', '1', '--scatter-actions', '--no-cpu-baseline', '--no-extra']
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith('{')]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d['n_gpus'] == 2 and d['value'] > 0 and d['config']['partitions'] == 3
+    assert 'per partition and tick' in d['config']['collective'] and 'torch.distributed' in d['config']['collective']
+
+
 def test_create_rejects_malformed_inputs(built):
     import pdbatch
     lib = pc.load_product()
