@@ -204,11 +204,12 @@ typedef struct pdb_scoring {
  * load time, like addMeshCollider's geom offset).  The box meets TRACK surfaces (C_MASK_CAR_BOX = 1), the hull meets what
  * C_MASK_CAR_MESH = 30 selects (WALL) -- Sim/SimulatorCommon.h:7-13. */
 #define PDB_MAX_COLL_VERTS 128
+#define PDB_MAX_BOXES 3
 #define PDB_MAX_COLL_TRIS 192
 typedef struct pdb_collider {
     int32_t enabled;          /* evaluate body contacts (the loader sets 1 when colliders.ini / collider.bin were read) */
-    int32_t hasBox, numVerts, numTris;
-    float boxCentre[3], boxHalf[3];
+    int32_t numBoxes, numVerts, numTris;   /* numBoxes: COLLIDER_0 .. of colliders.ini (CarColliderManager.cpp:17-33 takes every section there is; every shipped car has one) */
+    float boxCentre[PDB_MAX_BOXES][3], boxHalf[PDB_MAX_BOXES][3];
     float boundsLo[3], boundsHi[3];   /* body-frame box around hull and belly box: the broad phase works on its world AABB */
     float verts[PDB_MAX_COLL_VERTS][3];
     uint8_t tris[PDB_MAX_COLL_TRIS][3];
@@ -481,7 +482,7 @@ typedef struct pdb_ray_rec {
 }
 /* sizes are part of the ABI (tests/test_abi.py reads these numbers) */
 static_assert(sizeof(pdb_car_state) == 664, "pdb_car_state must equal the reference CarState (pack 4)");
-static_assert(sizeof(pdb_car_params) == 22648, "pdb_car_params layout");
+static_assert(sizeof(pdb_car_params) == 22696, "pdb_car_params layout");
 static_assert(sizeof(pdb_dyn_state) == 2352, "pdb_dyn_state layout (multiple of 16 bytes)");
 static_assert(sizeof(pdb_step_out) == 104, "pdb_step_out layout");
 static_assert(sizeof(pdb_contact) == 32, "pdb_contact layout");

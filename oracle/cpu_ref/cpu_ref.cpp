@@ -1460,16 +1460,16 @@ void Car::collisionStep() {
         const int cat = Tk.surfaces[s].collisionCategory;
         // collisionNearCallback (PhysicsEngineODE.cpp:258-264): (cat1 & mask2) && (cat2 & mask1), car geoms are category 4,
         // surfaces collide with mask 20, the box with mask 1, the hull with mask 30 (Sim/SimulatorCommon.h:7-13)
-        const bool meshPair = (cat & 30) != 0 && C.numTris > 0, boxPair = (cat & 1) != 0 && C.hasBox;
+        const bool meshPair = (cat & 30) != 0 && C.numTris > 0, boxPair = (cat & 1) != 0 && C.numBoxes != 0;
         if (!meshPair && !boxPair) continue;
         const bool noDamage = (cat == 1 || cat == 16);   // Car.cpp:948-958: bFlag for groups 1 and 16
         for (int t = Tk.surfaces[s].triStart; t < Tk.surfaces[s].triStart + Tk.surfaces[s].triCount; ++t) {
             const pdcol::V p0 = pdcol::ld(Tk.tris + 9 * t), p1 = pdcol::ld(Tk.tris + 9 * t + 3), p2 = pdcol::ld(Tk.tris + 9 * t + 6);
             if (!pdcol::triMeetsAabb(p0, p1, p2, aLo, aHi)) continue;
-            if (boxPair) {
+            if (boxPair) for (int bx = 0; bx < C.numBoxes; ++bx) {   // every box geom of the chassis meets the triangle on its own (CarColliderManager.cpp:17-33: one geom per COLLIDER_n)
                 float ny;
-                if (pdcol::boxContacts(pose, C.boxCentre, C.boxHalf, p0, p1, p2, ny, [&](const pdcol::V& pw, const pdcol::V& nw, float depth, int item) {
-                        contactSet.insert(pw, nw, depth, 1, (unsigned)t * pdcol::ID_STRIDE + (unsigned)item);
+                if (pdcol::boxContacts(pose, C.boxCentre[bx], C.boxHalf[bx], p0, p1, p2, ny, [&](const pdcol::V& pw, const pdcol::V& nw, float depth, int item) {
+                        contactSet.insert(pw, nw, depth, 1, (unsigned)t * pdcol::ID_STRIDE + (unsigned)item + 16u * (unsigned)bx);
                         ++contactCandidates;
                     }) && ny >= 0.9f) flag = true;   // PhysicsEngineODE.cpp:303-312
             }

@@ -307,6 +307,20 @@ def make_dynctrl_ae86(base, src='ks_toyota_ae86_drift', dst='pdb_dynctrl_ae86'):
         '[CONTROLLER_1]', 'INPUT=GAS', 'COMBINATOR=MULT', 'LUT=(|0=0.5|1=1.4|)', 'FILTER=0.7', 'UP_LIMIT=100', 'DOWN_LIMIT=5', '']))
 
 
+def make_twobox_car(base, src='ks_toyota_ae86_drift', dst='pdb_twobox_ae86'):
+    """Every shipped car has exactly one box collider; CarColliderManager::init (CarColliderManager.cpp:17-33) takes every COLLIDER_n section there is, each
+    a box geom of its own on the chassis.  The AE86 with a second, lower box under its nose (a splitter) pins the loop."""
+    s = os.path.join(REF, 'content', 'cars', src, 'data'); d = os.path.join(base, 'content', 'cars', dst, 'data')
+    if os.path.isdir(d):
+        shutil.rmtree(d)
+    shutil.copytree(s, d)
+    os.system('chmod -R u+w "%s"' % d)
+    p = os.path.join(d, 'colliders.ini')
+    raw = open(p, newline='').read()
+    eol = '\r\n' if '\r\n' in raw else '\n'
+    open(p, 'w', newline='').write(raw.rstrip('\r\n') + eol + eol.join(['', '[COLLIDER_1]', 'CENTRE=0 ,-0.33 ,1.55', 'GROUND_ENABLE=1', 'SIZE=1.30,0.06 ,0.50', '']))
+
+
 def main():
     base = os.path.join(here, '_ref', 'base')
     os.makedirs(os.path.join(base, 'cfg'), exist_ok=True)
@@ -331,6 +345,7 @@ def main():
     make_brakectrl_car(base)
     make_ctrl_inputs_cars(base)
     make_braketemp_car(base)
+    make_twobox_car(base)
     gen_track.gen_flat(os.path.join(base, 'content', 'tracks', 'flat'))
     gen_track.gen_touge(os.path.join(base, 'content', 'tracks', 'touge'))
     gen_track.gen_walled(os.path.join(base, 'content', 'tracks', 'walled'))

@@ -237,11 +237,14 @@ void EnginePD::collisionStep() {
                 const unsigned tid = (triBase + (unsigned)(ti / 3)) * pdcol::ID_STRIDE;
                 const pdcol::V p0 = pdcol::ld(&sm.verts[3 * sm.indices[ti]]), p1 = pdcol::ld(&sm.verts[3 * sm.indices[ti + 1]]), p2 = pdcol::ld(&sm.verts[3 * sm.indices[ti + 2]]);
                 if (!pdcol::triMeetsAabb(p0, p1, p2, aLo, aHi)) continue;
+                unsigned boxIndex = 0;   // which of the body's box geoms, in creation order: sixteen contact-item ids per box
                 for (auto& b : boxes) {
-                    if (b.body != body || !((b.cat & sm.mask) && (sm.category & b.mask))) continue;   // collisionNearCallback, :258-264
+                    if (b.body != body) continue;
+                    const unsigned bx = boxIndex++;
+                    if (!((b.cat & sm.mask) && (sm.category & b.mask))) continue;   // collisionNearCallback, :258-264
                     float ny;
                     if (!pdcol::boxContacts(pose, b.centre, b.half, p0, p1, p2, ny, [&](const pdcol::V& pw, const pdcol::V& nw, float depth, int item) {
-                            contactSet.insert(pw, nw, depth, 1, tid + (unsigned)item);
+                            contactSet.insert(pw, nw, depth, 1, tid + (unsigned)item + 16u * bx);
                         }) || ny < 0.9f) continue;   // onCollision, :303-312
                     pdcol::V n = pdcol::norm(pdcol::cross(p1 - p0, p2 - p0));
                     const pdcol::V cw = pdcol::toWorld(pose, pdcol::ld(b.centre));

@@ -103,8 +103,11 @@ static const Scenario kScenarios[] = {
     {"braketemp", 2400, 200, 10, 1, 1, 1, 1, "flat", 0, "pdb_braketemp_rx7", 0, 0, 1300, 0, 0, 0, 0},
     // the wing controllers' other inputs (rear suspension travel, longitudinal g, steer) on a derived car -- the brake script
     {"wingctrl2", 2400, 200, 10, 1, 1, 1, 1, "flat", 0, "pdb_wingctrl2_fc3s", 0, 0, 0, 0, 0, 0, 0},
+    // a second box collider (CarColliderManager.cpp:17-33 takes every COLLIDER_n of colliders.ini; every shipped car has one): the AE86 with a front
+    // splitter box that hangs lower than the belly box, full throttle down the walled strip -- the splitter meets the ridge first, then both boxes scrape
+    {"twobox", 2150, 0, 3, 0, 1, 1, 1, "walled", 0, "pdb_twobox_ae86", 0, 1, 0, 0, 0, 0, 0},
 };
-static const int kNumScenarios = 49;
+static const int kNumScenarios = 50;
 static const float kTeleDist[4] = {0.13f, 0.41f, 0.77f, 0.95f};
 struct ScoreVar { const char* name; float value; };
 static const ScoreVar kScoringSetA[] = {
@@ -154,7 +157,7 @@ inline void scenarioAction(int sid, int tick, float& a0, float& a1) {
     const double t = (double)tick * (1.0 / 333.0);
     switch (sid) {
     case 0: a0 = 0.0f; a1 = -1.0f; break;
-    case 1: case 15: case 25: case 29: a0 = 0.0f; a1 = 1.0f; break;
+    case 1: case 15: case 25: case 29: case 49: a0 = 0.0f; a1 = 1.0f; break;
     case 2: a0 = 0.35f; a1 = 0.2f; break;
     case 30: case 32: a0 = 0.04f; a1 = 0.8f; break;
     case 31: case 34: a0 = 0.0f; a1 = 1.0f; break;

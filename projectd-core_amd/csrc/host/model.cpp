@@ -1039,16 +1039,18 @@ void buildCarModel(const std::string& basePathIn, const std::string& modelName, 
         float lo[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, hi[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
         auto grow = [&](const float* v) { for (int k = 0; k < 3; ++k) { lo[k] = std::min(lo[k], v[k]); hi[k] = std::max(hi[k], v[k]); } };
         Ini col(dataPath + "colliders.ini");
-        if (col.ready && col.hasSection("COLLIDER_0")) {
-            if (col.hasSection("COLLIDER_1")) throw std::runtime_error("pdb: more than one box collider unsupported");
+        for (int id = 0; col.ready; ++id) {   // CarColliderManager.cpp:17-33: every COLLIDER_n there is, each a box geom of its own on the chassis
+            char sec[32]; snprintf(sec, sizeof(sec), "COLLIDER_%d", id);
+            if (!col.hasSection(sec)) break;
+            if (id >= PDB_MAX_BOXES) throw std::runtime_error("pdb: more than " + std::to_string(PDB_MAX_BOXES) + " box colliders unsupported");
             float size[3];
-            col.getFloat3("COLLIDER_0", "CENTRE", C.boxCentre);
-            col.getFloat3("COLLIDER_0", "SIZE", size);
-            for (int k = 0; k < 3; ++k) C.boxHalf[k] = size[k] * 0.5f;
-            C.hasBox = 1;
+            col.getFloat3(sec, "CENTRE", C.boxCentre[id]);
+            col.getFloat3(sec, "SIZE", size);
+            for (int k = 0; k < 3; ++k) C.boxHalf[id][k] = size[k] * 0.5f;
+            C.numBoxes = id + 1;
             for (int c = 0; c < 8; ++c) {
-                const float v[3] = {C.boxCentre[0] + ((c & 1) ? C.boxHalf[0] : -C.boxHalf[0]), C.boxCentre[1] + ((c & 2) ? C.boxHalf[1] : -C.boxHalf[1]),
-                                    C.boxCentre[2] + ((c & 4) ? C.boxHalf[2] : -C.boxHalf[2])};
+                const float v[3] = {C.boxCentre[id][0] + ((c & 1) ? C.boxHalf[id][0] : -C.boxHalf[id][0]), C.boxCentre[id][1] + ((c & 2) ? C.boxHalf[id][1] : -C.boxHalf[id][1]),
+                                    C.boxCentre[id][2] + ((c & 4) ? C.boxHalf[id][2] : -C.boxHalf[id][2])};
                 grow(v);
             }
         }
@@ -1079,7 +1081,7 @@ void buildCarModel(const std::string& basePathIn, const std::string& modelName, 
                     C.tris[t][k] = (uint8_t)ib[3 * (size_t)t + k];
                 }
         }
-        if (C.hasBox || C.numTris) { for (int k = 0; k < 3; ++k) { C.boundsLo[k] = lo[k]; C.boundsHi[k] = hi[k]; } C.enabled = 1; }
+        if (C.numBoxes || C.numTris) { for (int k = 0; k < 3; ++k) { C.boundsLo[k] = lo[k]; C.boundsHi[k] = hi[k]; } C.enabled = 1; }
     }
     // ScoringConfig defaults (ScoringSystem.cpp:46-71)
     pdb_scoring& sc = P.scoring;

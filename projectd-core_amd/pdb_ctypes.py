@@ -45,8 +45,8 @@ class Heave(C.Structure):
 class Turbo(C.Structure):
     _fields_ = [(n, C.c_float) for n in ('lagDN', 'lagUP', 'maxBoost', 'wastegate', 'rpmRef', 'gamma', 'userSetting')] + [('isAdjustable', C.c_int32)]
 class Collider(C.Structure):
-    _fields_ = [(n, C.c_int32) for n in ('enabled', 'hasBox', 'numVerts', 'numTris')] + \
-        [('boxCentre', C.c_float * 3), ('boxHalf', C.c_float * 3), ('boundsLo', C.c_float * 3), ('boundsHi', C.c_float * 3),
+    _fields_ = [(n, C.c_int32) for n in ('enabled', 'numBoxes', 'numVerts', 'numTris')] + \
+        [('boxCentre', (C.c_float * 3) * 3), ('boxHalf', (C.c_float * 3) * 3), ('boundsLo', C.c_float * 3), ('boundsHi', C.c_float * 3),
          ('verts', (C.c_float * 3) * 128), ('tris', (C.c_uint8 * 3) * 192)]
 class Spline(C.Structure):
     _fields_ = [('n', C.c_int32), ('b0', C.c_float), ('c0', C.c_float), ('pad', C.c_int32)] + [(k, C.c_float * 16) for k in ('x', 'y', 'a', 'b', 'c')]

@@ -26,15 +26,15 @@ def test_packed_cars_carry_their_colliders():
     for model, nv, nt in ((AE86, 50, 96), ('ks_mazda_rx7_tuned', 113, 178), ('ks_toyota_supra_mkiv_drift', 69, 102),
                           ('dthwsh_mazda_rx7_fc3s_sr20', 107, 170), ('gravygarage_street_ae86_readie', 50, 96)):
         c = car_params(model).collider
-        assert (c.enabled, c.hasBox, c.numVerts, c.numTris) == (1, 1, nv, nt)
+        assert (c.enabled, c.numBoxes, c.numVerts, c.numTris) == (1, 1, nv, nt)
         v = np.array([list(c.verts[i]) for i in range(nv)])
         t = np.array([list(c.tris[i]) for i in range(nt)])
         assert t.max() < nv
         assert np.allclose(v.min(0), list(c.boundsLo)[:3], atol=0.2) or c.boundsLo[1] < v[:, 1].min()    # the belly box hangs below the hull
-        assert np.all(np.array(list(c.boundsLo)) <= np.minimum(v.min(0), np.array(list(c.boxCentre)) - np.array(list(c.boxHalf))) + 1e-6)
+        assert np.all(np.array(list(c.boundsLo)) <= np.minimum(v.min(0), np.array(list(c.boxCentre[0])) - np.array(list(c.boxHalf[0]))) + 1e-6)
         assert abs(v[:, 0].min() + v[:, 0].max()) < 1e-3 and 3.5 < v[:, 2].max() - v[:, 2].min() < 5.0     # symmetric, car-sized
         assert -0.45 < v[:, 1].min() < -0.15 and 0.6 < v[:, 1].max() < 1.0                               # sill .. roof around the CoG
-    assert list(car_params(AE86).collider.boxHalf) == pytest.approx([0.74, 0.05, 1.95])
+    assert list(car_params(AE86).collider.boxHalf[0]) == pytest.approx([0.74, 0.05, 1.95])
 
 
 def _drive(orc, hostlib, blob, P, ticks, shift_z=0.0, speed=0.0, frame0=0):

@@ -17,7 +17,7 @@ from conftest import load_golden
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..', 'oracle'))
 import probe_io  # noqa: E402
 
-NSC = 49
+NSC = 50
 INT_LIKE = ('gear', 'Gear', 'Id', 'Flag', 'flag', 'isLocked', 'limiterOn', 'sleepingFrames', 'Counter', 'drifting', 'driftExtreme', 'driftInvalid', 'acSeq', 'clutchOpenState', 'surface')
 
 
