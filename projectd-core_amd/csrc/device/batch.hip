@@ -263,7 +263,7 @@ static void launchTick(pdb_batch* b, hipStream_t st, int c0, int c1, pdb_step_ou
     void* Q = b->dQueue[q];
     const bool own = q < PDB_MAX_PARTS && b->partHas[q];
     const pdb_car_params* DP = own ? b->dPartParams[q] : b->dParams;
-    const DevConst* DK = own ? b->dPartK[q] : b->dK;
+    const DevConst* DK = (q < PDB_MAX_PARTS && b->dPartK[q]) ? b->dPartK[q] : b->dK;   // a partition launch: the block whose per-car tables start at the partition's first car
     const pdb_car_params& HP = own ? b->partParams[q] : b->params;
     // every launch's snapshot region starts at the ALLOCATION's stride (partitions may carry car blocks of different kernel classes: with the
     // launch's own, narrower stride a later partition's region would begin inside an earlier, wider one's); the kernel indexes its slots with its own stride inside it
@@ -322,12 +322,15 @@ static void launchWhole(pdb_batch* b, hipStream_t st, pdb_step_out* out) {
 // the constants blocks to the device: the batch's, and every partition's own (its model-derived part + the batch's run-time part)
 static int pushK(pdb_batch* b, hipStream_t st, bool async) {
     if (async) HIPCHK(hipMemcpyAsync(b->dK, &b->K, sizeof(DevConst), hipMemcpyHostToDevice, st)); else HIPCHK(hipMemcpy(b->dK, &b->K, sizeof(DevConst), hipMemcpyHostToDevice));
-    for (int p = 0; p < PDB_MAX_PARTS; ++p) {
-        if (!b->partHas[p]) continue;
+    // every partition has a constants block of its own on the device: its car block's model-derived part where it has one (else the batch's), and the
+    // batch's per-car tables (lane tunes, hold mask) offset to the partition's first car -- a launch over the cars [c0, c1) indexes everything from c0
+    for (int p = 0; p < b->parts && p < PDB_MAX_PARTS; ++p) {
+        if (!b->dPartK[p]) continue;   // (one part: no partition launches)
         DevConst& K = b->partK[p];
-        fillConst(b->partParams[p], K, b->K.actionMode);
-        K.laneTunes = b->K.laneTunes;
-        K.holdMask = b->K.holdMask;
+        if (b->partHas[p]) fillConst(b->partParams[p], K, b->K.actionMode); else K = b->K;
+        const int c0 = partFirst(b, p);
+        K.laneTunes = b->K.laneTunes ? b->K.laneTunes + c0 : nullptr;
+        K.holdMask = b->K.holdMask ? b->K.holdMask + c0 : nullptr;
         K.dt = b->K.dt; K.fps = b->K.fps; K.dtD = b->K.dtD; K.stuckTimeout = b->K.stuckTimeout; K.wantCarState = b->K.wantCarState; K.stamps = b->K.stamps; K.stampCars = b->K.stampCars;
         K.envHitPenalty = b->K.envHitPenalty; K.envOffPenalty = b->K.envOffPenalty; K.envStuckPenalty = b->K.envStuckPenalty; K.envLowReward = b->K.envLowReward;
         K.envMode = b->K.envMode; K.envTermHit = b->K.envTermHit; K.envTermOff = b->K.envTermOff; K.envTermStuck = b->K.envTermStuck;
@@ -607,7 +610,8 @@ int pdb_set_partition_params(pdb_batch* b, int part, const pdb_car_params* param
     if (params->numCtrlStages != 0 || params->hasBrakeTemps != 0) { pdb::setError("pdb_set_partition_params: this development build (PDB_FAST_BUILD) holds no controller kernels"); return PDB_ERR_ARG; }
 #endif
     if (!same) { pdb::setError("pdb_set_partition_params: the block's rigid-body topology differs from the batch's (one kernel variant per batch)"); return PDB_ERR_ARG; }
-    if (!b->dPartParams[part]) { HIPCHK(hipMalloc(&b->dPartParams[part], sizeof(pdb_car_params))); HIPCHK(hipMalloc(&b->dPartK[part], sizeof(DevConst))); }
+    if (!b->dPartParams[part]) HIPCHK(hipMalloc(&b->dPartParams[part], sizeof(pdb_car_params)));
+    if (!b->dPartK[part]) HIPCHK(hipMalloc(&b->dPartK[part], sizeof(DevConst)));
     b->partParams[part] = *params;
     b->partHas[part] = true;
     HIPCHK(hipMemcpy(b->dPartParams[part], params, sizeof(pdb_car_params), hipMemcpyHostToDevice));
@@ -759,7 +763,8 @@ int pdb_set_partitions(pdb_batch* b, int parts) {
     if (!b->partFork) HIPCHK(hipEventCreateWithFlags(&b->partFork, hipEventDisableTiming));
     if (b->graphExec) { (void)hipGraphExecDestroy(b->graphExec); b->graphExec = nullptr; }   // captured launches follow the old cut
     b->parts = parts;
-    return PDB_OK;
+    if (parts > 1) for (int p = 0; p < parts; ++p) if (!b->dPartK[p]) HIPCHK(hipMalloc(&b->dPartK[p], sizeof(DevConst)));
+    return pushK(b, b->stream, false);   // the partitions' constants blocks: the per-car tables start at each partition's first car
 }
 
 int pdb_step_ring(pdb_batch* b, float dt, int n_ticks, pdb_step_out* ring, int ring_slots, int first_slot, int join) {

@@ -708,3 +708,42 @@ def test_lane_tunes_can_be_taken_back_and_follow_the_partitions(built):
     st_own = bytes(own.get_state()); own.close()
     strip = lambda raw: b''.join(raw[i * sz:(i + 1) * sz] for i in range(n))
     assert strip(whole) == strip(st_own)                                              # a row = that lane stepped with the tuned block
+
+    # free-running partitions index the batch's per-car tables from their own first car: different rows per lane, three partitions (nine of the twelve cars
+    # are not in the first one), against the whole-batch launch; and a held step with a partition that carries a block of its own
+    blocks = []
+    for i in range(n):
+        Qi = pc.CarParams.from_buffer_copy(bytes(P)); _randomised_lane(40 + i, Qi); blocks.append(Qi)
+
+    def by_partitions(b):
+        b.set_lane_tunes(blocks)
+        b.upload_actions(acts)
+        b.set_partitions(3)
+        b.step_ring(300, join=True)
+        b.sync()
+    parts3 = bytes((lambda b: (by_partitions(b), b.get_state(), b.close())[1])(pdbatch.Batch(n, P, trk, device=0, action_mode=1)))
+    assert parts3 == run(lambda b: b.set_lane_tunes(blocks))
+
+    def held(b, own_block):
+        b.set_partitions(3)
+        if own_block:
+            b.set_partition_params(2, P)             # the same values, but the whole-batch entry points now launch partition by partition
+        hold = np.zeros(n, np.uint8); hold[[1, 5, 6, 10]] = 1
+        for t in range(120):
+            if t % 3 == 0:
+                b.lib.pdb_step_host_held.argtypes = [C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.c_void_p]
+                b._chk(b.lib.pdb_step_host_held(b.h, acts.ctypes.data_as(C.c_void_p), C.c_float(1.0 / 333.0), hold.ctypes.data_as(C.c_void_p), None))
+            else:
+                b.step_host(acts)
+    assert run(lambda b: held(b, True)) == run(lambda b: held(b, False))
+    b = pdbatch.Batch(n, P, trk, device=0, action_mode=1)
+    for _ in range(50):
+        b.step_host(acts)
+    before = bytes(b.get_state())
+    hold = np.zeros(n, np.uint8); hold[[0, 4, 11]] = 1
+    b.lib.pdb_step_host_held.argtypes = [C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.c_void_p]
+    b._chk(b.lib.pdb_step_host_held(b.h, acts.ctypes.data_as(C.c_void_p), C.c_float(1.0 / 333.0), hold.ctypes.data_as(C.c_void_p), None))
+    after = bytes(b.get_state()); b.close()
+    for i in range(n):
+        same = before[i * sz:(i + 1) * sz] == after[i * sz:(i + 1) * sz]
+        assert same == bool(hold[i]), i                                              # held cars: not a byte of the record moves; the others step
