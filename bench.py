@@ -143,7 +143,7 @@ def measure(args, world, rank, local_rank, dist, want_cpu=False):
         hw3 = torch.randn(256, 2, generator=g) / 16.0; hb3 = torch.tensor([0.0, 0.5])
         import projectd_env
         h_scale = 1.0 / torch.from_numpy(projectd_env.obs_bounds(projectd_env.EnvConfig())[1])
-        torch.set_num_threads(max(1, min(16, (os.cpu_count() or 2) // 2)))   # 2.7 k rows x 256 x 256: a few cores' worth; torch's default (every hardware thread of a 256-thread host) spends the tick waking its pool
+        torch.set_num_threads(int(os.environ.get('PDB_HOST_MLP_THREADS', max(1, min(16, (os.cpu_count() or 2) // 2)))))   # 2.7 k rows x 256 x 256: a few cores' worth; torch's default (every hardware thread of a 256-thread host) spends the tick waking its pool
     if policy == 'feedback':
         fw = np.zeros((24, 2), np.float32)
         fw[21, 0] = 0.03; fw[20, 0] = -0.03; fw[19, 0] = 0.015; fw[18, 0] = -0.015; fw[4, 0] = 0.15; fw[2, 1] = -0.3
