@@ -291,6 +291,41 @@ def test_bench_multi_rank_path_on_one_gpu(built):
 
 
 @pytest.mark.gpu
+def test_library_exchange_equals_plain_stepping(built):
+    """pdb_comm_init / pdb_step_exchange_partition with one rank (two cannot share this box's GPU under RCCL): per partition and tick the learner's
+    action rows in -- different every tick --, the partition's tick, its output rows out through the library's own RCCL communicators; every gathered
+    block and the final records equal a plain batch stepped with the same actions"""
+    import torch, pdbatch, sharding
+    n, ticks, parts = 600, 60, 3
+    P = pdbatch.packed_params(); trk = pdbatch.synthetic_track('touge')
+    a = pdbatch.Batch(n, P, trk, device=0, action_mode=1)
+    b = pdbatch.Batch(n, P, trk, device=0, action_mode=1)
+    b.set_stream(torch.cuda.current_stream().cuda_stream)
+    b.set_partitions(parts)
+    rng = [b.partition_range(p) for p in range(parts)]
+    try:
+        ex = sharding.LibraryExchange(b, rng, 1, 0, 'cuda:0', None)
+    except RuntimeError as e:
+        pytest.fail('the library could not set up its RCCL communicators: %s' % e)
+    r = np.random.RandomState(4)
+    for t in range(ticks):
+        acts = np.stack([r.uniform(-0.4, 0.4, n), r.uniform(-1, 1, n)], 1).astype(np.float32)
+        ref = a.step_host(acts)
+        ex.load_actions(torch.from_numpy(acts).to('cuda:0'))
+        torch.cuda.synchronize()
+        for p in range(parts):
+            ex.step(p)
+        b.wait_partitions(); torch.cuda.synchronize()
+        for p, (f, c) in enumerate(rng):
+            g = ex.gathered[p][0].cpu().numpy()
+            want = np.zeros((c, 26), np.float32)
+            want[:, :24] = ref['obs'][f:f + c]; want[:, 24] = ref['reward'][f:f + c]; want[:, 25].view(np.int32)[:] = ref['flags'][f:f + c]
+            assert np.array_equal(g.view(np.uint32), want.view(np.uint32)), (t, p)
+    assert bytes(a.get_state()) == bytes(b.get_state())
+    a.close(); b.close()
+
+
+@pytest.mark.gpu
 def test_bench_per_partition_exchange_with_two_ranks_on_one_gpu(built):
     """configs[3] as SURVEY 8d words it -- a gather and an action scatter EVERY tick -- over free-running partitions, each with its own process
     group (sharding.PartitionExchange), with two ranks: over gloo, sharing the box's one GPU, the device rows going through the host.  What the
