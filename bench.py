@@ -199,6 +199,7 @@ def measure(args, world, rank, local_rank, dist, want_cpu=False):
     if split:
         b.set_partitions(args.partitions)
     lib_exchange = False
+    part_graph = None
     if part_exchange:
         part_st = [torch.cuda.ExternalStream(b.partition_stream(p), device=dev) for p in range(args.partitions)]
         part_rng = [b.partition_range(p) for p in range(args.partitions)]
@@ -222,6 +223,29 @@ def measure(args, world, rank, local_rank, dist, want_cpu=False):
     if part_loops:
         part_st = [torch.cuda.ExternalStream(b.partition_stream(p), device=dev) for p in range(args.partitions)]
         part_rng = [b.partition_range(p) for p in range(args.partitions)]
+        # the policy's handful of small launches per partition and tick as ONE graph launch (the loop is launch-bound on the host below ~8192 cars: twelve torch
+        # dispatches + six kernel launches per 60-100 us tick).  The kernels then write the library's own output block (a fixed address, which the graph holds)
+        # instead of the trajectory ring.  The scripted law reads the tick number: it stays uncaptured.
+        part_graph = None
+        if not args.no_graph_policy and policy in ('feedback', 'mlp') and n < 8192:   # (measured: 4096 cars 45.0 -> 46.5 M with the env loop, 32.5 -> 35.6 M reset-free; at 16384 cars the loop is GPU-bound and the graph loses: 47.4 against 52.2 M)
+            try:
+                for p in range(args.partitions):   # (first use of the library's GEMM kernels outside a capture)
+                    f, c = part_rng[p]
+                    with torch.cuda.stream(part_st[p]):
+                        policy_step(out_t[f:f + c], act_t[f:f + c], 0, f)
+                torch.cuda.synchronize()
+                act_t.copy_(torch.from_numpy(actions).to(dev)); torch.cuda.synchronize()
+                gs = []
+                for p in range(args.partitions):
+                    f, c = part_rng[p]
+                    g = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(g, stream=part_st[p]):
+                        policy_step(out_t[f:f + c], act_t[f:f + c], 0, f)
+                    gs.append(g)
+                part_graph = gs
+            except Exception as e:
+                sys.stderr.write('bench: the policy could not be captured (%r): plain launches\n' % (e,))
+                part_graph = None
 
     host_act = [np.ascontiguousarray(actions, dtype=np.float32).copy()]
 
@@ -259,8 +283,12 @@ def measure(args, world, rank, local_rank, dist, want_cpu=False):
             for p in range(args.partitions):
                 f, c = part_rng[p]
                 with torch.cuda.stream(part_st[p]):
-                    b.step_partition(p, o.data_ptr())
-                    policy_step(o[f:f + c], act_t[f:f + c], t, f)
+                    if part_graph is not None:
+                        b.step_partition(p, out_t.data_ptr())
+                        part_graph[p].replay()
+                    else:
+                        b.step_partition(p, o.data_ptr())
+                        policy_step(o[f:f + c], act_t[f:f + c], t, f)
             return
         if do_scatter:
             act_t.copy_(sharding.scatter_actions(scatter_src, n, world, rank, dev, dist))
@@ -396,7 +424,7 @@ def measure(args, world, rank, local_rank, dist, want_cpu=False):
             ends = torch.zeros((), dtype=torch.int64, device=dev)
             for _ in range(300):
                 tick()
-                ends += ((gather.slot(tick_id[0] - 1)[:, 25].view(torch.int32) & 8) != 0).sum()
+                ends += (((out_t if (part_loops and part_graph is not None) else gather.slot(tick_id[0] - 1))[:, 25].view(torch.int32) & 8) != 0).sum()
             res["episode_ends_per_tick"] = float(ends.item()) / 300.0
         if want_cpu:   # the CPU leg is timed at N = 1 only
             res["cpu_baseline"] = cpu_baseline(P, trk, S0, all_actions)
@@ -441,7 +469,7 @@ def parser():
     ap.add_argument('--settle', type=int, default=333, help='ticks of state preparation before warm-up (cars come off their springs and get rolling); neither warm-up nor timed')
     ap.add_argument('--cars', type=int, default=CARS_PER_GPU)
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--part-loop-min', type=int, default=8192, help='per-tick policies: from this many cars up every partition runs its own closed loop on its own stream')
+    ap.add_argument('--part-loop-min', type=int, default=4096, help='per-tick policies: from this many cars up every partition runs its own closed loop on its own stream')
     ap.add_argument('--no-extra', action='store_true', help='skip the `extra` block (the other configs measured in the same run)')
     ap.add_argument('--partitions', type=int, default=3, choices=[1, 2, 3, 4],
                     help='free-running car ranges per GPU, one HIP stream each (pdb_set_partitions / pdb_step_ring; constant policy only -- a per-tick policy joins the ranges every tick); 1 = one launch per tick')
@@ -456,6 +484,7 @@ def parser():
     ap.add_argument('--gather-ticks', type=int, default=32, help='ticks per trajectory ring gathered to the learner (N > 1): 1 = plain per-tick gather')
     ap.add_argument('--scatter-actions', action='store_true', help='with a gather: rank 0 scatters the [N,2] action block back every tick (configs[3] as SURVEY 8d words it)')
     ap.add_argument('--library-exchange', action='store_true', help='N > 1: the per-partition exchange through the library\'s own RCCL communicators (pdb_step_exchange_partition); default with one rank, opt-in with more')
+    ap.add_argument('--no-graph-policy', action='store_true', help='per-partition policy loops: the policy as plain torch launches instead of one captured graph per partition (A/B)')
     ap.add_argument('--torch-exchange', action='store_true', help='the per-partition exchange (--scatter-actions with --gather-ticks 1) through torch.distributed instead of the library\'s own RCCL communicators (A/B)')
     ap.add_argument('--force-gather', action='store_true', help='run the observation all-gather even with one rank (exercises the RCCL + side-stream path on a single GPU)')
     ap.add_argument('--backend', default='nccl', help='torch.distributed backend for N > 1 (nccl = RCCL; gloo only to exercise the multi-rank path on a single-GPU box)')
