@@ -171,6 +171,8 @@ struct pdb_batch {
     hipStream_t partStream[PDB_MAX_PARTS] = {nullptr, nullptr, nullptr, nullptr};
     hipEvent_t partFork = nullptr, partEnd[PDB_MAX_PARTS] = {nullptr, nullptr, nullptr, nullptr}, partStart[PDB_MAX_PARTS] = {nullptr, nullptr, nullptr, nullptr};
     bool partMark = false;
+    bool partEndStale[PDB_MAX_PARTS] = {false, false, false, false};   // work enqueued on the partition's stream since its end event was last recorded (pdb_step_partition records it
+                                                                      // only when somebody asks: one runtime call less per partition and tick in the launch-bound closed loops)
     bool partDirty = false;   // partition kernels enqueued that the batch's stream has not been ordered after
     bool batchDirty = false;  // asynchronous work queued on the batch's stream that pdb_step_partition's streams have not been ordered after
     float* hActions = nullptr;          // page-locked host mirrors (pdb_host_actions / pdb_host_out): the pipelined host-policy loop
@@ -191,10 +193,14 @@ static void commFree(pdb_batch* b);
 static void wideContactPasses(pdb_batch* b);
 // Every entry point that works through the batch's stream first lets that stream wait for the partitions' kernels still in
 // flight (pdb_step_ring with join == 0): state reads, resets and plain launches are always ordered after them.
+static int freshEnd(pdb_batch* b, int p) {   // the partition's end event, brought up to what has been enqueued on its stream
+    if (b->partEndStale[p] && b->partEnd[p] && b->partStream[p]) { HIPCHK(hipEventRecord(b->partEnd[p], b->partStream[p])); b->partEndStale[p] = false; }
+    return PDB_OK;
+}
 static int joinParts(pdb_batch* b) {
     if (b->parts > 1 && b->partDirty) {
         for (int p = 0; p < b->parts; ++p)
-            if (b->partEnd[p] && partFirst(b, p + 1) > partFirst(b, p)) HIPCHK(hipStreamWaitEvent(b->stream, b->partEnd[p], 0));
+            if (b->partEnd[p] && partFirst(b, p + 1) > partFirst(b, p)) { if (int rcf = freshEnd(b, p)) return rcf; HIPCHK(hipStreamWaitEvent(b->stream, b->partEnd[p], 0)); }
         b->partDirty = false;
     }
     return PDB_OK;
@@ -799,7 +805,7 @@ int pdb_step_ring(pdb_batch* b, float dt, int n_ticks, pdb_step_out* ring, int r
     for (int p = 0; p < np; ++p) {
         const int c0 = forked ? partFirst(b, p) : 0, c1 = forked ? partFirst(b, p + 1) : b->n;
         if (c1 <= c0) continue;
-        if (forked) { HIPCHK(hipEventRecord(b->partEnd[p], b->partStream[p])); if (join) HIPCHK(hipStreamWaitEvent(b->stream, b->partEnd[p], 0)); }
+        if (forked) { HIPCHK(hipEventRecord(b->partEnd[p], b->partStream[p])); b->partEndStale[p] = false; if (join) HIPCHK(hipStreamWaitEvent(b->stream, b->partEnd[p], 0)); }
     }
     if (forked) { b->partMark = false; if (!join) b->partDirty = true; }
     return PDB_OK;
@@ -826,7 +832,7 @@ int pdb_step_partition(pdb_batch* b, float dt, int part, pdb_step_out* out) {
     pdb_step_out* o = out ? out : b->dOutActive;
     launchTick(b, st, c0, c1, o, part);
     LAUNCHCHK(b);
-    HIPCHK(hipEventRecord(b->partEnd[part], st));
+    b->partEndStale[part] = true;   // (recorded when somebody waits for it: freshEnd)
     b->partDirty = true;
     return PDB_OK;
 }
@@ -849,10 +855,12 @@ int pdb_step_host_partition(pdb_batch* b, float dt, int part) {
     if (rc != PDB_OK) return rc;
     HIPCHK(hipMemcpyAsync(b->hOut + c0, b->dOutActive + c0, sizeof(pdb_step_out) * (size_t)(c1 - c0), hipMemcpyDeviceToHost, st));
     HIPCHK(hipEventRecord(b->partEnd[part], st));   // the partition's end now includes the download
+    b->partEndStale[part] = false;
     return PDB_OK;
 }
 int pdb_wait_host_partition(pdb_batch* b, int part) {
     if (!b || part < 0 || part >= b->parts || b->parts < 2 || !b->partEnd[part]) { pdb::setError("pdb_wait_host_partition: no such partition"); return PDB_ERR_ARG; }
+    if (int rcf = freshEnd(b, part)) return rcf;
     HIPCHK(hipEventSynchronize(b->partEnd[part]));
     return PDB_OK;
 }
@@ -942,7 +950,7 @@ int pdb_step_exchange_partition(pdb_batch* b, float dt, int part, const float* s
     if (rc != PDB_OK) return rc;
     static_assert(sizeof(pdb_step_out) % 4 == 0, "rows as floats");
     NCCLCHK(R, R->allGather(b->dOutActive + c0, gathered, (size_t)c * (sizeof(pdb_step_out) / 4), ncclFloat, b->comm[part], st));
-    HIPCHK(hipEventRecord(b->partEnd[part], st));   // the partition's end now includes the gather
+    b->partEndStale[part] = true;   // the partition's end includes the gather (recorded by whoever waits: freshEnd)
     return PDB_OK;
 }
 int pdb_wait_partitions(pdb_batch* b, void* hip_stream) {
@@ -950,7 +958,7 @@ int pdb_wait_partitions(pdb_batch* b, void* hip_stream) {
     hipStream_t s = hip_stream ? (hipStream_t)hip_stream : b->stream;
     if (s == b->stream) return joinParts(b);
     if (b->parts > 1)
-        for (int p = 0; p < b->parts; ++p) if (b->partEnd[p] && partFirst(b, p + 1) > partFirst(b, p)) HIPCHK(hipStreamWaitEvent(s, b->partEnd[p], 0));
+        for (int p = 0; p < b->parts; ++p) if (b->partEnd[p] && partFirst(b, p + 1) > partFirst(b, p)) { if (int rcf = freshEnd(b, p)) return rcf; HIPCHK(hipStreamWaitEvent(s, b->partEnd[p], 0)); }
     return PDB_OK;
 }
 int pdb_partition_mark(pdb_batch* b) {
@@ -960,6 +968,7 @@ int pdb_partition_mark(pdb_batch* b) {
 }
 int pdb_partition_elapsed_ms(pdb_batch* b, int part, float* ms, int* cars) {
     if (!b || !ms || part < 0 || part >= b->parts || b->parts < 2 || !b->partEnd[part]) { pdb::setError("pdb_partition_elapsed_ms: no such partition"); return PDB_ERR_ARG; }
+    if (int rcf = freshEnd(b, part)) return rcf;
     HIPCHK(hipEventSynchronize(b->partEnd[part]));
     HIPCHK(hipEventElapsedTime(ms, b->partStart[part], b->partEnd[part]));
     if (cars) *cars = partFirst(b, part + 1) - partFirst(b, part);
