@@ -121,7 +121,9 @@ def measure(args, world, rank, local_rank, dist, want_cpu=False):
         b.set_state(st)
 
     out_t = torch.as_tensor(_Arr(b.out_device_ptr(), (n, 26)), device=dev)
-    gather = sharding.TrajectoryGather(n, world, dev, dist, k=args.gather_ticks, force=args.force_gather, producer_wait=b.wait_partitions)
+    ring_streams = []
+    gather = sharding.TrajectoryGather(n, world, dev, dist, k=args.gather_ticks, force=args.force_gather, producer_wait=b.wait_partitions,
+                                       producer_streams=(lambda: ring_streams) if not args.ring_fork else None)
     act_t = torch.as_tensor(_Arr(b.actions_device_ptr(), (n, 2)), device=dev)
     do_scatter = bool(args.scatter_actions and gather.active)   # configs[3]: the learner (rank 0) scatters every tick's actions back
     scatter_src = torch.from_numpy(all_actions).to(dev) if (do_scatter and rank == 0) else None
@@ -198,6 +200,8 @@ def measure(args, world, rank, local_rank, dist, want_cpu=False):
     split = use_ring or part_loops or host_pipe or part_exchange   # the cars step as free-running partitions
     if split:
         b.set_partitions(args.partitions)
+    if use_ring and not args.ring_fork:   # the gather orders a ring's reuse on the partitions' own streams: the rings then start without waiting for the batch's stream
+        ring_streams.extend(torch.cuda.ExternalStream(b.partition_stream(p), device=dev) for p in range(args.partitions))
     lib_exchange = False
     part_graph = None
     if part_exchange:
@@ -307,7 +311,7 @@ def measure(args, world, rank, local_rank, dist, want_cpu=False):
         t = tick_id[0]; end = t + nsteps
         while t < end:
             m = min(k - t % k, end - t)
-            b.step_ring(m, gather.ring(t).data_ptr(), k, t % k, join=False)   # every partition's kernels of these m ticks, written straight into the ring;
+            b.step_ring(m, gather.ring(t).data_ptr(), k, t % k, join=False, fork=bool(args.ring_fork))   # every partition's kernels of these m ticks, written straight into the ring;
                                                                               # the partitions are never joined inside the loop: only the gather waits for a ring
             t += m
             gather.after_tick(t - 1)                              # a full ring starts its all-gather (N > 1)
@@ -485,6 +489,7 @@ def parser():
     ap.add_argument('--scatter-actions', action='store_true', help='with a gather: rank 0 scatters the [N,2] action block back every tick (configs[3] as SURVEY 8d words it)')
     ap.add_argument('--library-exchange', action='store_true', help='N > 1: the per-partition exchange through the library\'s own RCCL communicators (pdb_step_exchange_partition); default with one rank, opt-in with more')
     ap.add_argument('--no-graph-policy', action='store_true', help='per-partition policy loops: the policy as plain torch launches instead of one captured graph per partition (A/B)')
+    ap.add_argument('--ring-fork', action='store_true', help='ring mode: every ring starts behind the batch stream (the older form; A/B)')
     ap.add_argument('--torch-exchange', action='store_true', help='the per-partition exchange (--scatter-actions with --gather-ticks 1) through torch.distributed instead of the library\'s own RCCL communicators (A/B)')
     ap.add_argument('--force-gather', action='store_true', help='run the observation all-gather even with one rank (exercises the RCCL + side-stream path on a single GPU)')
     ap.add_argument('--backend', default='nccl', help='torch.distributed backend for N > 1 (nccl = RCCL; gloo only to exercise the multi-rank path on a single-GPU box)')

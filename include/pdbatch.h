@@ -153,6 +153,8 @@ int pdb_set_partition_params(pdb_batch* b, int part, const pdb_car_params* param
  * pdb_set_lane_tunes(b, first, count, rows) installs rows for the cars [first, first + count) (rows == NULL: those lanes back to their block). */
 int pdb_lane_tune_from_params(const pdb_car_params* params, pdb_lane_tune* row);
 int pdb_set_lane_tunes(pdb_batch* b, int first, int count, const pdb_lane_tune* rows);
+/* join: bit 0 = the batch's stream waits for the ring's kernels; bit 1 = the partitions do NOT wait for what is queued on the batch's stream (the caller orders
+ * its own dependencies on pdb_partition_stream; asynchronous resets queued through the library are still waited for) */
 int pdb_step_ring(pdb_batch* b, float dt, int n_ticks, pdb_step_out* ring, int ring_slots, int first_slot, int join);
 int pdb_wait_partitions(pdb_batch* b, void* hip_stream);
 /* Per-partition loops: pdb_step_partition enqueues one tick of one part on that part's stream (pdb_partition_stream), nothing

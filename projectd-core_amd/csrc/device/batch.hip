@@ -781,7 +781,13 @@ int pdb_step_ring(pdb_batch* b, float dt, int n_ticks, pdb_step_out* ring, int r
         if (int rck = pushK(b, b->stream, true)) return rck;
     }
     const bool forked = b->parts > 1 && b->partStream[0];
-    if (forked) HIPCHK(hipEventRecord(b->partFork, b->stream));
+    // join bit 1 (PDB_RING_NO_FORK): the partitions are not held back behind what is queued on the batch's stream -- for a caller that orders its own dependencies
+    // on the partitions' streams (sharding.TrajectoryGather: a ring is not rewritten before its previous gather has read it).  Without it every ring starts behind
+    // the batch's stream, and a stream that shares that stream's hardware queue -- the gather's -- holds every partition up for as long as its kernel runs
+    const bool noFork = (join & 2) != 0 && !b->batchDirty;
+    join &= 1;
+    if (forked && !noFork) HIPCHK(hipEventRecord(b->partFork, b->stream));
+    if (forked && !noFork) b->batchDirty = false;
     // enqueued tick by tick across the partitions, not partition by partition: every range starts (and ends) within a few launches
     // of the others -- partition-major order left the last range idle for the first hundreds of microseconds of a short call and
     // alone on the GPU for the last ones
@@ -790,7 +796,7 @@ int pdb_step_ring(pdb_batch* b, float dt, int n_ticks, pdb_step_out* ring, int r
         const int c0 = forked ? partFirst(b, p) : 0, c1 = forked ? partFirst(b, p + 1) : b->n;
         if (c1 <= c0) continue;
         hipStream_t st = forked ? b->partStream[p] : b->stream;
-        if (forked) HIPCHK(hipStreamWaitEvent(st, b->partFork, 0));
+        if (forked && !noFork) HIPCHK(hipStreamWaitEvent(st, b->partFork, 0));
         if (forked && b->partMark) HIPCHK(hipEventRecord(b->partStart[p], st));
     }
     for (int i = 0; i < n_ticks; ++i) {

@@ -61,10 +61,11 @@ class Batch:
         """a car block of its own for one partition (None: the batch's): same model, different tunes / weights"""
         self._chk(self.lib.pdb_set_partition_params(self.h, part, C.byref(params) if params is not None else None))
 
-    def step_ring(self, n_ticks, ring_ptr=None, ring_slots=1, first_slot=0, join=True):
+    def step_ring(self, n_ticks, ring_ptr=None, ring_slots=1, first_slot=0, join=True, fork=True):
         """enqueue n_ticks ticks of every car, partition by partition; tick i writes outputs to ring slot (first_slot + i) % ring_slots.
-        join=False: the batch's stream is not held back; order consumers with wait_partitions()"""
-        self._chk(self.lib.pdb_step_ring(self.h, C.c_float(SIM_DT), n_ticks, C.c_void_p(ring_ptr) if ring_ptr else None, ring_slots, first_slot, 1 if join else 0))
+        join=False: the batch's stream is not held back; order consumers with wait_partitions().  fork=False: the partitions do not wait for what is queued
+        on the batch's stream (the caller orders its dependencies on the partitions' streams itself)"""
+        self._chk(self.lib.pdb_step_ring(self.h, C.c_float(SIM_DT), n_ticks, C.c_void_p(ring_ptr) if ring_ptr else None, ring_slots, first_slot, (1 if join else 0) | (0 if fork else 2)))
 
     def wait_partitions(self, stream_ptr=None):
         """make a stream (default: the batch's) wait for every partition's last enqueued kernel"""

@@ -39,7 +39,7 @@ class TrajectoryGather:
     not rewritten before its previous gather has completed.  k = 1 is the plain per-tick gather.  On CPU tensors (gloo,
     tests) everything is synchronous and `write(t, block)` stands in for the kernel."""
 
-    def __init__(self, n_local, world, device, dist=None, k=8, force=False, producer_wait=None):
+    def __init__(self, n_local, world, device, dist=None, k=8, force=False, producer_wait=None, producer_streams=None):
         import torch
         self.dist, self.world, self.n_local, self.k = dist, world, n_local, max(1, int(k))
         self.active = (world > 1 or force) and dist is not None
@@ -49,17 +49,29 @@ class TrajectoryGather:
         self.overlap = self.active and self.cuda and dist.get_backend() == 'nccl'
         self.work = [None, None]
         self.last = None
+        self.producer_streams = producer_streams   # callable() -> the streams whose kernels fill the rings (free-running partitions): a ring's previous gather is then waited
+                                                   # for on THOSE streams, and the caller need not hold them back behind the current stream (pdb_step_ring with fork=False)
         self.producer_wait = producer_wait   # callable(stream_ptr): make that stream wait for the kernels that fill the rings when they
                                              # do not run on the current stream (free-running partitions: pdbatch.Batch.wait_partitions)
         if self.overlap:
-            self.comm = torch.cuda.Stream(device=device)
+            # the gather's stream.  With producers that run on streams of their own and are not held back behind the current stream (producer_streams), the
+            # current stream itself: it is otherwise idle, and one more stream would share a hardware queue with one of the producers' (four per process) --
+            # a 1 ms kernel on such a stream held a partition up for 1 ms per ring (measured with a sleep kernel: 66.4 -> 48.2 M)
+            self.comm = torch.cuda.current_stream(device) if producer_streams is not None else torch.cuda.Stream(device=device)
             self.e_full = torch.cuda.Event()
 
     def slot(self, t):
         """tensor [n_local, 26] the kernel of tick t must write (its data_ptr() goes to pdb_set_out_device)"""
         r = (t // self.k) & 1
         if self.overlap and t % self.k == 0 and self.work[r] is not None:
-            self.work[r].wait()            # current stream waits: this ring's previous gather still reads it
+            ps = self.producer_streams() if self.producer_streams is not None else None
+            if ps:
+                import torch
+                for st in ps:
+                    with torch.cuda.stream(st):
+                        self.work[r].wait()   # the producers' own streams wait: this ring's previous gather still reads it
+            else:
+                self.work[r].wait()            # current stream waits: this ring's previous gather still reads it
             self.work[r] = None
         return self.rings[r][t % self.k]
 
@@ -98,6 +110,8 @@ class TrajectoryGather:
                 if self.producer_wait is not None:
                     self.producer_wait(self.comm.cuda_stream)
                 self.work[r] = self.dist.all_gather_into_tensor(flat_out, flat_in, async_op=True)
+                if os.environ.get('PDB_EXP_COMM_SLEEP'):   # experiment: a long, CU-free kernel on the gather's stream (does a partition's stream share its hardware queue?)
+                    torch.cuda._sleep(int(os.environ['PDB_EXP_COMM_SLEEP']))
         elif self.cuda and self.dist.get_backend() == 'gloo':   # single-GPU test of the multi-rank path: through the host
             if self.producer_wait is not None:
                 self.producer_wait(None)   # the batch's (= current) stream waits for the ring's kernels before the copy to the host
