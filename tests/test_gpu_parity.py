@@ -291,6 +291,18 @@ def test_bench_multi_rank_path_on_one_gpu(built):
 
 
 @pytest.mark.gpu
+def test_ring_gather_holds_every_tick(built):
+    """the N > 1 headline path as far as one GPU allows (one-rank RCCL group): free-running partitions write k-tick trajectory rings in place, started
+    without waiting for the batch's stream; the all-gather of every full ring runs on the current stream, a ring's reuse is ordered on the partitions'
+    own streams -- every gathered ring equals the blocks a plain batch produces for those ticks, and the final records agree"""
+    import subprocess, socket
+    s = socket.socket(); s.bind(('127.0.0.1', 0)); port = s.getsockname()[1]; s.close()
+    r = subprocess.run([sys.executable, os.path.join(os.path.dirname(os.path.abspath(__file__)), '_ring_gather_gpu.py'), str(port)],
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+    assert r.returncode == 0 and 'RING_GATHER OK' in r.stdout, (r.stdout[-500:], r.stderr[-1500:])
+
+
+@pytest.mark.gpu
 def test_library_exchange_equals_plain_stepping(built):
     """pdb_comm_init / pdb_step_exchange_partition with one rank (two cannot share this box's GPU under RCCL): per partition and tick the learner's
     action rows in -- different every tick --, the partition's tick, its output rows out through the library's own RCCL communicators; every gathered
