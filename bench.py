@@ -77,6 +77,8 @@ class _Arr:   # zero-copy torch view of a library-owned device block
 
 
 def measure(args, world, rank, local_rank, dist, want_cpu=False):
+    if args.partitions is None:
+        args.partitions = 3 if world == 1 else 2
     """one configuration, measured by the contract's rule; returns the result dict on rank 0 (None elsewhere)"""
     import numpy as np
     import torch
@@ -475,8 +477,8 @@ def parser():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--part-loop-min', type=int, default=4096, help='per-tick policies: from this many cars up every partition runs its own closed loop on its own stream')
     ap.add_argument('--no-extra', action='store_true', help='skip the `extra` block (the other configs measured in the same run)')
-    ap.add_argument('--partitions', type=int, default=3, choices=[1, 2, 3, 4],
-                    help='free-running car ranges per GPU, one HIP stream each (pdb_set_partitions / pdb_step_ring; constant policy only -- a per-tick policy joins the ranges every tick); 1 = one launch per tick')
+    ap.add_argument('--partitions', type=int, default=None, choices=[1, 2, 3, 4],
+                    help='free-running car ranges per GPU, one HIP stream each (pdb_set_partitions / pdb_step_ring); 1 = one launch per tick.  Default: 3 on one rank; 2 with more ranks -- a process has four hardware queues, three partitions and the null stream use them up, and the process group\'s collective stream would then share one with a partition and hold it up for as long as a gather runs (tools/hwqueue_probe.py: 47 M against 69 M with a 1 ms kernel per ring on a fifth stream; with two partitions 63-67 M against 67 M)')
     ap.add_argument('--walls', action='store_true', help='touge workload: line both edges of the road with WALL surfaces (configs[4] shape: hull-vs-wall narrow phase next to the guard rails)')
     ap.add_argument('--spline-step', type=float, default=0.0, help='touge workload: metres between spline points (default 5 m = 891 points; 0.9 = 4.9 k points, the density of the reference tracks)')
     ap.add_argument('--no-body-contacts', action='store_true', help='diagnostic A/B: switch the collision pass off in the car block (never the bench line)')

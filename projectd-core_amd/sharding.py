@@ -111,7 +111,13 @@ class TrajectoryGather:
                     self.producer_wait(self.comm.cuda_stream)
                 self.work[r] = self.dist.all_gather_into_tensor(flat_out, flat_in, async_op=True)
                 if os.environ.get('PDB_EXP_COMM_SLEEP'):   # experiment: a long, CU-free kernel on the gather's stream (does a partition's stream share its hardware queue?)
-                    torch.cuda._sleep(int(os.environ['PDB_EXP_COMM_SLEEP']))
+                    if os.environ.get('PDB_EXP_LATE_STREAM'):   # ... or on a stream created now, as the process group's own collective stream is: after the partitions' streams
+                        if not hasattr(self, '_late'):
+                            self._late = torch.cuda.Stream(device=self.rings[0].device)
+                        with torch.cuda.stream(self._late):
+                            torch.cuda._sleep(int(os.environ['PDB_EXP_COMM_SLEEP']))
+                    else:
+                        torch.cuda._sleep(int(os.environ['PDB_EXP_COMM_SLEEP']))
         elif self.cuda and self.dist.get_backend() == 'gloo':   # single-GPU test of the multi-rank path: through the host
             if self.producer_wait is not None:
                 self.producer_wait(None)   # the batch's (= current) stream waits for the ring's kernels before the copy to the host

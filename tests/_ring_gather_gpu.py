@@ -42,7 +42,8 @@ def main():
         torch.cuda._sleep(1500000)     # the gather's stream is late (as a gather over xGMI is): the partitions run ahead and have to be held at the ring they would overwrite
         full = g.after_tick(t + k - 1)
         assert full is not None
-        got.append(full[0].clone())    # on the gather's stream, behind the gather: what it delivered for this ring
+        g.work[r & 1].wait()           # the current stream waits for this ring's collective (it runs on the process group's own stream) ...
+        got.append(full[0].clone())    # ... and takes what it delivered
     g.finish(); torch.cuda.synchronize()
     got = np.concatenate([x.cpu().numpy() for x in got], 0)
     ok = np.array_equal(got.view(np.uint32), ref.view(np.uint32))
