@@ -77,9 +77,9 @@ class _Arr:   # zero-copy torch view of a library-owned device block
 
 
 def measure(args, world, rank, local_rank, dist, want_cpu=False):
+    """one configuration, measured by the contract's rule; returns the result dict on rank 0 (None elsewhere)"""
     if args.partitions is None:
         args.partitions = 3 if world == 1 else 2
-    """one configuration, measured by the contract's rule; returns the result dict on rank 0 (None elsewhere)"""
     import numpy as np
     import torch
     import pdbatch, pdb_ctypes as pc, sharding
