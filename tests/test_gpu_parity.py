@@ -353,7 +353,7 @@ def test_bench_per_partition_exchange_with_two_ranks_on_one_gpu(built):
     lines = [l for l in r.stdout.splitlines() if l.startswith('{')]
     assert len(lines) == 1
     d = json.loads(lines[0])
-    assert d['n_gpus'] == 2 and d['value'] > 0 and d['config']['partitions'] == 3
+    assert d['n_gpus'] == 2 and d['value'] > 0 and d['config']['partitions'] == 2      # (two per GPU with more than one rank: bench.py --partitions)
     assert 'per partition and tick' in d['config']['collective'] and 'torch.distributed' in d['config']['collective']
 
 
