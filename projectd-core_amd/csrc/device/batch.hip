@@ -607,7 +607,7 @@ int pdb_set_partition_params(pdb_batch* b, int part, const pdb_car_params* param
     if (!params) {
         b->partHas[part] = false;
         if (b->graphExec) { (void)hipGraphExecDestroy(b->graphExec); b->graphExec = nullptr; }   // the captured launches carry the partitions' own blocks
-        return PDB_OK;
+        return pushK(b, b->stream, false);   // the partition's constants block goes back to the batch's values
     }
     const pdb_car_params& A = b->params;
     bool same = params->numBodies == A.numBodies && params->numJoints == A.numJoints && params->numRows == A.numRows;

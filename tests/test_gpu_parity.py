@@ -604,6 +604,25 @@ def test_partitions_with_their_own_car_blocks(built):
                         orc.cpuref_set_state(hs[i], C.byref(sc))
         diff = sum(1 for i in range(f1, f1 + c1) if sg[i].totalReward != sg[i - f1].totalReward)
         assert diff > c1 // 2      # the second partition really drives something else
+        # back to the batch's block (the cached graph of pdb_step_n, and -- since every partition has its own constants block -- that block too):
+        # from one common state both halves now step alike, through the graph, the ring and a partition call
+        b.set_partition_params(1, None)
+        st = b.get_state()
+        for i in range(n):
+            C.memmove(C.byref(st[i]), C.byref(st[i % f1]), C.sizeof(S0))
+        b.set_state(st)
+        b.step(ticks - 40 - 60)                      # same n and dt as the graph captured above
+        b.step_ring(30, None, 1, 0, join=True)
+        b.sync()
+        sg = b.get_state()
+        for i in range(f1, f1 + c1):
+            j = i % f1
+            assert acts[i, 0] != acts[j, 0] or bytes(sg[i]) == bytes(sg[j])
+        b.upload_actions(np.tile(acts[:f1], (2, 1))[:n])
+        b.set_state(st)
+        b.step(ticks - 40 - 60); b.step_ring(30, None, 1, 0, join=True); b.sync()
+        sg = b.get_state()
+        assert all(bytes(sg[i]) == bytes(sg[i % f1]) for i in range(f1, f1 + c1))
         for h in hs:
             orc.cpuref_destroy(h)
     finally:
