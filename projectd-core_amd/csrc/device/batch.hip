@@ -768,6 +768,7 @@ int pdb_set_partitions(pdb_batch* b, int parts) {
     }
     if (!b->partFork) HIPCHK(hipEventCreateWithFlags(&b->partFork, hipEventDisableTiming));
     if (b->graphExec) { (void)hipGraphExecDestroy(b->graphExec); b->graphExec = nullptr; }   // captured launches follow the old cut
+    if (parts != b->parts) commFree(b);   // the partitions' communicators belong to the old cut (pdb_comm_init again)
     b->parts = parts;
     if (parts > 1) for (int p = 0; p < parts; ++p) if (!b->dPartK[p]) HIPCHK(hipMalloc(&b->dPartK[p], sizeof(DevConst)));
     return pushK(b, b->stream, false);   // the partitions' constants blocks: the per-car tables start at each partition's first car
@@ -1027,9 +1028,9 @@ int pdb_step_host_held(pdb_batch* b, const float* actions, float dt, const uint8
     b->K.holdMask = b->dHold;
     if (int rck = pushK(b, b->stream, false)) return rck;
     int rc = launch(b, dt, true);
-    if (rc == PDB_OK && out) HIPCHK(hipMemcpyAsync(out, b->dOutActive, sizeof(pdb_step_out) * (size_t)b->n, hipMemcpyDeviceToHost, b->stream));
-    HIPCHK(hipStreamSynchronize(b->stream));   // ... and off again
-    b->K.holdMask = nullptr;
+    if (rc == PDB_OK && out && hipMemcpyAsync(out, b->dOutActive, sizeof(pdb_step_out) * (size_t)b->n, hipMemcpyDeviceToHost, b->stream) != hipSuccess) { pdb::setError("pdb_step_host_held: output copy failed"); rc = PDB_ERR_HIP; }
+    if (hipStreamSynchronize(b->stream) != hipSuccess && rc == PDB_OK) { pdb::setError("pdb_step_host_held: the held step failed on the device"); rc = PDB_ERR_HIP; }
+    b->K.holdMask = nullptr;                   // ... and off again, whatever happened in between
     if (int rck = pushK(b, b->stream, false)) return rck;
     return rc;
 }
