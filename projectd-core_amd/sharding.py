@@ -29,6 +29,17 @@ def global_actions(n_global, seed, lo=-0.3, hi=0.3):
     return a
 
 
+class _StreamEvent:
+    """what TrajectoryGather keeps of a collective it enqueued on a stream of its choosing: an event behind it; wait() = the caller's current stream waits for it"""
+    def __init__(self, stream):
+        import torch
+        self.e = torch.cuda.Event(); self.e.record(stream)
+
+    def wait(self):
+        import torch
+        torch.cuda.current_stream().wait_event(self.e)
+
+
 class TrajectoryGather:
     """Learner-side exchange of the per-tick output blocks ("per tick (or per k-tick macro-step)").
 
@@ -109,7 +120,15 @@ class TrajectoryGather:
                 self.comm.wait_event(self.e_full)
                 if self.producer_wait is not None:
                     self.producer_wait(self.comm.cuda_stream)
-                self.work[r] = self.dist.all_gather_into_tensor(flat_out, flat_in, async_op=True)
+                if self.producer_streams is not None and not os.environ.get('PDB_GATHER_ASYNC'):
+                    # the "synchronous" form: torch then enqueues the collective on the CURRENT stream (here the otherwise idle one the producers no longer
+                    # wait for) instead of the process group's own side stream, which with three partitions shares a hardware queue with one of them --
+                    # one rank, 4096 cars: 67.7 M against 65.5 M with 32-tick rings, 66.4 against 57.4 M with 8-tick rings (no gather at all: 68.6 M).
+                    # Nothing blocks on the host; completion is an event of our own on that stream
+                    self.dist.all_gather_into_tensor(flat_out, flat_in, async_op=False)
+                    self.work[r] = _StreamEvent(self.comm)
+                else:
+                    self.work[r] = self.dist.all_gather_into_tensor(flat_out, flat_in, async_op=True)
                 if os.environ.get('PDB_EXP_COMM_SLEEP'):   # experiment: a long, CU-free kernel on the gather's stream (does a partition's stream share its hardware queue?)
                     if os.environ.get('PDB_EXP_LATE_STREAM'):   # ... or on a stream created now, as the process group's own collective stream is: after the partitions' streams
                         if not hasattr(self, '_late'):
