@@ -205,7 +205,7 @@ def measure(args, world, rank, local_rank, dist, want_cpu=False):
     if use_ring and not args.ring_fork:   # the gather orders a ring's reuse on the partitions' own streams: the rings then start without waiting for the batch's stream
         ring_streams.extend(torch.cuda.ExternalStream(b.partition_stream(p), device=dev) for p in range(args.partitions))
     lib_exchange = False
-    part_graph = None
+    part_graph = None; part_graph_whole = False
     if part_exchange:
         part_st = [torch.cuda.ExternalStream(b.partition_stream(p), device=dev) for p in range(args.partitions)]
         part_rng = [b.partition_range(p) for p in range(args.partitions)]
@@ -235,20 +235,26 @@ def measure(args, world, rank, local_rank, dist, want_cpu=False):
         part_graph = None
         if not args.no_graph_policy and policy in ('feedback', 'mlp') and n < 8192:   # (measured: 4096 cars 45.0 -> 46.5 M with the env loop, 32.5 -> 35.6 M reset-free; at 16384 cars the loop is GPU-bound and the graph loses: 47.4 against 52.2 M)
             try:
-                for p in range(args.partitions):   # (first use of the library's GEMM kernels outside a capture)
+                for p in range(args.partitions):   # (first use of the library's GEMM kernels, of the partition's launch path and its buffers outside a capture)
                     f, c = part_rng[p]
                     with torch.cuda.stream(part_st[p]):
+                        b.step_partition(p, out_t.data_ptr())
                         policy_step(out_t[f:f + c], act_t[f:f + c], 0, f)
                 torch.cuda.synchronize()
                 act_t.copy_(torch.from_numpy(actions).to(dev)); torch.cuda.synchronize()
                 gs = []
+                whole = not args.graph_policy_only
+                if whole:   # the partition's tick itself goes into the graph too (two more launches): the contact pass's grid is then fixed
+                    b.set_contact_grid(args.graph_contact_grid)
                 for p in range(args.partitions):
                     f, c = part_rng[p]
                     g = torch.cuda.CUDAGraph()
                     with torch.cuda.graph(g, stream=part_st[p]):
+                        if whole:
+                            b.step_partition(p, out_t.data_ptr())
                         policy_step(out_t[f:f + c], act_t[f:f + c], 0, f)
                     gs.append(g)
-                part_graph = gs
+                part_graph = gs; part_graph_whole = whole
             except Exception as e:
                 sys.stderr.write('bench: the policy could not be captured (%r): plain launches\n' % (e,))
                 part_graph = None
@@ -290,7 +296,8 @@ def measure(args, world, rank, local_rank, dist, want_cpu=False):
                 f, c = part_rng[p]
                 with torch.cuda.stream(part_st[p]):
                     if part_graph is not None:
-                        b.step_partition(p, out_t.data_ptr())
+                        if not part_graph_whole:
+                            b.step_partition(p, out_t.data_ptr())
                         part_graph[p].replay()
                     else:
                         b.step_partition(p, o.data_ptr())
@@ -490,6 +497,8 @@ def parser():
     ap.add_argument('--gather-ticks', type=int, default=32, help='ticks per trajectory ring gathered to the learner (N > 1): 1 = plain per-tick gather')
     ap.add_argument('--scatter-actions', action='store_true', help='with a gather: rank 0 scatters the [N,2] action block back every tick (configs[3] as SURVEY 8d words it)')
     ap.add_argument('--library-exchange', action='store_true', help='N > 1: the per-partition exchange through the library\'s own RCCL communicators (pdb_step_exchange_partition); default with one rank, opt-in with more')
+    ap.add_argument('--graph-policy-only', action='store_true', help='per-partition loops below 8192 cars: only the policy in the captured graph, the tick as plain launches (A/B)')
+    ap.add_argument('--graph-contact-grid', type=int, default=32, help='workgroups of the contact pass inside a captured per-partition tick')
     ap.add_argument('--no-graph-policy', action='store_true', help='per-partition policy loops: the policy as plain torch launches instead of one captured graph per partition (A/B)')
     ap.add_argument('--ring-fork', action='store_true', help='ring mode: every ring starts behind the batch stream (the older form; A/B)')
     ap.add_argument('--torch-exchange', action='store_true', help='the per-partition exchange (--scatter-actions with --gather-ticks 1) through torch.distributed instead of the library\'s own RCCL communicators (A/B)')

@@ -142,6 +142,10 @@ int pdb_set_partitions(pdb_batch* b, int parts);
 /* diagnostic: how many cars the most recent contact pass of a launch site held (site = partition index, 4 = the batch's own
  * stream); read without waiting for anything, so it lags the launches still in flight */
 int pdb_contact_pass_load(pdb_batch* b, int site);
+/* The contact pass's grid (workgroups per launch): 0 = follow the load (the default: the host sizes every launch from the number of cars the last passes
+ * held); > 0 = fixed -- for a caller that records the launches of pdb_step_partition into a graph of its own (a captured grid cannot follow the load; a
+ * pass with fewer workgroups than queued car groups takes them in turn) */
+int pdb_set_contact_grid(pdb_batch* b, int workgroups);
 /* A car block of its own for one partition (NULL: back to the batch's): same car model and rigid-body topology, different tunes,
  * assists, scoring weights, auto-teleport -- what the reference gives every simulator separately (PyProjectD.cpp:328-365) --
  * e.g. to randomise the setup over the cars of a batch.  The partition's cars step, reset and teleport with it, through every

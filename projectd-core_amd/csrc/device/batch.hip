@@ -755,6 +755,12 @@ int pdb_contact_pass_load(pdb_batch* b, int site) {
     if (!b || site < 0 || site > PDB_MAX_PARTS || !b->hHint) return -1;
     return *(volatile int*)(b->hHint + site);
 }
+int pdb_set_contact_grid(pdb_batch* b, int workgroups) {
+    if (!b || workgroups < 0 || workgroups > 2048) { pdb::setError("pdb_set_contact_grid: 0 (adaptive) .. 2048 workgroups"); return PDB_ERR_ARG; }
+    b->contactGrid = workgroups;
+    if (b->graphExec) { (void)hipGraphExecDestroy(b->graphExec); b->graphExec = nullptr; }
+    return PDB_OK;
+}
 int pdb_set_partitions(pdb_batch* b, int parts) {
     if (!b || parts < 1 || parts > PDB_MAX_PARTS) { pdb::setError("pdb_set_partitions: 1..4 parts"); return PDB_ERR_ARG; }
     HIPCHK(hipSetDevice(b->device));

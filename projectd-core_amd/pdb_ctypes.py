@@ -184,6 +184,8 @@ def load_product(host_only=False):
         lib.pdb_set_seed.argtypes = [C.c_void_p, C.c_void_p]
         lib.pdb_set_env.argtypes = [C.c_void_p, C.c_void_p]
         lib.pdb_set_partition_params.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+        if hasattr(lib, 'pdb_set_contact_grid'):
+            lib.pdb_set_contact_grid.argtypes = [C.c_void_p, C.c_int]
         if hasattr(lib, 'pdb_set_lane_tunes'):
             lib.pdb_set_lane_tunes.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]
         lib.pdb_actions_device.restype = C.c_void_p; lib.pdb_actions_device.argtypes = [C.c_void_p]

@@ -200,6 +200,10 @@ class Batch:
         """device array of n bytes: a car whose byte is 1 + mode is teleported at the top of its next tick, which clears the byte"""
         return self.lib.pdb_reset_mask_device(self.h)
 
+    def set_contact_grid(self, workgroups):
+        """0 = the contact pass's grid follows the load (default); > 0 = fixed (for launches recorded into a caller's graph)"""
+        self._chk(self.lib.pdb_set_contact_grid(self.h, int(workgroups)))
+
     def set_lane_tunes(self, blocks, first=0):
         """per-lane setup and reward weights (PyProjectD.cpp:328-365 is per simulator = per env): lane first + i takes the eight env tunes
         (FRONT_BIAS, DIFF_POWER, DIFF_COAST, FINAL_RATIO, PRESSURE_*) and the scoring variables of blocks[i], a pdb_car_params that went
