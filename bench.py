@@ -363,7 +363,8 @@ def measure(args, world, rank, local_rank, dist, want_cpu=False):
         fence()
         elapsed = sharding.max_over_ranks(time.perf_counter() - t0, dev, dist, world)
         region_ms = b.event_elapsed_ms()
-        part = b.partition_elapsed_ms(0) if split else (None, n)
+        # (a partition's whole tick replayed from a graph never passes the library's event marks: the wall time of the region stands in for them)
+        part = b.partition_elapsed_ms(0) if (split and not part_graph_whole) else ((elapsed * 1000.0, b.partition_range(0)[1]) if split else (None, n))
         regions.append((elapsed, region_ms, part[0], part[1]))
         total += elapsed
         if regions[0][0] >= 0.2 or total >= 0.25 or len(regions) >= 400:   # the same decision on every rank (max-over-ranks times)
