@@ -6,8 +6,9 @@ line() { lib=$1; shift; label=$1; shift; if [ -n "$lib" ]; then export PDB_LIB=$
 S="--steps 300 --warmup 50 --settle 200"
 for v in "$@" ""; do n=${v:-in-tree}
   line "$v" "$n, playground 16384 mlp" --workload playground --cars 16384 --policy mlp $S
-  line "$v" "$n, playground 16384 episodes" --workload playground --cars 16384 --episodes $S
+  line "$v" "$n, nordring 16384 mlp" --workload nordring --cars 16384 --policy mlp $S
   line "$v" "$n, driftplayground 16384 mlp episodes" --workload driftplayground --cars 16384 --policy mlp --episodes --teleport-mode 2 $S
   line "$v" "$n, walled road 4096 reset-free" --workload touge --walls --cars 4096 --policy feedback --steps 600 --warmup 100 --settle 200
-  line "$v" "$n, walled road 16384 reset-free" --workload touge --walls --cars 16384 --policy feedback $S
+  line "$v" "$n, walled road 4096 mlp" --workload touge --walls --cars 4096 --policy mlp --steps 600 --warmup 100 --settle 200
+  line "$v" "$n, walled road 16384 mlp" --workload touge --walls --cars 16384 --policy mlp $S
 done
