@@ -32,6 +32,10 @@ def test_first_pass_kernels_keep_six_workgroups_per_cu():
     for name in ('pdb_contact_kernel', 'pdb_contact_kernel_generic', 'pdb_contact_kernel_wide', 'pdb_contact_kernel_ctrl'):
         assert k[name]['vgprs'] <= 256 and k[name]['occupancy'] >= 2, (name, k[name])
         assert k[name]['lds'] <= 65536 and k[name]['scratch'] <= 128, (name, k[name])
+    # the pass's idle launch (every tick of a contact-free workload) has to find a CU with room: beside four first-pass workgroups (4 x 26880 bytes
+    # allocated) 56320 bytes of LDS are left -- at 58760 the bench line lost 2.3 % (round 4) without any test noticing
+    for name in ('pdb_contact_kernel', 'pdb_contact_kernel_generic'):
+        assert k[name]['lds'] <= 56320, (name, k[name])
     # scratch of the first pass: the cold teleport block's frame (round 2: 72 bytes).  A hot-path spill shows up as a larger frame first.
     for name in ('pdb_step_kernel', 'pdb_step_kernel_generic'):
         assert k[name]['scratch'] <= 96, (name, k[name])
