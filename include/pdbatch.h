@@ -137,7 +137,11 @@ int pdb_set_out_device(pdb_batch* b, pdb_step_out* out);
  * writes, resets, plain steps, pdb_sync) order themselves after the parts' kernels in flight.  Tick i writes its outputs to ring + ((first_slot + i) % ring_slots) * n_cars; ring == NULL: the active
  * output block, every tick.  With one part this is n_ticks plain launches on the batch's stream.  Results do not depend on
  * the partitioning.  pdb_partition_mark / pdb_partition_elapsed_ms: HIP-event time of one part's kernels between the mark
- * and the last pdb_step_ring (synchronises on that part), and the number of cars in the part. */
+ * and the last pdb_step_ring (synchronises on that part), and the number of cars in the part.
+ * Streams: a process has four hardware queues and its null stream holds one; kernels of two streams that share a queue run one after the other.
+ * While the batch runs on the library's own stream (no pdb_set_stream), part 0 runs on that stream, so that three parts are three streams of the
+ * library's; after pdb_set_stream every part has a stream of its own (the caller's stream + three parts: keep other streams of the process idle
+ * while they step, or use two parts -- DESIGN.md section 7). */
 int pdb_set_partitions(pdb_batch* b, int parts);
 /* diagnostic: how many cars the most recent contact pass of a launch site held (site = partition index, 4 = the batch's own
  * stream); read without waiting for anything, so it lags the launches still in flight */
