@@ -6,22 +6,26 @@
     plainly: without WORLD_SIZE in the environment bench.py starts its own N rank processes (before anything touches a GPU),
     one per GPU, rendezvous on 127.0.0.1, and relays rank 0's JSON line.
 
-One "step" = one physics tick (dt = 1/333 s) of every car resident on the GPU = one launch of the HIP step kernel per car range.
-Workload = BASELINE.json configs[1]: 4096 AE86 cars per GPU on the synthetic flat-plane track, per-car constant random
-actions (steer ~ U(-0.3,0.3), a1 ~ U(-1,1), numpy RandomState(1234) indexed by GLOBAL car id).  State, actions and
-outputs are resident in HBM before the timed region; the cars have settled on their springs and are driving (--settle ticks
-of state preparation, outside warm-up and timing).  On each GPU the cars step as --partitions free-running ranges (one HIP
-stream each: cars are independent, the ranges' kernels overlap).  Multi-GPU: cars are sharded contiguously (weak scaling,
-4096 per GPU); the only collective is the RCCL all-gather of k-tick trajectory rings of the [N,26] observation/reward/flag
-block to the learner, on a side stream.
+One "step" = one physics tick (dt = 1/333 s) of every car resident on the GPU = one launch of the HIP step kernel per car range
+(+ the contact pass behind it).
+Workload (no --workload given) = BASELINE.json configs[2] as SURVEY 8d words it, the largest single-GPU configuration: 16384 AE86
+cars per GPU on the reference's ek_akina spline (road ribbon around it), scripted inputs evaluated on the GPU every tick from the
+observation rows (gas = 0.6 + 0.4 sin(2 pi t / 7 s + phi_i), phi_i from seed 2345 by GLOBAL car id; P-steer on lookAhead[0] + the side
+probes), env loop inside the kernel (a car that leaves the road is put back at a random point of the lap).  `secondary` in the same
+line = configs[1] (4096 cars, flat plane, per-car constant random actions from RandomState(1234) by global car id), measured by the
+same rule in the same process; `cpu_baseline` is timed on configs[1]'s inputs.  State, actions and outputs
+are resident in HBM before the timed region.  On each GPU the cars step as --partitions free-running ranges (one HIP stream each:
+cars are independent, each range runs its own kernel -> contact pass -> policy loop).  Multi-GPU: cars are sharded contiguously (weak
+scaling, the same cars per GPU); the only collective is the RCCL all-gather of k-tick trajectory rings of the [N,26]
+observation/reward/flag block to the learner.
 
 Timing: W untimed warm-up steps, then EXACTLY K timed steps between barrier + synchronize on both sides, max over ranks.  A
 region shorter than 0.2 s is repeated (same K steps each time, same bracketing) until 0.25 s of timed work has accumulated;
 `ms_per_step` / `value` are then the median region's, `repeats` and `timed_region_s` say what was measured.
 
-Prints ONE JSON line on rank 0; at N = 1 it also carries `cpu_baseline` and an `extra` block: the other BASELINE configs'
-shapes measured the same way in the same process (16384 cars on the dense mountain-road spline, guard rails + MLP policy,
-the 8192-car shard of configs[3], per-tick gather + action scatter, episodes with terminations and resets).
+Rank 0 prints ONE compact JSON line (< 2 KB) on stdout, as soon as the headline and `secondary` are measured.  --extra (or
+PDB_BENCH_EXTRA=key,key) then measures the other configs' shapes the same way; those results go to stderr and to
+gpurun_out/bench_extra.json, never into the line.
 """
 import argparse, ctypes as C, json, os, socket, subprocess, sys, time
 
@@ -33,7 +37,9 @@ CARS_PER_GPU = 4096
 # algorithmic bytes per car-tick (DESIGN.md "Algorithmic bytes"): record read + record write + action + output row
 B_ALG = 2352 + 2352 + 8 + 104   # sizeof(pdb_dyn_state) in and out, float[2] action, pdb_step_out (checked against the ctypes mirrors in measure)
 HBM_PEAK_GBS = 8000.0
-PROFILE_TAG = 'r04'
+PROFILE_TAG = 'r05'
+HEADLINE = dict(workload='ek_akina', cars=16384, policy='scripted', episodes=True, teleport_mode=2, settle=200)   # BASELINE configs[2] as worded
+SECONDARY_ARGV = ['--workload', 'flat', '--cars', '4096']   # BASELINE configs[1]
 
 
 def cpu_baseline(P, trk, S0, actions, seconds_target=15.0):
@@ -200,7 +206,9 @@ def measure(args, world, rank, local_rank, dist, want_cpu=False):
     use_ring = policy == 'constant' and args.partitions > 1 and not do_scatter
     # a per-tick policy: per-partition closed loops, unless a gather has to see whole ticks (N > 1)
     # and only where a tick is long enough to hide the doubled number of (small) policy launches: the host enqueues ~10 per partition and tick
-    part_loops = policy not in ('constant', 'host', 'host_sync', 'host_mlp') and args.partitions > 1 and not gather.active and n >= args.part_loop_min
+    # (N > 1: the partitions' kernels write their rows of the trajectory ring's slot; a ring's gather waits for every partition's last kernel of
+    #  that ring and a ring's reuse is ordered on the partitions' own streams -- the same scheme as the open-loop rings)
+    part_loops = policy not in ('constant', 'host', 'host_sync', 'host_mlp') and args.partitions > 1 and n >= args.part_loop_min and not do_scatter
     host_pipe = policy in ('host', 'host_mlp') and args.partitions > 1
     # configs[3] as worded (a gather and an action scatter EVERY tick) over free-running partitions: one set of collectives per partition
     part_exchange = do_scatter and args.partitions > 1 and policy == 'constant' and n >= args.part_loop_min and (dist is not None)
@@ -238,7 +246,9 @@ def measure(args, world, rank, local_rank, dist, want_cpu=False):
         # dispatches + six kernel launches per 60-100 us tick).  The kernels then write the library's own output block (a fixed address, which the graph holds)
         # instead of the trajectory ring.  The scripted law reads the tick number: it stays uncaptured.
         part_graph = None
-        if not args.no_graph_policy and policy in ('feedback', 'mlp') and n < 8192:   # (measured: 4096 cars 45.0 -> 46.5 M with the env loop, 32.5 -> 35.6 M reset-free; at 16384 cars the loop is GPU-bound and the graph loses: 47.4 against 52.2 M)
+        if gather.active and not args.ring_fork:
+            ring_streams.extend(part_st)
+        if not args.no_graph_policy and policy in ('feedback', 'mlp') and n < 8192 and not gather.active:   # (measured: 4096 cars 45.0 -> 46.5 M with the env loop, 32.5 -> 35.6 M reset-free; at 16384 cars the loop is GPU-bound and the graph loses: 47.4 against 52.2 M)
             try:
                 for p in range(args.partitions):   # (first use of the library's GEMM kernels, of the partition's launch path and its buffers outside a capture)
                     f, c = part_rng[p]
@@ -307,6 +317,7 @@ def measure(args, world, rank, local_rank, dist, want_cpu=False):
                     else:
                         b.step_partition(p, o.data_ptr())
                         policy_step(o[f:f + c], act_t[f:f + c], t, f)
+            gather.after_tick(t)
             return
         if do_scatter:
             act_t.copy_(sharding.scatter_actions(scatter_src, n, world, rank, dev, dist))
@@ -355,6 +366,12 @@ def measure(args, world, rank, local_rank, dist, want_cpu=False):
 
     regions = []          # (wall seconds (max over ranks), event ms on the batch stream, partition-0 event ms, cars per launch)
     total = 0.0
+    # the dominant kernel's own duration, live: HIP events around every k-th first-pass launch of every launch site, on the stream it is launched on
+    sample_every = max(4, args.steps // 16)
+    can_sample = hasattr(lib, 'pdb_sample_kernel') and not (part_loops and part_graph is not None and part_graph_whole)   # (launches replayed from a graph pass no event)
+    k_us = 0.0; k_n = 0; k_cars = 0.0
+    if can_sample:
+        b.sample_kernel(sample_every)
     while True:
         b.event_record(0)
         if split:
@@ -372,50 +389,55 @@ def measure(args, world, rank, local_rank, dist, want_cpu=False):
         part = b.partition_elapsed_ms(0) if (split and not part_graph_whole) else ((elapsed * 1000.0, b.partition_range(0)[1]) if split else (None, n))
         regions.append((elapsed, region_ms, part[0], part[1]))
         total += elapsed
+        if can_sample:
+            us, cnt, cars = b.sampled_kernel_us()
+            k_us += us * cnt; k_n += cnt; k_cars += cars * cnt
         if regions[0][0] >= 0.2 or total >= 0.25 or len(regions) >= 400:   # the same decision on every rank (max-over-ranks times)
             break
+    if can_sample:
+        b.sample_kernel(0)
     regions.sort(key=lambda r: r[0])
     elapsed, region_ms, part_ms, launch_cars = regions[len(regions) // 2]
 
     res = None
     if rank == 0:
         traffic = None; valu_busy = None; prof = None
-        for tag in (PROFILE_TAG, 'r01'):
+        for tag in (PROFILE_TAG, 'r04'):
             try:   # memory-side bytes per launch from the committed PMC passes of this same command (profiles/, tools/profile_round.sh)
                 pm = json.load(open(os.path.join(ROOT, 'profiles', tag + '_pmc.json')))
                 pc_cfg = pm.get('bench', {}).get('config', {})
-                if args.workload == 'flat' and n == CARS_PER_GPU and pc_cfg.get('cars_per_gpu') == n and pc_cfg.get('partitions', 1) == (args.partitions if split else 1):
+                if pc_cfg.get('cars_per_gpu') == n and pc_cfg.get('partitions', 1) == (args.partitions if split else 1) and pm.get('workload_key', 'flat') == args.workload:
                     traffic = pm.get('traffic_bytes_per_launch'); valu_busy = pm.get('valu_issue_busy_frac', pm.get('valu_busy_frac_approx')); prof = tag
                     break
             except Exception:
                 continue
         conc = 1
-        kernel_us = region_ms * 1000.0 / args.steps          # HIP events on the kernel's stream around the timed region
-        if split:   # one launch = one partition's cars; HIP events on that partition's own stream
-            kernel_us = part_ms * 1000.0 / args.steps
+        tick_us = region_ms * 1000.0 / args.steps          # HIP events on the batch's stream around the timed region: one whole tick of the launch site
+        if split:   # one launch = one partition's cars; HIP events on that partition's own stream (its whole loop: first pass, contact pass, policy)
+            tick_us = part_ms * 1000.0 / args.steps
             conc = args.partitions
         else:
             launch_cars = n
+        if k_n > 0:   # the first pass's own duration from the sampled launches' events
+            kernel_us = k_us / k_n; launch_cars = k_cars / k_n; k_src = "HIP events around %d sampled pdb_step_kernel launches (every %d-th, on their own streams) inside the timed regions" % (k_n, sample_every)
+        else:
+            kernel_us = tick_us; k_src = "HIP events around the launch site's whole ticks (first pass + contact pass + gaps)"
         achieved = B_ALG * launch_cars / (kernel_us * 1e-6) / 1e9
         hdr = pc.TrackHeader.from_buffer_copy(trk[:C.sizeof(pc.TrackHeader)])
-        wl = ("configs[4] shape: %d cars/GPU, AE86, %s (%d surfaces, %d triangles, %d spline points, %.1f MB track blob), policy=%s, dt=1/333 s" %
-              (n, {'playground': "synthetic paddock of the reference's driftplayground scale: barriers, tyre stacks, cones, islands as separate WALL meshes",
-                   'nordring': "synthetic open ribbon of the reference's ks_nordschleife scale with guard rails"}[args.workload],
-               hdr.numSurfaces, hdr.numTris, hdr.numFat, len(trk) / 1e6, policy)) if args.workload in ('playground', 'nordring') else \
-             ("%s: %d cars/GPU, AE86, the reference's %s (%d surfaces, %d triangles, %d spline points, %.1f MB track blob), policy=%s, dt=1/333 s" %
-              ("configs[2]" if args.workload == 'ek_akina' else "configs[4]", n,
-               {'ek_akina': "ek_akina spline (shipped) with the road generated around it as a ribbon (its surfaces.bin is a missing blob)",
-                'ks_nordschleife': "ks_nordschleife spline (shipped) with the road generated around it as a ribbon",
-                'ks_nordschleife_walls': "ks_nordschleife spline (shipped) with the road and guard rails (WALL surfaces) generated around it"}.get(args.workload, args.workload + " as shipped (surfaces.bin, spline.bin, spline.cache)"),
-               hdr.numSurfaces, hdr.numTris, hdr.numFat, len(trk) / 1e6,
-               {'host': "probe-feedback law in numpy on the HOST, pipelined over the partitions (actions up / observations down every tick)",
-                'host_mlp': "SAC-sized 24-256-256-2 MLP with fixed random weights evaluated by torch on the HOST's cores, pipelined over the partitions (actions up / observations down every tick)",
-                'scripted': "gas = 0.6 + 0.4 sin(2 pi t / 7 s + phi_i), P-steer on lookAhead[0] + side probes, on the GPU"}.get(policy, policy))) if is_ref else \
-             ("configs[1]: %d cars/GPU, AE86, flat-plane track, %s, dt=1/333 s" % (n, "per-car constant random actions" if policy == "constant" else "policy=" + policy)) if args.workload == 'flat' else \
-             ("configs[2] shape: %d cars/GPU, AE86, synthetic closed mountain road (%s%s), policy=%s on the GPU, dt=1/333 s" %
-              (n, "spline point every %.1f m" % args.spline_step if args.spline_step else "1782 triangles, 891 spline points", ", guard rails (WALL surfaces) along both edges" if args.walls else "", policy))
-        if args.episodes:
-            wl += "; episodes: the env's rewards, terminations (hit / off track / stuck / low reward) and reset ticks inside the step kernel (pdb_set_env)"
+        pol = {'constant': "per-car constant random actions", 'scripted': "scripted gas 0.6+0.4sin(2pi t/7s+phi_i) + P-steer, on the GPU every tick", 'feedback': "probe-feedback law on the GPU",
+               'mlp': "24-256-256-2 MLP on the GPU", 'host': "probe-feedback law on the HOST, pipelined", 'host_sync': "probe-feedback law on the HOST, synchronous",
+               'host_mlp': "24-256-256-2 MLP on the HOST, pipelined", 'random': "fresh random actions every tick"}[policy]
+        where = ("reference %s spline (%d pts) as a road ribbon" % (args.workload, hdr.numFat)) if args.workload in ('ek_akina', 'ks_nordschleife') else \
+                ("reference ks_nordschleife spline (%d pts) as a ribbon with guard rails" % hdr.numFat) if args.workload == 'ks_nordschleife_walls' else \
+                ("reference track %s (%d triangles)" % (args.workload, hdr.numTris)) if is_ref else \
+                "flat-plane track" if args.workload == 'flat' else \
+                ("synthetic %s (%d triangles, %d spline pts%s)" % (args.workload, hdr.numTris, hdr.numFat, ", guard rails" if args.walls else ""))
+        tag = {'flat': "configs[1]", 'ek_akina': "configs[2]", 'touge': "configs[2] shape"}.get(args.workload, "configs[4] shape")
+        wl = "%s: %d cars/GPU, AE86, %s, %s%s, dt=1/333 s" % (tag, n, where, pol, ", env loop in the kernel (random-point resets)" if args.episodes and args.teleport_mode == 2 else ", env loop in the kernel" if args.episodes else "")
+        coll = "none"
+        if world > 1 or args.force_gather:
+            coll = ("per partition and tick: action scatter from rank 0 -> tick -> RCCL all-gather of its [n,26] rows, issued by %s" % ("the library" if lib_exchange else "torch.distributed")) if part_exchange else \
+                   ("RCCL all-gather of %d-tick trajectory rings [k,N,26] on the idle current stream, kernels write the ring in place%s" % (args.gather_ticks, "; actions scattered from rank 0 every tick" if args.scatter_actions else ""))
         res = {
             "metric": "env-steps/sec (333 Hz tick, 4-wheel car)",
             "value": n * world * args.steps / elapsed,
@@ -425,17 +447,13 @@ def measure(args, world, rank, local_rank, dist, want_cpu=False):
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32 (+f64 drivetrain)", "data": "synthetic",
             "repeats": len(regions), "timed_region_s": total,
-            "config": {"workload": wl, "cars_per_gpu": n, "partitions": (args.partitions if split else 1), "settle_ticks": args.settle,
-                       "collective": (("per partition and tick, on the partition's own stream and RCCL communicator: scatter of its [n,2] action rows from rank 0 -> tick -> all-gather of its [n,26] output rows (the partitions are never joined); issued by %s" % ("the library (pdb_step_exchange_partition: three enqueues from C per partition and tick)" if lib_exchange else "torch.distributed (six calls per tick)")) if part_exchange else
-                                      "RCCL all-gather of %d-tick trajectory rings [k,N,26] obs/reward/flags on a side stream, kernel writes the ring in place%s" %
-                                      (args.gather_ticks, "; actions scattered from rank 0 every tick" if args.scatter_actions else "")) if (world > 1 or args.force_gather) else "none",
-                       "parity": "bit-exact vs CPU oracle (tests/, -m gpu); rigid-body solver and contact generation unpinned (ODE absent from the reference tree)"},
+            "config": {"workload": wl, "cars_per_gpu": n, "partitions": (args.partitions if split else 1), "settle_ticks": args.settle, "collective": coll,
+                       "parity": "GPU bit-exact vs CPU oracle; oracle bit-exact vs reference-TU goldens; rigid-body solve + contact generation unpinned (ODE absent)"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": traffic, "traffic_source": ("profiles/%s_pmc.json: (2*FETCH_SIZE + WRITE_SIZE)*1024 per launch, rocprofv3 --pmc passes of this command" % prof if traffic else None),
-                         "kernel": "pdb_step_kernel", "kernel_avg_us": kernel_us, "alg_bytes_per_car_tick": B_ALG, "cars_per_launch": launch_cars,
-                         "concurrent_launches": conc, "device_achieved": B_ALG * n * args.steps / elapsed / 1e9, "device_frac": B_ALG * n * args.steps / elapsed / 1e9 / HBM_PEAK_GBS,   # whole device, from the wall time of the timed region
-                         "valu_issue_busy_frac": valu_busy,   # the resource that actually bounds the kernel (profiles/*_pmc.json; definition in DESIGN.md section 3)
-                         "note": ("one launch = one partition (%d cars); %d partitions step concurrently on their own streams, device_achieved = this GPU's algorithmic bytes over the wall time of the timed region" % (launch_cars, conc)) if conc > 1 else None},
+                         "traffic": traffic, "kernel": "pdb_step_kernel", "kernel_avg_us": kernel_us, "kernel_avg_source": k_src,
+                         "alg_bytes_per_car_tick": B_ALG, "cars_per_launch": launch_cars, "concurrent_launches": conc, "site_tick_us": tick_us,
+                         "device_achieved": B_ALG * n * args.steps / elapsed / 1e9, "device_frac": B_ALG * n * args.steps / elapsed / 1e9 / HBM_PEAK_GBS,   # whole device, from the wall time of the timed region
+                         "traffic_source": ("profiles/%s_pmc.json" % prof if traffic else None), "valu_issue_busy_frac": valu_busy},
         }
         if hasattr(lib, 'pdb_contact_pass_load'):
             res["contact_pass_cars"] = [int(lib.pdb_contact_pass_load(b.h, q)) for q in (list(range(args.partitions)) if split else [4])]   # cars the last contact passes held (diagnostic)
@@ -485,11 +503,13 @@ def parser():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=3000)
     ap.add_argument('--warmup', type=int, default=333)
-    ap.add_argument('--settle', type=int, default=333, help='ticks of state preparation before warm-up (cars come off their springs and get rolling); neither warm-up nor timed')
-    ap.add_argument('--cars', type=int, default=CARS_PER_GPU)
+    ap.add_argument('--settle', type=int, default=None, help='ticks of state preparation before warm-up (cars come off their springs and get rolling); neither warm-up nor timed')
+    ap.add_argument('--cars', type=int, default=None, help='cars per GPU (default: 16384 for the headline workload, 4096 with an explicit --workload)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--part-loop-min', type=int, default=4096, help='per-tick policies: from this many cars up every partition runs its own closed loop on its own stream')
-    ap.add_argument('--no-extra', action='store_true', help='skip the `extra` block (the other configs measured in the same run)')
+    ap.add_argument('--no-extra', action='store_true', help='(accepted for older command lines: the extra legs are opt-in now)')
+    ap.add_argument('--extra', action='store_true', help='after the line is printed: measure the other configs\' shapes too (results to stderr and gpurun_out/bench_extra.json)')
+    ap.add_argument('--no-secondary', action='store_true', help='skip the configs[1] measurement that rides in the line as `secondary`')
     ap.add_argument('--partitions', type=int, default=None, choices=[1, 2, 3, 4],
                     help='free-running car ranges per GPU, one HIP stream each (pdb_set_partitions / pdb_step_ring); 1 = one launch per tick.  Default: 3 on one rank; 2 with more ranks -- a process has four hardware queues, three partitions and the null stream use them up, and the process group\'s collective stream would then share one with a partition and hold it up for as long as a gather runs (tools/hwqueue_probe.py: 47 M against 69 M with a 1 ms kernel per ring on a fifth stream; with two partitions 63-67 M against 67 M)')
     ap.add_argument('--walls', action='store_true', help='touge workload: line both edges of the road with WALL surfaces (configs[4] shape: hull-vs-wall narrow phase next to the guard rails)')
@@ -511,8 +531,8 @@ def parser():
     ap.add_argument('--force-gather', action='store_true', help='run the observation all-gather even with one rank (exercises the RCCL + side-stream path on a single GPU)')
     ap.add_argument('--backend', default='nccl', help='torch.distributed backend for N > 1 (nccl = RCCL; gloo only to exercise the multi-rank path on a single-GPU box)')
     ap.add_argument('--teleport-mode', type=int, default=0, choices=[0, 1, 2], help='--episodes: where a reset puts the car (projectd_env.py teleport_mode: 0 start, 1 nearest, 2 random point of the lap)')
-    ap.add_argument('--workload', choices=['flat', 'touge', 'playground', 'nordring', 'driftplayground', 'ebisu_touge', 'yamanashi_short', 'euphoria_hillside_park', 'ek_akina', 'ks_nordschleife', 'ks_nordschleife_walls'], default='flat',
-                    help='flat = BASELINE configs[1] (the bench line); touge = configs[2] shape: closed hilly road, cars spread around the lap, probe-feedback steering computed on the GPU each tick')
+    ap.add_argument('--workload', choices=['flat', 'touge', 'playground', 'nordring', 'driftplayground', 'ebisu_touge', 'yamanashi_short', 'euphoria_hillside_park', 'ek_akina', 'ks_nordschleife', 'ks_nordschleife_walls'], default=None,
+                    help='default (none given): BASELINE configs[2] as worded -- 16384 cars on the ek_akina ribbon, scripted inputs, env loop.  flat = configs[1]; touge = configs[2] shape on the synthetic closed hilly road')
     return ap
 
 
@@ -535,9 +555,78 @@ def spawn_ranks(n):
     sys.exit(rc)
 
 
+def resolve(args):
+    """no --workload: the headline configuration (BASELINE configs[2] as worded); an explicit workload keeps the older defaults"""
+    if args.workload is None:
+        args.workload = HEADLINE['workload']
+        args.cars = args.cars or HEADLINE['cars']
+        args.policy = args.policy or HEADLINE['policy']
+        args.episodes = True
+        args.teleport_mode = HEADLINE['teleport_mode']
+        if args.settle is None:
+            args.settle = HEADLINE['settle']
+        args.is_headline = True
+    else:
+        args.cars = args.cars or CARS_PER_GPU
+        if args.settle is None:
+            args.settle = 333 if args.workload == 'flat' else 200
+        args.is_headline = False
+    return args
+
+
+def _short(x, n):
+    return x if not isinstance(x, str) or len(x) <= n else x[:n - 1] + '~'
+
+
+def compact(res, secondary=None, rccl=None, extra_file=None):
+    """the ONE stdout line: the contract's keys + roofline + cpu_baseline (+ secondary, rccl), kept under 2 KB"""
+    r = res["roofline"]; c = res["config"]
+    out = {k: res[k] for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "repeats", "timed_region_s")}
+    for k in ("value", "ms_per_step", "timed_region_s"):
+        out[k] = float('%.6g' % out[k])
+    out["config"] = {"workload": _short(c["workload"], 230), "cars_per_gpu": c["cars_per_gpu"], "partitions": c["partitions"], "collective": _short(c["collective"], 120), "parity": _short(c["parity"], 150)}
+    out["roofline"] = {"bound": r["bound"], "achieved": float('%.5g' % r["achieved"]), "peak": r["peak"], "unit": r["unit"], "frac": float('%.4g' % r["frac"]),
+                       "traffic": (float('%.5g' % r["traffic"]) if r.get("traffic") else None), "kernel": r["kernel"], "kernel_avg_us": float('%.5g' % r["kernel_avg_us"]),
+                       "alg_bytes_per_car_tick": r["alg_bytes_per_car_tick"], "cars_per_launch": float('%.6g' % r["cars_per_launch"]), "concurrent_launches": r["concurrent_launches"],
+                       "device_frac": float('%.4g' % r["device_frac"])}
+    cb = res.get("cpu_baseline") or (secondary or {}).get("cpu_baseline")
+    if cb:
+        out["cpu_baseline"] = {"value": float('%.6g' % cb["value"]), "unit": cb["unit"], "cores": cb["cores"], "kind": cb["kind"], "sample": _short(cb["sample"], 110),
+                               "all_cores_value": float('%.6g' % cb["all_cores_value"]), "all_cores": cb["all_cores"]}
+    if secondary:
+        out["secondary"] = {"workload": _short(secondary["config"]["workload"], 100), "value": float('%.6g' % secondary["value"]), "ms_per_step": float('%.6g' % secondary["ms_per_step"]),
+                            "roofline_frac": float('%.4g' % secondary["roofline"]["frac"]), "kernel_avg_us": float('%.5g' % secondary["roofline"]["kernel_avg_us"]),
+                            "traffic": (float('%.5g' % secondary["roofline"]["traffic"]) if secondary["roofline"].get("traffic") else None)}
+    if rccl:
+        out["rccl"] = rccl
+    if extra_file:
+        out["extra_file"] = extra_file
+    return out
+
+
+def rccl_block(world, rank, local_rank, dist, dev_index):
+    """who RCCL saw: every rank reports (rank, PCI bus id of its GPU) through the process group the bench uses"""
+    import torch
+    pr = torch.cuda.get_device_properties(dev_index)
+    me = "%s:%s" % (getattr(pr, 'pci_bus_id', '?'), getattr(pr, 'pci_device_id', '?'))
+    try:
+        me = "%04x:%02x:%02x" % (getattr(pr, 'pci_domain_id', 0), pr.pci_bus_id, pr.pci_device_id)
+    except Exception:
+        pass
+    if dist is None or not dist.is_initialized():
+        return {"world": 1, "ranks_seen": 1, "backend": None, "devices": [me]}
+    box = [None] * world
+    dist.all_gather_object(box, (rank, me))
+    # and one device collective through the backend itself: the sum of (rank + 1) over the ranks it reached
+    t = torch.tensor([float(rank + 1)], device=('cuda:%d' % dev_index) if dist.get_backend() == 'nccl' else 'cpu')
+    dist.all_reduce(t)
+    return {"world": world, "ranks_seen": len({r for r, _ in box}), "backend": dist.get_backend(), "devices": [d for _, d in sorted(box)],
+            "distinct_devices": len({d for _, d in box}), "allreduce_ok": bool(abs(float(t.item()) - world * (world + 1) / 2.0) < 1e-3)}
+
+
 def main():
     ap = parser()
-    args = ap.parse_args()
+    args = resolve(ap.parse_args())
     if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
         spawn_ranks(args.gpus)
 
@@ -556,21 +645,56 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs an MI355X: there is no CPU fallback for the product path')
     dist = None
+    rccl = None
+    dev_index = local_rank % torch.cuda.device_count()
     if world > 1 or args.force_gather:
+        import datetime
         import torch.distributed as dist
         if world == 1:
             os.environ.setdefault('MASTER_ADDR', '127.0.0.1'); os.environ.setdefault('MASTER_PORT', '29511')
             os.environ.setdefault('RANK', '0'); os.environ.setdefault('WORLD_SIZE', '1')
-        torch.cuda.set_device(local_rank % torch.cuda.device_count())
-        dist.init_process_group(args.backend, init_method='env://')
+        torch.cuda.set_device(dev_index)
+        try:   # a rank that cannot set the collectives up leaves with a non-zero code -- and so does every other rank (the rendezvous / the check below time out on them)
+            dist.init_process_group(args.backend, init_method='env://', timeout=datetime.timedelta(seconds=300))
+            rccl = rccl_block(world, rank, local_rank, dist, dev_index)
+            if rccl["ranks_seen"] != world or not rccl["allreduce_ok"]:
+                raise RuntimeError('the process group reached %d of %d ranks' % (rccl["ranks_seen"], world))
+        except Exception as e:
+            sys.stderr.write('bench: rank %d: collective set-up failed: %r\n' % (rank, e))
+            os._exit(3)
+    else:
+        rccl = rccl_block(1, 0, local_rank, None, dev_index)
 
-    res = measure(args, world, rank, local_rank, dist, want_cpu=(not args.no_cpu_baseline and world == 1))
-    is_headline = world == 1 and not args.no_extra and args.workload == 'flat' and args.cars == CARS_PER_GPU and not args.episodes and not args.force_gather
-    if is_headline:
-        extra = {}
-        only = [k for k in os.environ.get('PDB_BENCH_EXTRA', '').split(',') if k]   # diagnostic: a subset of the legs, in the order given
+    res = measure(args, world, rank, local_rank, dist, want_cpu=(not args.no_cpu_baseline and world == 1 and not args.is_headline))
+    secondary = None
+    if args.is_headline and world == 1 and not args.no_secondary:   # configs[1] beside it, same rule, same process; the CPU leg is timed on ITS inputs
+        a2 = resolve(parser().parse_args(SECONDARY_ARGV + ['--steps', str(args.steps), '--warmup', str(args.warmup)] + (['--no-cpu-baseline'] if args.no_cpu_baseline else [])))
+        try:
+            secondary = measure(a2, 1, 0, local_rank, None, want_cpu=not args.no_cpu_baseline)
+        except Exception as e:   # never at the cost of the headline
+            sys.stderr.write('bench: the secondary (configs[1]) measurement failed: %r\n' % (e,))
+    only = [k for k in os.environ.get('PDB_BENCH_EXTRA', '').split(',') if k]
+    want_extra = world == 1 and (args.extra or only) and args.is_headline
+    extra_file = None
+    if want_extra:
+        try:
+            os.makedirs(os.path.join(ROOT, 'gpurun_out'), exist_ok=True)
+            extra_file = 'gpurun_out/bench_extra.json'
+        except OSError:
+            extra_file = None
+    if rank == 0:
+        line = json.dumps(compact(res, secondary, rccl, extra_file), separators=(',', ':'))
+        json_out.write(line + '\n')
+        json_out.flush()
+        sys.stderr.write('bench: full headline record: %s\n' % json.dumps(res))
+        if secondary:
+            sys.stderr.write('bench: full secondary record: %s\n' % json.dumps(secondary))
+
+    # ---- everything below is optional and can no longer cost the line ----
+    if want_extra:
+        extra = {"headline": res, "secondary": secondary}
         for key, argv in ([(k, dict(EXTRA)[k]) for k in only] if only else EXTRA):
-            a = parser().parse_args(argv + ['--no-cpu-baseline', '--no-extra'])
+            a = resolve(parser().parse_args(argv + ['--no-cpu-baseline']))
             d2 = None
             try:
                 if a.force_gather:
@@ -579,46 +703,31 @@ def main():
                         os.environ.setdefault('MASTER_ADDR', '127.0.0.1'); os.environ.setdefault('MASTER_PORT', '29512')
                         os.environ.setdefault('RANK', '0'); os.environ.setdefault('WORLD_SIZE', '1')
                         d2.init_process_group(args.backend, init_method='env://')
-                r = measure(a, 1, 0, 0, d2)
-                extra[key] = {"value": r["value"], "ms_per_step": r["ms_per_step"], "steps": r["steps"], "repeats": r["repeats"], "workload": r["config"]["workload"],
-                              "partitions": r["config"]["partitions"], "collective": r["config"]["collective"], "kernel_avg_us": r["roofline"]["kernel_avg_us"],
-                              "roofline": {k: r["roofline"][k] for k in ("bound", "achieved", "peak", "unit", "frac", "kernel", "kernel_avg_us", "cars_per_launch", "concurrent_launches", "device_achieved", "device_frac")}}
-                if "contact_pass_cars" in r:
-                    extra[key]["contact_pass_cars"] = r["contact_pass_cars"]
-                if "episode_ends_per_tick" in r:
-                    extra[key]["episode_ends_per_tick"] = r["episode_ends_per_tick"]
-            except Exception as e:   # an extra line must never cost the headline
-                extra[key] = {"error": repr(e)[:200]}
-        res["extra"] = extra
-    if world > 1 and not args.scatter_actions and not args.no_extra:   # the other collective variant SURVEY 8d words (a gather + an action scatter every tick), same process, same rule
-        a2 = parser().parse_args(sys.argv[1:] + ['--gather-ticks', '1', '--scatter-actions', '--no-cpu-baseline', '--no-extra'])
-        # this optional second measurement must never cost the headline already measured: if it does not come back (a rank that failed alone
-        # leaves the others inside a collective), rank 0 prints the line it has and every rank leaves
+                r = measure(a, 1, 0, local_rank, d2)
+                extra[key] = r
+                sys.stderr.write('bench: extra %s: %.4g env-steps/s, %.4g ms/step, first pass %.4g us\n' % (key, r["value"], r["ms_per_step"], r["roofline"]["kernel_avg_us"]))
+            except Exception as e:
+                extra[key] = {"error": repr(e)[:300]}
+                sys.stderr.write('bench: extra %s failed: %r\n' % (key, e))
+            if extra_file:
+                json.dump(extra, open(os.path.join(ROOT, extra_file), 'w'), indent=1)
+    if world > 1 and args.extra and not args.scatter_actions:   # the other collective variant SURVEY 8d words (a gather + an action scatter every tick on configs[3]'s shard), after the line
+        a2 = resolve(parser().parse_args(['--workload', 'flat', '--cars', '8192', '--gpus', str(args.gpus), '--steps', str(args.steps), '--warmup', str(args.warmup), '--gather-ticks', '1', '--scatter-actions', '--no-cpu-baseline',
+                                          '--backend', args.backend] + (['--library-exchange'] if args.library_exchange else [])))
         import threading
-
-        def _give_up():
-            if rank == 0:
-                res.setdefault("extra", {})["configs3_gather_k1_scatter"] = {"error": "did not finish within 240 s"}
-                json_out.write(json.dumps(res) + '\n'); json_out.flush()
-            os._exit(0)
-        watchdog = threading.Timer(240.0, _give_up)
+        watchdog = threading.Timer(240.0, lambda: os._exit(0))   # a rank that failed alone leaves the others inside a collective: everybody leaves (the line is out)
         watchdog.daemon = True
         watchdog.start()
         try:
             r2 = measure(a2, world, rank, local_rank, dist)
             if rank == 0:
-                res.setdefault("extra", {})["configs3_gather_k1_scatter"] = {"value": r2["value"], "ms_per_step": r2["ms_per_step"], "steps": r2["steps"], "repeats": r2["repeats"],
-                                                                             "partitions": r2["config"]["partitions"], "collective": r2["config"]["collective"]}
+                sys.stderr.write('bench: configs3_gather_k1_scatter: %s\n' % json.dumps(r2))
         except Exception as e:
-            if rank == 0:
-                res.setdefault("extra", {})["configs3_gather_k1_scatter"] = {"error": repr(e)[:200]}
+            sys.stderr.write('bench: configs3_gather_k1_scatter failed: %r\n' % (e,))
         watchdog.cancel()
-    if rank == 0:
-        json_out.write(json.dumps(res) + '\n')
-        json_out.flush()
     if dist is not None and dist.is_initialized():
         dist.destroy_process_group()
-    elif is_headline:
+    else:
         import torch.distributed as d3
         if d3.is_initialized():
             d3.destroy_process_group()

@@ -141,7 +141,11 @@ int pdb_set_out_device(pdb_batch* b, pdb_step_out* out);
  * Streams: a process has four hardware queues and its null stream holds one; kernels of two streams that share a queue run one after the other.
  * While the batch runs on the library's own stream (no pdb_set_stream), part 0 runs on that stream, so that three parts are three streams of the
  * library's; after pdb_set_stream every part has a stream of its own (the caller's stream + three parts: keep other streams of the process idle
- * while they step, or use two parts -- DESIGN.md section 7). */
+ * while they step, or use two parts -- DESIGN.md section 7).
+ * ALIASING: while part 0 runs on the batch's own stream, pdb_partition_stream(b, 0) == pdb_stream(b): pdb_step_ring with join == 0 and
+ * pdb_step_partition(b, dt, 0, ...) then DO queue behind (and hold back) whatever else is put on the batch's stream, and a caller's work on that stream
+ * serialises with part 0.  pdb_set_stream gives part 0 a NEW stream: query pdb_partition_stream again after it -- a handle taken before (a torch
+ * ExternalStream, a communicator or graph keyed to it) is stale. */
 int pdb_set_partitions(pdb_batch* b, int parts);
 /* diagnostic: how many cars the most recent contact pass of a launch site held (site = partition index, 4 = the batch's own
  * stream); read without waiting for anything, so it lags the launches still in flight */
@@ -224,6 +228,12 @@ int pdb_step_host_held(pdb_batch* b, const float* actions, float dt, const uint8
 /* convenience: upload actions, one tick, download outputs */
 int pdb_step_host(pdb_batch* b, const float* actions, float dt, pdb_step_out* out);
 int pdb_get_car_state(pdb_batch* b, int first, int count, pdb_car_state* out);
+/* Measurement (bench.py's roofline block): HIP events around every `every`-th first-pass launch (pdb_step_kernel*) of each launch site -- the
+ * partitions' streams and the batch's own -- recorded on the stream the kernel is launched on; 0 = off; at most 64 samples per site between two reads.
+ * pdb_sampled_kernel_us waits for the sampled launches and returns their average duration (microseconds), their number and the average number of
+ * cars per sampled launch, and clears the samples. */
+int pdb_sample_kernel(pdb_batch* b, int every);
+int pdb_sampled_kernel_us(pdb_batch* b, double* avg_us, int* samples, double* avg_cars);
 /* average device time of the step kernel over the launches since the last call, in microseconds (HIP events) */
 int pdb_kernel_time_us(pdb_batch* b, double* avg_us, int* launches);
 

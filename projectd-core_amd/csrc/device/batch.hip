@@ -107,8 +107,28 @@ static constexpr size_t kSnapStrideWide = k33::kSnapStride;
 namespace pdb { void setError(const std::string& s); }
 
 #include <dlfcn.h>
-#include <rccl/rccl.h>   // types and prototypes only: the library is taken at run time (rcclApi), never linked
-#define LAUNCHCHK(b) do { HIPCHK(hipGetLastError()); if ((b)->launchRefused) return PDB_ERR_HIP; } while (0)
+// RCCL: types and prototypes only -- the library is taken at run time (rcclApi), never linked.  Where the headers are absent the few declarations the
+// exchange uses are made here (the ABI of RCCL 2.x: a 128-byte id, an opaque communicator, int-sized enums), so the build does not depend on them either.
+#if __has_include(<rccl/rccl.h>)
+#include <rccl/rccl.h>
+#else
+extern "C" {
+typedef struct ncclComm* ncclComm_t;
+typedef struct { char internal[128]; } ncclUniqueId;
+typedef enum { ncclSuccess = 0 } ncclResult_t;
+typedef enum { ncclFloat = 7 } ncclDataType_t;
+ncclResult_t ncclGetUniqueId(ncclUniqueId*);
+ncclResult_t ncclCommInitRank(ncclComm_t*, int, ncclUniqueId, int);
+ncclResult_t ncclCommDestroy(ncclComm_t);
+ncclResult_t ncclAllGather(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t);
+ncclResult_t ncclSend(const void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t);
+ncclResult_t ncclRecv(void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t);
+ncclResult_t ncclGroupStart();
+ncclResult_t ncclGroupEnd();
+const char* ncclGetErrorString(ncclResult_t);
+}
+#endif
+#define LAUNCHCHK(b) do { HIPCHK(hipGetLastError()); if ((b)->launchRefused) { (b)->launchRefused = false; pdb::setError("pdbatch: the tick was not launched: no hand-over snapshots for the contact pass (device memory; they are allocated by pdb_create / pdb_reset_mask_device / pdb_set_partition_params)"); return PDB_ERR_HIP; } } while (0)
 #define HIPCHK(expr)                                                                                 \
     do {                                                                                             \
         hipError_t _e = (expr);                                                                      \
@@ -125,6 +145,8 @@ namespace pdb { void setError(const std::string& s); }
 #ifndef PDB_CONTACT_GRID_IDLE
 #define PDB_CONTACT_GRID_IDLE 1
 #endif
+#define PDB_KERNEL_SAMPLES 64
+struct KernelSamples { hipEvent_t ev[2 * PDB_KERNEL_SAMPLES] = {}; int cars[PDB_KERNEL_SAMPLES] = {}; int n = 0; unsigned tick = 0; };
 struct pdb_batch {
     int device = 0;
     int n = 0;
@@ -186,6 +208,8 @@ struct pdb_batch {
     // the per-tick exchange with the learner issued by the library itself (pdb_comm_init / pdb_step_exchange_partition): one RCCL communicator per partition
     ncclComm_t comm[PDB_MAX_PARTS] = {nullptr, nullptr, nullptr, nullptr};
     int commWorld = 0, commRank = 0;
+    int sampleEvery = 0;   // pdb_sample_kernel: events around every k-th first-pass launch of each launch site
+    KernelSamples samples[PDB_MAX_PARTS + 1];
     int* hHint = nullptr;  // page-locked, device-visible: per launch site, the number of cars the last contact pass held (written by its last workgroup; read here without waiting)
     int* dHint = nullptr;
 };
@@ -253,6 +277,8 @@ static void fillConst(const pdb_car_params& P, DevConst& K, int actionMode) {
 // The hand-over snapshots (about 10 KB per car, four times the record) exist only once a contact pass can run: body colliders on, the
 // reset mask armed or the in-tick auto-teleport set.  Allocated on first need, outside any graph capture (pdb_step_n calls this before it records).
 static bool passNeeded(const pdb_batch* b, const pdb_car_params& HP) { return HP.collider.enabled != 0 || b->resetMaskArmed || HP.autoTeleport != 0; }
+// Called by the entry points that can turn a contact pass on (pdb_create, pdb_reset_mask_device, pdb_set_partition_params), never from a launch: a
+// hipMalloc inside a caller's stream capture would invalidate the capture, and running out of memory belongs to set-up, not to the middle of a run.
 static void ensureSnap(pdb_batch* b) {
     if (b->dSnap) return;
     bool need = passNeeded(b, b->params);
@@ -260,7 +286,6 @@ static void ensureSnap(pdb_batch* b) {
     if (need && hipMalloc(&b->dSnap, kSnapStrideWide * (size_t)b->n) != hipSuccess) { b->dSnap = nullptr; pdb::setError("pdbatch: out of device memory for the contact pass's hand-over snapshots"); }
 }
 static void launchTick(pdb_batch* b, hipStream_t st, int c0, int c1, pdb_step_out* out, int q) {
-    ensureSnap(b);
     const int nblk = (c1 - c0 + PDB_CPB - 1) / PDB_CPB, m = b->params.numRows;
     pdb_dyn_state* S = b->dStates + c0;
     const float* Aact = b->dActions + (size_t)c0 * b->actionStride;
@@ -279,7 +304,7 @@ static void launchTick(pdb_batch* b, hipStream_t st, int c0, int c1, pdb_step_ou
     const int n = c1 - c0;
     // the contact pass also serves episode resets asked for through the reset mask and the in-tick auto-teleport
     const bool contacts = passNeeded(b, HP);
-    if (contacts && !b->dSnap) { b->launchRefused = true; return; }   // (ensureSnap left the message) never a first pass whose queued cars nobody finishes
+    if (contacts && !b->dSnap) { b->launchRefused = true; return; }   // never a first pass whose queued cars nobody finishes (LAUNCHCHK reports it once and clears the flag)
     // the contact pass's grid: enough workgroups for twice the cars its last pass held (a stale number, read without waiting: it only
     // sizes the grid -- workgroups take the queued cars in turn whatever their number), at least PDB_CONTACT_GRID, at most what is resident at once
     int cg = b->contactGrid;
@@ -295,22 +320,30 @@ static void launchTick(pdb_batch* b, hipStream_t st, int c0, int c1, pdb_step_ou
     const dim3 grid(nblk), block(PDB_BLOCK_THREADS), cblock(PDB_WAVE * (PDB_CONTACT_CPB + 1)), cgrid(((n + PDB_CONTACT_CPB - 1) / PDB_CONTACT_CPB) < cg ? ((n + PDB_CONTACT_CPB - 1) / PDB_CONTACT_CPB) : cg);
     // a car with DynamicController files goes through the kernel pair compiled with the controllers' call sites (40-row class, row-guarded: any car)
     const bool ctrl = HP.numCtrlStages != 0 || HP.hasBrakeTemps != 0;
-    if (ctrl) {
+    const int kind = ctrl ? 0 : (m == 33 ? 1 : (m < 33 ? 2 : 3));
+    // measurement (pdb_sample_kernel): HIP events around every k-th first-pass launch of this site, on the stream it is launched on
+    KernelSamples& KS = b->samples[q];
+    const bool sampled = b->sampleEvery > 0 && !b->capturing && KS.ev[0] && (KS.tick++ % b->sampleEvery) == 0 && KS.n < PDB_KERNEL_SAMPLES;
+    if (sampled) (void)hipEventRecord(KS.ev[2 * KS.n], st);
+    switch (kind) {
 #ifndef PDB_FAST_BUILD
-        hipLaunchKernelGGL(k40::pdb_step_kernel_ctrl, grid, block, 0, st, S, Aact, O, CS, DP, DK, b->dTrack, (k40::RedoQueue*)Q, RM, n, SN);
-        if (contacts) hipLaunchKernelGGL(k40c::pdb_contact_kernel_ctrl, cgrid, cblock, 0, st, S, Aact, O, CS, DP, DK, b->dTrack, CT, (k40c::RedoQueue*)Q, RM, n, HN, SN);
+    case 0: hipLaunchKernelGGL(k40::pdb_step_kernel_ctrl, grid, block, 0, st, S, Aact, O, CS, DP, DK, b->dTrack, (k40::RedoQueue*)Q, RM, n, SN); break;
+    case 3: hipLaunchKernelGGL(k40::pdb_step_kernel_wide, grid, block, 0, st, S, Aact, O, CS, DP, DK, b->dTrack, (k40::RedoQueue*)Q, RM, n, SN); break;
 #endif
-    } else if (m == 33) {
-        hipLaunchKernelGGL(k33::pdb_step_kernel, grid, block, 0, st, S, Aact, O, CS, DP, DK, b->dTrack, (k33::RedoQueue*)Q, RM, n, SN);
-        if (contacts) hipLaunchKernelGGL(k33c::pdb_contact_kernel, cgrid, cblock, 0, st, S, Aact, O, CS, DP, DK, b->dTrack, CT, (k33c::RedoQueue*)Q, RM, n, HN, SN);
-    } else if (m < 33) {
-        hipLaunchKernelGGL(k33::pdb_step_kernel_generic, grid, block, 0, st, S, Aact, O, CS, DP, DK, b->dTrack, (k33::RedoQueue*)Q, RM, n, SN);
-        if (contacts) hipLaunchKernelGGL(k33c::pdb_contact_kernel_generic, cgrid, cblock, 0, st, S, Aact, O, CS, DP, DK, b->dTrack, CT, (k33c::RedoQueue*)Q, RM, n, HN, SN);
-    } else {
+    case 1: hipLaunchKernelGGL(k33::pdb_step_kernel, grid, block, 0, st, S, Aact, O, CS, DP, DK, b->dTrack, (k33::RedoQueue*)Q, RM, n, SN); break;
+    case 2: hipLaunchKernelGGL(k33::pdb_step_kernel_generic, grid, block, 0, st, S, Aact, O, CS, DP, DK, b->dTrack, (k33::RedoQueue*)Q, RM, n, SN); break;
+    default: break;
+    }
+    if (sampled) { (void)hipEventRecord(KS.ev[2 * KS.n + 1], st); KS.cars[KS.n] = n; ++KS.n; }
+    if (!contacts) return;
+    switch (kind) {
 #ifndef PDB_FAST_BUILD
-        hipLaunchKernelGGL(k40::pdb_step_kernel_wide, grid, block, 0, st, S, Aact, O, CS, DP, DK, b->dTrack, (k40::RedoQueue*)Q, RM, n, SN);
-        if (contacts) hipLaunchKernelGGL(k40c::pdb_contact_kernel_wide, cgrid, cblock, 0, st, S, Aact, O, CS, DP, DK, b->dTrack, CT, (k40c::RedoQueue*)Q, RM, n, HN, SN);
+    case 0: hipLaunchKernelGGL(k40c::pdb_contact_kernel_ctrl, cgrid, cblock, 0, st, S, Aact, O, CS, DP, DK, b->dTrack, CT, (k40c::RedoQueue*)Q, RM, n, HN, SN); break;
+    case 3: hipLaunchKernelGGL(k40c::pdb_contact_kernel_wide, cgrid, cblock, 0, st, S, Aact, O, CS, DP, DK, b->dTrack, CT, (k40c::RedoQueue*)Q, RM, n, HN, SN); break;
 #endif
+    case 1: hipLaunchKernelGGL(k33c::pdb_contact_kernel, cgrid, cblock, 0, st, S, Aact, O, CS, DP, DK, b->dTrack, CT, (k33c::RedoQueue*)Q, RM, n, HN, SN); break;
+    case 2: hipLaunchKernelGGL(k33c::pdb_contact_kernel_generic, cgrid, cblock, 0, st, S, Aact, O, CS, DP, DK, b->dTrack, CT, (k33c::RedoQueue*)Q, RM, n, HN, SN); break;
+    default: break;
     }
 }
 
@@ -436,6 +469,8 @@ pdb_batch* pdb_create(int device, int n_cars, const pdb_car_params* params, cons
         pdb::initialState(b->params, tv, b->resetTemplate);
     } catch (const std::exception& e) { pdb::setError(e.what()); pdb_destroy(b); return nullptr; }
     if (pdb_set_state_all(b, &b->resetTemplate) != PDB_OK) { pdb_destroy(b); return nullptr; }
+    ensureSnap(b);
+    if (passNeeded(b, b->params) && !b->dSnap) { pdb_destroy(b); return nullptr; }   // (ensureSnap left the message)
     return b;
 }
 
@@ -450,6 +485,7 @@ void pdb_destroy(pdb_batch* b) {
     if (b->hActions) (void)hipHostFree(b->hActions);
     if (b->hOut) (void)hipHostFree(b->hOut);
     for (int q = 0; q <= PDB_MAX_PARTS; ++q) (void)hipFree(b->dQueue[q]);
+    for (int q = 0; q <= PDB_MAX_PARTS; ++q) for (hipEvent_t e : b->samples[q].ev) if (e) (void)hipEventDestroy(e);
     (void)hipFree(b->dSnap);
     (void)hipFree(b->dLaneTunes);
     (void)hipFree(b->dHold);
@@ -588,6 +624,8 @@ int pdb_clear_episodes(pdb_batch* b, const uint8_t* device_mask) {
 uint8_t* pdb_reset_mask_device(pdb_batch* b) {
     if (!b) return nullptr;
     b->resetMaskArmed = true;
+    ensureSnap(b);
+    if (!b->dSnap) { b->resetMaskArmed = false; return nullptr; }   // (out of device memory: the message is set)
     if (b->graphExec) { (void)hipGraphExecDestroy(b->graphExec); b->graphExec = nullptr; }   // captured launches carry the old argument
     return b->dResetMask;
 }
@@ -621,6 +659,8 @@ int pdb_set_partition_params(pdb_batch* b, int part, const pdb_car_params* param
     if (!b->dPartK[part]) HIPCHK(hipMalloc(&b->dPartK[part], sizeof(DevConst)));
     b->partParams[part] = *params;
     b->partHas[part] = true;
+    ensureSnap(b);
+    if (passNeeded(b, *params) && !b->dSnap) { b->partHas[part] = false; return PDB_ERR_HIP; }
     HIPCHK(hipMemcpy(b->dPartParams[part], params, sizeof(pdb_car_params), hipMemcpyHostToDevice));
     if (b->graphExec) { (void)hipGraphExecDestroy(b->graphExec); b->graphExec = nullptr; }
     return pushK(b, b->stream, false);
@@ -715,7 +755,6 @@ int pdb_step_n(pdb_batch* b, float dt, int n) {
     if (!b->graphExec || b->graphTicks != n || b->graphDt != dt) {
         if (b->graphExec) { (void)hipGraphExecDestroy(b->graphExec); b->graphExec = nullptr; }
         hipGraph_t g = nullptr;
-        ensureSnap(b);
         HIPCHK(hipStreamBeginCapture(b->stream, hipStreamCaptureModeThreadLocal));
         b->capturing = true;
         for (int i = 0; i < n; ++i)
@@ -795,6 +834,7 @@ int pdb_step_ring(pdb_batch* b, float dt, int n_ticks, pdb_step_out* ring, int r
         if (int rcj = joinParts(b)) return rcj;   // the constants change under kernels that may still read them: those first
         b->K.dt = dt; b->K.fps = 1.0f / dt; b->K.dtD = (dt == (float)(1.0 / 333.0)) ? (1.0 / 333.0) : (double)dt; b->K.wantCarState = 0;
         if (int rck = pushK(b, b->stream, true)) return rck;
+        b->batchDirty = true;   // the copies are queued on the batch's stream: this ring forks behind them even when the caller asked for join bit 1 (no fork)
     }
     const bool forked = b->parts > 1 && b->partStream[0];
     // join bit 1 (PDB_RING_NO_FORK): the partitions are not held back behind what is queued on the batch's stream -- for a caller that orders its own dependencies
@@ -907,7 +947,10 @@ static RcclApi* rcclApi() {
     static RcclApi api;
     if (api.tried) return api.lib ? &api : nullptr;
     api.tried = true;
-    void* h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+    // the RCCL already in the process first (torch's own: a second copy from another path would be a second set of communicators' bookkeeping), then by soname
+    void* h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL | RTLD_NOLOAD);
+    if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL | RTLD_NOLOAD);
+    if (!h) h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
     if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
     if (!h) { pdb::setError(std::string("pdb_comm: RCCL not found in this process (") + dlerror() + ")"); return nullptr; }
     bool ok = true;
@@ -942,7 +985,12 @@ int pdb_comm_init(pdb_batch* b, int world, int rank, const void* ids, int n_ids)
     HIPCHK(hipSetDevice(b->device));
     for (int p = 0; p < b->parts; ++p) {   // every rank creates the partitions' communicators in the same order
         ncclUniqueId id; memcpy(&id, (const uint8_t*)ids + (size_t)p * sizeof(id), sizeof(id));
-        NCCLCHK(R, R->commInitRank(&b->comm[p], world, id, rank));
+        const ncclResult_t r = R->commInitRank(&b->comm[p], world, id, rank);
+        if (r != ncclSuccess) {   // the communicators made so far go at once (the caller falls back on every rank: sharding.LibraryExchange agrees over the ranks)
+            b->comm[p] = nullptr; commFree(b);
+            pdb::setError(std::string("RCCL: ") + R->errorString(r) + " at ncclCommInitRank (partition " + std::to_string(p) + ")");
+            return PDB_ERR_HIP;
+        }
     }
     b->commWorld = world; b->commRank = rank;
     return PDB_OK;
@@ -1066,6 +1114,36 @@ int pdb_debug_stamps(pdb_batch* b, unsigned long long* out) {
     return PDB_OK;
 }
 #endif
+
+// Measurement: HIP events around every `every`-th first-pass launch of each launch site (partition streams and the batch's own), recorded on the stream the
+// kernel is launched on; at most PDB_KERNEL_SAMPLES per site between two reads.  0 switches it off.  Launches recorded into a graph are not sampled.
+int pdb_sample_kernel(pdb_batch* b, int every) {
+    if (!b || every < 0) { pdb::setError("pdb_sample_kernel: bad argument"); return PDB_ERR_ARG; }
+    HIPCHK(hipSetDevice(b->device));
+    if (every > 0)
+        for (int q = 0; q <= PDB_MAX_PARTS; ++q) for (hipEvent_t& e : b->samples[q].ev) if (!e) HIPCHK(hipEventCreate(&e));
+    for (int q = 0; q <= PDB_MAX_PARTS; ++q) { b->samples[q].n = 0; b->samples[q].tick = 0; }
+    b->sampleEvery = every;
+    return PDB_OK;
+}
+// waits for the sampled launches; average duration in microseconds, their number and the average number of cars per sampled launch; clears the samples
+int pdb_sampled_kernel_us(pdb_batch* b, double* avg_us, int* samples, double* avg_cars) {
+    if (!b) { pdb::setError("null argument"); return PDB_ERR_ARG; }
+    double sum = 0, cars = 0; int cnt = 0;
+    for (int q = 0; q <= PDB_MAX_PARTS; ++q) {
+        KernelSamples& KS = b->samples[q];
+        for (int i = 0; i < KS.n; ++i) {
+            HIPCHK(hipEventSynchronize(KS.ev[2 * i + 1]));
+            float ms = 0; HIPCHK(hipEventElapsedTime(&ms, KS.ev[2 * i], KS.ev[2 * i + 1]));
+            sum += ms; cars += KS.cars[i]; ++cnt;
+        }
+        KS.n = 0;
+    }
+    if (avg_us) *avg_us = cnt ? sum * 1000.0 / cnt : 0.0;
+    if (samples) *samples = cnt;
+    if (avg_cars) *avg_cars = cnt ? cars / cnt : 0.0;
+    return PDB_OK;
+}
 
 int pdb_kernel_time_us(pdb_batch* b, double* avg_us, int* launches) {
     if (!b) { pdb::setError("null argument"); return PDB_ERR_ARG; }

@@ -222,6 +222,9 @@ def load_product(host_only=False):
         lib.pdb_partition_elapsed_ms.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
         lib.pdb_get_car_state.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]
         lib.pdb_kernel_time_us.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        if hasattr(lib, 'pdb_sample_kernel'):
+            lib.pdb_sample_kernel.argtypes = [C.c_void_p, C.c_int]
+            lib.pdb_sampled_kernel_us.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     return lib
 
 ENV_TUNES = {'FRONT_BIAS': 55.0, 'DIFF_POWER': 30.0, 'DIFF_COAST': 30.0, 'FINAL_RATIO': 5.0,

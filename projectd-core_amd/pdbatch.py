@@ -236,6 +236,16 @@ class Batch:
         s = np.ascontiguousarray(seeds, dtype=np.uint32).reshape(self.n)
         self._chk(self.lib.pdb_set_seed(self.h, s.ctypes.data_as(C.c_void_p)))
 
+    def sample_kernel(self, every):
+        """HIP events around every `every`-th first-pass launch of each launch site (0 = off)"""
+        self._chk(self.lib.pdb_sample_kernel(self.h, int(every)))
+
+    def sampled_kernel_us(self):
+        """(average first-pass duration in us, number of sampled launches, average cars per sampled launch); waits for them, clears the samples"""
+        us = C.c_double(); n = C.c_int(); cars = C.c_double()
+        self._chk(self.lib.pdb_sampled_kernel_us(self.h, C.byref(us), C.byref(n), C.byref(cars)))
+        return us.value, n.value, cars.value
+
     def kernel_time_us(self):
         us = C.c_double(); n = C.c_int()
         self._chk(self.lib.pdb_kernel_time_us(self.h, C.byref(us), C.byref(n)))

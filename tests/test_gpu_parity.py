@@ -280,7 +280,7 @@ def test_bench_multi_rank_path_on_one_gpu(built):
     s = socket.socket(); s.bind(('127.0.0.1', 0)); port = s.getsockname()[1]; s.close()
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1', '--master-port', str(port),
-           os.path.join(root, 'bench.py'), '--gpus', '2', '--steps', '40', '--warmup', '10', '--cars', '256', '--backend', 'gloo', '--no-cpu-baseline']
+           os.path.join(root, 'bench.py'), '--gpus', '2', '--steps', '40', '--warmup', '10', '--workload', 'flat', '--cars', '256', '--backend', 'gloo', '--no-cpu-baseline']
     r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith('{')]
@@ -288,6 +288,49 @@ def test_bench_multi_rank_path_on_one_gpu(built):
     d = json.loads(lines[0])
     assert d['n_gpus'] == 2 and d['steps'] == 40 and d['scaling'] == 'weak' and d['value'] > 0 and d['config']['cars_per_gpu'] == 256
     assert 'all-gather' in d['config']['collective']
+    assert d['rccl']['world'] == 2 and d['rccl']['ranks_seen'] == 2 and d['rccl']['backend'] == 'gloo' and len(d['rccl']['devices']) == 2
+
+
+def test_bench_headline_workload_with_two_ranks_on_one_gpu(built):
+    """the N > 1 form of the headline workload (configs[2]: ek_akina ribbon, scripted inputs per partition loop, env loop in the kernel) with the
+    trajectory-ring gather behind the per-partition loops: two gloo ranks on the box's one GPU, small car count"""
+    import json, subprocess, socket
+    s = socket.socket(); s.bind(('127.0.0.1', 0)); port = s.getsockname()[1]; s.close()
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1', '--master-port', str(port),
+           os.path.join(root, 'bench.py'), '--gpus', '2', '--steps', '40', '--warmup', '10', '--cars', '384', '--part-loop-min', '128', '--gather-ticks', '8', '--backend', 'gloo']
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith('{')]
+    assert len(lines) == 1 and len(lines[0]) < 4096
+    d = json.loads(lines[0])
+    assert d['n_gpus'] == 2 and d['value'] > 0 and d['config']['cars_per_gpu'] == 384 and d['config']['partitions'] == 2
+    assert d['config']['workload'].startswith('configs[2]') and 'ek_akina' in d['config']['workload'] and 'trajectory rings' in d['config']['collective']
+
+
+def test_bench_driver_command_prints_one_compact_line(built):
+    """the driver's own command: ONE stdout line, under 4 KB, that json.loads and carries the contract's keys, `roofline`, `cpu_baseline`,
+    `secondary` (configs[1]) and `rccl`; the headline is configs[2] as worded (r04's 22 KB line could not be parsed)"""
+    import json, subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '1', '--steps', '20', '--warmup', '5'], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=1200)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, lines
+    assert len(lines[-1]) < 4096, len(lines[-1])
+    d = json.loads(lines[-1])
+    for k in ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling', 'vs_baseline', 'dtype', 'data', 'config', 'roofline', 'cpu_baseline', 'secondary', 'rccl'):
+        assert k in d, k
+    assert d['steps'] == 20 and d['warmup'] == 5 and d['n_gpus'] == 1 and d['config']['cars_per_gpu'] == 16384 and 'ek_akina' in d['config']['workload']
+    for k in ('bound', 'achieved', 'peak', 'unit', 'frac', 'traffic', 'kernel', 'kernel_avg_us', 'alg_bytes_per_car_tick', 'cars_per_launch'):
+        assert k in d['roofline'], k
+    assert abs(d['roofline']['frac'] - d['roofline']['achieved'] / d['roofline']['peak']) < 1e-6 and 0 < d['roofline']['frac'] < 1
+    assert abs(d['roofline']['achieved'] - d['roofline']['alg_bytes_per_car_tick'] * d['roofline']['cars_per_launch'] / d['roofline']['kernel_avg_us'] / 1e3) < 0.01 * d['roofline']['achieved']
+    for k in ('value', 'unit', 'cores', 'kind', 'sample'):
+        assert k in d['cpu_baseline'], k
+    assert d['cpu_baseline']['kind'] == 'port' and d['cpu_baseline']['cores'] == 1 and d['cpu_baseline']['value'] > 1e4
+    assert d['secondary']['value'] > 1e6 and d['secondary']['workload'].startswith('configs[1]')
+    assert d['value'] > 1e6 and abs(d['value'] - 16384 * 1000.0 / d['ms_per_step']) < 1e-3 * d['value']
 
 
 @pytest.mark.gpu
@@ -382,11 +425,26 @@ def test_bench_rccl_gather_side_stream_on_one_gpu(built):
     s = socket.socket(); s.bind(('127.0.0.1', 0)); port = s.getsockname()[1]; s.close()
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '1', '--master-addr', '127.0.0.1', '--master-port', str(port),
-           os.path.join(root, 'bench.py'), '--gpus', '1', '--steps', '200', '--warmup', '20', '--cars', '1024', '--force-gather', '--no-cpu-baseline']
+           os.path.join(root, 'bench.py'), '--gpus', '1', '--steps', '200', '--warmup', '20', '--workload', 'flat', '--cars', '1024', '--force-gather', '--no-cpu-baseline']
     r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600, env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0'))
     assert r.returncode == 0, r.stderr[-2000:]
     d = json.loads([l for l in r.stdout.splitlines() if l.startswith('{')][0])
-    assert d['n_gpus'] == 1 and 'side stream' in d['config']['collective'] and d['value'] > 1e6
+    assert d['n_gpus'] == 1 and 'trajectory rings' in d['config']['collective'] and d['value'] > 1e6
+    assert d['rccl']['backend'] == 'nccl' and d['rccl']['ranks_seen'] == 1 and d['rccl']['allreduce_ok']
+
+
+def test_bench_headline_loops_with_rccl_rings_on_one_gpu(built):
+    """the headline workload's N > 1 code path over RCCL itself, as far as one GPU allows: one rank, nccl backend, --force-gather -- per-partition
+    kernel -> contact pass -> scripted-policy loops writing the trajectory ring in place, a ring's all-gather ordered after every partition's last kernel of it"""
+    import json, subprocess, socket
+    s = socket.socket(); s.bind(('127.0.0.1', 0)); port = s.getsockname()[1]; s.close()
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '1', '--master-addr', '127.0.0.1', '--master-port', str(port),
+           os.path.join(root, 'bench.py'), '--gpus', '1', '--steps', '100', '--warmup', '20', '--cars', '4096', '--force-gather', '--gather-ticks', '8', '--no-cpu-baseline', '--no-secondary']
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900, env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0'))
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = json.loads([l for l in r.stdout.splitlines() if l.startswith('{')][0])
+    assert d['n_gpus'] == 1 and 'trajectory rings' in d['config']['collective'] and d['config']['partitions'] == 3 and d['value'] > 1e6
 
 
 @pytest.mark.parametrize('n_cars,track', [(4099, 'flat'), (8192, 'flat'), (16384, 'touge')])   # configs[1] (+ a ragged tail), the per-GPU shard of configs[3], configs[2]
