@@ -457,7 +457,7 @@ def measure(args, world, rank, local_rank, dist, want_cpu=False):
         }
         if hasattr(lib, 'pdb_contact_pass_load'):
             res["contact_pass_cars"] = [int(lib.pdb_contact_pass_load(b.h, q)) for q in (list(range(args.partitions)) if split else [4])]   # cars the last contact passes held (diagnostic)
-        if args.episodes and not policy.startswith('host'):   # how often episodes end in this workload: counted over 300 more ticks, outside the timed region
+        if args.episodes and not policy.startswith('host') and world == 1:   # how often episodes end in this workload: counted over 300 more ticks, outside the timed region (one rank only: these ticks would be collectives of rank 0 alone)
             ends = torch.zeros((), dtype=torch.int64, device=dev)
             for _ in range(300):
                 tick()
