@@ -217,3 +217,126 @@ def run_parity(n_cars=8, ticks=200, seed=1234, resync=False, verbose=False, chec
     if verbose:
         print('parity: n=%d ticks=%d resync=%s worst rel=%.3e at %s' % (n_cars, ticks, resync, worst, worst_info))
     return worst
+
+
+def run_replicated(n_cars, distinct, ticks, track, model='ks_toyota_ae86_drift', seed=7, spread=(0.0, 1.0), check_every=50, partitions=None, threads=8,
+                   law=None, resets=None, verbose=False):
+    """Full-size parity by replication (BASELINE's car counts, the oracle at `distinct` cars): `distinct` different (start point on the lap, input) pairs tiled over
+    a batch of n_cars.  Size-independent properties, checked every `check_every` ticks and at the end:
+      (1) every replica of a representative holds the byte-identical record AND the byte-identical live contact joints wherever it sits in the batch (any
+          workgroup, any partition, any place in the contact pass's queue, any snapshot slot);
+      (2) the `distinct` representatives equal the CPU oracle: every float and integer of the record, the live contact joints byte for byte.
+    law=None: per-car constant actions (make_actions), the ticks between two checks enqueued back to back (partitions: free-running ranges through pdb_step_ring).
+    law(obs[m,24] float32, t, ids[m]) -> actions[m,2] float32: closed loop, evaluated on the host from the observation rows in float32 -- for the GPU batch from the rows
+    pdb_step_host returns, for the oracle from cpuref_get_out -- so equal observations give equal actions.
+    resets=(bits, mode): the env's episode rule on the host (projectd_env.py:173-227 without the reward sums): a car whose output flags meet `bits` is teleported by
+    Car::teleportByMode(mode) before its next tick, which it takes with the zero action; GPU: pdb_reset_mode, oracle: the product's host function on the oracle's record.
+    Returns dict(worst, max_in_contact (cars with live joints at a check, over the whole batch), contact_checks, resets)."""
+    import pdbatch
+    from concurrent.futures import ThreadPoolExecutor
+    P = pdbatch.packed_params(model + '.env')
+    trk = track if isinstance(track, (bytes, bytearray)) else (pdbatch.reference_track(track) if track in pdbatch.REFERENCE_TRACKS else pdbatch.synthetic_track(track))
+    lib = pc.load_product(); orc = oracle_ctypes.load_oracle(portable_math=True)
+    S0 = pc.DynState()
+    assert lib.pdb_initial_state(C.byref(P), trk, C.byref(S0)) == 0
+    rep = np.arange(n_cars) % distinct                      # car i replicates representative i % distinct: the replicas of one representative are spread over every partition
+    init = (pc.DynState * distinct)()
+    for k in range(distinct):
+        C.memmove(C.byref(init[k]), C.byref(S0), C.sizeof(S0))
+        assert lib.pdb_teleport_to_spline(C.byref(P), trk, C.c_float(spread[0] + (spread[1] - spread[0]) * k / distinct), C.byref(init[k])) == 0
+        init[k].randState = 1 + 7919 * k                   # (the Random teleport mode draws from the car's own generator)
+    raw0 = np.frombuffer(bytes(init), dtype=np.uint8).reshape(distinct, C.sizeof(pc.DynState))
+    allinit = (pc.DynState * n_cars).from_buffer_copy(raw0[rep].tobytes())
+    b = pdbatch.Batch(n_cars, P, trk, device=0, action_mode=1)
+    b.set_state(allinit)
+    if partitions:
+        b.set_partitions(partitions)
+    hs = [orc.cpuref_create(C.byref(P), trk, len(trk), C.byref(init[k])) for k in range(distinct)]
+    pool = ThreadPoolExecutor(threads)
+    base = make_actions(distinct, seed)
+    base[:, 1] = np.abs(base[:, 1])                         # enough throttle that every car gets going
+    res = dict(worst=0.0, max_in_contact=0, contact_checks=0, resets=0)
+    nb = C.sizeof(pc.DynState)
+    off_nc = pc.DynState.numContacts.offset
+
+    def check(t):
+        st = b.get_state(); ct = b.get_contacts()
+        raw = np.frombuffer(st, dtype=np.uint8).reshape(n_cars, nb)
+        craw = np.frombuffer(ct, dtype=np.uint8).reshape(n_cars, pc.MAX_CONTACTS * 32)
+        nc = raw[:, off_nc:off_nc + 4].copy().view(np.int32)[:, 0]
+        res['max_in_contact'] = max(res['max_in_contact'], int((nc > 0).sum()))
+        for k in range(distinct):
+            reps = raw[k::distinct]
+            if not (reps == reps[0]).all():
+                bad = int(np.argmax((reps != reps[0]).any(axis=1)))
+                raise AssertionError('tick %d: replicas of representative %d differ (first bad lane %d, byte %d)' % (t, k, bad * distinct + k, int(np.argmax(reps[bad] != reps[0]))))
+            live = int(nc[k]) * 32
+            if live > 0:
+                creps = craw[k::distinct, :live]
+                if not (creps == creps[0]).all():
+                    raise AssertionError('tick %d: live contact joints of the replicas of representative %d differ' % (t, k))
+            sc = pc.DynState(); orc.cpuref_get_state(hs[k], C.byref(sc))
+            rel, name, vg, vc, bad_int = compare_states(st[k], sc)
+            if bad_int:
+                raise AssertionError('tick %d: integer state mismatch, representative %d: %s' % (t, k, bad_int[:5]))
+            if sc.numContacts > 0:
+                cc = (pc.Contact * pc.MAX_CONTACTS)(); orc.cpuref_get_contacts(hs[k], C.byref(cc))
+                if bytes(cc)[:32 * sc.numContacts] != craw[k, :32 * sc.numContacts].tobytes():
+                    raise AssertionError('tick %d: contact joints differ from the oracle, representative %d' % (t, k))
+                res['contact_checks'] += 1
+            if rel > res['worst']:
+                res['worst'] = rel
+                if verbose:
+                    print('tick %d representative %d: %s gpu %r oracle %r rel %.3e' % (t, k, name, vg, vc, rel))
+    try:
+        if law is None:
+            acts = base[rep]
+            b.step_host(acts)                               # uploads the actions; tick 0
+            list(pool.map(lambda k: orc.cpuref_step_env(hs[k], float(base[k, 0]), float(base[k, 1])), range(distinct)))
+            t = 1
+            while t < ticks:
+                m = min(check_every, ticks - t)
+                b.step_ring(m, join=True)                     # plain launches, the contact pass's grid following the load (one part: on the batch's own stream)
+
+                def many(k):
+                    for _ in range(m):
+                        orc.cpuref_step_env(hs[k], float(base[k, 0]), float(base[k, 1]))
+                list(pool.map(many, range(distinct)))
+                t += m
+                check(t)
+        else:
+            ids = np.arange(distinct)
+            obs_o = np.zeros((distinct, 24), np.float32); obs_g = np.zeros((n_cars, 24), np.float32)
+            pend_o = np.zeros(distinct, bool); pend_g = np.zeros(n_cars, bool)
+            oo = pc.StepOut()
+            for t in range(ticks):
+                # the law on the representatives' rows, the same call (same shapes) for both sides; the replicas take their representative's action -- their
+                # observation rows are held equal to it every tick (below), their records at every check
+                ag = law(obs_g[:distinct], t, ids).astype(np.float32)[rep]; ao = law(obs_o, t, ids).astype(np.float32)
+                if resets is not None:
+                    bits, mode = resets
+                    if pend_g.any():
+                        b.reset(pend_g.astype(np.uint8), mode); ag[pend_g] = 0.0
+                    for k in np.where(pend_o)[0]:
+                        s = pc.DynState(); orc.cpuref_get_state(hs[k], C.byref(s))
+                        assert lib.pdb_teleport_by_mode(C.byref(P), trk, mode, C.byref(s)) == 0
+                        orc.cpuref_set_state(hs[k], C.byref(s)); ao[k] = 0.0
+                        res['resets'] += 1
+                out = b.step_host(ag)
+                list(pool.map(lambda k: orc.cpuref_step_env(hs[k], float(ao[k, 0]), float(ao[k, 1])), range(distinct)))
+                obs_g = np.array(out['obs'], dtype=np.float32); fg = np.array(out['flags'])
+                if n_cars % distinct == 0:
+                    assert (obs_g.reshape(-1, distinct, 24).view(np.uint32) == obs_g[:distinct].view(np.uint32)).all() and (fg.reshape(-1, distinct) == fg[:distinct]).all(), 'tick %d: a replica\'s output row differs' % t
+                fo = np.zeros(distinct, np.int32)
+                for k in range(distinct):
+                    orc.cpuref_get_out(hs[k], C.byref(oo)); obs_o[k] = np.frombuffer(oo, dtype=np.float32, count=24); fo[k] = oo.flags
+                if resets is not None:
+                    was_g, was_o = pend_g, pend_o
+                    pend_g = ((fg & resets[0]) != 0) & ~was_g; pend_o = ((fo & resets[0]) != 0) & ~was_o   # (the reset tick's own termination is discarded)
+                if (t + 1) % check_every == 0 or t == ticks - 1:
+                    check(t + 1)
+    finally:
+        b.close(); pool.shutdown()
+        for h in hs:
+            orc.cpuref_destroy(h)
+    return res

@@ -214,3 +214,19 @@ def test_gpu_matches_oracle_on_the_nordschleife_ribbon(built):
     assert h.numFat == 13323
     assert worst == 0.0, worst
     assert len(seen['cars']) >= 4 and seen['contacts'] > 20, seen
+
+
+# ---- the contact path at BASELINE's sizes: configs[4]'s per-GPU shard is 8192 cars; the oracle cannot follow that many, replication can
+@pytest.mark.gpu
+@pytest.mark.parametrize('track,model,parts', [('driftplayground', AE86, 3), ('ks_nordschleife_walls', 'ks_toyota_supra_mkiv_drift', None)])
+def test_full_size_contact_batches_by_replication(built, track, model, parts):
+    """8192 cars = 32 different (start point, constant action) pairs x 256 replicas on the reference's own driftplayground mesh (three free-running partitions,
+    as bench.py runs it) and on the walled Nordschleife ribbon, 1600 ticks without an env loop: the cars leave the road within seconds and STAY in the barriers,
+    tyre stacks and rails, so thousands of cars sit in the contact pass at once -- its queue, the hand-over snapshots, the staging blocks, the 32-candidate cap,
+    the adaptive grid.  Every replica byte-identical to its representative (record + live contact joints) wherever it sits; the representatives equal the oracle,
+    contact joints included, every 50 ticks."""
+    import parity_util
+    r = parity_util.run_replicated(8192, 32, 1600, track, model=model, seed=11, check_every=50, partitions=parts)
+    print('%s: worst %.3e, up to %d of 8192 cars with live contact joints at a check, %d representative checks with live joints' % (track, r['worst'], r['max_in_contact'], r['contact_checks']))
+    assert r['worst'] == 0.0, r
+    assert r['max_in_contact'] >= 512 and r['contact_checks'] >= 20, r

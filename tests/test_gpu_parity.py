@@ -389,7 +389,7 @@ def test_bench_per_partition_exchange_with_two_ranks_on_one_gpu(built):
     s = socket.socket(); s.bind(('127.0.0.1', 0)); port = s.getsockname()[1]; s.close()
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1', '--master-port', str(port),
-           os.path.join(root, 'bench.py'), '--gpus', '2', '--steps', '30', '--warmup', '10', '--settle', '20', '--cars', '384', '--part-loop-min', '128', '--backend', 'gloo',
+           os.path.join(root, 'bench.py'), '--gpus', '2', '--steps', '30', '--warmup', '10', '--settle', '20', '--workload', 'flat', '--cars', '384', '--part-loop-min', '128', '--backend', 'gloo',
            '--gather-ticks', '1', '--scatter-actions', '--no-cpu-baseline', '--no-extra']
     r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
@@ -479,6 +479,26 @@ def test_full_size_batches_by_replication(built, n_cars, track):
         sc = pc.DynState(); orc.cpuref_get_state(h, C.byref(sc)); orc.cpuref_destroy(h)
         rel, name, vg, vc, bad_int = parity_util.compare_states(st[k], sc)
         assert not bad_int and rel == 0.0, (k, name, vg, vc, bad_int[:3])
+
+
+def test_configs2_as_worded_by_replication(built):
+    """BASELINE configs[2] as SURVEY 8d words it, at its size: 16384 cars on the reference's ek_akina spline (road ribbon), the scripted inputs bench.py's headline
+    runs -- gas = 0.6 + 0.4 sin(2 pi t / 7 s + phi), P-steer on lookAhead[0] + the side probes -- evaluated per tick from the observation rows, and the env's
+    episode rule (off track / hit / stuck -> Car::teleportByMode(Random) + the zero action) kept on the host for both sides.  64 different (start point, phase)
+    pairs x 256 replicas, 1500 ticks: replicas byte-identical to their representative every tick (output rows) and every 100 ticks (records, contact joints);
+    representatives bit-equal to the oracle."""
+    distinct = 64
+    phi = np.random.RandomState(2345).uniform(0.0, 2.0 * np.pi, distinct).astype(np.float32)
+
+    def law(o, t, ids):
+        a = np.empty((len(ids), 2), np.float32)
+        a[:, 0] = np.clip(np.float32(0.03) * (o[:, 21] - o[:, 20]) - o[:, 12] + np.float32(0.15) * o[:, 4], -1.0, 1.0)
+        gas = np.float32(0.6) + np.float32(0.4) * np.sin(phi[ids] + np.float32(2.0 * np.pi / 7.0 * (t / 333.0)))
+        a[:, 1] = (gas - np.float32(0.1)) / np.float32(0.45) - np.float32(1.0)    # env action -> gas is linscale(a1, -1, 1, 0.1, 1.0) (projectd_env.py:160)
+        return a
+    r = parity_util.run_replicated(16384, distinct, 1500, 'ek_akina', seed=3, check_every=100, law=law, resets=(1 | 2 | 4, 2))
+    print('ek_akina, scripted: worst %.3e, %d representative resets, up to %d cars with live contact joints' % (r['worst'], r['resets'], r['max_in_contact']))
+    assert r['worst'] == 0.0, r
 
 
 def test_snapshot_restore_replays_identically(built):

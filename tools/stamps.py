@@ -32,7 +32,7 @@ P = pdbatch.packed_params()
 pc.load_product = orig
 kind = sys.argv[2] if len(sys.argv) > 2 else 'flat'
 gen = {'step': float(sys.argv[3])} if len(sys.argv) > 3 else {}
-trk = pdbatch.synthetic_track(kind, **gen)
+trk = pdbatch.reference_track(kind) if kind in pdbatch.REFERENCE_TRACKS else pdbatch.synthetic_track(kind, **gen)
 pc.load_product = lp
 b = pdbatch.Batch(n, P, trk, 0, 1)
 a = pu.make_actions(n, 1234)
@@ -43,7 +43,7 @@ if kind == 'touge':   # spread the cars around the lap, drive them with a mild c
         hl.pdb_teleport_to_spline(C.byref(P), trk, C.c_float((i % 4096) / 4096.0), C.byref(st[i]))
     b.set_state(st)
     a[:, 0] = 0.0; a[:, 1] = -0.5
-if kind in ('playground', 'nordring'):   # every car to its own random point of the lap (device teleports), driven by a mild constant action
+if kind in ('playground', 'nordring') or kind in pdbatch.REFERENCE_TRACKS:   # every car to its own random point of the lap (device teleports), driven by a mild constant action
     lib.pdb_set_seed.argtypes = [C.c_void_p, C.c_void_p]; lib.pdb_reset_mode.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
     b.set_seed(np.arange(1, n + 1, dtype=np.uint32) * 7919)
     b.reset(mode=2)
