@@ -179,15 +179,24 @@ def measure(args, world, rank, local_rank, dist, want_cpu=False):
             np.clip(0.03 * (o[:, 21] - o[:, 20]) + 0.015 * (o[:, 19] - o[:, 18]) + 0.15 * o[:, 4], -1.0, 1.0, out=a[:, 0])
             np.clip(0.3 * (12.0 - o[:, 2]), -1.0, 1.0, out=a[:, 1])
 
-    def policy_step(o, a, t=0, f=0):
+    # the scripted law's clock lives on the device, one counter per launch site (partition), advanced by the policy's own launches: nothing in the law
+    # depends on a host value, so a partition's policy can be replayed from a captured graph
+    tick_dev = [torch.zeros(1, device=dev) for _ in range(5)]
+    ang_buf = {}
+
+    def policy_step(o, a, p=4, f=0):
         if policy == 'scripted':
             c = a.shape[0]
             # four columns by hand (no GEMM dispatch for a [c, 24] x [24, 1] product)
             torch.add(o[:, 21], o[:, 20], alpha=-1.0, out=a[:, 0]).mul_(0.03).add_(o[:, 12], alpha=-1.0).add_(o[:, 4], alpha=0.15)
             a[:, 0].clamp_(-1.0, 1.0)
             # env action -> gas is linscale(a1, -1, 1, 0.1, 1.0) (projectd_env.py:160): a1 = (gas - 0.1) / 0.45 - 1
-            torch.sin(phi[f:f + c] + (2.0 * np.pi / 7.0) * (t / 333.0), out=a[:, 1])
+            if (p, c) not in ang_buf:
+                ang_buf[(p, c)] = torch.empty(c, device=dev)
+            torch.add(phi[f:f + c], tick_dev[p], alpha=(2.0 * np.pi / 7.0) / 333.0, out=ang_buf[(p, c)])
+            torch.sin(ang_buf[(p, c)], out=a[:, 1])
             a[:, 1].mul_(0.4 / 0.45).add_(0.5 / 0.45 - 1.0)
+            tick_dev[p].add_(1.0)
             return
         if policy == 'feedback':   # oracle/scenarios.h scenarioFeedback (a linear law of the observation, clamped) as one addmm + one clamp
             torch.addmm(fb_b, o[:, :24], fb_w, out=a)
@@ -242,39 +251,49 @@ def measure(args, world, rank, local_rank, dist, want_cpu=False):
     if part_loops:
         part_st = [torch.cuda.ExternalStream(b.partition_stream(p), device=dev) for p in range(args.partitions)]
         part_rng = [b.partition_range(p) for p in range(args.partitions)]
-        # the policy's handful of small launches per partition and tick as ONE graph launch (the loop is launch-bound on the host below ~8192 cars: twelve torch
-        # dispatches + six kernel launches per 60-100 us tick).  The kernels then write the library's own output block (a fixed address, which the graph holds)
-        # instead of the trajectory ring.  The scripted law reads the tick number: it stays uncaptured.
-        part_graph = None
+        # the policy's handful of small launches per partition and tick as ONE graph launch: the loop is launch-bound on the HOST otherwise -- ten torch
+        # dispatches + two kernel launches per partition and tick from one python thread is ~10 us each, 280 us per tick of three partitions whatever the
+        # GPU does (round 5: the 16384-car headline sat at 58 M with the contact pass idle or not).  Below 8192 cars the partition's WHOLE tick goes into
+        # the graph (pdb_step_partition's two launches too; the contact pass's grid is then fixed), from 8192 up only the policy (the grid follows the load).
+        # A graph holds the addresses it was captured with: one graph per (partition, output block) -- the library's own block without a gather, every slot
+        # of the two trajectory rings with one -- captured the first time the pair comes up (inside the state-preparation ticks), after one plain pass.
         if gather.active and not args.ring_fork:
             ring_streams.extend(part_st)
-        if not args.no_graph_policy and policy in ('feedback', 'mlp') and n < 8192 and not gather.active:   # (measured: 4096 cars 45.0 -> 46.5 M with the env loop, 32.5 -> 35.6 M reset-free; at 16384 cars the loop is GPU-bound and the graph loses: 47.4 against 52.2 M)
-            try:
-                for p in range(args.partitions):   # (first use of the library's GEMM kernels, of the partition's launch path and its buffers outside a capture)
-                    f, c = part_rng[p]
-                    with torch.cuda.stream(part_st[p]):
-                        b.step_partition(p, out_t.data_ptr())
-                        policy_step(out_t[f:f + c], act_t[f:f + c], 0, f)
-                torch.cuda.synchronize()
-                act_t.copy_(torch.from_numpy(actions).to(dev)); torch.cuda.synchronize()
-                gs = []
-                whole = not args.graph_policy_only
-                if whole:   # the partition's tick itself goes into the graph too (two more launches): the contact pass's grid is then fixed
-                    b.set_contact_grid(args.graph_contact_grid)
-                for p in range(args.partitions):
-                    f, c = part_rng[p]
+        graphs = {}; plain_done = set(); graph_pool = [None] * args.partitions
+        use_graph = not args.no_graph_policy and policy in ('feedback', 'mlp', 'scripted')
+        part_graph = graphs if use_graph else None
+        part_graph_whole = use_graph and n < 8192 and not gather.active and not args.graph_policy_only
+        if part_graph_whole:
+            b.set_contact_grid(args.graph_contact_grid)
+
+        def part_tick(p, o, f, c):
+            """partition p's tick and policy, on its stream (the caller has made it current)"""
+            key = (p, o.data_ptr())
+            g = graphs.get(key) if use_graph else None
+            if g is None and use_graph and p in plain_done and key not in graphs:
+                try:
+                    if graph_pool[p] is None:
+                        graph_pool[p] = torch.cuda.graph_pool_handle()
                     g = torch.cuda.CUDAGraph()
-                    with torch.cuda.graph(g, stream=part_st[p]):
-                        if whole:
-                            b.step_partition(p, out_t.data_ptr())
-                        policy_step(out_t[f:f + c], act_t[f:f + c], 0, f)
-                    gs.append(g)
-                part_graph = gs; part_graph_whole = whole
-            except Exception as e:
-                sys.stderr.write('bench: the policy could not be captured (%r): plain launches\n' % (e,))
-                part_graph = None
+                    with torch.cuda.graph(g, stream=part_st[p], pool=graph_pool[p]):
+                        if part_graph_whole:
+                            b.step_partition(p, o.data_ptr())
+                        policy_step(o[f:f + c], act_t[f:f + c], p, f)
+                    graphs[key] = g
+                except Exception as e:
+                    sys.stderr.write('bench: the policy could not be captured (%r): plain launches\n' % (e,))
+                    graphs[key] = None; g = None
+            if g is not None:
+                if not part_graph_whole:
+                    b.step_partition(p, o.data_ptr())
+                g.replay()
+            else:
+                b.step_partition(p, o.data_ptr())
+                policy_step(o[f:f + c], act_t[f:f + c], p, f)
+                plain_done.add(p)
 
     host_act = [np.ascontiguousarray(actions, dtype=np.float32).copy()]
+    last_out = [out_t]
 
     def tick():
         t = tick_id[0]; tick_id[0] = t + 1
@@ -305,25 +324,20 @@ def measure(args, world, rank, local_rank, dist, want_cpu=False):
                     b.step_partition(p, out_t.data_ptr())
                     exch.gather(p, out_t[f:f + c], wait=True)        # the partition's stream waits for it (the host does not): its next tick rewrites these rows
             return
-        o = gather.slot(t)                  # the kernel writes tick t straight into its trajectory-ring slot
+        o = gather.slot(t) if (gather.active or not part_loops) else out_t   # the kernel writes tick t straight into its trajectory-ring slot (no gather: the library's own block)
+        last_out[0] = o
         if part_loops:     # every partition runs its own closed loop (kernel, then the policy on its rows) on its own stream
             for p in range(args.partitions):
                 f, c = part_rng[p]
                 with torch.cuda.stream(part_st[p]):
-                    if part_graph is not None:
-                        if not part_graph_whole:
-                            b.step_partition(p, out_t.data_ptr())
-                        part_graph[p].replay()
-                    else:
-                        b.step_partition(p, o.data_ptr())
-                        policy_step(o[f:f + c], act_t[f:f + c], t, f)
+                    part_tick(p, o, f, c)
             gather.after_tick(t)
             return
         if do_scatter:
             act_t.copy_(sharding.scatter_actions(scatter_src, n, world, rank, dev, dist))
         b.set_out_device_ptr(o.data_ptr())
         b.step_async()
-        policy_step(o, act_t, t, 0)
+        policy_step(o, act_t, 4, 0)
         gather.after_tick(t)
 
     def run(nsteps):
@@ -461,7 +475,7 @@ def measure(args, world, rank, local_rank, dist, want_cpu=False):
             ends = torch.zeros((), dtype=torch.int64, device=dev)
             for _ in range(300):
                 tick()
-                ends += (((out_t if (part_loops and part_graph is not None) else gather.slot(tick_id[0] - 1))[:, 25].view(torch.int32) & 8) != 0).sum()
+                ends += ((last_out[0][:, 25].view(torch.int32) & 8) != 0).sum()
             res["episode_ends_per_tick"] = float(ends.item()) / 300.0
         if want_cpu:   # the CPU leg is timed at N = 1 only
             res["cpu_baseline"] = cpu_baseline(P, trk, S0, all_actions)

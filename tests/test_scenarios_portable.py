@@ -231,6 +231,16 @@ def test_gpu_car_state_stays_on_the_reference_trajectories(built, sid):
     assert good >= MINW and good_int >= MINW, (sc['name'], good, good_int, first)
 
 
+# The bridge's gates sit on the measurement (round 5, PDB_BRIDGE_TICKS=7000: every tick of all 50 scenarios, 142 900 ticks): NO integer field ever differs; 56 ticks
+# (0.039 %) land above 1e-4 -- all but two of them in the angular velocity of a hub or strut body, where the constraint solve (condition numbers up to 1e6,
+# tests/test_physics_invariants.py) amplifies the one-ulp differences of the tick's sines and cosines most; the other two in a tyre force / moment -- and the worst is
+# 1.4e-3 (euphoria tick 2376, tyre[0].localMX), the next 7.8e-4 (wallpush).  So north_star's "within 1e-4 relative on float state" is NOT met on every single tick
+# against the reference's own arithmetic (glibc libm); it is met on 99.96 % of them.  Per scenario: the number of ticks above 1e-4 that was measured (a scenario
+# not listed: at most one), and the worst deviation allowed (1e-3 where not listed).
+BRIDGE_OVER = {'readie': 19, 'euphoria': 10, 'wingctrl2': 6, 'wallpush': 5, 'akina_tele': 4, 'wingctrl': 3, 'cold': 3}
+BRIDGE_WORST = {'euphoria': 2e-3}
+
+
 class _ResyncedPortable:
     """stands where SU.drive expects the GPU batch: the portable-math oracle (= the GPU's arithmetic, bit for bit), put back on the reference
     arithmetic's state after every tick, so that each of its ticks starts from a state the reference trajectory visits"""
@@ -270,8 +280,8 @@ def test_one_tick_from_every_state_of_the_reference_trajectory(built, hostlib, b
     (..._rounding_noise_amplified).  What can be held over the WHOLE scenario is the step itself: at every tick the portable-math oracle -- the GPU's
     arithmetic, to which the GPU is bit-identical over thousands of ticks -- starts from the state the glibc oracle is in (= the reference translation
     units' state: test_oracle_golden.py holds that trajectory bit for bit), takes the tick with the same input, and lands within 1e-4 of where the
-    reference arithmetic lands -- every float of the record on more than 99 % of the ticks (the rest, a few dozen ticks in 126 k, stay below 6e-4: printed) --
-    integers equal.  Every branch the scenario's reference trajectory takes is compared this way -- resets, teleports, contacts, gear changes, wheel
+    reference arithmetic lands -- every float of the record on 99.96 % of the ticks (the rest: BRIDGE_OVER / BRIDGE_WORST above, the measured counts) --
+    integers equal, always.  Every branch the scenario's reference trajectory takes is compared this way -- resets, teleports, contacts, gear changes, wheel
     lock -- not only the first four records."""
     glibc = oracle_ctypes.load_oracle(portable_math=False)
     port = oracle_ctypes.load_oracle(portable_math=True)
@@ -312,19 +322,16 @@ def test_one_tick_from_every_state_of_the_reference_trajectory(built, hostlib, b
         sc['name'], n, n - len(stats['over']) - len(stats['ints']), stats['worst'], stats['worst_at'], len(stats['over']), worst_over,
         max(stats['over'], key=lambda o: o[2])[:2] if stats['over'] else None, len(stats['ints']), (': ' + str(stats['ints'][:3])) if stats['ints'] else ''))
     assert n >= min(sc['ticks'], limit)
-    # measured over the 49 scenarios (126 k ticks): no integer field ever differs; 52 ticks land between 1.0e-4 and 5.4e-4 -- every one of them in the angular
-    # velocity of a hub or strut body, where the constraint solve (condition numbers up to 1e6, tests/test_physics_invariants.py) amplifies the one-ulp
-    # differences of the tick's sines and cosines most
-    assert len(stats['ints']) <= 1, (sc['name'], stats['ints'][:5])
-    assert len(stats['over']) <= max(3, n // 50) and worst_over < 2e-3, (sc['name'], len(stats['over']), stats['over'][:5])
+    assert len(stats['ints']) == 0, (sc['name'], stats['ints'][:5])
+    assert len(stats['over']) <= BRIDGE_OVER.get(sc['name'], 1) and worst_over < BRIDGE_WORST.get(sc['name'], 1e-3), (sc['name'], len(stats['over']), stats['over'][:5])
 
 
 @pytest.mark.gpu
 @pytest.mark.parametrize('sid', range(NSC))
 def test_gpu_one_tick_from_every_state_of_the_reference_trajectory(built, sid):
     """the same bridge with the GPU itself in the portable oracle's place: every tick of the scenario's first 1500 the batch is put on the glibc
-    oracle's state (= the reference translation units' trajectory) and steps once -- within 1e-4 of the reference arithmetic's next state on more
-    than 99 % of the ticks, never beyond 2e-3, integer fields equal"""
+    oracle's state (= the reference translation units' trajectory) and steps once -- within 1e-4 of the reference arithmetic's next state except on
+    the handful of ticks BRIDGE_OVER lists per scenario (measured), never beyond BRIDGE_WORST, integer fields equal"""
     import pdbatch
     glibc = oracle_ctypes.load_oracle(portable_math=False)
     hostlib = pc.load_product(host_only=True)
@@ -358,5 +365,5 @@ def test_gpu_one_tick_from_every_state_of_the_reference_trajectory(built, sid):
         b.close()
     worst = max([r for _, _, r in over], default=0.0)
     print('%s: GPU, %d ticks each from the reference trajectory\'s own state: %d above 1e-4 (worst %.2e), %d integer mismatches' % (sc['name'], n[0], len(over), worst, len(ints)))
-    assert len(ints) <= 1, (sc['name'], ints[:5])
-    assert len(over) <= max(3, n[0] // 50) and worst < 2e-3, (sc['name'], len(over), over[:5])
+    assert len(ints) == 0, (sc['name'], ints[:5])
+    assert len(over) <= BRIDGE_OVER.get(sc['name'], 1) and worst < BRIDGE_WORST.get(sc['name'], 1e-3), (sc['name'], len(over), over[:5])
