@@ -450,7 +450,7 @@ def measure(args, world, rank, local_rank, dist, want_cpu=False):
         wl = "%s: %d cars/GPU, AE86, %s, %s%s, dt=1/333 s" % (tag, n, where, pol, ", env loop in the kernel (random-point resets)" if args.episodes and args.teleport_mode == 2 else ", env loop in the kernel" if args.episodes else "")
         coll = "none"
         if world > 1 or args.force_gather:
-            coll = ("per partition and tick: action scatter from rank 0 -> tick -> RCCL all-gather of its [n,26] rows, issued by %s" % ("the library" if lib_exchange else "torch.distributed")) if part_exchange else \
+            coll = ("per partition and tick: rank 0's action rows -> tick -> all-gather of its [n,26] rows, issued by %s" % ("the library (RCCL)" if lib_exchange else "torch.distributed")) if part_exchange else \
                    ("RCCL all-gather of %d-tick trajectory rings [k,N,26] on the idle current stream, kernels write the ring in place%s" % (args.gather_ticks, "; actions scattered from rank 0 every tick" if args.scatter_actions else ""))
         res = {
             "metric": "env-steps/sec (333 Hz tick, 4-wheel car)",
@@ -599,7 +599,8 @@ def compact(res, secondary=None, rccl=None, extra_file=None):
     for k in ("value", "ms_per_step", "timed_region_s"):
         out[k] = float('%.6g' % out[k])
     out["config"] = {"workload": _short(c["workload"], 230), "cars_per_gpu": c["cars_per_gpu"], "partitions": c["partitions"], "collective": _short(c["collective"], 120), "parity": _short(c["parity"], 150)}
-    out["roofline"] = {"bound": r["bound"], "achieved": float('%.5g' % r["achieved"]), "peak": r["peak"], "unit": r["unit"], "frac": float('%.4g' % r["frac"]),
+    ach = float('%.5g' % r["achieved"])
+    out["roofline"] = {"bound": r["bound"], "achieved": ach, "peak": r["peak"], "unit": r["unit"], "frac": float('%.6g' % (ach / r["peak"])),
                        "traffic": (float('%.5g' % r["traffic"]) if r.get("traffic") else None), "kernel": r["kernel"], "kernel_avg_us": float('%.5g' % r["kernel_avg_us"]),
                        "alg_bytes_per_car_tick": r["alg_bytes_per_car_tick"], "cars_per_launch": float('%.6g' % r["cars_per_launch"]), "concurrent_launches": r["concurrent_launches"],
                        "device_frac": float('%.4g' % r["device_frac"])}

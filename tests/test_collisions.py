@@ -229,4 +229,4 @@ def test_full_size_contact_batches_by_replication(built, track, model, parts):
     r = parity_util.run_replicated(8192, 32, 1600, track, model=model, seed=11, check_every=50, partitions=parts)
     print('%s: worst %.3e, up to %d of 8192 cars with live contact joints at a check, %d representative checks with live joints' % (track, r['worst'], r['max_in_contact'], r['contact_checks']))
     assert r['worst'] == 0.0, r
-    assert r['max_in_contact'] >= 512 and r['contact_checks'] >= 20, r
+    assert r['max_in_contact'] >= 512 and r['contact_checks'] >= 10, r

@@ -324,7 +324,7 @@ def test_bench_driver_command_prints_one_compact_line(built):
     assert d['steps'] == 20 and d['warmup'] == 5 and d['n_gpus'] == 1 and d['config']['cars_per_gpu'] == 16384 and 'ek_akina' in d['config']['workload']
     for k in ('bound', 'achieved', 'peak', 'unit', 'frac', 'traffic', 'kernel', 'kernel_avg_us', 'alg_bytes_per_car_tick', 'cars_per_launch'):
         assert k in d['roofline'], k
-    assert abs(d['roofline']['frac'] - d['roofline']['achieved'] / d['roofline']['peak']) < 1e-6 and 0 < d['roofline']['frac'] < 1
+    assert abs(d['roofline']['frac'] - d['roofline']['achieved'] / d['roofline']['peak']) < 1e-3 * d['roofline']['frac'] and 0 < d['roofline']['frac'] < 1   # (both rounded to a few digits in the line)
     assert abs(d['roofline']['achieved'] - d['roofline']['alg_bytes_per_car_tick'] * d['roofline']['cars_per_launch'] / d['roofline']['kernel_avg_us'] / 1e3) < 0.01 * d['roofline']['achieved']
     for k in ('value', 'unit', 'cores', 'kind', 'sample'):
         assert k in d['cpu_baseline'], k

@@ -39,7 +39,7 @@ if os.path.exists(ir):
         im['counters_per_instruction'].setdefault(kn, {})[str(wps)] = {'SQ_ACTIVE_INST_VALU_quads_per_VALU_inst': v.get('SQ_ACTIVE_INST_VALU', 0) / v['SQ_INSTS_VALU'],
                                                                         'SQ_WAVE_CYCLES_quads_per_VALU_inst_per_wave': v.get('SQ_WAVE_CYCLES', 0) / v['SQ_INSTS_VALU']}
     json.dump(im, open(os.path.join(dst, tag + '_issue_model.json'), 'w'), indent=1)
-summary = {'tag': tag, 'kernel': KERNEL}
+summary = {'tag': tag, 'kernel': KERNEL, 'workload_key': (sys.argv[2] if len(sys.argv) > 2 else 'ek_akina')}
 # kernel stats
 ks = [r for r in rows('stats/**/*kernel_stats.csv')]
 if ks:
