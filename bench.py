@@ -179,24 +179,27 @@ def measure(args, world, rank, local_rank, dist, want_cpu=False):
             np.clip(0.03 * (o[:, 21] - o[:, 20]) + 0.015 * (o[:, 19] - o[:, 18]) + 0.15 * o[:, 4], -1.0, 1.0, out=a[:, 0])
             np.clip(0.3 * (12.0 - o[:, 2]), -1.0, 1.0, out=a[:, 1])
 
-    # the scripted law's clock lives on the device, one counter per launch site (partition), advanced by the policy's own launches: nothing in the law
-    # depends on a host value, so a partition's policy can be replayed from a captured graph
-    tick_dev = [torch.zeros(1, device=dev) for _ in range(5)]
-    ang_buf = {}
+    # the scripted law in three launches: a = obs @ W (the P-steer's four columns), a += [sin phi_i, cos phi_i, 1] @ C_t (the throttle: k sin(phi_i + w t) + c0 =
+    # k cos(w t) sin phi_i + k sin(w t) cos phi_i + c0, with C_t from a table over the law's period of 7 s = 2331 ticks), clamp.  The loop is bound by the HOST's launches
+    # (one python thread, ~9 us per torch call; three partitions): as eight elementwise launches the law held the 16384-car headline at 58 M whatever the kernels did
+    site_tick = [0] * 5
+    if policy == 'scripted':
+        sw = np.zeros((24, 2), np.float32); sw[21, 0] = 0.03; sw[20, 0] = -0.03; sw[12, 0] = -1.0; sw[4, 0] = 0.15
+        s_w = torch.from_numpy(sw).to(dev)
+        s_sc = torch.stack([torch.sin(phi), torch.cos(phi), torch.ones_like(phi)], 1).contiguous()
+        T_per = 7 * 333
+        wt = (2.0 * np.pi / 7.0) * (np.arange(T_per, dtype=np.float64) / 333.0)
+        # env action -> gas is linscale(a1, -1, 1, 0.1, 1.0) (projectd_env.py:160): a1 = (gas - 0.1) / 0.45 - 1, gas = 0.6 + 0.4 sin(.)
+        cf = np.zeros((T_per, 3, 2), np.float32); cf[:, 0, 1] = (0.4 / 0.45) * np.cos(wt); cf[:, 1, 1] = (0.4 / 0.45) * np.sin(wt); cf[:, 2, 1] = 0.5 / 0.45 - 1.0
+        s_cf = torch.from_numpy(cf).to(dev)
 
     def policy_step(o, a, p=4, f=0):
         if policy == 'scripted':
             c = a.shape[0]
-            # four columns by hand (no GEMM dispatch for a [c, 24] x [24, 1] product)
-            torch.add(o[:, 21], o[:, 20], alpha=-1.0, out=a[:, 0]).mul_(0.03).add_(o[:, 12], alpha=-1.0).add_(o[:, 4], alpha=0.15)
-            a[:, 0].clamp_(-1.0, 1.0)
-            # env action -> gas is linscale(a1, -1, 1, 0.1, 1.0) (projectd_env.py:160): a1 = (gas - 0.1) / 0.45 - 1
-            if (p, c) not in ang_buf:
-                ang_buf[(p, c)] = torch.empty(c, device=dev)
-            torch.add(phi[f:f + c], tick_dev[p], alpha=(2.0 * np.pi / 7.0) / 333.0, out=ang_buf[(p, c)])
-            torch.sin(ang_buf[(p, c)], out=a[:, 1])
-            a[:, 1].mul_(0.4 / 0.45).add_(0.5 / 0.45 - 1.0)
-            tick_dev[p].add_(1.0)
+            torch.mm(o[:, :24], s_w, out=a)
+            a.addmm_(s_sc[f:f + c], s_cf[site_tick[p] % T_per])
+            a.clamp_(-1.0, 1.0)
+            site_tick[p] += 1
             return
         if policy == 'feedback':   # oracle/scenarios.h scenarioFeedback (a linear law of the observation, clamped) as one addmm + one clamp
             torch.addmm(fb_b, o[:, :24], fb_w, out=a)
@@ -251,16 +254,14 @@ def measure(args, world, rank, local_rank, dist, want_cpu=False):
     if part_loops:
         part_st = [torch.cuda.ExternalStream(b.partition_stream(p), device=dev) for p in range(args.partitions)]
         part_rng = [b.partition_range(p) for p in range(args.partitions)]
-        # the policy's handful of small launches per partition and tick as ONE graph launch: the loop is launch-bound on the HOST otherwise -- ten torch
-        # dispatches + two kernel launches per partition and tick from one python thread is ~10 us each, 280 us per tick of three partitions whatever the
-        # GPU does (round 5: the 16384-car headline sat at 58 M with the contact pass idle or not).  Below 8192 cars the partition's WHOLE tick goes into
-        # the graph (pdb_step_partition's two launches too; the contact pass's grid is then fixed), from 8192 up only the policy (the grid follows the load).
-        # A graph holds the addresses it was captured with: one graph per (partition, output block) -- the library's own block without a gather, every slot
-        # of the two trajectory rings with one -- captured the first time the pair comes up (inside the state-preparation ticks), after one plain pass.
+        # Below 8192 cars the partition's WHOLE tick -- pdb_step_partition's two launches and the policy's -- is replayed from one captured graph (the loop is
+        # launch-bound on the host there: 4096-car env loop 46.5 -> 53 M; the contact pass's grid is then fixed).  From 8192 cars up a graph launch costs the host
+        # more than the launches it replaces (round 5: 54 against 57 M on the 16384-car headline) and the launches stay plain.  A graph holds the addresses it was
+        # captured with: one per (partition, output block), captured the first time the pair comes up (inside the state-preparation ticks), after one plain pass.
         if gather.active and not args.ring_fork:
             ring_streams.extend(part_st)
         graphs = {}; plain_done = set(); graph_pool = [None] * args.partitions
-        use_graph = not args.no_graph_policy and policy in ('feedback', 'mlp', 'scripted')
+        use_graph = not args.no_graph_policy and policy in ('feedback', 'mlp') and n < 8192 and not gather.active   # (from 8192 cars up a graph launch costs the host more than the launches it replaces: 54 against 57 M on the 16384-car headline)
         part_graph = graphs if use_graph else None
         part_graph_whole = use_graph and n < 8192 and not gather.active and not args.graph_policy_only
         if part_graph_whole:
@@ -329,8 +330,9 @@ def measure(args, world, rank, local_rank, dist, want_cpu=False):
         if part_loops:     # every partition runs its own closed loop (kernel, then the policy on its rows) on its own stream
             for p in range(args.partitions):
                 f, c = part_rng[p]
-                with torch.cuda.stream(part_st[p]):
-                    part_tick(p, o, f, c)
+                torch.cuda.set_stream(part_st[p])      # (the context manager costs more host time than the launches it wraps)
+                part_tick(p, o, f, c)
+            torch.cuda.set_stream(stream)
             gather.after_tick(t)
             return
         if do_scatter:
