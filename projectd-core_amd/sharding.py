@@ -166,9 +166,10 @@ class PartitionExchange:
     gathered[p] ([world, cars of p, 26]).  Collectives are enqueued under `with torch.cuda.stream(partition stream)`: the
     partition's stream waits for them (stream-side, the host never does)."""
 
-    def __init__(self, part_ranges, world, rank, device, dist, backend=None):
+    def __init__(self, part_ranges, world, rank, device, dist, backend=None, strict=False):
         import torch
         self.dist, self.world, self.rank, self.ranges = dist, world, rank, list(part_ranges)
+        self.strict = strict and dist is not None   # one rank takes no shortcut: its scatter is a collective too (the exact calls N > 1 makes)
         # every rank creates the groups in the same order
         self.groups = [dist.new_group(ranks=list(range(world)), backend=backend) for _ in self.ranges] if dist is not None else [None] * len(self.ranges)
         self.gathered2 = [[torch.empty((world, c, OUT_COLS), dtype=torch.float32, device=device) for (f, c) in self.ranges] for _ in range(2)]
@@ -188,7 +189,7 @@ class PartitionExchange:
 
     def scatter(self, p, act_rows):
         """this rank's action rows of partition p <- the learner's (act_rows: the [c, 2] view of the batch's action block)"""
-        if self.world == 1:
+        if self.world == 1 and not self.strict:
             act_rows.copy_(self.scatter_src[p][0])
         elif self._via_host(act_rows):
             import torch
@@ -232,9 +233,10 @@ class LibraryExchange:
     torch process group once, at construction (which is collective).  Raises RuntimeError on every rank if any rank cannot set it up (no RCCL in
     the process, two ranks on one GPU, ...): the caller falls back to PartitionExchange."""
 
-    def __init__(self, batch, part_ranges, world, rank, device, dist, action_stride=2):
+    def __init__(self, batch, part_ranges, world, rank, device, dist, action_stride=2, strict=False):
         import torch
         self.batch, self.world, self.rank, self.ranges = batch, world, rank, list(part_ranges)
+        multi = world > 1 or (strict and dist is not None and dist.is_initialized())   # strict: one rank goes through the id broadcast and the agreement like N ranks
         if dist is not None and dist.is_initialized() and dist.get_backend() == 'nccl' and os.environ.get('PDB_EXCHANGE_NO_PREWARM') is None:
             # torch's own RCCL communicator first: created AFTER the library's (at the first torch collective) it left every later kernel of the process
             # 25 % slower, for good (measured: tools/exchange_residue2.py)
@@ -246,7 +248,7 @@ class LibraryExchange:
                 ids = batch.comm_unique_ids(len(self.ranges))
         except RuntimeError as e:
             ok, err = 0, e
-        if world > 1:
+        if multi:
             box = [ids if ok else None]
             dist.broadcast_object_list(box, src=0)
             ids = box[0]
@@ -256,7 +258,7 @@ class LibraryExchange:
                 batch.comm_init(world, rank, ids)
             except RuntimeError as e:
                 ok, err = 0, e
-        if world > 1:   # agree before anybody enters a collective the others will not
+        if multi:   # agree before anybody enters a collective the others will not
             flag = torch.tensor([ok], dtype=torch.int32, device=(device if dist.get_backend() == 'nccl' else 'cpu'))
             dist.all_reduce(flag, op=dist.ReduceOp.MIN)
             ok = int(flag.item())
@@ -276,11 +278,11 @@ class LibraryExchange:
         self.batch.step_exchange_partition(p, self.scatter_src[p].data_ptr() if self.rank == 0 else 0, self.gathered[p].data_ptr())
 
 
-def scatter_actions(all_actions, n_local, world, rank, device, dist=None):
-    """Learner (rank 0) -> every rank: this rank's [n_local, 2] slice of the global action tensor."""
+def scatter_actions(all_actions, n_local, world, rank, device, dist=None, strict=False):
+    """Learner (rank 0) -> every rank: this rank's [n_local, 2] slice of the global action tensor.  strict: one rank scatters to itself through the backend."""
     import torch
     mine = torch.empty((n_local, 2), dtype=torch.float32, device=device)
-    if world == 1:
+    if world == 1 and not (strict and dist is not None):
         mine.copy_(all_actions)
         return mine
     chunks = list(all_actions.reshape(world, n_local, 2).unbind(0)) if rank == 0 else None
@@ -288,9 +290,9 @@ def scatter_actions(all_actions, n_local, world, rank, device, dist=None):
     return mine
 
 
-def max_over_ranks(value, device, dist=None, world=1):
+def max_over_ranks(value, device, dist=None, world=1, strict=False):
     """bench.py timing rule: the job's time is the slowest rank's."""
-    if world == 1:
+    if world == 1 and not (strict and dist is not None):
         return float(value)
     import torch
     t = torch.tensor([value], dtype=torch.float64, device=('cpu' if dist.get_backend() == 'gloo' else device))

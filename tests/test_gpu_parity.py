@@ -346,6 +346,18 @@ def test_ring_gather_holds_every_tick(built):
 
 
 @pytest.mark.gpu
+def test_multi_rank_code_paths_with_one_rccl_rank(built):
+    """no second GPU to give RCCL two ranks: every N > 1 code path of sharding.py / pdb_comm_* run by ONE nccl rank through the exact calls N ranks make
+    (strict=True: no world == 1 shortcut -- DESIGN.md section 7 lists the shortcuts) -- LibraryExchange, PartitionExchange, scatter_actions, max_over_ranks,
+    and the trajectory rings behind per-partition loops (the headline's N > 1 form); every gathered block equals a plain batch's"""
+    import subprocess, socket
+    s = socket.socket(); s.bind(('127.0.0.1', 0)); port = s.getsockname()[1]; s.close()
+    r = subprocess.run([sys.executable, os.path.join(os.path.dirname(os.path.abspath(__file__)), '_exchange_strict_gpu.py'), str(port)],
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900, env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0'))
+    assert r.returncode == 0 and 'STRICT_PATHS OK' in r.stdout, (r.stdout[-800:], r.stderr[-1500:])
+
+
+@pytest.mark.gpu
 def test_library_exchange_equals_plain_stepping(built):
     """pdb_comm_init / pdb_step_exchange_partition with one rank (two cannot share this box's GPU under RCCL): per partition and tick the learner's
     action rows in -- different every tick --, the partition's tick, its output rows out through the library's own RCCL communicators; every gathered
