@@ -540,7 +540,7 @@ def parser():
     ap.add_argument('--scatter-actions', action='store_true', help='with a gather: rank 0 scatters the [N,2] action block back every tick (configs[3] as SURVEY 8d words it)')
     ap.add_argument('--library-exchange', action='store_true', help='N > 1: the per-partition exchange through the library\'s own RCCL communicators (pdb_step_exchange_partition); default with one rank, opt-in with more')
     ap.add_argument('--graph-policy-only', action='store_true', help='per-partition loops below 8192 cars: only the policy in the captured graph, the tick as plain launches (A/B)')
-    ap.add_argument('--graph-contact-grid', type=int, default=32, help='workgroups of the contact pass inside a captured per-partition tick')
+    ap.add_argument('--graph-contact-grid', type=int, default=96, help='workgroups of the contact pass inside a captured per-partition tick')
     ap.add_argument('--no-graph-policy', action='store_true', help='per-partition policy loops: the policy as plain torch launches instead of one captured graph per partition (A/B)')
     ap.add_argument('--ring-fork', action='store_true', help='ring mode: every ring starts behind the batch stream (the older form; A/B)')
     ap.add_argument('--torch-exchange', action='store_true', help='the per-partition exchange (--scatter-actions with --gather-ticks 1) through torch.distributed instead of the library\'s own RCCL communicators (A/B)')

@@ -22,7 +22,13 @@
 #define PDB_FIRST_CPB 3
 #endif
 #ifndef PDB_CONTACT_CPB
-#define PDB_CONTACT_CPB 3
+#define PDB_CONTACT_CPB 1
+#endif
+// Round 5: the contact pass is ONE car per workgroup -- its wave, a pack wave, and PDB_CONTACT_HELPERS helper waves that only work in the narrow phase of the car's
+// collision pass (collisionNarrow: the surviving wall triangles dealt round the four waves).  A launch of the pass lasts as long as its heaviest car; with three cars
+// per workgroup a car waited for its neighbours' narrow phases as well, whether they ran side by side (round 4) or one after the other on all four waves.
+#ifndef PDB_CONTACT_HELPERS
+#define PDB_CONTACT_HELPERS 2
 #endif
 #ifndef PDB_KMINWAVES_C
 #define PDB_KMINWAVES_C 2
@@ -37,17 +43,21 @@
 #define PDB_KERNEL_GUARDED_C pdb_contact_kernel_generic
 #define PDB_KNS k33
 #define PDB_CPB PDB_FIRST_CPB
+#define PDB_HELPERS 0
 #define PDB_FIRST_ONLY
 #include "step_kernel.hip.inc"
 #undef PDB_FIRST_ONLY
+#undef PDB_HELPERS
 #undef PDB_CPB
 #undef PDB_BLOCK_THREADS
 #undef PDB_KNS
 #define PDB_KNS k33c
 #define PDB_CPB PDB_CONTACT_CPB
+#define PDB_HELPERS PDB_CONTACT_HELPERS
 #define PDB_CONTACT_ONLY
 #include "step_kernel.hip.inc"
 #undef PDB_CONTACT_ONLY
+#undef PDB_HELPERS
 #undef PDB_CPB
 #undef PDB_BLOCK_THREADS
 #undef PDB_KNS
@@ -70,17 +80,21 @@
 #define PDB_KERNEL_GUARDED_C pdb_contact_kernel_wide
 #define PDB_KNS k40
 #define PDB_CPB PDB_FIRST_CPB
+#define PDB_HELPERS 0
 #define PDB_FIRST_ONLY
 #include "step_kernel.hip.inc"
 #undef PDB_FIRST_ONLY
+#undef PDB_HELPERS
 #undef PDB_CPB
 #undef PDB_BLOCK_THREADS
 #undef PDB_KNS
 #define PDB_KNS k40c
 #define PDB_CPB PDB_CONTACT_CPB
+#define PDB_HELPERS PDB_CONTACT_HELPERS
 #define PDB_CONTACT_ONLY
 #include "step_kernel.hip.inc"
 #undef PDB_CONTACT_ONLY
+#undef PDB_HELPERS
 #undef PDB_CPB
 #undef PDB_BLOCK_THREADS
 #undef PDB_KNS
@@ -313,11 +327,11 @@ static void launchTick(pdb_batch* b, hipStream_t st, int c0, int c1, pdb_step_ou
         cg = (2 * held + PDB_CONTACT_CPB - 1) / PDB_CONTACT_CPB;
         if (cg < (held > 0 ? PDB_CONTACT_GRID : PDB_CONTACT_GRID_IDLE)) cg = held > 0 ? PDB_CONTACT_GRID : PDB_CONTACT_GRID_IDLE;   // nobody touched anything lately: a handful of workgroups is launched, found empty and gone
         if (b->capturing && cg < PDB_CONTACT_GRID) cg = PDB_CONTACT_GRID;   // a replayed graph cannot follow the load
-        if (!b->capturing && b->burst[q] > 0) { --b->burst[q]; if (cg < 512) cg = 512; }
-        if (cg > 2048) cg = 2048;
+        if (!b->capturing && b->burst[q] > 0) { --b->burst[q]; if (cg < 1536) cg = 1536; }   // (one car per workgroup since round 5: 512 of them are resident at once)
+        if (cg > 4096) cg = 4096;
     }
     int* HN = b->dHint ? b->dHint + q : nullptr;
-    const dim3 grid(nblk), block(PDB_BLOCK_THREADS), cblock(PDB_WAVE * (PDB_CONTACT_CPB + 1)), cgrid(((n + PDB_CONTACT_CPB - 1) / PDB_CONTACT_CPB) < cg ? ((n + PDB_CONTACT_CPB - 1) / PDB_CONTACT_CPB) : cg);
+    const dim3 grid(nblk), block(PDB_BLOCK_THREADS), cblock(PDB_WAVE * (PDB_CONTACT_CPB + 1 + PDB_CONTACT_HELPERS)), cgrid(((n + PDB_CONTACT_CPB - 1) / PDB_CONTACT_CPB) < cg ? ((n + PDB_CONTACT_CPB - 1) / PDB_CONTACT_CPB) : cg);
     // a car with DynamicController files goes through the kernel pair compiled with the controllers' call sites (40-row class, row-guarded: any car)
     const bool ctrl = HP.numCtrlStages != 0 || HP.hasBrakeTemps != 0;
     const int kind = ctrl ? 0 : (m == 33 ? 1 : (m < 33 ? 2 : 3));
@@ -800,7 +814,7 @@ int pdb_contact_pass_load(pdb_batch* b, int site) {
     return *(volatile int*)(b->hHint + site);
 }
 int pdb_set_contact_grid(pdb_batch* b, int workgroups) {
-    if (!b || workgroups < 0 || workgroups > 2048) { pdb::setError("pdb_set_contact_grid: 0 (adaptive) .. 2048 workgroups"); return PDB_ERR_ARG; }
+    if (!b || workgroups < 0 || workgroups > 4096) { pdb::setError("pdb_set_contact_grid: 0 (adaptive) .. 4096 workgroups"); return PDB_ERR_ARG; }
     b->contactGrid = workgroups;
     if (b->graphExec) { (void)hipGraphExecDestroy(b->graphExec); b->graphExec = nullptr; }
     return PDB_OK;
