@@ -24,11 +24,26 @@
 #ifndef PDB_CONTACT_CPB
 #define PDB_CONTACT_CPB 1
 #endif
-// Round 5: the contact pass is ONE car per workgroup -- its wave, a pack wave, and PDB_CONTACT_HELPERS helper waves that only work in the narrow phase of the car's
-// collision pass (collisionNarrow: the surviving wall triangles dealt round the four waves).  A launch of the pass lasts as long as its heaviest car; with three cars
-// per workgroup a car waited for its neighbours' narrow phases as well, whether they ran side by side (round 4) or one after the other on all four waves.
+// Round 5: the contact pass is ONE WAVE per car (PDB_CONTACT_SOLO): the car's wave is its own pack wave, one role after the other, and a workgroup is 64 threads.
+// On the contact-heavy legs the pass is bound by what its waves cost the CUs while they live -- 212 VGPRs a lane, two waves per SIMD -- not by a car's chain: in a
+// workgroup of three car waves and a pack wave a car waited at the barriers for its slowest neighbour and the pack wave idled through the collision pass and the
+// LCP (four waves held for the slowest of three cars: about 45 % of the wave-time useful); one car on four waves (its wave, a pack wave, two helpers for the narrow
+// phase) cut a car's chain three-fold and moved no leg, because the four waves were held three times as long per car.  PDB_CONTACT_SOLO=0 keeps the
+// workgroup forms (PDB_CONTACT_CPB cars + a pack wave + PDB_CONTACT_HELPERS helper waves that work in collisionNarrow only) for the A/B.
+#ifndef PDB_CONTACT_SOLO
+#define PDB_CONTACT_SOLO 1
+#endif
+#if PDB_CONTACT_SOLO
+#undef PDB_CONTACT_CPB
+#define PDB_CONTACT_CPB 1
+#undef PDB_CONTACT_HELPERS
+#define PDB_CONTACT_HELPERS 0
+#define PDB_CONTACT_WAVES 1
+#else
 #ifndef PDB_CONTACT_HELPERS
-#define PDB_CONTACT_HELPERS 2
+#define PDB_CONTACT_HELPERS 0
+#endif
+#define PDB_CONTACT_WAVES (PDB_CONTACT_CPB + 1 + PDB_CONTACT_HELPERS)
 #endif
 #ifndef PDB_KMINWAVES_C
 #define PDB_KMINWAVES_C 2
@@ -44,9 +59,11 @@
 #define PDB_KNS k33
 #define PDB_CPB PDB_FIRST_CPB
 #define PDB_HELPERS 0
+#define PDB_SOLO 0
 #define PDB_FIRST_ONLY
 #include "step_kernel.hip.inc"
 #undef PDB_FIRST_ONLY
+#undef PDB_SOLO
 #undef PDB_HELPERS
 #undef PDB_CPB
 #undef PDB_BLOCK_THREADS
@@ -54,9 +71,11 @@
 #define PDB_KNS k33c
 #define PDB_CPB PDB_CONTACT_CPB
 #define PDB_HELPERS PDB_CONTACT_HELPERS
+#define PDB_SOLO PDB_CONTACT_SOLO
 #define PDB_CONTACT_ONLY
 #include "step_kernel.hip.inc"
 #undef PDB_CONTACT_ONLY
+#undef PDB_SOLO
 #undef PDB_HELPERS
 #undef PDB_CPB
 #undef PDB_BLOCK_THREADS
@@ -81,9 +100,11 @@
 #define PDB_KNS k40
 #define PDB_CPB PDB_FIRST_CPB
 #define PDB_HELPERS 0
+#define PDB_SOLO 0
 #define PDB_FIRST_ONLY
 #include "step_kernel.hip.inc"
 #undef PDB_FIRST_ONLY
+#undef PDB_SOLO
 #undef PDB_HELPERS
 #undef PDB_CPB
 #undef PDB_BLOCK_THREADS
@@ -91,9 +112,11 @@
 #define PDB_KNS k40c
 #define PDB_CPB PDB_CONTACT_CPB
 #define PDB_HELPERS PDB_CONTACT_HELPERS
+#define PDB_SOLO PDB_CONTACT_SOLO
 #define PDB_CONTACT_ONLY
 #include "step_kernel.hip.inc"
 #undef PDB_CONTACT_ONLY
+#undef PDB_SOLO
 #undef PDB_HELPERS
 #undef PDB_CPB
 #undef PDB_BLOCK_THREADS
@@ -331,7 +354,7 @@ static void launchTick(pdb_batch* b, hipStream_t st, int c0, int c1, pdb_step_ou
         if (cg > 4096) cg = 4096;
     }
     int* HN = b->dHint ? b->dHint + q : nullptr;
-    const dim3 grid(nblk), block(PDB_BLOCK_THREADS), cblock(PDB_WAVE * (PDB_CONTACT_CPB + 1 + PDB_CONTACT_HELPERS)), cgrid(((n + PDB_CONTACT_CPB - 1) / PDB_CONTACT_CPB) < cg ? ((n + PDB_CONTACT_CPB - 1) / PDB_CONTACT_CPB) : cg);
+    const dim3 grid(nblk), block(PDB_BLOCK_THREADS), cblock(PDB_WAVE * PDB_CONTACT_WAVES), cgrid(((n + PDB_CONTACT_CPB - 1) / PDB_CONTACT_CPB) < cg ? ((n + PDB_CONTACT_CPB - 1) / PDB_CONTACT_CPB) : cg);
     // a car with DynamicController files goes through the kernel pair compiled with the controllers' call sites (40-row class, row-guarded: any car)
     const bool ctrl = HP.numCtrlStages != 0 || HP.hasBrakeTemps != 0;
     const int kind = ctrl ? 0 : (m == 33 ? 1 : (m < 33 ? 2 : 3));
