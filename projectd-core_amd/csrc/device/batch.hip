@@ -22,16 +22,20 @@
 #define PDB_FIRST_CPB 3
 #endif
 #ifndef PDB_CONTACT_CPB
-#define PDB_CONTACT_CPB 1
+#define PDB_CONTACT_CPB 3
 #endif
-// Round 5: the contact pass is ONE WAVE per car (PDB_CONTACT_SOLO): the car's wave is its own pack wave, one role after the other, and a workgroup is 64 threads.
-// On the contact-heavy legs the pass is bound by what its waves cost the CUs while they live -- 212 VGPRs a lane, two waves per SIMD -- not by a car's chain: in a
-// workgroup of three car waves and a pack wave a car waited at the barriers for its slowest neighbour and the pack wave idled through the collision pass and the
-// LCP (four waves held for the slowest of three cars: about 45 % of the wave-time useful); one car on four waves (its wave, a pack wave, two helpers for the narrow
-// phase) cut a car's chain three-fold and moved no leg, because the four waves were held three times as long per car.  PDB_CONTACT_SOLO=0 keeps the
-// workgroup forms (PDB_CONTACT_CPB cars + a pack wave + PDB_CONTACT_HELPERS helper waves that work in collisionNarrow only) for the A/B.
+// The contact pass's workgroup shape (round 5: four forms built, measured on the contact-heavy legs and on the headline, all bit-identical):
+//   default            PDB_CONTACT_CPB = 3 car waves + a pack wave, every car's collision pass by its own wave (collisionGather + collisionNarrow<1>), side by side;
+//   PDB_NARROW_COOP=1  the same workgroup, the narrow phase of one car at a time shared by all four waves;
+//   PDB_CONTACT_CPB=1 PDB_CONTACT_HELPERS=2   one car per workgroup: its wave, a pack wave, two helper waves that work in the narrow phase only;
+//   PDB_CONTACT_SOLO=1 one WAVE per car: the car's wave is its own pack wave, one role after the other (64-thread workgroups).
+// In-kernel stamps say what each does to a car's chain (collision pass done 228 k / 86 k clocks after the car started for the coop forms, record stored 391 k /
+// 140 k); the legs say it does not matter: playground MLP 35.2-36.3 / 33.4-33.7 / 32.9 M against 35.1-35.6 M for round 4's structure, the env loops and the
+// headline within 2 % -- under the other partitions' first passes the pass is bound by what its 210-VGPR waves and 54 KB of LDS cost a CU while they live (a
+// contact workgroup displaces two to three first-pass workgroups), not by the length of a car's chain.  The default is the form without
+// any barrier of its own.
 #ifndef PDB_CONTACT_SOLO
-#define PDB_CONTACT_SOLO 1
+#define PDB_CONTACT_SOLO 0
 #endif
 #if PDB_CONTACT_SOLO
 #undef PDB_CONTACT_CPB
