@@ -411,7 +411,11 @@ typedef struct pdb_lane_tune {
 /* Env mode: the reward / termination / reset bookkeeping of pyprojectd/projectd_env.py:173-227, per car, inside the tick --
  * reward = stepReward minus the penalties of the rules that fired, terminate on hit / off track / stuck / cumulative reward below
  * low_reward; the tick after a termination is the env's reset(): teleport by teleport_mode (if teleport_on_reset) at its top, the
- * zero action, its reward and termination discarded, the episode sums cleared.  One kernel launch = one VecEnv.step(). */
+ * zero action, its reward and termination discarded, the episode sums cleared.  One kernel launch = one VecEnv.step().
+ * Not in the reference env: a car whose chassis pose or velocity is no longer finite (pdb_step_out.flags bit 5) also ends its episode
+ * (reward 0), and at the top of its next tick its record is re-created from a fresh car's before the teleport -- Car::reset cannot repair a
+ * record once NaNs are in it (it leaves the struts' velocities, the steering filter, the tyres' loads ... as they are), and a vector env would
+ * otherwise carry a dead lane for ever. */
 typedef struct pdb_env_config {
     int32_t enabled;
     int32_t terminate_on_hit, terminate_off_track, terminate_when_stuck;

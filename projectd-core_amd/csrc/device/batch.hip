@@ -218,6 +218,7 @@ struct pdb_batch {
     bool resetMaskArmed = false;     // pdb_reset_mask_device was asked for: the step kernels look at the mask
     unsigned char* dHold = nullptr;   // [n] hold mask of pdb_step_host_held, allocated on first use
     pdb_lane_tune* dLaneTunes = nullptr;   // [n] per-lane tunes and reward weights (pdb_set_lane_tunes), allocated on first use; rows with valid == 0 fall back to the block
+    pdb_dyn_state* dFresh = nullptr;     // device copy of resetTemplate (DevConst::freshState)
     pdb_contact* dContacts = nullptr;   // [n][PDB_MAX_CONTACTS]: each car's live contact joints (the first pdb_dyn_state.numContacts of its row)
     hipEvent_t ev0 = nullptr, ev1 = nullptr, tev0 = nullptr, tev1 = nullptr;
     bool ownStream = true;
@@ -410,6 +411,7 @@ static int pushK(pdb_batch* b, hipStream_t st, bool async) {
         DevConst& K = b->partK[p];
         if (b->partHas[p]) fillConst(b->partParams[p], K, b->K.actionMode); else K = b->K;
         const int c0 = partFirst(b, p);
+        K.freshState = b->K.freshState;
         K.laneTunes = b->K.laneTunes ? b->K.laneTunes + c0 : nullptr;
         K.holdMask = b->K.holdMask ? b->K.holdMask + c0 : nullptr;
         K.dt = b->K.dt; K.fps = b->K.fps; K.dtD = b->K.dtD; K.stuckTimeout = b->K.stuckTimeout; K.wantCarState = b->K.wantCarState; K.stamps = b->K.stamps; K.stampCars = b->K.stampCars;
@@ -510,6 +512,11 @@ pdb_batch* pdb_create(int device, int n_cars, const pdb_car_params* params, cons
         pdb::initialState(b->params, tv, b->resetTemplate);
     } catch (const std::exception& e) { pdb::setError(e.what()); pdb_destroy(b); return nullptr; }
     if (pdb_set_state_all(b, &b->resetTemplate) != PDB_OK) { pdb_destroy(b); return nullptr; }
+    if (hipMalloc(&b->dFresh, sizeof(pdb_dyn_state)) != hipSuccess || hipMemcpy(b->dFresh, &b->resetTemplate, sizeof(pdb_dyn_state), hipMemcpyHostToDevice) != hipSuccess) {
+        pdb::setError("pdb_create: HIP allocation / upload failed"); pdb_destroy(b); return nullptr;
+    }
+    b->K.freshState = b->dFresh;
+    if (pushK(b, b->stream, false) != PDB_OK) { pdb_destroy(b); return nullptr; }
     ensureSnap(b);
     if (passNeeded(b, b->params) && !b->dSnap) { pdb_destroy(b); return nullptr; }   // (ensureSnap left the message)
     return b;
@@ -521,7 +528,7 @@ void pdb_destroy(pdb_batch* b) {
     commFree(b);
     if (b->graphExec) (void)hipGraphExecDestroy(b->graphExec);
     if (b->stream) (void)hipStreamSynchronize(b->stream);
-    (void)hipFree(b->dStates); (void)hipFree(b->dActions); (void)hipFree(b->dOut); (void)hipFree(b->dCarStates); (void)hipFree(b->dParams); (void)hipFree(b->dK); (void)hipFree(b->dTrack); (void)hipFree(b->dContacts); (void)hipFree(b->dResetMask); (void)hipFree(b->dResetScratch);
+    (void)hipFree(b->dStates); (void)hipFree(b->dActions); (void)hipFree(b->dOut); (void)hipFree(b->dCarStates); (void)hipFree(b->dParams); (void)hipFree(b->dK); (void)hipFree(b->dTrack); (void)hipFree(b->dContacts); (void)hipFree(b->dFresh); (void)hipFree(b->dResetMask); (void)hipFree(b->dResetScratch);
     if (b->hHint) (void)hipHostFree(b->hHint);
     if (b->hActions) (void)hipHostFree(b->hActions);
     if (b->hOut) (void)hipHostFree(b->hOut);

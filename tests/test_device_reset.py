@@ -152,3 +152,39 @@ def test_torch_env_runs_episodes_without_the_host(built):
         if term.any():
             b.reset(term.astype(np.uint8), 0)
     b.close()
+
+
+def test_env_mode_recreates_a_car_whose_state_is_no_longer_finite(built):
+    """not in the reference env: a NaN in a car's record (a solver blow-up; here injected) raises flags bit 5, ends the episode, and the next tick re-creates the
+    car from a fresh record and teleports it -- the lane is alive again two ticks later, every other lane is byte-identical to a run without the injection, and the
+    launch does not crawl (on an open track the locator's fallback trace walked 250 000 steps for such a car: 9 ms per tick)"""
+    import time, pdbatch, projectd_env, parity_util
+    n = 96
+    P = pdbatch.packed_params(); trk = pdbatch.reference_track('ek_akina')
+    acts = parity_util.make_actions(n, 5); acts[:, 1] = np.abs(acts[:, 1])
+    runs = []
+    for inject in (False, True):
+        b = pdbatch.Batch(n, P, trk, device=0, action_mode=1)
+        b.set_seed(np.arange(n, dtype=np.uint32) * 7919 + 1)
+        b.reset(mode=2)
+        b.set_env(projectd_env.EnvConfig(teleport_mode=2))
+        for _ in range(120):
+            b.step_host(acts)
+        if inject:
+            st = b.get_state()
+            st[17].body[0].avel[1] = float('nan'); st[17].body[2].lvel[0] = float('inf')
+            b.set_state(st)
+        flags, dts = [], []
+        for _ in range(40):
+            t0 = time.perf_counter(); o = b.step_host(acts); dts.append(time.perf_counter() - t0)
+            flags.append(np.array(o['flags']))
+        runs.append((b.get_state(), np.array(flags), np.median(dts)))
+        b.close()
+    (s0, f0, d0), (s1, f1, d1) = runs
+    assert (f1[0, 17] & 32) != 0 and (f1[0, 17] & 8) != 0            # faulted and terminated on the tick it shows
+    assert (f1[1, 17] & 16) != 0 and (f1[2:, 17] & 32).max() == 0    # reset tick, then finite for good
+    raw0 = np.frombuffer(bytes(s0), dtype=np.uint8).reshape(n, -1); raw1 = np.frombuffer(bytes(s1), dtype=np.uint8).reshape(n, -1)
+    others = np.arange(n) != 17
+    assert (raw0[others] == raw1[others]).all()
+    assert np.isfinite(np.frombuffer(bytes(s1[17]), dtype=np.float32)[24:200]).all()
+    assert d1 < 3.0 * d0 + 1e-3, (d0, d1)
