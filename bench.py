@@ -489,10 +489,10 @@ EXTRA = [   # (key, argv) -- the other BASELINE configs' shapes, each measured b
     ("configs2_16384_dense_spline", ['--workload', 'touge', '--cars', '16384', '--spline-step', '0.9', '--steps', '300', '--warmup', '50', '--settle', '200']),
     ("configs2_16384", ['--workload', 'touge', '--cars', '16384', '--steps', '300', '--warmup', '50', '--settle', '200']),
     ("configs4_shape_16384_walls_mlp", ['--workload', 'touge', '--cars', '16384', '--walls', '--policy', 'mlp', '--steps', '300', '--warmup', '50', '--settle', '200']),
-    ("configs3_shard_8192", ['--cars', '8192', '--steps', '600', '--warmup', '100']),
-    ("configs3_shard_8192_gather_k1_scatter", ['--cars', '8192', '--steps', '300', '--warmup', '50', '--force-gather', '--gather-ticks', '1', '--scatter-actions']),
-    ("configs3_shard_8192_gather_k1_scatter_torch", ['--cars', '8192', '--steps', '300', '--warmup', '50', '--force-gather', '--gather-ticks', '1', '--scatter-actions', '--torch-exchange']),
-    ("configs3_shard_8192_gather_k32", ['--cars', '8192', '--steps', '600', '--warmup', '100', '--force-gather', '--gather-ticks', '32']),
+    ("configs3_shard_8192", ['--workload', 'flat', '--cars', '8192', '--steps', '600', '--warmup', '100']),
+    ("configs3_shard_8192_gather_k1_scatter", ['--workload', 'flat', '--cars', '8192', '--steps', '300', '--warmup', '50', '--force-gather', '--gather-ticks', '1', '--scatter-actions']),
+    ("configs3_shard_8192_gather_k1_scatter_torch", ['--workload', 'flat', '--cars', '8192', '--steps', '300', '--warmup', '50', '--force-gather', '--gather-ticks', '1', '--scatter-actions', '--torch-exchange']),
+    ("configs3_shard_8192_gather_k32", ['--workload', 'flat', '--cars', '8192', '--steps', '600', '--warmup', '100', '--force-gather', '--gather-ticks', '32']),
     ("configs4_shape_16384_walls_host_policy", ['--workload', 'touge', '--cars', '16384', '--walls', '--policy', 'host', '--steps', '200', '--warmup', '30', '--settle', '100']),
     ("configs4_shape_16384_walls_host_policy_sync", ['--workload', 'touge', '--cars', '16384', '--walls', '--policy', 'host_sync', '--steps', '200', '--warmup', '30', '--settle', '100']),
     ("configs4_playground_16384_mlp", ['--workload', 'playground', '--cars', '16384', '--policy', 'mlp', '--steps', '300', '--warmup', '50', '--settle', '200']),

@@ -11,14 +11,22 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 
 @pytest.fixture(scope='module')
 def stubs():
+    used = {}
     for name in ('gym', 'gymnasium'):
         try:
-            importlib.import_module(name)
+            m = importlib.import_module(name)
         except ImportError:
             if os.path.join(HERE, 'stubs') not in sys.path:
                 sys.path.append(os.path.join(HERE, 'stubs'))
-            importlib.import_module(name)
-    return True
+            m = importlib.import_module(name)
+        used[name] = 'tests/stubs stand-in' if os.path.join(HERE, 'stubs') in os.path.abspath(getattr(m, '__file__', '')) else 'the installed package %s' % getattr(m, '__version__', '')
+    try:
+        import stable_baselines3 as _sb3
+        used['stable_baselines3'] = 'the installed package %s' % _sb3.__version__
+    except ImportError:
+        used['stable_baselines3'] = 'absent (projectd_sb3 is exercised through its own VecEnv-shaped surface)'
+    print('adapter tests run against: ' + '; '.join('%s = %s' % kv for kv in used.items()))   # (pytest -s / the report's captured output says which)
+    return used
 
 
 @pytest.fixture(scope='module')
