@@ -85,7 +85,11 @@ class _Arr:   # zero-copy torch view of a library-owned device block
 def measure(args, world, rank, local_rank, dist, want_cpu=False):
     """one configuration, measured by the contract's rule; returns the result dict on rank 0 (None elsewhere)"""
     if args.partitions is None:
-        args.partitions = 3 if world == 1 else 2
+        # three free-running ranges per GPU at every N.  (Rounds 3-4 used two with more than one rank, to leave a hardware queue for a collective that ends up on a stream
+        # of the process group's own; the ring gather is issued in torch's synchronous form, which enqueues on the CURRENT stream -- three partition streams + that one
+        # are the process's four queues -- and two partitions cost the headline 7 % on one rank: 61.9 against 66-67 M.  --partitions 2 is the fallback if a node shows
+        # the gather holding a partition up.)
+        args.partitions = 3
     import numpy as np
     import torch
     import pdbatch, pdb_ctypes as pc, sharding
@@ -527,7 +531,7 @@ def parser():
     ap.add_argument('--extra', action='store_true', help='after the line is printed: measure the other configs\' shapes too (results to stderr and gpurun_out/bench_extra.json)')
     ap.add_argument('--no-secondary', action='store_true', help='skip the configs[1] measurement that rides in the line as `secondary`')
     ap.add_argument('--partitions', type=int, default=None, choices=[1, 2, 3, 4],
-                    help='free-running car ranges per GPU, one HIP stream each (pdb_set_partitions / pdb_step_ring); 1 = one launch per tick.  Default: 3 on one rank; 2 with more ranks -- a process has four hardware queues, three partitions and the null stream use them up, and the process group\'s collective stream would then share one with a partition and hold it up for as long as a gather runs (tools/hwqueue_probe.py: 47 M against 69 M with a 1 ms kernel per ring on a fifth stream; with two partitions 63-67 M against 67 M)')
+                    help='free-running car ranges per GPU, one HIP stream each (pdb_set_partitions / pdb_step_ring); 1 = one launch per tick.  Default 3: a process has four hardware queues -- three partitions and the current stream, on which the ring gather is issued, use them up; a FIFTH busy stream would share a queue with a partition and hold it up for as long as its kernels run (tools/hwqueue_probe.py: 47 M against 69 M with a 1 ms kernel per ring on a fifth stream; with two partitions 63-67 M against 67 M): --partitions 2 if a node shows that')
     ap.add_argument('--walls', action='store_true', help='touge workload: line both edges of the road with WALL surfaces (configs[4] shape: hull-vs-wall narrow phase next to the guard rails)')
     ap.add_argument('--spline-step', type=float, default=0.0, help='touge workload: metres between spline points (default 5 m = 891 points; 0.9 = 4.9 k points, the density of the reference tracks)')
     ap.add_argument('--no-body-contacts', action='store_true', help='diagnostic A/B: switch the collision pass off in the car block (never the bench line)')

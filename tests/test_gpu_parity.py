@@ -304,7 +304,7 @@ def test_bench_headline_workload_with_two_ranks_on_one_gpu(built):
     lines = [l for l in r.stdout.splitlines() if l.startswith('{')]
     assert len(lines) == 1 and len(lines[0]) < 4096
     d = json.loads(lines[0])
-    assert d['n_gpus'] == 2 and d['value'] > 0 and d['config']['cars_per_gpu'] == 384 and d['config']['partitions'] == 2
+    assert d['n_gpus'] == 2 and d['value'] > 0 and d['config']['cars_per_gpu'] == 384 and d['config']['partitions'] == 3
     assert d['config']['workload'].startswith('configs[2]') and 'ek_akina' in d['config']['workload'] and 'trajectory rings' in d['config']['collective']
 
 
@@ -408,7 +408,7 @@ def test_bench_per_partition_exchange_with_two_ranks_on_one_gpu(built):
     lines = [l for l in r.stdout.splitlines() if l.startswith('{')]
     assert len(lines) == 1
     d = json.loads(lines[0])
-    assert d['n_gpus'] == 2 and d['value'] > 0 and d['config']['partitions'] == 2      # (two per GPU with more than one rank: bench.py --partitions)
+    assert d['n_gpus'] == 2 and d['value'] > 0 and d['config']['partitions'] == 3
     assert 'per partition and tick' in d['config']['collective'] and 'torch.distributed' in d['config']['collective']
 
 
