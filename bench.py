@@ -119,7 +119,8 @@ def measure(args, world, rank, local_rank, dist, want_cpu=False):
     actions = all_actions[first:last]
     b = pdbatch.Batch(n, P, trk, device=dev_index, action_mode=1)
     stream = torch.cuda.current_stream()
-    b.set_stream(stream.cuda_stream)
+    if not os.environ.get('PDB_BENCH_KEEP_OWN_STREAM'):   # (experiment: the batch stays on the library's own stream, which partition 0 then shares -- four partitions on four streams)
+        b.set_stream(stream.cuda_stream)
     b.upload_actions(actions)
     if args.workload in ('playground', 'nordring') or is_ref:   # reference-scale meshes: every car to its own random point of the lap, on the device
         b.set_seed(np.arange(first, first + n, dtype=np.uint32) * 2654435761 % 4294967291 + 1)   # Car::teleportByMode(Random) draws from the car's own rand()

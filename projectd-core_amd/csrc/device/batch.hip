@@ -411,7 +411,7 @@ static int pushK(pdb_batch* b, hipStream_t st, bool async) {
         DevConst& K = b->partK[p];
         if (b->partHas[p]) fillConst(b->partParams[p], K, b->K.actionMode); else K = b->K;
         const int c0 = partFirst(b, p);
-        K.freshState = b->K.freshState;
+        K.freshState = b->K.freshState; K.noTeam = b->K.noTeam;
         K.laneTunes = b->K.laneTunes ? b->K.laneTunes + c0 : nullptr;
         K.holdMask = b->K.holdMask ? b->K.holdMask + c0 : nullptr;
         K.dt = b->K.dt; K.fps = b->K.fps; K.dtD = b->K.dtD; K.stuckTimeout = b->K.stuckTimeout; K.wantCarState = b->K.wantCarState; K.stamps = b->K.stamps; K.stampCars = b->K.stampCars;
@@ -467,6 +467,7 @@ pdb_batch* pdb_create(int device, int n_cars, const pdb_car_params* params, cons
     b->track.assign((const uint8_t*)track_blob, (const uint8_t*)track_blob + track_bytes);
     fillConst(b->params, b->K, action_mode);
     b->K.dt = (float)(1.0 / 333.0); b->K.fps = 1.0f / b->K.dt; b->K.dtD = 1.0 / 333.0;
+    if (const char* nt = getenv("PDB_NO_TEAM")) b->K.noTeam = atoi(nt) != 0 ? 1 : 0;   // diagnostic: the per-wave form of the car waves' stage (tests, A/B)
     bool ok = true;
     ok = ok && hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking) == hipSuccess;
     ok = ok && hipMalloc(&b->dStates, sizeof(pdb_dyn_state) * (size_t)n_cars) == hipSuccess;

@@ -32,6 +32,7 @@ struct DevConst {
     const unsigned char* holdMask;        // [cars of the batch] or null: cars whose byte is non-zero sit this launch out (pdb_step_host_held: the reset tick of the lanes whose episode just ended)
     const pdb_dyn_state* freshState;      // the record of a fresh car at the start pose (device memory): env mode re-creates a car whose pose is no longer finite from it
     unsigned long long* stamps;   // diagnostic build only (-DPDB_STAMPS): [car][32] shader-clock stamps of the first pass, then [stampCars + car][32] of the contact pass
-    int stampCars, _padStamp;
+    int stampCars;
+    int noTeam;   // diagnostic (PDB_NO_TEAM in the environment at pdb_create): the car waves each walk their own car's joint rows, bars, wings ... as before round 5 (the form a model with more than 21 joints takes)
 };
 

@@ -26,6 +26,16 @@ def test_free_running_parity_config2_sample(built):
     assert worst == 0.0
 
 
+def test_per_wave_form_of_the_car_waves_stage(built, monkeypatch):
+    """PDB_NO_TEAM=1: every car wave walks its own car's joint rows, bars, wings, rays-by-the-pack-wave ... as before round 5 -- the form a model with more than 21
+    joints takes (none shipped), kept alive here: bit-exact like the team form"""
+    monkeypatch.setenv('PDB_NO_TEAM', '1')   # read when the batch is created
+    worst = parity_util.run_parity(n_cars=32, ticks=600, seed=5, resync=False, check_every=20)
+    assert worst == 0.0
+    worst = parity_util.run_parity(n_cars=24, ticks=900, seed=99, track='walled', check_every=9)
+    assert worst == 0.0
+
+
 def test_free_running_parity_wide_actions(built):
     """harder inputs: full-range steer, per-tick changing actions (sinusoids with per-car phase)"""
     import math
