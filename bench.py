@@ -122,6 +122,17 @@ def measure(args, world, rank, local_rank, dist, want_cpu=False):
     if not os.environ.get('PDB_BENCH_KEEP_OWN_STREAM'):   # (experiment: the batch stays on the library's own stream, which partition 0 then shares -- four partitions on four streams)
         b.set_stream(stream.cuda_stream)
     b.upload_actions(actions)
+    if args.lane_setups:   # diagnostic: what the per-lane setup table's kernel pair costs -- every lane a row with its own springs, dampers, bars, ratios ...
+        rs = np.random.RandomState(99)
+        blocks = []
+        for i in range(64):
+            Q = pc.CarParams.from_buffer_copy(bytes(P))
+            Q.arbK[0] = float(np.float32(Q.arbK[0] * rs.uniform(0.7, 1.3))); Q.finalRatio = float(Q.finalRatio * rs.uniform(0.9, 1.1))
+            for w in range(4):
+                Q.susp[w].k = float(np.float32(Q.susp[w].k * rs.uniform(0.85, 1.2))); Q.susp[w].damper.bumpSlow = float(np.float32(Q.susp[w].damper.bumpSlow * rs.uniform(0.8, 1.2)))
+            blocks.append(Q)
+        for f0 in range(0, n, 64):
+            b.set_lane_tunes(blocks[:min(64, n - f0)], first=f0); b.set_lane_setups(blocks[:min(64, n - f0)], first=f0)
     if args.workload in ('playground', 'nordring') or is_ref:   # reference-scale meshes: every car to its own random point of the lap, on the device
         b.set_seed(np.arange(first, first + n, dtype=np.uint32) * 2654435761 % 4294967291 + 1)   # Car::teleportByMode(Random) draws from the car's own rand()
         b.reset(mode=2)
@@ -184,9 +195,11 @@ def measure(args, world, rank, local_rank, dist, want_cpu=False):
             np.clip(0.03 * (o[:, 21] - o[:, 20]) + 0.015 * (o[:, 19] - o[:, 18]) + 0.15 * o[:, 4], -1.0, 1.0, out=a[:, 0])
             np.clip(0.3 * (12.0 - o[:, 2]), -1.0, 1.0, out=a[:, 1])
 
-    # the scripted law in three launches: a = obs @ W (the P-steer's four columns), a += [sin phi_i, cos phi_i, 1] @ C_t (the throttle: k sin(phi_i + w t) + c0 =
-    # k cos(w t) sin phi_i + k sin(w t) cos phi_i + c0, with C_t from a table over the law's period of 7 s = 2331 ticks), clamp.  The loop is bound by the HOST's launches
-    # (one python thread, ~9 us per torch call; three partitions): as eight elementwise launches the law held the 16384-car headline at 58 M whatever the kernels did
+    # the scripted law in ONE launch: a = T_t + obs @ W (addmm: W = the P-steer's four columns; T_t = [sin phi_i, cos phi_i, 1] @ C_t, the throttle k sin(phi_i + w t) + c0 =
+    # k cos(w t) sin phi_i + k sin(w t) cos phi_i + c0, tabulated per car over the law's period of 7 s = 2331 ticks: 305 MB at 16384 cars).  The law's clamp to [-1, 1] is
+    # the env's own clip of its action space (projectd_env.py:159-160) and is done by the tick's pre-step on both components (step_kernel.hip.inc carPreStep: the same
+    # values whether or not the buffer was clamped first), so it is not launched a second time here.  Every kernel boundary in a partition's stream costs 2.5-4.5 % of the
+    # leg (profiles/r05_team_ab.txt); as eight elementwise launches the law held the 16384-car headline at 58 M whatever the kernels did
     site_tick = [0] * 5
     if policy == 'scripted':
         sw = np.zeros((24, 2), np.float32); sw[21, 0] = 0.03; sw[20, 0] = -0.03; sw[12, 0] = -1.0; sw[4, 0] = 0.15
@@ -197,18 +210,16 @@ def measure(args, world, rank, local_rank, dist, want_cpu=False):
         # env action -> gas is linscale(a1, -1, 1, 0.1, 1.0) (projectd_env.py:160): a1 = (gas - 0.1) / 0.45 - 1, gas = 0.6 + 0.4 sin(.)
         cf = np.zeros((T_per, 3, 2), np.float32); cf[:, 0, 1] = (0.4 / 0.45) * np.cos(wt); cf[:, 1, 1] = (0.4 / 0.45) * np.sin(wt); cf[:, 2, 1] = 0.5 / 0.45 - 1.0
         s_cf = torch.from_numpy(cf).to(dev)
+        s_tab = torch.matmul(s_sc, s_cf).contiguous()   # [T_per, n, 2]
 
     def policy_step(o, a, p=4, f=0):
         if policy == 'scripted':
             c = a.shape[0]
-            torch.mm(o[:, :24], s_w, out=a)
-            a.addmm_(s_sc[f:f + c], s_cf[site_tick[p] % T_per])
-            a.clamp_(-1.0, 1.0)
+            torch.addmm(s_tab[site_tick[p] % T_per][f:f + c], o[:, :24], s_w, out=a)
             site_tick[p] += 1
             return
-        if policy == 'feedback':   # oracle/scenarios.h scenarioFeedback (a linear law of the observation, clamped) as one addmm + one clamp
+        if policy == 'feedback':   # oracle/scenarios.h scenarioFeedback (a linear law of the observation, clamped) as one addmm; the clamp is the pre-step's (above)
             torch.addmm(fb_b, o[:, :24], fb_w, out=a)
-            a.clamp_(-1.0, 1.0)
         elif policy == 'mlp':      # obs -> normalise -> 256 -> 256 -> 2, tanh-squashed like SAC's actor mean (hyperparams/sac.yml net_arch)
             # six launches: three GEMMs with their bias (addmm), two ReLUs and the tanh in place, hidden layers in buffers kept per row count
             c = a.shape[0]
@@ -535,6 +546,7 @@ def parser():
                     help='free-running car ranges per GPU, one HIP stream each (pdb_set_partitions / pdb_step_ring); 1 = one launch per tick.  Default 3: a process has four hardware queues -- three partitions and the current stream, on which the ring gather is issued, use them up; a FIFTH busy stream would share a queue with a partition and hold it up for as long as its kernels run (tools/hwqueue_probe.py: 47 M against 69 M with a 1 ms kernel per ring on a fifth stream; with two partitions 63-67 M against 67 M): --partitions 2 if a node shows that')
     ap.add_argument('--walls', action='store_true', help='touge workload: line both edges of the road with WALL surfaces (configs[4] shape: hull-vs-wall narrow phase next to the guard rails)')
     ap.add_argument('--spline-step', type=float, default=0.0, help='touge workload: metres between spline points (default 5 m = 891 points; 0.9 = 4.9 k points, the density of the reference tracks)')
+    ap.add_argument('--lane-setups', action='store_true', help='every lane with a setup row of its own (pdb_set_lane_tunes + pdb_set_lane_setups: the kernel pair compiled for the table; never the bench line)')
     ap.add_argument('--no-body-contacts', action='store_true', help='diagnostic A/B: switch the collision pass off in the car block (never the bench line)')
     ap.add_argument('--policy', choices=['constant', 'feedback', 'mlp', 'random', 'host', 'host_sync', 'host_mlp', 'scripted'], default=None,
                     help='where actions come from each tick: constant (configs[1]), feedback (probe controller on the GPU, default for touge), '

@@ -408,6 +408,28 @@ typedef struct pdb_lane_tune {
     int32_t _pad[3];
 } pdb_lane_tune;
 
+/* Per-LANE setup, the rest of it (pdb_set_lane_setups): every other SetupManager tune that is a plain field of the car block (Car/SetupManager.cpp:10-120) --
+ * BRAKE_POWER_MULT, DIFF_PRELOAD, INTERNAL_GEAR_n, ARB_FRONT/REAR, ENGINE_LIMITER, TURBO_n, and per wheel DAMP_(FAST_)BUMP/REBOUND, BUMP_STOP_RATE, SPRING_RATE,
+ * PROGRESSIVE_SPRING_RATE, ROD_LENGTH, PACKER_RANGE, TOE_OUT, CAMBER (as the three entries of the camber rotation the tick uses: DevConst camC/camS/camM33).  The row
+ * holds the RESOLVED values of a block that went through pdb_set_car_tune (pdb_lane_setup_from_params).  WING_n is accepted by the reference and overwritten on every
+ * tick (csrc/host/model.cpp findTune): nothing to carry.  Cars of the 33-row kernel class only (no DynamicController files, no brake temperatures). */
+typedef struct pdb_lane_wheel {
+    float bumpFast, bumpSlow, reboundFast, reboundSlow;
+    float bumpStopRate, k, progressiveK, rodLength;
+    float packerRange, toeOutLinear, camC, camS;
+    float camM33, _pad[3];
+} pdb_lane_wheel;
+typedef struct pdb_lane_setup {
+    double diffPreLoad;
+    double gearRatio[PDB_MAX_GEARS];
+    float brakePowerMultiplier, limiterMultiplier;
+    float arbK[2];
+    float turboUserSetting[PDB_MAX_TURBOS];
+    float _pad0;
+    pdb_lane_wheel wheel[4];
+    int32_t _pad1[2];
+} pdb_lane_setup;
+
 /* Env mode: the reward / termination / reset bookkeeping of pyprojectd/projectd_env.py:173-227, per car, inside the tick --
  * reward = stepReward minus the penalties of the rules that fired, terminate on hit / off track / stuck / cumulative reward below
  * low_reward; the tick after a termination is the env's reset(): teleport by teleport_mode (if teleport_on_reset) at its top, the
@@ -490,6 +512,7 @@ static_assert(sizeof(pdb_car_params) == 22696, "pdb_car_params layout");
 static_assert(sizeof(pdb_dyn_state) == 2352, "pdb_dyn_state layout (multiple of 16 bytes)");
 static_assert(sizeof(pdb_step_out) == 104, "pdb_step_out layout");
 static_assert(sizeof(pdb_contact) == 32, "pdb_contact layout");
+static_assert(sizeof(pdb_lane_setup) == 384 && sizeof(pdb_lane_wheel) == 64, "pdb_lane_setup layout");
 static_assert(sizeof(pdb_lane_tune) == 144, "pdb_lane_tune layout (a multiple of 16 bytes: it rides in the car's LDS block)");
 static_assert(sizeof(pdb_ray_rec) == 48, "pdb_ray_rec layout");
 #endif

@@ -58,8 +58,10 @@
 #define PDB_KSLOT0_EXACT true    /* the class's first kernel pair: exactly 33 rows, no run-time row guards */
 #define PDB_KSLOT0_CTRL false
 #define PDB_KERNEL_GUARDED pdb_step_kernel_generic
+#define PDB_KERNEL_LANE pdb_step_kernel_lane       /* the guarded form reading the per-lane setup table (33-row class only) */
 #define PDB_KERNEL_EXACT_C pdb_contact_kernel
 #define PDB_KERNEL_GUARDED_C pdb_contact_kernel_generic
+#define PDB_KERNEL_LANE_C pdb_contact_kernel_lane
 #define PDB_KNS k33
 #define PDB_CPB PDB_FIRST_CPB
 #define PDB_HELPERS 0
@@ -92,6 +94,8 @@
 #undef PDB_KERNEL_GUARDED
 #undef PDB_KERNEL_EXACT_C
 #undef PDB_KERNEL_GUARDED_C
+#undef PDB_KERNEL_LANE
+#undef PDB_KERNEL_LANE_C
 #ifndef PDB_FAST_BUILD   /* development builds (make dev) compile the 33-row size class only */
 #define PDB_KROWS 40
 #define PDB_KMINWAVES 5
@@ -217,6 +221,7 @@ struct pdb_batch {
     uint8_t* dResetMask = nullptr;   // [n]: 1 + teleport mode for cars to be reset at the top of their next tick (consumed and cleared by that tick)
     bool resetMaskArmed = false;     // pdb_reset_mask_device was asked for: the step kernels look at the mask
     unsigned char* dHold = nullptr;   // [n] hold mask of pdb_step_host_held, allocated on first use
+    pdb_lane_setup* dLaneSetups = nullptr;   // [n] per-lane setup rows (pdb_set_lane_setups), allocated on first use and then complete: every lane's row holds its block's values or the caller's
     pdb_lane_tune* dLaneTunes = nullptr;   // [n] per-lane tunes and reward weights (pdb_set_lane_tunes), allocated on first use; rows with valid == 0 fall back to the block
     pdb_dyn_state* dFresh = nullptr;     // device copy of resetTemplate (DevConst::freshState)
     pdb_contact* dContacts = nullptr;   // [n][PDB_MAX_CONTACTS]: each car's live contact joints (the first pdb_dyn_state.numContacts of its row)
@@ -307,6 +312,7 @@ static void fillConst(const pdb_car_params& P, DevConst& K, int actionMode) {
     }
     (void)pdb_lane_tune_from_params(&P, &K.laneDefault);
     K.laneTunes = nullptr;
+    K.laneSetups = nullptr;
     K.actionMode = actionMode;
     K.wantCarState = 0;
     K.stuckTimeout = 5.0;   // projectd_env.py:47
@@ -362,7 +368,7 @@ static void launchTick(pdb_batch* b, hipStream_t st, int c0, int c1, pdb_step_ou
     const dim3 grid(nblk), block(PDB_BLOCK_THREADS), cblock(PDB_WAVE * PDB_CONTACT_WAVES), cgrid(((n + PDB_CONTACT_CPB - 1) / PDB_CONTACT_CPB) < cg ? ((n + PDB_CONTACT_CPB - 1) / PDB_CONTACT_CPB) : cg);
     // a car with DynamicController files goes through the kernel pair compiled with the controllers' call sites (40-row class, row-guarded: any car)
     const bool ctrl = HP.numCtrlStages != 0 || HP.hasBrakeTemps != 0;
-    const int kind = ctrl ? 0 : (m == 33 ? 1 : (m < 33 ? 2 : 3));
+    const int kind = ctrl ? 0 : (b->dLaneSetups ? 4 : (m == 33 ? 1 : (m < 33 ? 2 : 3)));   // (pdb_set_lane_setups has refused the cars of the 40-row class)
     // measurement (pdb_sample_kernel): HIP events around every k-th first-pass launch of this site, on the stream it is launched on
     KernelSamples& KS = b->samples[q];
     const bool sampled = b->sampleEvery > 0 && !b->capturing && KS.ev[0] && (KS.tick++ % b->sampleEvery) == 0 && KS.n < PDB_KERNEL_SAMPLES;
@@ -374,6 +380,7 @@ static void launchTick(pdb_batch* b, hipStream_t st, int c0, int c1, pdb_step_ou
 #endif
     case 1: hipLaunchKernelGGL(k33::pdb_step_kernel, grid, block, 0, st, S, Aact, O, CS, DP, DK, b->dTrack, (k33::RedoQueue*)Q, RM, n, SN); break;
     case 2: hipLaunchKernelGGL(k33::pdb_step_kernel_generic, grid, block, 0, st, S, Aact, O, CS, DP, DK, b->dTrack, (k33::RedoQueue*)Q, RM, n, SN); break;
+    case 4: hipLaunchKernelGGL(k33::pdb_step_kernel_lane, grid, block, 0, st, S, Aact, O, CS, DP, DK, b->dTrack, (k33::RedoQueue*)Q, RM, n, SN); break;
     default: break;
     }
     if (sampled) { (void)hipEventRecord(KS.ev[2 * KS.n + 1], st); KS.cars[KS.n] = n; ++KS.n; }
@@ -385,6 +392,7 @@ static void launchTick(pdb_batch* b, hipStream_t st, int c0, int c1, pdb_step_ou
 #endif
     case 1: hipLaunchKernelGGL(k33c::pdb_contact_kernel, cgrid, cblock, 0, st, S, Aact, O, CS, DP, DK, b->dTrack, CT, (k33c::RedoQueue*)Q, RM, n, HN, SN); break;
     case 2: hipLaunchKernelGGL(k33c::pdb_contact_kernel_generic, cgrid, cblock, 0, st, S, Aact, O, CS, DP, DK, b->dTrack, CT, (k33c::RedoQueue*)Q, RM, n, HN, SN); break;
+    case 4: hipLaunchKernelGGL(k33c::pdb_contact_kernel_lane, cgrid, cblock, 0, st, S, Aact, O, CS, DP, DK, b->dTrack, CT, (k33c::RedoQueue*)Q, RM, n, HN, SN); break;
     default: break;
     }
 }
@@ -413,6 +421,7 @@ static int pushK(pdb_batch* b, hipStream_t st, bool async) {
         const int c0 = partFirst(b, p);
         K.freshState = b->K.freshState; K.noTeam = b->K.noTeam;
         K.laneTunes = b->K.laneTunes ? b->K.laneTunes + c0 : nullptr;
+        K.laneSetups = b->K.laneSetups ? b->K.laneSetups + c0 : nullptr;
         K.holdMask = b->K.holdMask ? b->K.holdMask + c0 : nullptr;
         K.dt = b->K.dt; K.fps = b->K.fps; K.dtD = b->K.dtD; K.stuckTimeout = b->K.stuckTimeout; K.wantCarState = b->K.wantCarState; K.stamps = b->K.stamps; K.stampCars = b->K.stampCars;
         K.envHitPenalty = b->K.envHitPenalty; K.envOffPenalty = b->K.envOffPenalty; K.envStuckPenalty = b->K.envStuckPenalty; K.envLowReward = b->K.envLowReward;
@@ -537,6 +546,7 @@ void pdb_destroy(pdb_batch* b) {
     for (int q = 0; q <= PDB_MAX_PARTS; ++q) for (hipEvent_t e : b->samples[q].ev) if (e) (void)hipEventDestroy(e);
     (void)hipFree(b->dSnap);
     (void)hipFree(b->dLaneTunes);
+    (void)hipFree(b->dLaneSetups);
     (void)hipFree(b->dHold);
     for (int q = 0; q < PDB_MAX_PARTS; ++q) { (void)hipFree(b->dPartParams[q]); (void)hipFree(b->dPartK[q]); }
     if (b->ev0) (void)hipEventDestroy(b->ev0);
@@ -689,6 +699,7 @@ int pdb_set_stuck_timeout(pdb_batch* b, double seconds) {
 }
 int pdb_set_partition_params(pdb_batch* b, int part, const pdb_car_params* params) {
     if (!b || part < 0 || part >= b->parts || b->parts < 2) { pdb::setError("pdb_set_partition_params: no such partition (pdb_set_partitions first)"); return PDB_ERR_ARG; }
+    if (b->dLaneSetups) { pdb::setError("pdb_set_partition_params: the per-lane setup table exists and holds the lanes' RESOLVED values (install the partitions' blocks before pdb_set_lane_setups)"); return PDB_ERR_ARG; }
     if (int rcj = joinParts(b)) return rcj;
     for (int p = 0; p < PDB_MAX_PARTS; ++p) if (b->partStream[p]) HIPCHK(hipStreamSynchronize(b->partStream[p]));
     HIPCHK(hipStreamSynchronize(b->stream));
@@ -714,6 +725,20 @@ int pdb_set_partition_params(pdb_batch* b, int part, const pdb_car_params* param
     if (b->graphExec) { (void)hipGraphExecDestroy(b->graphExec); b->graphExec = nullptr; }
     return pushK(b, b->stream, false);
 }
+// the rows of the lanes [first, first + count) from their own blocks: the partition's where it has one, else the batch's
+static int laneSetupDefaults(pdb_batch* b, int first, int count) {
+    std::vector<pdb_lane_setup> rows((size_t)count);
+    pdb_lane_setup own, part[PDB_MAX_PARTS];
+    (void)pdb_lane_setup_from_params(&b->params, &own);
+    for (int p = 0; p < PDB_MAX_PARTS; ++p) if (b->partHas[p]) (void)pdb_lane_setup_from_params(&b->partParams[p], &part[p]);
+    for (int i = 0; i < count; ++i) {
+        int p = 0;
+        while (p + 1 < b->parts && first + i >= partFirst(b, p + 1)) ++p;
+        rows[(size_t)i] = (b->parts > 1 && p < PDB_MAX_PARTS && b->partHas[p]) ? part[p] : own;
+    }
+    HIPCHK(hipMemcpy(b->dLaneSetups + first, rows.data(), sizeof(pdb_lane_setup) * (size_t)count, hipMemcpyHostToDevice));
+    return PDB_OK;
+}
 int pdb_set_lane_tunes(pdb_batch* b, int first, int count, const pdb_lane_tune* rows) {
     if (!b || first < 0 || count < 0 || first + count > b->n) { pdb::setError("pdb_set_lane_tunes: bad range"); return PDB_ERR_ARG; }
     if (int rcj = joinParts(b)) return rcj;
@@ -731,6 +756,28 @@ int pdb_set_lane_tunes(pdb_batch* b, int first, int count, const pdb_lane_tune* 
         for (int i = 0; i < count; ++i) if (rows[i].valid != 0 && rows[i].valid != 1) { pdb::setError("pdb_set_lane_tunes: a row's valid field is neither 0 nor 1 (fill rows with pdb_lane_tune_from_params)"); return PDB_ERR_ARG; }
         HIPCHK(hipMemcpy(b->dLaneTunes + first, rows, sizeof(pdb_lane_tune) * (size_t)count, hipMemcpyHostToDevice));
     } else HIPCHK(hipMemset(b->dLaneTunes + first, 0, sizeof(pdb_lane_tune) * (size_t)count));
+    return PDB_OK;
+}
+static bool wideClass(const pdb_car_params& P) { return P.numCtrlStages != 0 || P.hasBrakeTemps != 0 || P.numRows > 33; }
+int pdb_set_lane_setups(pdb_batch* b, int first, int count, const pdb_lane_setup* rows) {
+    if (!b || first < 0 || count < 0 || first + count > b->n) { pdb::setError("pdb_set_lane_setups: bad range"); return PDB_ERR_ARG; }
+    bool wide = wideClass(b->params);
+    for (int p = 0; p < PDB_MAX_PARTS; ++p) wide = wide || (b->partHas[p] && wideClass(b->partParams[p]));
+    if (wide) { pdb::setError("pdb_set_lane_setups: the per-lane setup table is read by the 33-row kernel class only (no DynamicController files, no brake temperatures, at most 33 constraint rows)"); return PDB_ERR_ARG; }
+    if (int rcj = joinParts(b)) return rcj;
+    for (int p = 0; p < PDB_MAX_PARTS; ++p) if (b->partStream[p]) HIPCHK(hipStreamSynchronize(b->partStream[p]));
+    HIPCHK(hipStreamSynchronize(b->stream));
+    if (!b->dLaneSetups) {
+        if (!rows) return PDB_OK;   // nothing installed, nothing to take back
+        HIPCHK(hipMalloc(&b->dLaneSetups, sizeof(pdb_lane_setup) * (size_t)b->n));
+        if (int rcd = laneSetupDefaults(b, 0, b->n)) return rcd;
+        b->K.laneSetups = b->dLaneSetups;
+        if (b->graphExec) { (void)hipGraphExecDestroy(b->graphExec); b->graphExec = nullptr; b->graphTicks = 0; }   // recorded launches are the other kernel pair's
+        if (int rck = pushK(b, b->stream, false)) return rck;
+    }
+    if (count == 0) return PDB_OK;
+    if (rows) HIPCHK(hipMemcpy(b->dLaneSetups + first, rows, sizeof(pdb_lane_setup) * (size_t)count, hipMemcpyHostToDevice));
+    else if (int rcd = laneSetupDefaults(b, first, count)) return rcd;
     return PDB_OK;
 }
 int pdb_set_env(pdb_batch* b, const pdb_env_config* cfg) {

@@ -29,6 +29,7 @@ struct DevConst {
     int wantCarState;
     pdb_lane_tune laneDefault;            // the car block's own values of the per-lane tunes (a lane without a valid row reads these)
     const pdb_lane_tune* laneTunes;       // [cars of the batch] or null: pdb_set_lane_tunes
+    const pdb_lane_setup* laneSetups;     // [cars of the batch] or null: pdb_set_lane_setups (read by the kernel pair compiled for it only)
     const unsigned char* holdMask;        // [cars of the batch] or null: cars whose byte is non-zero sit this launch out (pdb_step_host_held: the reset tick of the lanes whose episode just ended)
     const pdb_dyn_state* freshState;      // the record of a fresh car at the start pose (device memory): env mode re-creates a car whose pose is no longer finite from it
     unsigned long long* stamps;   // diagnostic build only (-DPDB_STAMPS): [car][32] shader-clock stamps of the first pass, then [stampCars + car][32] of the contact pass

@@ -48,6 +48,27 @@ int pdb_lane_tune_from_params(const pdb_car_params* params, pdb_lane_tune* row) 
     row->valid = 1;
     return PDB_OK;
 }
+int pdb_lane_setup_from_params(const pdb_car_params* params, pdb_lane_setup* row) {
+    if (!params || !row) { pdb::setError("null argument"); return PDB_ERR_ARG; }
+    memset(row, 0, sizeof(*row));
+    row->diffPreLoad = params->diffPreLoad;
+    for (int g = 0; g < PDB_MAX_GEARS; ++g) row->gearRatio[g] = params->gearRatio[g];
+    row->brakePowerMultiplier = params->brakePowerMultiplier; row->limiterMultiplier = params->limiterMultiplier;
+    row->arbK[0] = params->arbK[0]; row->arbK[1] = params->arbK[1];
+    for (int t = 0; t < PDB_MAX_TURBOS; ++t) row->turboUserSetting[t] = params->turbos[t].userSetting;
+    for (int i = 0; i < 4; ++i) {
+        const pdb_susp& su = params->susp[i];
+        pdb_lane_wheel& w = row->wheel[i];
+        w.bumpFast = su.damper.bumpFast; w.bumpSlow = su.damper.bumpSlow; w.reboundFast = su.damper.reboundFast; w.reboundSlow = su.damper.reboundSlow;
+        w.bumpStopRate = su.bumpStopRate; w.k = su.k; w.progressiveK = su.progressiveK; w.rodLength = su.rodLength; w.packerRange = su.packerRange; w.toeOutLinear = su.toeOutLinear;
+        // the camber rotation as the tick uses it (mat44f::createFromAxisAngle((0,0,1), staticCamber): the expressions of the batch's constants block, csrc/device/batch.hip fillConst)
+        const float s = pm::sinf_(su.staticCamber), c = pm::cosf_(su.staticCamber), o = 1.0f - c;
+        w.camC = ((0.0f * 0.0f) * o) + c;
+        w.camS = (1.0f * s) + (0.0f * 0.0f) * o;
+        w.camM33 = ((1.0f * 1.0f) * o) + c;
+    }
+    return PDB_OK;
+}
 float pdb_get_scoring_var(const pdb_car_params* params, const char* name) {
     float w = 0;
     if (params && name) pdb::getScoringVar(*params, name, w);

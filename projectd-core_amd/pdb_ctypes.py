@@ -132,6 +132,13 @@ class LaneTune(C.Structure):   # pdb_lane_tune
     _fields_ = [('finalRatio', C.c_double), ('diffPowerRamp', C.c_double), ('diffCoastRamp', C.c_double), ('frontBias', C.c_float), ('pressureStatic', C.c_float * 4),
                 ('scoring', Scoring), ('valid', C.c_int32), ('_pad', C.c_int32 * 3)]
 assert C.sizeof(LaneTune) == 144
+class LaneWheel(C.Structure):   # pdb_lane_wheel
+    _fields_ = [(n, C.c_float) for n in ('bumpFast', 'bumpSlow', 'reboundFast', 'reboundSlow', 'bumpStopRate', 'k', 'progressiveK', 'rodLength', 'packerRange', 'toeOutLinear',
+                                         'camC', 'camS', 'camM33')] + [('_pad', C.c_float * 3)]
+class LaneSetup(C.Structure):   # pdb_lane_setup
+    _fields_ = [('diffPreLoad', C.c_double), ('gearRatio', C.c_double * MAX_GEARS), ('brakePowerMultiplier', C.c_float), ('limiterMultiplier', C.c_float), ('arbK', C.c_float * 2),
+                ('turboUserSetting', C.c_float * 3), ('_pad0', C.c_float), ('wheel', LaneWheel * 4), ('_pad1', C.c_int32 * 2)]
+assert C.sizeof(LaneSetup) == 384
 class Surface(C.Structure):   # pdb_surface
     _fields_ = [(n, C.c_float) for n in ('gripMod', 'damping', 'sinHeight', 'sinLength', 'granularity', 'dirtAdditiveK')] + \
                [(n, C.c_int32) for n in ('collisionCategory', 'isValidTrack', 'triStart', 'triCount', 'sectorID', '_pad')]
@@ -166,6 +173,7 @@ def load_product(host_only=False):
     lib.pdb_teleport_by_mode.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
     lib.pdb_set_auto_teleport.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int]
     lib.pdb_lane_tune_from_params.argtypes = [C.c_void_p, C.c_void_p]
+    lib.pdb_lane_setup_from_params.argtypes = [C.c_void_p, C.c_void_p]
     if not host_only:
         lib.pdb_create.restype = C.c_void_p
         lib.pdb_create.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_uint64, C.c_int]
@@ -188,6 +196,8 @@ def load_product(host_only=False):
             lib.pdb_set_contact_grid.argtypes = [C.c_void_p, C.c_int]
         if hasattr(lib, 'pdb_set_lane_tunes'):
             lib.pdb_set_lane_tunes.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+        if hasattr(lib, 'pdb_set_lane_setups'):
+            lib.pdb_set_lane_setups.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]
         lib.pdb_actions_device.restype = C.c_void_p; lib.pdb_actions_device.argtypes = [C.c_void_p]
         lib.pdb_out_device.restype = C.c_void_p; lib.pdb_out_device.argtypes = [C.c_void_p]
         lib.pdb_set_out_device.argtypes = [C.c_void_p, C.c_void_p]

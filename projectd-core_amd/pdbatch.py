@@ -214,6 +214,17 @@ class Batch:
                 self._chk(self.lib.pdb_lane_tune_from_params(C.byref(P), C.byref(rows[i])))
         self._chk(self.lib.pdb_set_lane_tunes(self.h, first, len(blocks), rows))
 
+    def set_lane_setups(self, blocks, first=0):
+        """the rest of the setup lane by lane (pdb_set_lane_setups): lane first + i takes brake power, differential preload, gear ratios, anti-roll bars, rev limiter,
+        turbo settings and the per-wheel dampers / springs / bump stops / rod lengths / packers / toe / camber of blocks[i], a pdb_car_params that went through
+        pdb_set_car_tune; blocks=None with a count puts lanes back to their own block's values"""
+        if isinstance(blocks, int):
+            self._chk(self.lib.pdb_set_lane_setups(self.h, first, blocks, None)); return
+        rows = (pc.LaneSetup * len(blocks))()
+        for i, P in enumerate(blocks):
+            self._chk(self.lib.pdb_lane_setup_from_params(C.byref(P if P is not None else self.params), C.byref(rows[i])))
+        self._chk(self.lib.pdb_set_lane_setups(self.h, first, len(blocks), rows))
+
     def set_env(self, cfg=None, **kw):
         """env mode (pdb_set_env): the reward / termination / reset rules of projectd_env.py:173-227 inside the tick.  cfg: an object with
         the reference env's attribute names (projectd_env.EnvConfig), or keyword overrides; set_env(enabled=False) switches it off."""

@@ -128,7 +128,7 @@ def make_actions(n, seed, lo=-0.3, hi=0.3):
 
 
 def run_parity(n_cars=8, ticks=200, seed=1234, resync=False, verbose=False, check_every=1, actions_fn=None, model='ks_toyota_ae86_drift', track='flat',
-               on_tick=None, params_fn=None, spread=None, threads=None, lane_params_fn=None):
+               on_tick=None, params_fn=None, spread=None, threads=None, lane_params_fn=None, lane_setups=False):
     """Step `n_cars` cars for `ticks` ticks on the GPU (through the C ABI) and in the CPU oracle, from the same
     initial state.  resync=True re-injects the oracle state into the GPU before every tick (single-tick parity).
     spread=(lo, hi): car i starts from teleportCarToSpline(lo + (hi - lo) * i / n_cars) (the product's host function, for both
@@ -151,6 +151,8 @@ def run_parity(n_cars=8, ticks=200, seed=1234, resync=False, verbose=False, chec
         for i in range(n_cars):
             Pi = pc.CarParams.from_buffer_copy(bytes(P)); lane_params_fn(i, Pi); Pl.append(Pi)
         b.set_lane_tunes(Pl)
+        if lane_setups:   # the rest of SetupManager's tunes, lane by lane (pdb_set_lane_setups)
+            b.set_lane_setups(Pl)
     if spread is None:
         hs = [orc.cpuref_create(C.byref(Pl[i]), trk, len(trk), C.byref(S0)) for i in range(n_cars)]
     else:

@@ -840,6 +840,90 @@ def test_every_lane_with_its_own_tunes_and_reward_weights(built, track, model):
     assert len({v[1] for v in seen.values()}) >= 20 and len({v[0] for v in seen.values()}) >= 20, seen
 
 
+def _randomised_setup(i, P):
+    """on top of _randomised_lane: every other SetupManager tune that is a field of the block (Car/SetupManager.cpp:10-120), different for every lane"""
+    _randomised_lane(i, P)
+    r = np.random.RandomState(5000 + i)
+    f32 = lambda x: float(np.float32(x))
+    P.brakePowerMultiplier = f32(P.brakePowerMultiplier * r.uniform(0.7, 1.2))
+    P.diffPreLoad = float(P.diffPreLoad * r.uniform(0.5, 2.0) + r.uniform(0.0, 20.0))
+    for g in range(P.numGears):
+        P.gearRatio[g] = float(P.gearRatio[g] * r.uniform(0.9, 1.1))
+    P.arbK[0] = f32(P.arbK[0] * r.uniform(0.5, 1.5)); P.arbK[1] = f32(P.arbK[1] * r.uniform(0.5, 1.5))
+    P.limiterMultiplier = f32(r.uniform(0.8, 1.0))
+    for t in range(P.numTurbos):
+        P.turbos[t].userSetting = f32(r.uniform(0.3, 1.0))
+    for w in range(4):
+        su = P.susp[w]
+        for k in ('bumpFast', 'bumpSlow', 'reboundFast', 'reboundSlow'):
+            setattr(su.damper, k, f32(getattr(su.damper, k) * r.uniform(0.7, 1.3)))
+        su.bumpStopRate = f32(su.bumpStopRate * r.uniform(0.7, 1.3)); su.k = f32(su.k * r.uniform(0.8, 1.25)); su.progressiveK = f32(su.progressiveK * r.uniform(0.5, 1.5))
+        su.rodLength = f32(su.rodLength + r.uniform(-0.01, 0.01)); su.packerRange = f32(su.packerRange * r.uniform(0.9, 1.1))
+        su.toeOutLinear = f32(su.toeOutLinear + r.uniform(-0.0005, 0.0005)); su.staticCamber = f32(su.staticCamber + r.uniform(-0.02, 0.02))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('track,model', [('touge', 'ks_toyota_ae86_drift'), ('walled', 'ks_toyota_supra_mkiv_drift'), ('touge', 'ks_mazda_rx7_tuned')])
+def test_every_lane_with_its_own_whole_setup(built, track, model):
+    """pdb_set_lane_setups on top of pdb_set_lane_tunes: 24 lanes, each with its own brake power, differential preload, gear ratios, anti-roll bars, rev limiter,
+    turbo settings and per-wheel dampers / springs / bump stops / rod lengths / packers / toe / camber (every SetupManager tune, Car/SetupManager.cpp:10-120) through
+    the kernel pair compiled for the table -- struts, a live axle, double wishbones, turbos; walls on one of the tracks, so the contact pass reads the rows too.  The
+    oracle steps every car with its own block: every state scalar bit for bit; and the lanes do differ"""
+    import parity_util
+    seen = {}
+
+    def on_tick(t, i, sg, sc):
+        if t >= 1500:
+            seen[i] = (sg.totalReward, sg.suspTravel[0], sg.driveVel)
+    worst = parity_util.run_parity(n_cars=24, ticks=1600, seed=19, track=track, model=model, check_every=10, lane_params_fn=_randomised_setup, lane_setups=True, on_tick=on_tick,
+                                   spread=(0.0, 0.9) if track == 'touge' else None, threads=8)
+    assert worst == 0.0, worst
+    assert len({v[1] for v in seen.values()}) >= 20 and len({v[2] for v in seen.values()}) >= 20, seen
+
+
+@pytest.mark.gpu
+def test_lane_setups_default_rows_take_back_and_refusals(built):
+    """the table's default rows are the lanes' own blocks (the run equals the plain kernels' bit for bit, free-running partitions included); rows can be put back; a row =
+    that lane stepped with the tuned block; cars of the 40-row kernel class and a partition block after the table are refused"""
+    import pdbatch, parity_util
+    P = pdbatch.packed_params(); trk = pdbatch.synthetic_track('touge')
+    n = 12
+    acts = parity_util.make_actions(n, 5)
+    sz = C.sizeof(pc.DynState)
+
+    def run(setup, block=P, parts=0):
+        b = pdbatch.Batch(n, block, trk, device=0, action_mode=1)
+        setup(b)
+        if parts:
+            b.upload_actions(acts); b.set_partitions(parts); b.step_ring(300, join=True); b.sync()
+        else:
+            for _ in range(300):
+                b.step_host(acts)
+        st = bytes(b.get_state()); b.close()
+        return st
+    plain = run(lambda b: None)
+    Q = pc.CarParams.from_buffer_copy(bytes(P)); _randomised_setup(3, Q)
+    assert run(lambda b: b.set_lane_setups([P] * 2, first=4)) == plain                 # the lane kernels with every row at its block's values
+    assert run(lambda b: (b.set_lane_setups([Q] * n), b.set_lane_tunes([Q] * n), b.set_lane_setups(n), b.set_lane_tunes([None] * n))) == plain
+    tuned = run(lambda b: (b.set_lane_setups([Q] * 6, first=3), b.set_lane_tunes([Q] * 6, first=3)))
+    assert tuned != plain and tuned[:3 * sz] == plain[:3 * sz] and tuned[9 * sz:] == plain[9 * sz:]
+    assert tuned[3 * sz:9 * sz] == run(lambda b: None, block=Q)[3 * sz:9 * sz]          # a row = that lane stepped with the tuned block
+    blocks = []
+    for i in range(n):
+        Qi = pc.CarParams.from_buffer_copy(bytes(P)); _randomised_setup(60 + i, Qi); blocks.append(Qi)
+    both = lambda b: (b.set_lane_setups(blocks), b.set_lane_tunes(blocks))
+    assert run(both, parts=3) == run(both)                                               # partitions index the table from their own first car
+    b = pdbatch.Batch(n, P, trk, device=0, action_mode=1)
+    b.set_partitions(3); b.set_lane_setups([Q], first=1)
+    with pytest.raises(RuntimeError):
+        b.set_partition_params(2, P)
+    b.close()
+    W = pdbatch.Batch(4, pdbatch.packed_params('pdb_dynctrl_ae86.env'), trk, device=0, action_mode=1)
+    with pytest.raises(RuntimeError):
+        W.set_lane_setups([P])
+    W.close()
+
+
 @pytest.mark.gpu
 def test_lane_tunes_can_be_taken_back_and_follow_the_partitions(built):
     """rows with valid = 0 (never set, or set back with None) read the lane's own block -- the partition's, where it has one; free-running
