@@ -224,6 +224,7 @@ float getScoringVar(int simId, int carId, const std::string& name) { Sim* s = ge
 // ---- vectorised extension: one lane of a batch takes the setup and the reward weights of a simulator (the reference's setCarTune / setScoringVar
 //      are per simulator, i.e. per env: configure a simulator with them, then hand its values to the lanes that should drive that setup) ----
 bool setBatchLaneTune(int batchId, int lane, int simId);
+bool setBatchLaneSetup(int batchId, int lane, int simId);
 // ---- vectorised extension: N lanes configured like simulator simId ----
 int createBatch(int simId, int nCars, int device) {
     Sim* s = getSim(simId);
@@ -254,6 +255,19 @@ bool setBatchLaneTune(int batchId, int lane, int simId) {   // simId < 0: the la
         if (!s || !s->hasCar || pdb_lane_tune_from_params(&s->P, &row) != PDB_OK) return false;
     }
     if (pdb_set_lane_tunes(B->b, lane, 1, simId >= 0 ? &row : nullptr) != PDB_OK) { logf("EXCEPTION: %s", pdb_last_error()); return false; }
+    return true;
+}
+// the rest of simulator simId's setup for one lane (every other SetupManager tune: pdb_set_lane_setups; the batch then steps with the kernel pair compiled for the table);
+// simId < 0: the lane back to its own block's values
+bool setBatchLaneSetup(int batchId, int lane, int simId) {
+    Batch* B = getBatch(batchId);
+    if (!B || lane < 0 || lane >= B->n) return false;
+    pdb_lane_setup row; memset(&row, 0, sizeof(row));
+    if (simId >= 0) {
+        Sim* s = getSim(simId);
+        if (!s || !s->hasCar || pdb_lane_setup_from_params(&s->P, &row) != PDB_OK) return false;
+    }
+    if (pdb_set_lane_setups(B->b, lane, 1, simId >= 0 ? &row : nullptr) != PDB_OK) { logf("EXCEPTION: %s", pdb_last_error()); return false; }
     return true;
 }
 // actions [N,2] float32 (a0 = steer, a1 -> gas like projectd_env.py:159-160) -> [N,26] float32: obs[24], reward, flags (bit-cast int32)
@@ -412,6 +426,7 @@ PYBIND11_MODULE(PyProjectD, m) {
     m.def("createBatch", &createBatch, "", py::arg("simId"), py::arg("nCars"), py::arg("device") = 0);
     m.def("destroyBatch", &destroyBatch, "");
     m.def("setBatchLaneTune", &setBatchLaneTune, "", py::arg("batchId"), py::arg("lane"), py::arg("simId"));
+    m.def("setBatchLaneSetup", &setBatchLaneSetup, "", py::arg("batchId"), py::arg("lane"), py::arg("simId"));
     m.def("stepBatch", &stepBatch, "", py::arg("batchId"), py::arg("actions"), py::arg("dt") = 1.0 / 333.0);
     m.def("stepBatchHeld", &stepBatchHeld, "", py::arg("batchId"), py::arg("actions"), py::arg("hold"), py::arg("dt") = 1.0 / 333.0);
     m.def("resetBatch", &resetBatch, "", py::arg("batchId"), py::arg("mask") = py::none(), py::arg("mode") = 0);

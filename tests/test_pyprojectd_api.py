@@ -142,6 +142,33 @@ def test_single_env_matches_oracle(pd, base):
 
 
 @pytest.mark.gpu
+def test_a_lane_takes_a_configured_simulators_whole_setup(pd, base):
+    """setBatchLaneSetup (+ setBatchLaneTune): a lane of simulator A's batch steps exactly like a batch made from simulator B, whose springs, bar, dampers, gear ratio
+    and brake power were tuned with the reference's own setCarRawTune; the other lanes are untouched"""
+    simA = pd.createSimulator(base); pd.loadTrack(simA, 'flat'); carA = pd.addCar(simA, 'ks_toyota_ae86_drift')
+    simB = pd.createSimulator(base); pd.loadTrack(simB, 'flat'); carB = pd.addCar(simB, 'ks_toyota_ae86_drift')
+    for name, v in (('SPRING_RATE_LF', 52000.0), ('SPRING_RATE_RF', 47000.0), ('ARB_FRONT', 9000.0), ('DAMP_BUMP_LR', 2100.0), ('DAMP_REBOUND_RR', 5200.0),
+                    ('INTERNAL_GEAR_2', 3.1), ('BRAKE_POWER_MULT', 0.8), ('ROD_LENGTH_RF', 0.004), ('CAMBER_LF', -0.05), ('FINAL_RATIO', 4.6)):
+        pd.setCarRawTune(simB, carB, name, v)
+    n = 4
+    bA = pd.createBatch(simA, n, 0); bB = pd.createBatch(simB, n, 0); bP = pd.createBatch(simA, n, 0)
+    assert min(bA, bB, bP) >= 0
+    assert pd.setBatchLaneTune(bA, 2, simB) and pd.setBatchLaneSetup(bA, 2, simB)
+    acts = np.tile(np.array([[0.12, 0.4]], np.float32), (n, 1))
+    differs = False
+    for t in range(400):
+        oA = pd.stepBatch(bA, acts); oB = pd.stepBatch(bB, acts); oP = pd.stepBatch(bP, acts)
+        assert np.array_equal(oA[2].view(np.int32), oB[0].view(np.int32)), t
+        assert np.array_equal(oA[0].view(np.int32), oP[0].view(np.int32)) and np.array_equal(oA[3].view(np.int32), oP[3].view(np.int32)), t
+        differs = differs or not np.array_equal(oA[2], oA[0])
+    assert differs
+    assert pd.setBatchLaneSetup(bA, 2, -1) and not pd.setBatchLaneSetup(bA, 9, simB)
+    for b in (bA, bB, bP):
+        pd.destroyBatch(b)
+    pd.destroySimulator(simA); pd.destroySimulator(simB)
+
+
+@pytest.mark.gpu
 def test_vec_env_matches_oracle_and_resets(pd, base):
     import projectd_env as E, pdbatch, pdb_ctypes as pc, oracle_ctypes, sharding
     n = 16
