@@ -903,6 +903,8 @@ int pdb_set_contact_grid(pdb_batch* b, int workgroups) {
 }
 int pdb_set_partitions(pdb_batch* b, int parts) {
     if (!b || parts < 1 || parts > PDB_MAX_PARTS) { pdb::setError("pdb_set_partitions: 1..4 parts"); return PDB_ERR_ARG; }
+    if (b->dLaneSetups && parts != b->parts) for (int p = 0; p < PDB_MAX_PARTS; ++p) if (b->partHas[p]) {   // (the table's default rows were read out of the old cut's blocks)
+        pdb::setError("pdb_set_partitions: the per-lane setup table holds rows resolved from the partitions' own car blocks: cut the batch before pdb_set_lane_setups"); return PDB_ERR_ARG; }
     HIPCHK(hipSetDevice(b->device));
     if (int rcj = joinParts(b)) return rcj;
     for (int p = 0; p < PDB_MAX_PARTS; ++p) if (b->partStream[p]) HIPCHK(hipStreamSynchronize(b->partStream[p]));   // the old cut's kernels
