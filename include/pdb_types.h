@@ -412,7 +412,7 @@ typedef struct pdb_lane_tune {
  * BRAKE_POWER_MULT, DIFF_PRELOAD, INTERNAL_GEAR_n, ARB_FRONT/REAR, ENGINE_LIMITER, TURBO_n, and per wheel DAMP_(FAST_)BUMP/REBOUND, BUMP_STOP_RATE, SPRING_RATE,
  * PROGRESSIVE_SPRING_RATE, ROD_LENGTH, PACKER_RANGE, TOE_OUT, CAMBER (as the three entries of the camber rotation the tick uses: DevConst camC/camS/camM33).  The row
  * holds the RESOLVED values of a block that went through pdb_set_car_tune (pdb_lane_setup_from_params).  WING_n is accepted by the reference and overwritten on every
- * tick (csrc/host/model.cpp findTune): nothing to carry.  Cars of the 33-row kernel class only (no DynamicController files, no brake temperatures). */
+ * tick (csrc/host/model.cpp findTune): nothing to carry. */
 typedef struct pdb_lane_wheel {
     float bumpFast, bumpSlow, reboundFast, reboundSlow;
     float bumpStopRate, k, progressiveK, rodLength;

@@ -169,8 +169,9 @@ int pdb_set_lane_tunes(pdb_batch* b, int first, int count, const pdb_lane_tune* 
  * dampers, springs, bump stops, rod lengths, packers, toe and camber per wheel -- with pdb_lane_tune every SetupManager tune, Car/SetupManager.cpp:10-120).
  * pdb_lane_setup_from_params (host library too) reads the row out of a block that went through pdb_set_car_tune.  The first pdb_set_lane_setups of a batch builds the
  * table -- every lane's row from its own block (the batch's, or its partition's) -- and switches the batch to the kernel pair compiled for it; rows == NULL puts the
- * lanes [first, first + count) back to their blocks' values.  PDB_ERR_ARG for a car of the 40-row kernel class (DynamicController files, brake temperatures, more than
- * 33 constraint rows); pdb_set_partition_params is refused once the table exists (install the partitions' blocks first). */
+ * lanes [first, first + count) back to their blocks' values.  (Cars of the 40-row kernel class -- DynamicController files, brake temperatures, more than 33
+ * constraint rows -- keep their two kernel pairs, which test for the table at run time; a controller that drives a tunable value overrides the row, as it overrides
+ * the block.)  pdb_set_partition_params is refused once the table exists (install the partitions' blocks first). */
 int pdb_lane_setup_from_params(const pdb_car_params* params, pdb_lane_setup* row);
 int pdb_set_lane_setups(pdb_batch* b, int first, int count, const pdb_lane_setup* rows);
 /* join: bit 0 = the batch's stream waits for the ring's kernels; bit 1 = the partitions do NOT wait for what is queued on the batch's stream (the caller orders

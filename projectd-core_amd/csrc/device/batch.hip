@@ -57,6 +57,7 @@
 #define PDB_KERNEL_EXACT pdb_step_kernel
 #define PDB_KSLOT0_EXACT true    /* the class's first kernel pair: exactly 33 rows, no run-time row guards */
 #define PDB_KSLOT0_CTRL false
+#define PDB_KCLASS_LS false     /* the per-lane setup table has a kernel pair of its own in this class (PDB_KERNEL_LANE) */
 #define PDB_KERNEL_GUARDED pdb_step_kernel_generic
 #define PDB_KERNEL_LANE pdb_step_kernel_lane       /* the guarded form reading the per-lane setup table (33-row class only) */
 #define PDB_KERNEL_EXACT_C pdb_contact_kernel
@@ -91,6 +92,7 @@
 #undef PDB_KERNEL_EXACT
 #undef PDB_KSLOT0_EXACT
 #undef PDB_KSLOT0_CTRL
+#undef PDB_KCLASS_LS
 #undef PDB_KERNEL_GUARDED
 #undef PDB_KERNEL_EXACT_C
 #undef PDB_KERNEL_GUARDED_C
@@ -102,6 +104,7 @@
 #define PDB_KERNEL_EXACT pdb_step_kernel_ctrl
 #define PDB_KSLOT0_EXACT false   /* the 40-row class's first kernel pair: row-guarded like the second, compiled with the DynamicController call sites (any car with controller files) */
 #define PDB_KSLOT0_CTRL true
+#define PDB_KCLASS_LS true      /* the 40-row class reads the per-lane setup table, where there is one, in its two kernel pairs (a run-time test) */
 #define PDB_KERNEL_GUARDED pdb_step_kernel_wide
 #define PDB_KERNEL_EXACT_C pdb_contact_kernel_ctrl
 #define PDB_KERNEL_GUARDED_C pdb_contact_kernel_wide
@@ -134,6 +137,7 @@
 #undef PDB_KERNEL_EXACT
 #undef PDB_KSLOT0_EXACT
 #undef PDB_KSLOT0_CTRL
+#undef PDB_KCLASS_LS
 #undef PDB_KERNEL_GUARDED
 #undef PDB_KERNEL_EXACT_C
 #undef PDB_KERNEL_GUARDED_C
@@ -368,7 +372,7 @@ static void launchTick(pdb_batch* b, hipStream_t st, int c0, int c1, pdb_step_ou
     const dim3 grid(nblk), block(PDB_BLOCK_THREADS), cblock(PDB_WAVE * PDB_CONTACT_WAVES), cgrid(((n + PDB_CONTACT_CPB - 1) / PDB_CONTACT_CPB) < cg ? ((n + PDB_CONTACT_CPB - 1) / PDB_CONTACT_CPB) : cg);
     // a car with DynamicController files goes through the kernel pair compiled with the controllers' call sites (40-row class, row-guarded: any car)
     const bool ctrl = HP.numCtrlStages != 0 || HP.hasBrakeTemps != 0;
-    const int kind = ctrl ? 0 : (b->dLaneSetups ? 4 : (m == 33 ? 1 : (m < 33 ? 2 : 3)));   // (pdb_set_lane_setups has refused the cars of the 40-row class)
+    const int kind = ctrl ? 0 : (m > 33 ? 3 : (b->dLaneSetups ? 4 : (m == 33 ? 1 : 2)));   // (4: the 33-row class's kernel pair compiled for the per-lane setup table; the 40-row class tests for the table at run time)
     // measurement (pdb_sample_kernel): HIP events around every k-th first-pass launch of this site, on the stream it is launched on
     KernelSamples& KS = b->samples[q];
     const bool sampled = b->sampleEvery > 0 && !b->capturing && KS.ev[0] && (KS.tick++ % b->sampleEvery) == 0 && KS.n < PDB_KERNEL_SAMPLES;
@@ -758,12 +762,8 @@ int pdb_set_lane_tunes(pdb_batch* b, int first, int count, const pdb_lane_tune* 
     } else HIPCHK(hipMemset(b->dLaneTunes + first, 0, sizeof(pdb_lane_tune) * (size_t)count));
     return PDB_OK;
 }
-static bool wideClass(const pdb_car_params& P) { return P.numCtrlStages != 0 || P.hasBrakeTemps != 0 || P.numRows > 33; }
 int pdb_set_lane_setups(pdb_batch* b, int first, int count, const pdb_lane_setup* rows) {
     if (!b || first < 0 || count < 0 || first + count > b->n) { pdb::setError("pdb_set_lane_setups: bad range"); return PDB_ERR_ARG; }
-    bool wide = wideClass(b->params);
-    for (int p = 0; p < PDB_MAX_PARTS; ++p) wide = wide || (b->partHas[p] && wideClass(b->partParams[p]));
-    if (wide) { pdb::setError("pdb_set_lane_setups: the per-lane setup table is read by the 33-row kernel class only (no DynamicController files, no brake temperatures, at most 33 constraint rows)"); return PDB_ERR_ARG; }
     if (int rcj = joinParts(b)) return rcj;
     for (int p = 0; p < PDB_MAX_PARTS; ++p) if (b->partStream[p]) HIPCHK(hipStreamSynchronize(b->partStream[p]));
     HIPCHK(hipStreamSynchronize(b->stream));

@@ -863,11 +863,13 @@ def _randomised_setup(i, P):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize('track,model', [('touge', 'ks_toyota_ae86_drift'), ('walled', 'ks_toyota_supra_mkiv_drift'), ('touge', 'ks_mazda_rx7_tuned')])
+@pytest.mark.parametrize('track,model', [('touge', 'ks_toyota_ae86_drift'), ('walled', 'ks_toyota_supra_mkiv_drift'), ('touge', 'ks_mazda_rx7_tuned'),
+                                         ('touge', 'pdb_dynctrl_ae86'), ('walled', 'dthwsh_mazda_rx7_fc3s_sr20')])
 def test_every_lane_with_its_own_whole_setup(built, track, model):
     """pdb_set_lane_setups on top of pdb_set_lane_tunes: 24 lanes, each with its own brake power, differential preload, gear ratios, anti-roll bars, rev limiter,
     turbo settings and per-wheel dampers / springs / bump stops / rod lengths / packers / toe / camber (every SetupManager tune, Car/SetupManager.cpp:10-120) through
-    the kernel pair compiled for the table -- struts, a live axle, double wishbones, turbos; walls on one of the tracks, so the contact pass reads the rows too.  The
+    the kernel pair compiled for the table -- struts, a live axle, double wishbones, turbos; walls on two of the tracks, so the contact pass reads the rows too; a car
+    with DynamicController files and one with 38 constraint rows, whose (40-row) kernel class tests for the table at run time.  The
     oracle steps every car with its own block: every state scalar bit for bit; and the lanes do differ"""
     import parity_util
     seen = {}
@@ -884,7 +886,7 @@ def test_every_lane_with_its_own_whole_setup(built, track, model):
 @pytest.mark.gpu
 def test_lane_setups_default_rows_take_back_and_refusals(built):
     """the table's default rows are the lanes' own blocks (the run equals the plain kernels' bit for bit, free-running partitions included); rows can be put back; a row =
-    that lane stepped with the tuned block; cars of the 40-row kernel class and a partition block after the table are refused"""
+    that lane stepped with the tuned block; a partition block after the table is refused"""
     import pdbatch, parity_util
     P = pdbatch.packed_params(); trk = pdbatch.synthetic_track('touge')
     n = 12
@@ -918,10 +920,6 @@ def test_lane_setups_default_rows_take_back_and_refusals(built):
     with pytest.raises(RuntimeError):
         b.set_partition_params(2, P)
     b.close()
-    W = pdbatch.Batch(4, pdbatch.packed_params('pdb_dynctrl_ae86.env'), trk, device=0, action_mode=1)
-    with pytest.raises(RuntimeError):
-        W.set_lane_setups([P])
-    W.close()
 
 
 @pytest.mark.gpu
