@@ -59,10 +59,12 @@
 #define PDB_KSLOT0_CTRL false
 #define PDB_KCLASS_LS false     /* the per-lane setup table has a kernel pair of its own in this class (PDB_KERNEL_LANE) */
 #define PDB_KERNEL_GUARDED pdb_step_kernel_generic
-#define PDB_KERNEL_LANE pdb_step_kernel_lane       /* the guarded form reading the per-lane setup table (33-row class only) */
+#define PDB_KERNEL_LANE pdb_step_kernel_lane_generic       /* the two forms reading the per-lane setup table (33-row class; the 40-row class tests for it at run time) */
+#define PDB_KERNEL_LANE_EXACT pdb_step_kernel_lane
 #define PDB_KERNEL_EXACT_C pdb_contact_kernel
 #define PDB_KERNEL_GUARDED_C pdb_contact_kernel_generic
-#define PDB_KERNEL_LANE_C pdb_contact_kernel_lane
+#define PDB_KERNEL_LANE_C pdb_contact_kernel_lane_generic
+#define PDB_KERNEL_LANE_EXACT_C pdb_contact_kernel_lane
 #define PDB_KNS k33
 #define PDB_CPB PDB_FIRST_CPB
 #define PDB_HELPERS 0
@@ -98,6 +100,8 @@
 #undef PDB_KERNEL_GUARDED_C
 #undef PDB_KERNEL_LANE
 #undef PDB_KERNEL_LANE_C
+#undef PDB_KERNEL_LANE_EXACT
+#undef PDB_KERNEL_LANE_EXACT_C
 #ifndef PDB_FAST_BUILD   /* development builds (make dev) compile the 33-row size class only */
 #define PDB_KROWS 40
 #define PDB_KMINWAVES 5
@@ -372,7 +376,7 @@ static void launchTick(pdb_batch* b, hipStream_t st, int c0, int c1, pdb_step_ou
     const dim3 grid(nblk), block(PDB_BLOCK_THREADS), cblock(PDB_WAVE * PDB_CONTACT_WAVES), cgrid(((n + PDB_CONTACT_CPB - 1) / PDB_CONTACT_CPB) < cg ? ((n + PDB_CONTACT_CPB - 1) / PDB_CONTACT_CPB) : cg);
     // a car with DynamicController files goes through the kernel pair compiled with the controllers' call sites (40-row class, row-guarded: any car)
     const bool ctrl = HP.numCtrlStages != 0 || HP.hasBrakeTemps != 0;
-    const int kind = ctrl ? 0 : (m > 33 ? 3 : (b->dLaneSetups ? 4 : (m == 33 ? 1 : 2)));   // (4: the 33-row class's kernel pair compiled for the per-lane setup table; the 40-row class tests for the table at run time)
+    const int kind = ctrl ? 0 : (m > 33 ? 3 : (b->dLaneSetups ? (m == 33 ? 5 : 4) : (m == 33 ? 1 : 2)));   // (4: the 33-row class's kernel pair compiled for the per-lane setup table; the 40-row class tests for the table at run time)
     // measurement (pdb_sample_kernel): HIP events around every k-th first-pass launch of this site, on the stream it is launched on
     KernelSamples& KS = b->samples[q];
     const bool sampled = b->sampleEvery > 0 && !b->capturing && KS.ev[0] && (KS.tick++ % b->sampleEvery) == 0 && KS.n < PDB_KERNEL_SAMPLES;
@@ -384,7 +388,8 @@ static void launchTick(pdb_batch* b, hipStream_t st, int c0, int c1, pdb_step_ou
 #endif
     case 1: hipLaunchKernelGGL(k33::pdb_step_kernel, grid, block, 0, st, S, Aact, O, CS, DP, DK, b->dTrack, (k33::RedoQueue*)Q, RM, n, SN); break;
     case 2: hipLaunchKernelGGL(k33::pdb_step_kernel_generic, grid, block, 0, st, S, Aact, O, CS, DP, DK, b->dTrack, (k33::RedoQueue*)Q, RM, n, SN); break;
-    case 4: hipLaunchKernelGGL(k33::pdb_step_kernel_lane, grid, block, 0, st, S, Aact, O, CS, DP, DK, b->dTrack, (k33::RedoQueue*)Q, RM, n, SN); break;
+    case 4: hipLaunchKernelGGL(k33::pdb_step_kernel_lane_generic, grid, block, 0, st, S, Aact, O, CS, DP, DK, b->dTrack, (k33::RedoQueue*)Q, RM, n, SN); break;
+    case 5: hipLaunchKernelGGL(k33::pdb_step_kernel_lane, grid, block, 0, st, S, Aact, O, CS, DP, DK, b->dTrack, (k33::RedoQueue*)Q, RM, n, SN); break;
     default: break;
     }
     if (sampled) { (void)hipEventRecord(KS.ev[2 * KS.n + 1], st); KS.cars[KS.n] = n; ++KS.n; }
@@ -396,7 +401,8 @@ static void launchTick(pdb_batch* b, hipStream_t st, int c0, int c1, pdb_step_ou
 #endif
     case 1: hipLaunchKernelGGL(k33c::pdb_contact_kernel, cgrid, cblock, 0, st, S, Aact, O, CS, DP, DK, b->dTrack, CT, (k33c::RedoQueue*)Q, RM, n, HN, SN); break;
     case 2: hipLaunchKernelGGL(k33c::pdb_contact_kernel_generic, cgrid, cblock, 0, st, S, Aact, O, CS, DP, DK, b->dTrack, CT, (k33c::RedoQueue*)Q, RM, n, HN, SN); break;
-    case 4: hipLaunchKernelGGL(k33c::pdb_contact_kernel_lane, cgrid, cblock, 0, st, S, Aact, O, CS, DP, DK, b->dTrack, CT, (k33c::RedoQueue*)Q, RM, n, HN, SN); break;
+    case 4: hipLaunchKernelGGL(k33c::pdb_contact_kernel_lane_generic, cgrid, cblock, 0, st, S, Aact, O, CS, DP, DK, b->dTrack, CT, (k33c::RedoQueue*)Q, RM, n, HN, SN); break;
+    case 5: hipLaunchKernelGGL(k33c::pdb_contact_kernel_lane, cgrid, cblock, 0, st, S, Aact, O, CS, DP, DK, b->dTrack, CT, (k33c::RedoQueue*)Q, RM, n, HN, SN); break;
     default: break;
     }
 }
