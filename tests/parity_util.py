@@ -222,7 +222,7 @@ def run_parity(n_cars=8, ticks=200, seed=1234, resync=False, verbose=False, chec
 
 
 def run_replicated(n_cars, distinct, ticks, track, model='ks_toyota_ae86_drift', seed=7, spread=(0.0, 1.0), check_every=50, partitions=None, threads=8,
-                   law=None, resets=None, verbose=False):
+                   law=None, resets=None, verbose=False, lane_params_fn=None):
     """Full-size parity by replication (BASELINE's car counts, the oracle at `distinct` cars): `distinct` different (start point on the lap, input) pairs tiled over
     a batch of n_cars.  Size-independent properties, checked every `check_every` ticks and at the end:
       (1) every replica of a representative holds the byte-identical record AND the byte-identical live contact joints wherever it sits in the batch (any
@@ -233,6 +233,8 @@ def run_replicated(n_cars, distinct, ticks, track, model='ks_toyota_ae86_drift',
     pdb_step_host returns, for the oracle from cpuref_get_out -- so equal observations give equal actions.
     resets=(bits, mode): the env's episode rule on the host (projectd_env.py:173-227 without the reward sums): a car whose output flags meet `bits` is teleported by
     Car::teleportByMode(mode) before its next tick, which it takes with the zero action; GPU: pdb_reset_mode, oracle: the product's host function on the oracle's record.
+    lane_params_fn(k, Pk): representative k's own copy of the car block (tunes, scoring variables): the oracle steps it with that block, the GPU batch carries it as the
+    rows of its replicas' lanes (pdb_set_lane_tunes + pdb_set_lane_setups).
     Returns dict(worst, max_in_contact (cars with live joints at a check, over the whole batch), contact_checks, resets)."""
     import pdbatch
     from concurrent.futures import ThreadPoolExecutor
@@ -253,7 +255,14 @@ def run_replicated(n_cars, distinct, ticks, track, model='ks_toyota_ae86_drift',
     b.set_state(allinit)
     if partitions:
         b.set_partitions(partitions)
-    hs = [orc.cpuref_create(C.byref(P), trk, len(trk), C.byref(init[k])) for k in range(distinct)]
+    Pk = [P] * distinct
+    if lane_params_fn is not None:
+        Pk = []
+        for k in range(distinct):
+            Q = pc.CarParams.from_buffer_copy(bytes(P)); lane_params_fn(k, Q); Pk.append(Q)
+        lanes = [Pk[int(r)] for r in rep]
+        b.set_lane_tunes(lanes); b.set_lane_setups(lanes)
+    hs = [orc.cpuref_create(C.byref(Pk[k]), trk, len(trk), C.byref(init[k])) for k in range(distinct)]
     pool = ThreadPoolExecutor(threads)
     base = make_actions(distinct, seed)
     base[:, 1] = np.abs(base[:, 1])                         # enough throttle that every car gets going

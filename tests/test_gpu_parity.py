@@ -884,6 +884,18 @@ def test_every_lane_with_its_own_whole_setup(built, track, model):
 
 
 @pytest.mark.gpu
+def test_full_size_lane_setups_by_replication(built):
+    """8192 cars on the walled road in three free-running partitions, 32 different whole setups x 256 replicas, 1000 ticks: every replica of a setup byte-identical to
+    its representative wherever it sits (any workgroup, any partition, any place in the contact pass's queue -- the cars do meet the walls), the representatives equal to
+    the oracle stepping each with its own block: the table's rows are found from every launch site at BASELINE's car counts"""
+    import parity_util
+    r = parity_util.run_replicated(8192, 32, 1000, 'walled', model='ks_toyota_ae86_drift', seed=23, check_every=50, partitions=3, lane_params_fn=_randomised_setup)
+    print('worst %.3e, up to %d of 8192 cars with live contact joints at a check' % (r['worst'], r['max_in_contact']))
+    assert r['worst'] == 0.0, r
+    assert r['max_in_contact'] >= 256, r
+
+
+@pytest.mark.gpu
 def test_lane_setups_default_rows_take_back_and_refusals(built):
     """the table's default rows are the lanes' own blocks (the run equals the plain kernels' bit for bit, free-running partitions included); rows can be put back; a row =
     that lane stepped with the tuned block; a partition block after the table is refused"""
