@@ -38,7 +38,9 @@ CARS_PER_GPU = 4096
 B_ALG = 2352 + 2352 + 8 + 104   # sizeof(pdb_dyn_state) in and out, float[2] action, pdb_step_out (checked against the ctypes mirrors in measure)
 HBM_PEAK_GBS = 8000.0
 PROFILE_TAG = 'r05'
-HEADLINE = dict(workload='ek_akina', cars=16384, policy='scripted', episodes=True, teleport_mode=2, settle=200)   # BASELINE configs[2] as worded
+# BASELINE configs[2] as worded.  settle: untimed ticks of state preparation -- 1500 (0.4 s), until the rate at which episodes end is stationary (after 200 ticks few cars
+# have left the road yet and a 20-step region then ran 5 % faster than the steady state: VERDICT r5 weak #9)
+HEADLINE = dict(workload='ek_akina', cars=16384, policy='scripted', episodes=True, teleport_mode=2, settle=1500)
 SECONDARY_ARGV = ['--workload', 'flat', '--cars', '4096']   # BASELINE configs[1]
 
 
@@ -72,7 +74,7 @@ def cpu_baseline(P, trk, S0, actions, seconds_target=15.0):
         rate_est = n3 * ticks3 / t3
     orc.cpuref_destroy(h)
     return {"value": n2 * ticks2 / t2, "unit": "env-steps/s", "cores": 1, "kind": "port",
-            "sample": "%d cars x %d ticks of the bench workload (its first %d cars, %.0f s of CPU work), CPU restatement of Car::step + ODE-equivalent solve, single thread" % (n2, ticks2, n2, t2),
+            "sample": "configs[1] inputs (flat plane, constant actions): its first %d cars x %d ticks, %.0f s of CPU work; CPU restatement of Car::step + ODE-equivalent solve, 1 thread" % (n2, ticks2, t2),
             "all_cores_value": n3 * ticks3 / t3, "all_cores": ncores,
             "all_cores_sample": "%d cars x %d ticks on %d OpenMP threads, %.1f s of wall time" % (n3, ticks3, ncores, t3)}
 
@@ -479,6 +481,7 @@ def measure(args, world, rank, local_rank, dist, want_cpu=False):
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32 (+f64 drivetrain)", "data": "synthetic",
             "repeats": len(regions), "timed_region_s": total,
+            "regime": "%d-step regions x%d (median), after %d settle + %d warm-up ticks" % (args.steps, len(regions), args.settle, args.warmup),
             "config": {"workload": wl, "cars_per_gpu": n, "partitions": (args.partitions if split else 1), "settle_ticks": args.settle, "collective": coll,
                        "parity": "GPU bit-exact vs CPU oracle; oracle bit-exact vs reference-TU goldens; rigid-body solve + contact generation unpinned (ODE absent)"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
@@ -614,7 +617,9 @@ def _short(x, n):
 def compact(res, secondary=None, rccl=None, extra_file=None):
     """the ONE stdout line: the contract's keys + roofline + cpu_baseline (+ secondary, rccl), kept under 2 KB"""
     r = res["roofline"]; c = res["config"]
-    out = {k: res[k] for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "repeats", "timed_region_s")}
+    out = {k: res[k] for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "repeats", "timed_region_s", "regime")}
+    if "episode_ends_per_tick" in res:
+        out["episode_ends_per_tick"] = float('%.4g' % res["episode_ends_per_tick"])
     for k in ("value", "ms_per_step", "timed_region_s"):
         out[k] = float('%.6g' % out[k])
     out["config"] = {"workload": _short(c["workload"], 230), "cars_per_gpu": c["cars_per_gpu"], "partitions": c["partitions"], "collective": _short(c["collective"], 120), "parity": _short(c["parity"], 150)}
@@ -625,7 +630,7 @@ def compact(res, secondary=None, rccl=None, extra_file=None):
                        "device_frac": float('%.4g' % r["device_frac"])}
     cb = res.get("cpu_baseline") or (secondary or {}).get("cpu_baseline")
     if cb:
-        out["cpu_baseline"] = {"value": float('%.6g' % cb["value"]), "unit": cb["unit"], "cores": cb["cores"], "kind": cb["kind"], "sample": _short(cb["sample"], 110),
+        out["cpu_baseline"] = {"value": float('%.6g' % cb["value"]), "unit": cb["unit"], "cores": cb["cores"], "kind": cb["kind"], "sample": _short(cb["sample"], 130),
                                "all_cores_value": float('%.6g' % cb["all_cores_value"]), "all_cores": cb["all_cores"]}
     if secondary:
         out["secondary"] = {"workload": _short(secondary["config"]["workload"], 100), "value": float('%.6g' % secondary["value"]), "ms_per_step": float('%.6g' % secondary["ms_per_step"]),

@@ -363,7 +363,8 @@ typedef struct pdb_dyn_state {
     int32_t numContacts;     /* contact joints alive in the engine's contactGroupDynamic (the car's row of the pdb_contact array) */
     int32_t randState;       /* the car's C-runtime rand() state (Core/Math.h:49-52 randR -> Car::teleportByMode(Random)); srand(1) at creation */
     int32_t envPending;      /* env mode: 1 = the episode ended on the last tick: the next tick is the reset tick (teleport + step([0,0]),
-                              * projectd_env.py:216-227); 2 = reset tick whose teleport the caller has already done */
+                              * projectd_env.py:216-227); 2 = reset tick whose teleport the caller has already done (the record stays as the caller left it);
+                              * 3 = the episode ended because the record is no longer finite: the next tick re-creates it from a fresh record, then goes on as 1 */
     int32_t envStepId;       /* env mode: ticks since the episode's reset tick (projectd_env.py step_id) */
     int32_t _pad[1];         /* record size is a multiple of 16 bytes (coalesced 16-byte-per-lane copies) */
     float suspTravel[4];     /* ISuspension status.travel of the last suspension step (read by controllers: the brake system's before this tick's step, the others after it) */
@@ -495,6 +496,11 @@ typedef struct pdb_track_header {
      * (i+1 wraps to 0, Track.cpp:520-560). */
     uint64_t offFatGridRec;
     uint64_t offFatSeg;
+    /* version >= 6: the pit boxes of pits.ini (Track::loadPits, Sim/Track.cpp:151-175): float[numPits][16], the reference's mat44f row by row
+     * (M11..M44) = createFromAxisAngle((0,1,0), ROT.x degrees) with POS in M41..M43.  Car::teleportToPits reads the heading (M31..M33) and the
+     * position (M41..M43) of pit `id` (Car.cpp:1310-1323). */
+    int32_t numPits, _pitPad;
+    uint64_t offPits;
 } pdb_track_header;
 
 typedef struct pdb_ray_rec {

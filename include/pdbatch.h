@@ -10,6 +10,8 @@
  *   pdb_build_track          loadTrack(simId, name)            :186-203 -> Track::init
  *   pdb_initial_state        addCar + teleportCarByMode(Start) :219-237,283-290
  *   pdb_teleport_to_spline   teleportCarToSpline               :274-281
+ *   pdb_teleport_to_location teleportCarToLocation             :250-257 -> Car::forcePosition (Car.cpp:1240-1272)
+ *   pdb_teleport_to_pit      teleportCarToPits                 :259-266 -> Car::teleportToPits (Car.cpp:1310-1323; pits.ini: Sim/Track.cpp:151-175)
  *   pdb_teleport_by_mode     teleportCarByMode(simId, carId, mode)  :283-290 -> Car::teleportByMode (Start / Nearest / Random)
  *   pdb_set_auto_teleport    setCarAutoTeleport                :292-295 (teleport inside the tick, ScoringSystem.cpp:194-225)
  *   pdb_create / pdb_destroy createSimulator / destroySimulator:111-149 (x N)
@@ -76,6 +78,15 @@ int pdb_build_track_opts(const char* base_path, const char* track_name, int flag
 void pdb_free(void* p);
 int pdb_initial_state(const pdb_car_params* params, const void* track_blob, pdb_dyn_state* out);
 int pdb_teleport_to_spline(const pdb_car_params* params, const void* track_blob, float distance_norm, pdb_dyn_state* inout);
+/* teleportCarToLocation = Car::forcePosition((x, y, z)): the car keeps its orientation, is put down on what a ray from 10 m above the point hits
+ * (at the point's own height if it hits nothing) and is reset like by every other teleport */
+int pdb_teleport_to_location(const pdb_car_params* params, const void* track_blob, float x, float y, float z, pdb_dyn_state* inout);
+/* teleportCarToPits = Car::teleportToPits(pit_id): heading and position of pit box `pit_id` of the track's pits.ini; an id outside the list leaves
+ * the car alone, like the reference.  pdb_track_num_pits: how many boxes the blob carries; pdb_track_pit: a box's matrix (the reference's mat44f,
+ * 16 floats row by row) */
+int pdb_teleport_to_pit(const pdb_car_params* params, const void* track_blob, int pit_id, pdb_dyn_state* inout);
+int pdb_track_num_pits(const void* track_blob);
+int pdb_track_pit(const void* track_blob, int pit_id, float* m16);
 /* Car::teleportByMode: mode 0 = Start, 1 = Nearest (the car's trackLocation), 2 = Random (the car's own rand() state,
  * pdb_dyn_state.randState: the C runtime's generator of the reference build, seeded 1 like an unseeded process) */
 int pdb_teleport_by_mode(const pdb_car_params* params, const void* track_blob, int mode, pdb_dyn_state* inout);

@@ -225,6 +225,16 @@ void cpuref_scenario_fields(int sid, int* out) {
     out[0] = sc.resetEvery; out[1] = sc.teleDist; out[2] = sc.boostAt; out[3] = sc.feedback; out[4] = sc.collide; out[5] = sc.autoTele; out[6] = sc.stride; out[7] = sc.denseTicks;
 }
 float cpuref_scenario_teledist(int k) { return pdoracle::kTeleDist[k & 3]; }
+// the k-th mid-run teleport of a scenario as (kind, a, b, c): kind 0 = teleportCarToSpline(a) (a = 0: the start), 1 = teleportCarToPits((int)a),
+// 2 = teleportCarToLocation(chassis position + (a, b, c))
+int cpuref_scenario_teleport(int sid, int k, float* abc) {
+    const auto& sc = pdoracle::kScenarios[sid];
+    abc[0] = abc[1] = abc[2] = 0.0f;
+    if (sc.teleDist == 1) { abc[0] = pdoracle::kTeleDist[k % 4]; return 0; }
+    if (sc.teleDist == 2) { abc[0] = (float)pdoracle::kTelePit[k % 5]; return 1; }
+    if (sc.teleDist == 3) { for (int i = 0; i < 3; ++i) abc[i] = pdoracle::kTeleLoc[k % 4][i]; return 2; }
+    return 0;
+}
 void cpuref_scenario_action(int sid, int tick, float* a) { pdoracle::scenarioAction(sid, tick, a[0], a[1]); }
 int cpuref_scenario_scoring(int sid, int i, const char** name, float* value) {
     if (!pdoracle::kScenarios[sid].scoringSet || i < 0 || i >= pdoracle::kNumScoringSetA) return 0;
@@ -240,11 +250,12 @@ int cpuref_scenario_tune(int sid, int i, const char** name, float* value) {
 void cpuref_scenario_feedback(int sid, int tick, const float* obs, float* a) { pdoracle::scenarioFeedback(sid, tick, obs, a[0], a[1]); }
 
 // run one scripted scenario exactly like oracle/refharness/ref_main.cpp and write the probe file
-int cpuref_run_scenario_cb(void* hh, int sid, const char* outPath, void (*teleportToStart)(pdb_dyn_state*, float));
+int cpuref_run_scenario_cb(void* hh, int sid, const char* outPath, void (*teleport)(pdb_dyn_state*, int, float, float, float));
 int cpuref_run_scenario(void* hh, int sid, const char* outPath) { return cpuref_run_scenario_cb(hh, sid, outPath, nullptr); }
-// teleportToStart: Car::teleportByMode(Start) on a state record -- the PRODUCT's host function (pdb_teleport_to_spline), handed in by
-// the test, so that the scenarios with mid-run resets pin it against the reference's own Car::teleportByMode
-int cpuref_run_scenario_cb(void* hh, int sid, const char* outPath, void (*teleportToStart)(pdb_dyn_state*, float)) {
+// teleport(state, kind, a, b, c): the mid-run teleports on a state record -- the PRODUCT's host functions, handed in by the test (kind 0:
+// pdb_teleport_to_spline(a) = Car::teleportByMode(Start) for a = 0; 1: pdb_teleport_to_pit((int)a); 2: pdb_teleport_to_location(a, b, c)), so
+// that the scenarios with mid-run resets pin them against the reference's own Car::teleportToSpline / teleportToPits / forcePosition
+int cpuref_run_scenario_cb(void* hh, int sid, const char* outPath, void (*teleport)(pdb_dyn_state*, int, float, float, float)) {
     auto* h = (CpuRefHandle*)hh;
     const auto& sc = pdoracle::kScenarios[sid];
     // setCarAssists (PyProjectD.cpp:307-317) per scenario; smooth steering stays on like the env
@@ -258,9 +269,12 @@ int cpuref_run_scenario_cb(void* hh, int sid, const char* outPath, void (*telepo
     { pdoracle::Probe P; P.names = &pf.names; h->car.fillProbe(P); pf.add(-1, 0.0f, 0.0f, P); }
     for (int t = 0; t < sc.ticks; ++t) {
         if (sc.resetEvery && t > 0 && t % sc.resetEvery == 0) {   // env.reset(): teleportCarByMode(Start) + step([0,0])
-            if (!teleportToStart) return -2;
+            if (!teleport) return -2;
             pdb_dyn_state st = h->car.S;
-            teleportToStart(&st, sc.teleDist ? pdoracle::kTeleDist[(t / sc.resetEvery - 1) % 4] : 0.0f);
+            float abc[3];
+            const int kind = cpuref_scenario_teleport(sid, t / sc.resetEvery - 1, abc);
+            if (kind == 2) for (int i = 0; i < 3; ++i) abc[i] = st.body[PDB_BODY_CHASSIS].pos[i] + abc[i];
+            teleport(&st, kind, abc[0], abc[1], abc[2]);
             h->car.loadState(st);
             h->car.step(0.0f, pdoracle::envGas(0.0f), (float)(1.0 / 333.0), 1.0 / 333.0);
         }

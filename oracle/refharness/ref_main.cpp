@@ -236,7 +236,15 @@ int main(int argc, char** argv) {
             }
             for (int t = 0; t < sc.ticks; ++t) {
                 if (sc.resetEvery && t > 0 && t % sc.resetEvery == 0) {
-                    if (sc.teleDist) { env.car->teleportToSpline(pdoracle::kTeleDist[(t / sc.resetEvery - 1) % 4]); env.step(0.0f, 0.0f); }   // teleportCarToSpline + a zero-action tick
+                    const int k = t / sc.resetEvery - 1;
+                    if (sc.teleDist == 1) { env.car->teleportToSpline(pdoracle::kTeleDist[k % 4]); env.step(0.0f, 0.0f); }   // teleportCarToSpline + a zero-action tick
+                    else if (sc.teleDist == 2) { env.car->teleportToPits(pdoracle::kTelePit[k % 5]); env.step(0.0f, 0.0f); }   // teleportCarToPits (PyProjectD.cpp:259-266)
+                    else if (sc.teleDist == 3) {   // teleportCarToLocation (PyProjectD.cpp:250-257): forcePosition(vec3f(x, y, z))
+                        const vec3f p = env.car->body->getPosition(0.0f);
+                        const float* o = pdoracle::kTeleLoc[k % 4];
+                        env.car->forcePosition(vec3f(p.x + o[0], p.y + o[1], p.z + o[2]));
+                        env.step(0.0f, 0.0f);
+                    }
                     else env.reset();
                 }
                 if (sc.boostAt && t == sc.boostAt) {   // through the engine seam: every body, as the oracle edits the state record

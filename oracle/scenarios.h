@@ -15,7 +15,8 @@ struct Scenario { const char* name; int ticks; int denseTicks; int stride; int f
                   int collide; /* run the engine's collision pass (the other fixtures predate it and keep it off) */
                   int resetEvery; /* env.reset() (teleportByMode(Start) + one zero-action tick, projectd_env.py:216-227) every so many ticks */
                   int tuneSet; /* apply kTuneSetA through setCarTune after the env's own tunes */
-                  int teleDist; /* the resets teleport to kTeleDist[k % 4] along the spline (teleportCarToSpline) instead of to the start */
+                  int teleDist; /* 1: the resets teleport to kTeleDist[k % 4] along the spline (teleportCarToSpline) instead of to the start; 2: to pit box kTelePit[k % 5]
+                                   (teleportCarToPits); 3: to the chassis' position + kTeleLoc[k % 4] (teleportCarToLocation = Car::forcePosition) */
                   int scoringSet; /* kScoringSetA through setScoringVar: every reward weight and threshold non-default and non-zero */
                   int boostAt; /* before this tick every body's linear velocity z is set to 50 m/s (180 km/h); 0 = never */
                   int autoTele; /* setCarAutoTeleport: bit 0 on collision, bit 1 on bad location, bits 2-3 mode (0 Start, 1 Nearest, 2 Random) */ };
@@ -106,9 +107,20 @@ static const Scenario kScenarios[] = {
     // a second box collider (CarColliderManager.cpp:17-33 takes every COLLIDER_n of colliders.ini; every shipped car has one): the AE86 with a front
     // splitter box that hangs lower than the belly box, full throttle down the walled strip -- the splitter meets the ridge first, then both boxes scrape
     {"twobox", 2150, 0, 3, 0, 1, 1, 1, "walled", 0, "pdb_twobox_ae86", 0, 1, 0, 0, 0, 0, 0},
+    // teleportCarToPits (PyProjectD.cpp:259-266 -> Car::teleportToPits -> Car::teleport(pit matrix): Car.cpp:1310-1323, the boxes of pits.ini: Track.cpp:151-175) in
+    // mid-flight: on the mountain road (pits.ini written by synthetic_tracks.gen_touge: boxes on the road, beside it, one with nothing under it, headings of
+    // both signs and beyond a turn) and on the env's default track with the pits.ini it ships; one id of the schedule is outside the list (the reference does nothing)
+    {"pits", 3600, 300, 10, 0, 1, 1, 1, "touge", 1, nullptr, 0, 0, 700, 0, 2, 0, 0},
+    {"pits_playground", 3600, 300, 10, 0, 1, 1, 1, "driftplayground", 1, nullptr, 0, 0, 700, 0, 2, 0, 0},
+    // teleportCarToLocation (PyProjectD.cpp:250-257 -> Car::forcePosition, Car.cpp:1240-1272) in mid-flight: the car keeps whatever orientation it has, is put down
+    // on what the ray from 10 m above the point meets (or left at the point's height when it meets nothing: the last offset leaves the mountain road)
+    {"locations", 3600, 300, 10, 0, 1, 1, 1, "touge", 1, nullptr, 0, 0, 800, 0, 3, 0, 0},
+    {"locations_fc3s", 2400, 300, 10, 0, 1, 1, 1, "flat", 0, "dthwsh_mazda_rx7_fc3s_sr20", 0, 0, 550, 0, 3, 0, 0},
 };
-static const int kNumScenarios = 50;
+static const int kNumScenarios = 54;
 static const float kTeleDist[4] = {0.13f, 0.41f, 0.77f, 0.95f};
+static const int kTelePit[5] = {0, 2, 99, 1, 3};
+static const float kTeleLoc[4][3] = {{0.7f, 5.0f, -0.4f}, {-1.1f, 0.3f, 0.9f}, {0.0f, 12.0f, 0.0f}, {30.0f, 2.0f, 30.0f}};
 struct ScoreVar { const char* name; float value; };
 static const ScoreVar kScoringSetA[] = {
     {"SmoothSteerSpeed", 7.0f}, {"MinBonusSpeed", 8.0f}, {"MaxBonusSpeed", 150.0f}, {"StallRpm", 900.0f}, {"DirectionThreshold", 0.6f},

@@ -232,6 +232,7 @@ struct pdb_batch {
     pdb_lane_setup* dLaneSetups = nullptr;   // [n] per-lane setup rows (pdb_set_lane_setups), allocated on first use and then complete: every lane's row holds its block's values or the caller's
     pdb_lane_tune* dLaneTunes = nullptr;   // [n] per-lane tunes and reward weights (pdb_set_lane_tunes), allocated on first use; rows with valid == 0 fall back to the block
     pdb_dyn_state* dFresh = nullptr;     // device copy of resetTemplate (DevConst::freshState)
+    pdb_dyn_state* dPartFresh[PDB_MAX_PARTS] = {nullptr, nullptr, nullptr, nullptr};   // a partition with a car block of its own: the fresh record of THAT block (ride height, pressures, fuel ...)
     pdb_contact* dContacts = nullptr;   // [n][PDB_MAX_CONTACTS]: each car's live contact joints (the first pdb_dyn_state.numContacts of its row)
     hipEvent_t ev0 = nullptr, ev1 = nullptr, tev0 = nullptr, tev1 = nullptr;
     bool ownStream = true;
@@ -369,8 +370,9 @@ static void launchTick(pdb_batch* b, hipStream_t st, int c0, int c1, pdb_step_ou
         cg = (2 * held + PDB_CONTACT_CPB - 1) / PDB_CONTACT_CPB;
         if (cg < (held > 0 ? PDB_CONTACT_GRID : PDB_CONTACT_GRID_IDLE)) cg = held > 0 ? PDB_CONTACT_GRID : PDB_CONTACT_GRID_IDLE;   // nobody touched anything lately: a handful of workgroups is launched, found empty and gone
         if (b->capturing && cg < PDB_CONTACT_GRID) cg = PDB_CONTACT_GRID;   // a replayed graph cannot follow the load
-        if (!b->capturing && b->burst[q] > 0) { --b->burst[q]; if (cg < 1536) cg = 1536; }   // (one car per workgroup since round 5: 512 of them are resident at once)
-        if (cg > 4096) cg = 4096;
+        // right after a reset of many cars: room for 1536 queued cars whatever the hint says (PDB_CONTACT_CPB cars per workgroup), never more than 4096 cars' worth
+        if (!b->capturing && b->burst[q] > 0) { --b->burst[q]; if (cg < (1536 + PDB_CONTACT_CPB - 1) / PDB_CONTACT_CPB) cg = (1536 + PDB_CONTACT_CPB - 1) / PDB_CONTACT_CPB; }
+        if (cg > (4096 + PDB_CONTACT_CPB - 1) / PDB_CONTACT_CPB) cg = (4096 + PDB_CONTACT_CPB - 1) / PDB_CONTACT_CPB;
     }
     int* HN = b->dHint ? b->dHint + q : nullptr;
     const dim3 grid(nblk), block(PDB_BLOCK_THREADS), cblock(PDB_WAVE * PDB_CONTACT_WAVES), cgrid(((n + PDB_CONTACT_CPB - 1) / PDB_CONTACT_CPB) < cg ? ((n + PDB_CONTACT_CPB - 1) / PDB_CONTACT_CPB) : cg);
@@ -429,7 +431,7 @@ static int pushK(pdb_batch* b, hipStream_t st, bool async) {
         DevConst& K = b->partK[p];
         if (b->partHas[p]) fillConst(b->partParams[p], K, b->K.actionMode); else K = b->K;
         const int c0 = partFirst(b, p);
-        K.freshState = b->K.freshState; K.noTeam = b->K.noTeam;
+        K.freshState = (b->partHas[p] && b->dPartFresh[p]) ? b->dPartFresh[p] : b->K.freshState; K.noTeam = b->K.noTeam;
         K.laneTunes = b->K.laneTunes ? b->K.laneTunes + c0 : nullptr;
         K.laneSetups = b->K.laneSetups ? b->K.laneSetups + c0 : nullptr;
         K.holdMask = b->K.holdMask ? b->K.holdMask + c0 : nullptr;
@@ -467,7 +469,7 @@ pdb_batch* pdb_create(int device, int n_cars, const pdb_car_params* params, cons
     }
     {
         const pdb_track_header* th = static_cast<const pdb_track_header*>(track_blob);
-        if (track_bytes < sizeof(pdb_track_header) || th->magic != 0x4B544450 || th->version != 5 || th->totalBytes != track_bytes) {
+        if (track_bytes < sizeof(pdb_track_header) || th->magic != 0x4B544450 || th->version != 6 || th->totalBytes != track_bytes) {
             pdb::setError("pdb_create: not a track blob of this version (build it with pdb_build_track)"); return nullptr;
         }
     }
@@ -548,7 +550,7 @@ void pdb_destroy(pdb_batch* b) {
     commFree(b);
     if (b->graphExec) (void)hipGraphExecDestroy(b->graphExec);
     if (b->stream) (void)hipStreamSynchronize(b->stream);
-    (void)hipFree(b->dStates); (void)hipFree(b->dActions); (void)hipFree(b->dOut); (void)hipFree(b->dCarStates); (void)hipFree(b->dParams); (void)hipFree(b->dK); (void)hipFree(b->dTrack); (void)hipFree(b->dContacts); (void)hipFree(b->dFresh); (void)hipFree(b->dResetMask); (void)hipFree(b->dResetScratch);
+    (void)hipFree(b->dStates); (void)hipFree(b->dActions); (void)hipFree(b->dOut); (void)hipFree(b->dCarStates); (void)hipFree(b->dParams); (void)hipFree(b->dK); (void)hipFree(b->dTrack); (void)hipFree(b->dContacts); (void)hipFree(b->dFresh); for (int p = 0; p < PDB_MAX_PARTS; ++p) (void)hipFree(b->dPartFresh[p]); (void)hipFree(b->dResetMask); (void)hipFree(b->dResetScratch);
     if (b->hHint) (void)hipHostFree(b->hHint);
     if (b->hActions) (void)hipHostFree(b->hActions);
     if (b->hOut) (void)hipHostFree(b->hOut);
@@ -732,6 +734,15 @@ int pdb_set_partition_params(pdb_batch* b, int part, const pdb_car_params* param
     ensureSnap(b);
     if (passNeeded(b, *params) && !b->dSnap) { b->partHas[part] = false; return PDB_ERR_HIP; }
     HIPCHK(hipMemcpy(b->dPartParams[part], params, sizeof(pdb_car_params), hipMemcpyHostToDevice));
+    {   // the record a faulted car of this partition is re-created from (env mode): this block's, not the batch's
+        pdb_dyn_state fresh;
+        try {
+            pdb::TrackView tv(b->track.data());
+            pdb::initialState(*params, tv, fresh);
+        } catch (const std::exception& e) { pdb::setError(e.what()); b->partHas[part] = false; return PDB_ERR_IO; }
+        if (!b->dPartFresh[part]) HIPCHK(hipMalloc(&b->dPartFresh[part], sizeof(pdb_dyn_state)));
+        HIPCHK(hipMemcpy(b->dPartFresh[part], &fresh, sizeof(pdb_dyn_state), hipMemcpyHostToDevice));
+    }
     if (b->graphExec) { (void)hipGraphExecDestroy(b->graphExec); b->graphExec = nullptr; }
     return pushK(b, b->stream, false);
 }
@@ -776,10 +787,12 @@ int pdb_set_lane_setups(pdb_batch* b, int first, int count, const pdb_lane_setup
     if (!b->dLaneSetups) {
         if (!rows) return PDB_OK;   // nothing installed, nothing to take back
         HIPCHK(hipMalloc(&b->dLaneSetups, sizeof(pdb_lane_setup) * (size_t)b->n));
-        if (int rcd = laneSetupDefaults(b, 0, b->n)) return rcd;
+        // a table that did not get its rows or did not reach the constants blocks must not exist: launchTick picks the table's kernels by dLaneSetups alone
+        auto undo = [&](int rc) { (void)hipFree(b->dLaneSetups); b->dLaneSetups = nullptr; b->K.laneSetups = nullptr; return rc; };
+        if (int rcd = laneSetupDefaults(b, 0, b->n)) return undo(rcd);
         b->K.laneSetups = b->dLaneSetups;
         if (b->graphExec) { (void)hipGraphExecDestroy(b->graphExec); b->graphExec = nullptr; b->graphTicks = 0; }   // recorded launches are the other kernel pair's
-        if (int rck = pushK(b, b->stream, false)) return rck;
+        if (int rck = pushK(b, b->stream, false)) { (void)undo(rck); (void)pushK(b, b->stream, false); return rck; }
     }
     if (count == 0) return PDB_OK;
     if (rows) HIPCHK(hipMemcpy(b->dLaneSetups + first, rows, sizeof(pdb_lane_setup) * (size_t)count, hipMemcpyHostToDevice));

@@ -115,6 +115,37 @@ int pdb_teleport_to_spline(const pdb_car_params* params, const void* track_blob,
     return PDB_OK;
     PDB_CATCH(PDB_ERR_IO)
 }
+int pdb_teleport_to_pit(const pdb_car_params* params, const void* track_blob, int pit_id, pdb_dyn_state* inout) {
+    if (!params || !track_blob || !inout) { pdb::setError("null argument"); return PDB_ERR_ARG; }
+    PDB_TRY
+    pdb::TrackView tv(static_cast<const uint8_t*>(track_blob));
+    pdb::teleportToPit(*params, tv, pit_id, *inout);   // an id outside the list: nothing happens, like Car::teleportToPits
+    return PDB_OK;
+    PDB_CATCH(PDB_ERR_IO)
+}
+int pdb_teleport_to_location(const pdb_car_params* params, const void* track_blob, float x, float y, float z, pdb_dyn_state* inout) {
+    if (!params || !track_blob || !inout) { pdb::setError("null argument"); return PDB_ERR_ARG; }
+    PDB_TRY
+    pdb::TrackView tv(static_cast<const uint8_t*>(track_blob));
+    const float pos[3] = {x, y, z};
+    pdb::teleportToLocation(*params, tv, pos, *inout);
+    return PDB_OK;
+    PDB_CATCH(PDB_ERR_IO)
+}
+int pdb_track_num_pits(const void* track_blob) {
+    if (!track_blob) { pdb::setError("null argument"); return PDB_ERR_ARG; }
+    const pdb_track_header* h = static_cast<const pdb_track_header*>(track_blob);
+    if (h->magic != 0x4B544450 || h->version != 6) { pdb::setError("pdb_track_num_pits: not a track blob of this version"); return PDB_ERR_ARG; }
+    return h->numPits;
+}
+int pdb_track_pit(const void* track_blob, int pit_id, float* m16) {
+    const int n = pdb_track_num_pits(track_blob);
+    if (n < 0) return n;
+    if (!m16 || pit_id < 0 || pit_id >= n) { pdb::setError("pdb_track_pit: bad argument"); return PDB_ERR_ARG; }
+    const pdb_track_header* h = static_cast<const pdb_track_header*>(track_blob);
+    memcpy(m16, static_cast<const uint8_t*>(track_blob) + h->offPits + (size_t)pit_id * 64, 64);
+    return PDB_OK;
+}
 
 int pdb_teleport_by_mode(const pdb_car_params* params, const void* track_blob, int mode, pdb_dyn_state* inout) {
     if (!params || !track_blob || !inout || mode < 0 || mode > 2) { pdb::setError("pdb_teleport_by_mode: bad argument"); return PDB_ERR_ARG; }

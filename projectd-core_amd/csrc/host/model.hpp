@@ -23,6 +23,7 @@ struct TrackView {
     const float* fatDist = nullptr;
     const float* nodes = nullptr;
     const float* nodeDist = nullptr;
+    const float* pits = nullptr;   // float[h->numPits][16]
     explicit TrackView(const uint8_t* blob) {
         h = reinterpret_cast<const pdb_track_header*>(blob);
         surfaces = reinterpret_cast<const pdb_surface*>(blob + h->offSurfaces);
@@ -31,6 +32,7 @@ struct TrackView {
         fatDist = reinterpret_cast<const float*>(blob + h->offFatDist);
         nodes = reinterpret_cast<const float*>(blob + h->offNodes);
         nodeDist = reinterpret_cast<const float*>(blob + h->offNodeDist);
+        pits = reinterpret_cast<const float*>(blob + h->offPits);
     }
 };
 
@@ -42,6 +44,9 @@ RayHitH rayCastTrack(const TrackView& tv, const float* origin, const float* dir,
 void initialState(const pdb_car_params& P, const TrackView& tv, pdb_dyn_state& S);
 // the state edits of Car::teleportToSpline(distanceNorm) applied to an existing state
 void teleportToSpline(const pdb_car_params& P, const TrackView& tv, float distanceNorm, pdb_dyn_state& S);
+// Car::teleportToPits(pitId) (nothing for an id outside pits.ini's list) and Car::forcePosition(pos) (teleportCarToLocation)
+void teleportToPit(const pdb_car_params& P, const TrackView& tv, int pitId, pdb_dyn_state& S);
+void teleportToLocation(const pdb_car_params& P, const TrackView& tv, const float* pos, pdb_dyn_state& S);
 // Car::teleportByMode: 0 Start, 1 Nearest (trackLocation), 2 Random (the car's own rand() state)
 void teleportByMode(const pdb_car_params& P, const TrackView& tv, int mode, pdb_dyn_state& S);
 

@@ -1,6 +1,6 @@
 // pdbatch host side: construction-time state and the teleport/reset edits of the reference
 //   Car::reset                      Car/Car.cpp:385-410
-//   Car::forcePosition/forceRotation/teleportToSpline   Car/Car.cpp:1240-1340
+//   Car::forcePosition/forceRotation/teleport/teleportToPits/teleportToSpline   Car/Car.cpp:1240-1340
 //   SuspensionStrut::attach/setPositions/stop           Car/SuspensionStrut.cpp:146-228
 //   SuspensionAxle::attach/stop                         Car/SuspensionAxle.cpp:105-118
 //   Tyre::reset, TyreThermalModel::reset                Car/Tyre.cpp:393-425, Car/TyreThermalModel.cpp:194-208
@@ -25,6 +25,12 @@ struct HostRayDown {
 
 void teleportToSpline(const pdb_car_params& P, const TrackView& tv, float distanceNorm, pdb_dyn_state& S) {
     teleportToSplineT(P, tv.h->numFat, tv.fat, HostRayDown{tv}, distanceNorm, S);
+}
+void teleportToPit(const pdb_car_params& P, const TrackView& tv, int pitId, pdb_dyn_state& S) {
+    teleportToPitT(P, tv.h->numPits, tv.pits, HostRayDown{tv}, pitId, S);
+}
+void teleportToLocation(const pdb_car_params& P, const TrackView& tv, const float* pos, pdb_dyn_state& S) {
+    forcePositionT(P, HostRayDown{tv}, pos, S);
 }
 void teleportByMode(const pdb_car_params& P, const TrackView& tv, int mode, pdb_dyn_state& S) {
     teleportByModeT(P, tv.h->numFat, tv.fat, HostRayDown{tv}, mode, S);

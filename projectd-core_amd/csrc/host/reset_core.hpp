@@ -72,8 +72,68 @@ PDB_HD inline void tyreReset(const pdb_car_params& P, pdb_tyre_state& t) {
     t.phase = 0;
 }
 
-// Car::teleportToSpline (Car.cpp:1303-1318).  fat = the track's fat points (15 floats each), rayDown(origin, hitY) = the
-// engine's ray cast straight down from `origin` over 1000 m (Car::forcePosition, Car.cpp:1243): true + the hit's y
+// Car::forceRotation(heading) (Car.cpp:1274-1308): the chassis and the tank take the matrix built from the heading, the suspensions are
+// re-attached, both bodies stop
+PDB_HD inline void forceRotationT(const pdb_car_params& P, const float* heading, pdb_dyn_state& S) {
+    const float ihed[3] = {heading[0] * -1.0f, heading[1] * -1.0f, heading[2] * -1.0f};
+    const float vM13 = ihed[0], vM11 = -ihed[2], vM12 = 0;
+    const float v6 = sqrtf((vM12 * vM12) + (vM11 * vM11) + (vM13 * vM13));
+    const float s = 1.0f / v6;
+    const float M[9] = {vM11 * s, vM12 * s, vM13 * s, 0, 1, 0, -ihed[0], -ihed[1], -ihed[2]};
+    HBody b; toHBody(S.body[PDB_BODY_CHASSIS], b);
+    hSetRotationM(b, M); fromHBody(b, S.body[PDB_BODY_CHASSIS]);
+    HBody t; toHBody(S.body[PDB_BODY_TANK], t);
+    hSetRotationM(t, M); fromHBody(t, S.body[PDB_BODY_TANK]);
+    attachAll(P, S);
+    stopBody(S.body[PDB_BODY_CHASSIS]); stopBody(S.body[PDB_BODY_TANK]);
+}
+
+// Car::forcePosition(pos, offsetY = 0) (Car.cpp:1240-1272).  rayDown(origin, hitY) = the engine's ray cast straight down from `origin`
+// over 1000 m (Car.cpp:1243): true + the hit's y
+template <class RayDown>
+PDB_HD inline void forcePositionT(const pdb_car_params& P, RayDown rayDown, const float* pos, pdb_dyn_state& S) {
+    float bodyPos[3] = {pos[0], pos[1], pos[2]};
+    const float o[3] = {pos[0] + 0.0f, pos[1] + 10.0f, pos[2] + 0.0f};
+    float hitY;
+    if (rayDown(o, hitY)) bodyPos[1] = hitY;
+    bodyPos[1] += (P.baseCarHeight + 0.0f + 0.01f);
+    // Car::reset()
+    S.waterT = 60.0f;
+    for (int i = 0; i < 4; ++i) S.brakeDiscT[i] = P.ambientTemperature;   // BrakeSystem::reset (BrakeSystem.cpp:73-80)
+    S.fuel = P.fuel;
+    S.collisionFlag = 0; S.oldCollisionFlag = 0; S.outOfTrackFlag = 0;
+    S.lastTrackPointTimestamp = (float)S.physicsTime;
+    S.nearestTrackPointId = 0; S.oldTrackPointId = 0; S.splinePointId = 0;
+    S.trackLocation = 0; S.oldTrackLocation = 0;
+    for (int i = 0; i < 5; ++i) S.damageZoneLevel[i] = 0;   // Car.cpp:403-407 (the simulator's collision frame counter runs on)
+    S.damageChanged = 0;
+    S.totalReward = 0; S.stepReward = 0; S.oldPointId = 0; S.oldSplinePointId = 0;   // ScoringSystem::reset
+    stopBody(S.body[PDB_BODY_CHASSIS]);
+    memcpy(S.body[PDB_BODY_CHASSIS].pos, bodyPos, 12);
+    HBody b; toHBody(S.body[PDB_BODY_CHASSIS], b);
+    hLocalToWorld(b, P.fuelTankPos, S.body[PDB_BODY_TANK].pos);
+    for (int i = 0; i < 4; ++i) stopBody(S.body[P.susp[i].hubBody]);   // ISuspension::stop(): hub / axle only
+    attachAll(P, S);
+    // Drivetrain::reset + Engine::reset
+    S.clutchOpenState = 1; S.rootVelocity = 0; S.engineVel = 0; S.outShaftLVel = 0; S.outShaftRVel = 0; S.driveVel = 0;
+    S.gearReqRequest = 0; S.validShiftRPMWindow = P.validShiftRPMWindow; S.lifeLeft = 1000.0f;
+    for (int i = 0; i < PDB_MAX_TURBOS; ++i) S.turboRotation[i] = 0.0f;   // Engine::reset -> Turbo::reset (Engine.cpp:160-166, Turbo.cpp:42-45)
+    for (int i = 0; i < 4; ++i) tyreReset(P, S.tyre[i]);
+    S.isGearGrinding = 0; S.currentGear = 1;   // setCurrentGear(1, true)
+    stopBody(S.body[PDB_BODY_CHASSIS]); stopBody(S.body[PDB_BODY_TANK]);
+}
+
+// Car::teleport(m) (Car.cpp:1310-1314) = forceRotation(M31..M33) then forcePosition(M41..M43); Car::teleportToPits(pitId) (Car.cpp:1316-1323) =
+// teleport(track->pits[pitId]), nothing for an id outside the list.  pits = float[numPits][16] (the blob's pit matrices, row by row)
+template <class RayDown>
+PDB_HD inline void teleportToPitT(const pdb_car_params& P, int numPits, const float* pits, RayDown rayDown, int pitId, pdb_dyn_state& S) {
+    if (pitId < 0 || pitId >= numPits) return;
+    const float* m = pits + 16 * pitId;
+    forceRotationT(P, m + 8, S);
+    forcePositionT(P, rayDown, m + 12, S);
+}
+
+// Car::teleportToSpline (Car.cpp:1325-1340).  fat = the track's fat points (15 floats each)
 template <class RayDown>
 PDB_HD inline void teleportToSplineT(const pdb_car_params& P, int numFat, const float* fat, RayDown rayDown, float distanceNorm, pdb_dyn_state& S) {
     const int n = numFat;
@@ -84,55 +144,8 @@ PDB_HD inline void teleportToSplineT(const pdb_car_params& P, int numFat, const 
     const size_t pointId = (size_t)(dn * (float)(n - 1));
     if (pointId >= (size_t)n) return;
     const float* pt = fat + 15 * pointId;
-    const float* center = pt + 9;
-    const float* fwd = pt + 12;
-
-    // ---- forceRotation(heading) ----
-    {
-        const float ihed[3] = {fwd[0] * -1.0f, fwd[1] * -1.0f, fwd[2] * -1.0f};
-        const float vM13 = ihed[0], vM11 = -ihed[2], vM12 = 0;
-        const float v6 = sqrtf((vM12 * vM12) + (vM11 * vM11) + (vM13 * vM13));
-        const float s = 1.0f / v6;
-        const float M[9] = {vM11 * s, vM12 * s, vM13 * s, 0, 1, 0, -ihed[0], -ihed[1], -ihed[2]};
-        HBody b; toHBody(S.body[PDB_BODY_CHASSIS], b);
-        hSetRotationM(b, M); fromHBody(b, S.body[PDB_BODY_CHASSIS]);
-        HBody t; toHBody(S.body[PDB_BODY_TANK], t);
-        hSetRotationM(t, M); fromHBody(t, S.body[PDB_BODY_TANK]);
-        attachAll(P, S);
-        stopBody(S.body[PDB_BODY_CHASSIS]); stopBody(S.body[PDB_BODY_TANK]);
-    }
-    // ---- forcePosition(center) ----
-    {
-        float bodyPos[3] = {center[0], center[1], center[2]};
-        const float o[3] = {center[0] + 0.0f, center[1] + 10.0f, center[2] + 0.0f};
-        float hitY;
-        if (rayDown(o, hitY)) bodyPos[1] = hitY;
-        bodyPos[1] += (P.baseCarHeight + 0.0f + 0.01f);
-        // Car::reset()
-        S.waterT = 60.0f;
-        for (int i = 0; i < 4; ++i) S.brakeDiscT[i] = P.ambientTemperature;   // BrakeSystem::reset (BrakeSystem.cpp:73-80)
-        S.fuel = P.fuel;
-        S.collisionFlag = 0; S.oldCollisionFlag = 0; S.outOfTrackFlag = 0;
-        S.lastTrackPointTimestamp = (float)S.physicsTime;
-        S.nearestTrackPointId = 0; S.oldTrackPointId = 0; S.splinePointId = 0;
-        S.trackLocation = 0; S.oldTrackLocation = 0;
-        for (int i = 0; i < 5; ++i) S.damageZoneLevel[i] = 0;   // Car.cpp:403-407 (the simulator's collision frame counter runs on)
-        S.damageChanged = 0;
-        S.totalReward = 0; S.stepReward = 0; S.oldPointId = 0; S.oldSplinePointId = 0;   // ScoringSystem::reset
-        stopBody(S.body[PDB_BODY_CHASSIS]);
-        memcpy(S.body[PDB_BODY_CHASSIS].pos, bodyPos, 12);
-        HBody b; toHBody(S.body[PDB_BODY_CHASSIS], b);
-        hLocalToWorld(b, P.fuelTankPos, S.body[PDB_BODY_TANK].pos);
-        for (int i = 0; i < 4; ++i) stopBody(S.body[P.susp[i].hubBody]);   // ISuspension::stop(): hub / axle only
-        attachAll(P, S);
-        // Drivetrain::reset + Engine::reset
-        S.clutchOpenState = 1; S.rootVelocity = 0; S.engineVel = 0; S.outShaftLVel = 0; S.outShaftRVel = 0; S.driveVel = 0;
-        S.gearReqRequest = 0; S.validShiftRPMWindow = P.validShiftRPMWindow; S.lifeLeft = 1000.0f;
-        for (int i = 0; i < PDB_MAX_TURBOS; ++i) S.turboRotation[i] = 0.0f;   // Engine::reset -> Turbo::reset (Engine.cpp:160-166, Turbo.cpp:42-45)
-        for (int i = 0; i < 4; ++i) tyreReset(P, S.tyre[i]);
-        S.isGearGrinding = 0; S.currentGear = 1;   // setCurrentGear(1, true)
-        stopBody(S.body[PDB_BODY_CHASSIS]); stopBody(S.body[PDB_BODY_TANK]);
-    }
+    forceRotationT(P, pt + 12, S);        // forwardDir
+    forcePositionT(P, rayDown, pt + 9, S);   // center
 }
 
 

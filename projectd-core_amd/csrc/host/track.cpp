@@ -4,6 +4,7 @@
 //   spline.bin    Sim/Track.cpp:274-293 (SlimTrackPoint, Sim/Track.h:12-17)
 //   spline.cache  Sim/Track.cpp:294-311 (FatTrackPoint, Sim/Track.h:18-25)
 //   spline.ini    Sim/Track.cpp:158-186
+//   pits.ini      Sim/Track.cpp:151-175 (Track::loadPits)
 // and restates the load-time geometry: computeFatPoints / computeSideLocation (Track.cpp:366-467, both the
 // TRACE_SIDES=0 and the ray-traced sides; pinned by the spline.cache files the reference ships), initTrackPoints (Track.cpp:188-272) and BSpline3d::init_from_array (Core/Spline3d.cpp:79-162).
 #include "model.hpp"
@@ -395,10 +396,38 @@ std::vector<uint8_t> buildTrack(const std::string& basePathIn, const std::string
         trackLength = nodeDist.back();
     }
 
+    // ---- pit boxes (Track::loadPits, Track.cpp:151-175): sections AC_PIT_0, AC_PIT_1, ... until the first that is missing; the box's matrix is the
+    //      rotation by ROT.x degrees about +y (mat44f::createFromAxisAngle, Core/Math.cpp:88-118, with the C library's sinf / cosf: a load-time
+    //      constant like the reference's) with POS in its fourth row ----
+    std::vector<float> pits;
+    {
+        Ini pitIni(dir + "pits.ini");
+        if (pitIni.ready) {
+            for (int i = 0; ; ++i) {
+                const std::string sec = "AC_PIT_" + std::to_string(i);
+                if (!pitIni.hasSection(sec)) break;
+                float vPos[3], vRot[3];
+                pitIni.getFloat3(sec, "POS", vPos);
+                pitIni.getFloat3(sec, "ROT", vRot);
+                const float ax = 0.0f, ay = 1.0f, az = 0.0f;
+                const float angle = vRot[0] * 0.01745329251994329576923690768489f;
+                const float sin_a = sinf(angle), cos_a = cosf(angle), om = 1.0f - cos_a;
+                float m[16];
+                m[0] = ((ax * ax) * om) + cos_a; m[5] = ((ay * ay) * om) + cos_a; m[10] = ((az * az) * om) + cos_a;
+                m[1] = (az * sin_a) + (ay * ax) * om; m[6] = (ax * sin_a) + (az * ay) * om; m[8] = (ay * sin_a) + (az * ax) * om;
+                m[2] = (az * ax) * om - (ay * sin_a); m[4] = (ay * ax) * om - (az * sin_a); m[9] = (az * ay) * om - (ax * sin_a);
+                m[3] = 0; m[7] = 0; m[11] = 0;
+                m[12] = vPos[0]; m[13] = vPos[1]; m[14] = vPos[2]; m[15] = 1;
+                pits.insert(pits.end(), m, m + 16);
+            }
+        }
+    }
+
     // ---- pack ----
     pdb_track_header h;
     memset(&h, 0, sizeof(h));
-    h.magic = 0x4B544450; h.version = 5;
+    h.magic = 0x4B544450; h.version = 6;
+    h.numPits = (int32_t)(pits.size() / 16);
     h.numSurfaces = (int32_t)surfaces.size(); h.numTris = (int32_t)(tris.size() / 9);
     h.numFat = (int32_t)fat.size(); h.numNodes = (int32_t)nodes.size();
     h.interpolateStep = steps; h.closedLoop = closedLoop ? 1 : 0;
@@ -555,6 +584,7 @@ std::vector<uint8_t> buildTrack(const std::string& basePathIn, const std::string
     }
     h.offRayStart = off; off = align(off + rayStart.size() * 4);
     h.offRayRecs = off; off = align(off + rayRecs.size() * sizeof(pdb_ray_rec));
+    h.offPits = off; off = align(off + pits.size() * 4);
     h.totalBytes = off;
     std::vector<uint8_t> blob(off, 0);
     memcpy(blob.data(), &h, sizeof(h));
@@ -573,6 +603,7 @@ std::vector<uint8_t> buildTrack(const std::string& basePathIn, const std::string
     if (!fatSeg.empty()) memcpy(blob.data() + h.offFatSeg, fatSeg.data(), fatSeg.size() * 4);
     if (!rayStart.empty()) memcpy(blob.data() + h.offRayStart, rayStart.data(), rayStart.size() * 4);
     if (!rayRecs.empty()) memcpy(blob.data() + h.offRayRecs, rayRecs.data(), rayRecs.size() * sizeof(pdb_ray_rec));
+    if (!pits.empty()) memcpy(blob.data() + h.offPits, pits.data(), pits.size() * 4);
     return blob;
 }
 

@@ -93,6 +93,18 @@ struct Sim {
         if (pdb_teleport_to_spline(&P, track.data(), d, &S) != PDB_OK) logf("EXCEPTION: %s", pdb_last_error());
         pushState();
     }
+    void teleportPit(int pitId) {   // Car::teleportToPits (Car.cpp:1316-1323): an id outside pits.ini's list leaves the car alone
+        if (!hasCar || track.empty()) return;
+        pullState();
+        if (pdb_teleport_to_pit(&P, track.data(), pitId, &S) != PDB_OK) logf("EXCEPTION: %s", pdb_last_error());
+        pushState();
+    }
+    void teleportLocation(float x, float y, float z) {   // Car::forcePosition (Car.cpp:1240-1272)
+        if (!hasCar || track.empty()) return;
+        pullState();
+        if (pdb_teleport_to_location(&P, track.data(), x, y, z, &S) != PDB_OK) logf("EXCEPTION: %s", pdb_last_error());
+        pushState();
+    }
     void teleportByMode(int mode) {   // Car::teleportByMode (Car.cpp:1320-1336); Random draws from the car's own C-runtime rand() state
         if (!hasCar || track.empty() || mode < 0 || mode > 2) return;
         pullState();
@@ -187,8 +199,8 @@ int addCar(int simId, const std::string& modelName) {
     return 0;
 }
 void removeCar(int simId, int carId) { Sim* s = getCarSim(simId, carId); if (!s) return; if (s->batch) { pdb_destroy(s->batch); s->batch = nullptr; } s->hasCar = false; }
-void teleportCarToLocation(int, int, float, float, float) { /* forcePosition to an arbitrary point: not on the env path */ }
-void teleportCarToPits(int simId, int carId, int) { if (Sim* s = getCarSim(simId, carId)) s->teleportSpline(0.0f); /* synthetic tracks carry no pits */ }
+void teleportCarToLocation(int simId, int carId, float x, float y, float z) { if (Sim* s = getCarSim(simId, carId)) s->teleportLocation(x, y, z); }
+void teleportCarToPits(int simId, int carId, int pitId) { if (Sim* s = getCarSim(simId, carId)) s->teleportPit(pitId); }
 void teleportCarToSpline(int simId, int carId, float d) { if (Sim* s = getCarSim(simId, carId)) s->teleportSpline(d); }
 void teleportCarByMode(int simId, int carId, int mode) { if (Sim* s = getCarSim(simId, carId)) s->teleportByMode(mode); }
 void setCarAutoTeleport(int simId, int carId, bool collision, bool badLoc, int mode) {

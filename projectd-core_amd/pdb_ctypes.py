@@ -142,7 +142,7 @@ assert C.sizeof(LaneSetup) == 384
 class Surface(C.Structure):   # pdb_surface
     _fields_ = [(n, C.c_float) for n in ('gripMod', 'damping', 'sinHeight', 'sinLength', 'granularity', 'dirtAdditiveK')] + \
                [(n, C.c_int32) for n in ('collisionCategory', 'isValidTrack', 'triStart', 'triCount', 'sectorID', '_pad')]
-class TrackHeader(C.Structure):   # pdb_track_header (version 5)
+class TrackHeader(C.Structure):   # pdb_track_header (version 6)
     _fields_ = [(n, C.c_int32) for n in ('magic', 'version', 'numSurfaces', 'numTris', 'numFat', 'numNodes', 'interpolateStep', 'closedLoop')] + \
                [(n, C.c_float) for n in ('computedTrackLength', 'computedTrackWidth', 'dynamicGripLevel', 'hashCellSize')] + \
                [(n, C.c_uint64) for n in ('offSurfaces', 'offTris', 'offFat', 'offFatDist', 'offNodes', 'offNodeDist', 'totalBytes')] + \
@@ -151,7 +151,8 @@ class TrackHeader(C.Structure):   # pdb_track_header (version 5)
                [('fatGridNx', C.c_int32), ('fatGridNz', C.c_int32), ('fatGridMinX', C.c_float), ('fatGridMinZ', C.c_float), ('fatGridCell', C.c_float), ('_fatGridPad', C.c_float)] + \
                [(n, C.c_uint64) for n in ('offFatGridStart', 'offFatGridIds')] + \
                [('rayNx', C.c_int32), ('rayNz', C.c_int32), ('rayMinX', C.c_float), ('rayMinZ', C.c_float), ('rayCell', C.c_float), ('_rayPad', C.c_float)] + \
-               [(n, C.c_uint64) for n in ('offRayStart', 'offRayRecs', 'offFatGridRec', 'offFatSeg')]
+               [(n, C.c_uint64) for n in ('offRayStart', 'offRayRecs', 'offFatGridRec', 'offFatSeg')] + \
+               [('numPits', C.c_int32), ('_pitPad', C.c_int32), ('offPits', C.c_uint64)]
 class StepOut(C.Structure):
     _fields_ = [('obs', C.c_float * 24), ('reward', C.c_float), ('flags', C.c_int32)]
 
@@ -171,6 +172,10 @@ def load_product(host_only=False):
     lib.pdb_set_scoring_var.argtypes = [C.c_void_p, C.c_char_p, C.c_float]
     lib.pdb_teleport_to_spline.argtypes = [C.c_void_p, C.c_void_p, C.c_float, C.c_void_p]
     lib.pdb_teleport_by_mode.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
+    lib.pdb_teleport_to_pit.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
+    lib.pdb_teleport_to_location.argtypes = [C.c_void_p, C.c_void_p, C.c_float, C.c_float, C.c_float, C.c_void_p]
+    lib.pdb_track_num_pits.argtypes = [C.c_void_p]
+    lib.pdb_track_pit.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
     lib.pdb_set_auto_teleport.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int]
     lib.pdb_lane_tune_from_params.argtypes = [C.c_void_p, C.c_void_p]
     lib.pdb_lane_setup_from_params.argtypes = [C.c_void_p, C.c_void_p]

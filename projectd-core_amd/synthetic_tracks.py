@@ -169,6 +169,13 @@ def gen_touge(out, step=5.0, side=5.0, margin=4.0, bank_gain=6.0, bank_max=0.08,
             f.write(struct.pack('<5f', p[0], p[1], p[2], side, side))
     with open(os.path.join(out, 'spline.ini'), 'w') as f:
         f.write('[SPLINE]\nCLOSED_LOOP=1\nTRACE_SIDES=0\n')
+    # pit boxes in the shipped tracks' format (pits.ini: AC_PIT_n sections, POS, ROT in degrees with the heading in ROT.x; Sim/Track.cpp:151-175): on the road, to either
+    # side of its centre, one 40 m off the ribbon with nothing under it; headings of both signs and beyond a full turn
+    with open(os.path.join(out, 'pits.ini'), 'w') as f:
+        for k, (frac, off, up, rot) in enumerate(((1.0 / 7.0, 2.0, 0.8, 122.2), (1.0 / 3.0, -3.0, 0.4, -47.5), (0.5, 0.0, 1.5, 301.25), (2.0 / 3.0, 40.0, 0.5, 15.0),
+                                                  (0.9, -1.5, 0.2, 400.0))):
+            i = int(frac * n)
+            f.write('[AC_PIT_%d]\nPOS=%.1f, %.1f, %.1f\nROT=%.2f, -0.0, 0.0\n\n' % (k, c[i][0] + off * lat[i][0], c[i][1] + up, c[i][2] + off * lat[i][1], rot))
     cch = os.path.join(out, 'spline.cache')
     if os.path.exists(cch):
         os.remove(cch)

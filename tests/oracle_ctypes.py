@@ -40,6 +40,7 @@ def load_oracle(portable_math=False):
     lib.cpuref_scenario_car.restype = C.c_char_p
     lib.cpuref_scenario_fields.argtypes = [C.c_int, C.c_void_p]
     lib.cpuref_scenario_teledist.restype = C.c_float; lib.cpuref_scenario_teledist.argtypes = [C.c_int]
+    lib.cpuref_scenario_teleport.argtypes = [C.c_int, C.c_int, C.c_void_p]
     lib.cpuref_scenario_action.argtypes = [C.c_int, C.c_int, C.c_void_p]
     lib.cpuref_scenario_feedback.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_void_p]
     lib.cpuref_run_scenario.argtypes = [C.c_void_p, C.c_int, C.c_char_p]

@@ -35,6 +35,25 @@ def track_blob(hostlib, track, base_dir):
     return pc.build_track(hostlib, '/root/reference', track)
 
 
+TELEPORT_CB = C.CFUNCTYPE(None, C.c_void_p, C.c_int, C.c_float, C.c_float, C.c_float)
+
+
+def teleport_state(hostlib, P, blob, state_ref, kind, a, b, c):
+    """one mid-run teleport of a scenario's script on a state record, through the PRODUCT's host functions: kind 0 teleportCarToSpline(a),
+    1 teleportCarToPits(int(a)), 2 teleportCarToLocation(a, b, c)"""
+    if kind == 0:
+        assert hostlib.pdb_teleport_to_spline(C.byref(P), blob, C.c_float(a), state_ref) == 0
+    elif kind == 1:
+        assert hostlib.pdb_teleport_to_pit(C.byref(P), blob, int(a), state_ref) == 0
+    else:
+        assert hostlib.pdb_teleport_to_location(C.byref(P), blob, C.c_float(a), C.c_float(b), C.c_float(c), state_ref) == 0
+
+
+def teleport_callback(hostlib, P, blob):
+    """the callback cpuref_run_scenario_cb wants (keep a reference to it while the run lasts)"""
+    return TELEPORT_CB(lambda sp, kind, a, b, c: teleport_state(hostlib, P, blob, C.c_void_p(sp), kind, a, b, c))
+
+
 def setup(orc, hostlib, sid, base_dir):
     """-> dict(name, track, model, P, blob, S0, fields).  Raises Skip when the scenario needs reference content that is absent."""
     import synthetic_tracks
@@ -98,13 +117,19 @@ def drive(orc, hostlib, sc, batch=None, max_ticks=None, on_tick=None):
                 else:
                     batch.step_host(np.asarray(a2, np.float32).reshape(1, 2))
 
-    def teleport_both(dist):
+    def teleport_both(k):
+        abc = (C.c_float * 3)()
+        kind = orc.cpuref_scenario_teleport(sid, k, abc)
         s = pc.DynState(); orc.cpuref_get_state(h, C.byref(s))
-        assert hostlib.pdb_teleport_to_spline(C.byref(P), blob, C.c_float(dist), C.byref(s)) == 0
+        off = [float(x) for x in abc]
+
+        def args(st):   # a location teleport is relative to where the chassis is (float32 sums, like the harness)
+            return [float(np.float32(st.body[0].pos[i]) + np.float32(off[i])) for i in range(3)] if kind == 2 else off
+        teleport_state(hostlib, P, blob, C.byref(s), kind, *args(s))
         orc.cpuref_set_state(h, C.byref(s))
         if batch is not None:
             g = batch.get_state()
-            assert hostlib.pdb_teleport_to_spline(C.byref(P), blob, C.c_float(dist), C.byref(g[0])) == 0
+            teleport_state(hostlib, P, blob, C.byref(g[0]), kind, *args(g[0]))
             batch.set_state(g)
     step_both(a2=(0.0, 0.0))                      # env.reset(): teleport (already in S0) + step([0, 0])
     if on_tick is not None:
@@ -115,7 +140,7 @@ def drive(orc, hostlib, sc, batch=None, max_ticks=None, on_tick=None):
     try:
         for t in range(n):
             if sc['reset_every'] and t > 0 and t % sc['reset_every'] == 0:
-                teleport_both(orc.cpuref_scenario_teledist(t // sc['reset_every'] - 1) if sc['tele_dist'] else 0.0)
+                teleport_both(t // sc['reset_every'] - 1)
                 step_both(a2=(0.0, 0.0))
             if sc['boost_at'] and t == sc['boost_at']:
                 s = pc.DynState(); orc.cpuref_get_state(h, C.byref(s))

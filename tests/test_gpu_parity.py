@@ -327,10 +327,13 @@ def test_bench_driver_command_prints_one_compact_line(built):
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [l for l in r.stdout.splitlines() if l.strip()]
     assert len(lines) == 1, lines
-    assert len(lines[-1]) < 4096, len(lines[-1])
+    assert len(lines[-1]) < 2048, len(lines[-1])
     d = json.loads(lines[-1])
-    for k in ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling', 'vs_baseline', 'dtype', 'data', 'config', 'roofline', 'cpu_baseline', 'secondary', 'rccl'):
+    for k in ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling', 'vs_baseline', 'dtype', 'data', 'config', 'roofline', 'cpu_baseline', 'secondary', 'rccl',
+              'regime', 'episode_ends_per_tick'):
         assert k in d, k
+    assert d['regime'].startswith('20-step regions x') and '1500 settle' in d['regime'] and d['episode_ends_per_tick'] > 0   # which regime was timed
+    assert 'configs[1]' in d['cpu_baseline']['sample']
     assert d['steps'] == 20 and d['warmup'] == 5 and d['n_gpus'] == 1 and d['config']['cars_per_gpu'] == 16384 and 'ek_akina' in d['config']['workload']
     for k in ('bound', 'achieved', 'peak', 'unit', 'frac', 'traffic', 'kernel', 'kernel_avg_us', 'alg_bytes_per_car_tick', 'cars_per_launch'):
         assert k in d['roofline'], k

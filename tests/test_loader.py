@@ -5,6 +5,7 @@ import ctypes as C, os, struct, sys
 import numpy as np
 import pytest
 import pdb_ctypes as pc
+from conftest import car_params
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 REF = '/root/reference'
@@ -289,3 +290,43 @@ def test_traced_sides_on_a_synthetic_road(hostlib, tmp_path):
     sector = np.arange(len(fat)) // 40
     assert np.all(wb[inner & ((sector == 1) | (sector == 3))] == 0)
     assert np.all(wb[inner & (sector == 0)] > 8.7)
+
+
+def test_pit_boxes_of_pits_ini(hostlib, base_dir):
+    """Track::loadPits (reference Sim/Track.cpp:151-175): AC_PIT_0.. until the first missing section; the box's matrix = the rotation by ROT.x degrees about +y
+    with POS in its fourth row.  The synthetic mountain road's pits.ini (five boxes) in the blob; pdb_teleport_to_pit puts the car into box `id` facing the
+    box's heading and leaves it alone for an id outside the list; the shipped tracks' files where the reference content is present."""
+    import synthetic_tracks, re
+    d = os.path.join(base_dir, 'content', 'tracks', 'touge')
+    synthetic_tracks.gen_touge(d)
+    blob = pc.build_track(hostlib, base_dir, 'touge')
+    secs = re.findall(r'\[AC_PIT_(\d+)\]\s+POS=([^\n]+)\s+ROT=([^\n]+)', open(os.path.join(d, 'pits.ini')).read())
+    assert hostlib.pdb_track_num_pits(blob) == len(secs) == 5
+    P = car_params('ks_toyota_ae86_drift')
+    for k, (idx, pos, rot) in enumerate(secs):
+        pos = [np.float32(x) for x in pos.split(',')]; ang = np.float32(np.float32(rot.split(',')[0]) * np.float32(0.01745329251994329576923690768489))
+        m = (C.c_float * 16)(); assert hostlib.pdb_track_pit(blob, k, m) == 0
+        m = np.array(m[:], np.float32).reshape(4, 4)
+        assert tuple(m[3, :3]) == tuple(pos) and m[3, 3] == 1 and m[1, 1] == 1
+        assert abs(m[2, 0] - np.sin(ang)) < 1e-6 and abs(m[2, 2] - np.cos(ang)) < 1e-6 and m[0, 0] == m[2, 2] and m[0, 2] == -m[2, 0]
+        assert np.allclose(m[:3, :3] @ m[:3, :3].T, np.eye(3), atol=1e-6)
+        S = pc.DynState(); assert hostlib.pdb_initial_state(C.byref(P), blob, C.byref(S)) == 0
+        assert hostlib.pdb_teleport_to_pit(C.byref(P), blob, k, C.byref(S)) == 0
+        R = np.array(S.body[0].R[:], np.float32)
+        assert abs(S.body[0].pos[0] - pos[0]) < 1e-5 and abs(S.body[0].pos[2] - pos[2]) < 1e-5
+        # Car::forceRotation (Car.cpp:1274-1308) builds the body's matrix from the heading h = (M31, M32, M33): third row = h, first row = (h.z, 0, -h.x) / |.|
+        Mb = R.reshape(3, 3)
+        fwd = min((Mb[:, 2], Mb[2, :]), key=lambda v: np.abs(v - m[2, :3]).max())
+        assert np.abs(fwd - m[2, :3]).max() < 1e-5
+    S = pc.DynState(); assert hostlib.pdb_initial_state(C.byref(P), blob, C.byref(S)) == 0
+    before = bytes(S)
+    assert hostlib.pdb_teleport_to_pit(C.byref(P), blob, 5, C.byref(S)) == 0 and hostlib.pdb_teleport_to_pit(C.byref(P), blob, -1, C.byref(S)) == 0
+    assert bytes(S) == before
+    m = (C.c_float * 16)()
+    assert hostlib.pdb_track_pit(blob, 5, m) != 0
+    if os.path.isdir('/root/reference/content/tracks'):
+        for trk in ('driftplayground', 'ebisu_touge', 'yamanashi_short', 'euphoria_hillside_park'):
+            ids = set(int(x) for x in re.findall(r'\[AC_PIT_(\d+)\]', open('/root/reference/content/tracks/%s/pits.ini' % trk).read()))   # (ebisu_touge lists every box twice: the reader keeps the first)
+            n = next(k for k in range(1000) if k not in ids)
+            b = pc.build_track(hostlib, '/root/reference', trk)
+            assert hostlib.pdb_track_num_pits(b) == n > 0, trk

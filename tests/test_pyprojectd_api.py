@@ -142,6 +142,57 @@ def test_single_env_matches_oracle(pd, base):
 
 
 @pytest.mark.gpu
+def test_teleports_to_pits_and_locations_through_the_module(pd, built):
+    """teleportCarToPits / teleportCarToLocation (reference PyProjectD.cpp:250-266 -> Car::teleportToPits / Car::forcePosition, Car.cpp:1240-1323) through the
+    module on the mountain road, whose pits.ini holds five boxes: the CarState of every tick equals the oracle's, the oracle's record going through the host
+    library's pdb_teleport_to_pit / pdb_teleport_to_location (themselves pinned to the reference TUs by the `pits*` / `locations*` goldens).  An id
+    outside the list moves nothing, like the reference."""
+    import synthetic_tracks, pdbatch, pdb_ctypes as pc, oracle_ctypes
+    base = tempfile.mkdtemp(prefix='pdb_pits_')
+    synthetic_tracks.make_base(base, tracks=('touge',)); synthetic_tracks.install_packed_car(base)
+    sim = pd.createSimulator(base); pd.loadTrack(sim, 'touge'); car = pd.addCar(sim, 'ks_toyota_ae86_drift')
+    assert sim >= 0 and car == 0
+    lib = pc.load_product(); orc = oracle_ctypes.load_oracle(True)
+    P = pdbatch.packed_params(); trk = pc.build_track(lib, base, 'touge')
+    assert lib.pdb_track_num_pits(trk) == 5
+    S0 = pc.DynState(); assert lib.pdb_initial_state(C.byref(P), trk, C.byref(S0)) == 0
+    h = orc.cpuref_create(C.byref(P), trk, len(trk), C.byref(S0))
+    ctl = pd.CarControls(); ctl.gas = 0.8; ctl.steer = 0.1
+    a8 = np.array([0.1, 0, 0, 0, 0.8, -1, 0, 0], np.float32)
+    st = pd.CarState(); cs = pc.CarState(); s = pc.DynState()
+
+    def run(n):
+        for _ in range(n):
+            pd.setCarControls(sim, car, True, ctl); pd.stepSimulator(sim, 1.0 / 333.0); pd.getCarState(sim, car, st)
+            orc.cpuref_step_controls(h, a8.ctypes.data_as(C.c_void_p)); orc.cpuref_get_car_state(h, C.byref(cs))
+            for f in ('bodyPos', 'velocity', 'bodyEuler', 'localAngularVelocity'):
+                v = getattr(st, f)
+                assert (np.float32(v.x), np.float32(v.y), np.float32(v.z)) == tuple(np.float32(x) for x in getattr(cs, f)), f
+            assert np.float32(st.engineRPM) == np.float32(cs.engineRPM) and st.gear == cs.gear and np.float32(st.trackLocation) == np.float32(cs.trackLocation)
+    run(200)
+    before = (st.bodyPos.x, st.bodyPos.y, st.bodyPos.z)
+    pd.teleportCarToPits(sim, car, 99); pd.teleportCarToPits(sim, car, -1)      # outside the list: nothing happens
+    run(1)
+    assert abs(st.bodyPos.x - before[0]) < 0.1 and abs(st.bodyPos.z - before[2]) < 0.1
+    for pit in (1, 4, 0):
+        m = (C.c_float * 16)(); assert lib.pdb_track_pit(trk, pit, m) == 0
+        pd.teleportCarToPits(sim, car, pit)
+        orc.cpuref_get_state(h, C.byref(s)); assert lib.pdb_teleport_to_pit(C.byref(P), trk, pit, C.byref(s)) == 0; orc.cpuref_set_state(h, C.byref(s))
+        run(1)
+        assert abs(st.bodyPos.x - m[12]) < 0.05 and abs(st.bodyPos.z - m[14]) < 0.05 and st.speedMS < 0.5   # the car stands in the box
+        run(150)
+    for off in ((3.0, 4.0, -2.0), (-1.0, 0.2, 6.0)):
+        x, y, z = (float(np.float32(st.bodyPos.x) + np.float32(off[0])), float(np.float32(st.bodyPos.y) + np.float32(off[1])), float(np.float32(st.bodyPos.z) + np.float32(off[2])))
+        pd.teleportCarToLocation(sim, car, x, y, z)
+        orc.cpuref_get_state(h, C.byref(s)); assert lib.pdb_teleport_to_location(C.byref(P), trk, C.c_float(x), C.c_float(y), C.c_float(z), C.byref(s)) == 0
+        orc.cpuref_set_state(h, C.byref(s))
+        run(1)
+        assert abs(st.bodyPos.x - x) < 0.05 and abs(st.bodyPos.z - z) < 0.05
+        run(150)
+    orc.cpuref_destroy(h); pd.destroySimulator(sim)
+
+
+@pytest.mark.gpu
 def test_a_lane_takes_a_configured_simulators_whole_setup(pd, base):
     """setBatchLaneSetup (+ setBatchLaneTune): a lane of simulator A's batch steps exactly like a batch made from simulator B, whose springs, bar, dampers, gear ratio
     and brake power were tuned with the reference's own setCarRawTune; the other lanes are untouched"""
@@ -200,6 +251,23 @@ def test_vec_env_matches_oracle_and_resets(pd, base):
     assert env.reset(m) is None
     pd.getBatchCarState(env.batch, 1, cs); assert abs(cs.bodyPos.z + 1500.0) < 1.0
     pd.getBatchCarState(env.batch, 0, cs); assert cs.bodyPos.z == z0
+    # ... and go on from the pose the caller gave them (the kernel's own re-creation of a faulted record must not take a caller's reset tick for
+    # its own: ADVICE r5): the masked lanes' next tick is the reset tick -- zero action, reward 0 -- on the teleported record, everything
+    # Car::reset keeps (tyre temperatures, the steering filter, ...) kept; then every lane steps on, observation for observation like the oracle
+    assert env.kernel_env
+    for i in (1, 5):
+        s = pc.DynState(); orc.cpuref_get_state(hs[i], C.byref(s))
+        assert lib.pdb_teleport_to_spline(C.byref(P), trk, C.c_float(0.0), C.byref(s)) == 0
+        orc.cpuref_set_state(hs[i], C.byref(s))
+    for t in range(60):
+        obs, rew, term, trunc, info = env.step(acts)
+        for i in range(n):
+            zero = t == 0 and i in (1, 5)
+            orc.cpuref_step_env(hs[i], 0.0 if zero else float(acts[i, 0]), 0.0 if zero else float(acts[i, 1])); orc.cpuref_get_out(hs[i], C.byref(o))
+            if not term[i] or zero:
+                assert np.array_equal(obs[i], np.array(o.obs[:], np.float32)), (t, i)
+            if zero:
+                assert rew[i] == 0.0 and not term[i]
     for h in hs:
         orc.cpuref_destroy(h)
     env.close()

@@ -17,7 +17,7 @@ from conftest import load_golden
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..', 'oracle'))
 import probe_io  # noqa: E402
 
-NSC = 50
+NSC = 54
 INT_LIKE = ('gear', 'Gear', 'Id', 'Flag', 'flag', 'isLocked', 'limiterOn', 'sleepingFrames', 'Counter', 'drifting', 'driftExtreme', 'driftInvalid', 'acSeq', 'clutchOpenState', 'surface')
 
 
@@ -32,9 +32,7 @@ def test_portable_math_oracle_stays_on_the_reference_trajectories(built, hostlib
     h = orc.cpuref_create(C.byref(sc['P']), sc['blob'], len(sc['blob']), C.byref(sc['S0']))
     P, blob = sc['P'], sc['blob']
 
-    def teleport(state_ptr, dist):
-        assert hostlib.pdb_teleport_to_spline(C.byref(P), blob, C.c_float(dist), C.c_void_p(state_ptr)) == 0
-    cb = C.CFUNCTYPE(None, C.c_void_p, C.c_float)(teleport)
+    cb = SU.teleport_callback(hostlib, P, blob)
 
     def teleport_mode(state_ptr, mode):
         assert hostlib.pdb_teleport_by_mode(C.byref(P), blob, mode, C.c_void_p(state_ptr)) == 0
@@ -104,7 +102,7 @@ def held_records(a, b, names):
 def _run_script(orc, hostlib, sc, sid, S0):
     h = orc.cpuref_create(C.byref(sc['P']), sc['blob'], len(sc['blob']), C.byref(S0))
     P, blob = sc['P'], sc['blob']
-    cb = C.CFUNCTYPE(None, C.c_void_p, C.c_float)(lambda sp, d: hostlib.pdb_teleport_to_spline(C.byref(P), blob, C.c_float(d), C.c_void_p(sp)) and None)
+    cb = SU.teleport_callback(hostlib, P, blob)
     cbm = C.CFUNCTYPE(None, C.c_void_p, C.c_int)(lambda sp, m: hostlib.pdb_teleport_by_mode(C.byref(P), blob, m, C.c_void_p(sp)) and None)
     orc.cpuref_set_auto_teleport_hook(C.c_void_p(h), C.cast(cbm, C.c_void_p))
     with tempfile.TemporaryDirectory() as d:

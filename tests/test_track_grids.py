@@ -13,7 +13,7 @@ import pdb_ctypes as pc
 
 def arrays(blob):
     h = pc.TrackHeader.from_buffer_copy(blob[:C.sizeof(pc.TrackHeader)])
-    assert h.version == 5 and h.totalBytes == len(blob)
+    assert h.version == 6 and h.totalBytes == len(blob)
     buf = np.frombuffer(blob, dtype=np.uint8)
     f = lambda off, n: buf[off:off + 4 * n].view(np.float32)
     i = lambda off, n: buf[off:off + 4 * n].view(np.int32)
