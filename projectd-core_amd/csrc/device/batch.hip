@@ -65,6 +65,11 @@
 #define PDB_KERNEL_GUARDED_C pdb_contact_kernel_generic
 #define PDB_KERNEL_LANE_C pdb_contact_kernel_lane_generic
 #define PDB_KERNEL_LANE_EXACT_C pdb_contact_kernel_lane
+#define PDB_KERNEL_COLLIDE pdb_collide_kernel              /* the contact pass as two kernels (round 6): collision pass proper, one wave per car ... */
+#define PDB_KERNEL_EXACT_R pdb_resume_kernel               /* ... and the tick's back half from the snapshot, in the first pass's workgroup shape */
+#define PDB_KERNEL_GUARDED_R pdb_resume_kernel_generic
+#define PDB_KERNEL_LANE_R pdb_resume_kernel_lane_generic
+#define PDB_KERNEL_LANE_EXACT_R pdb_resume_kernel_lane
 #define PDB_KNS k33
 #define PDB_CPB PDB_FIRST_CPB
 #define PDB_HELPERS 0
@@ -102,6 +107,11 @@
 #undef PDB_KERNEL_LANE_C
 #undef PDB_KERNEL_LANE_EXACT
 #undef PDB_KERNEL_LANE_EXACT_C
+#undef PDB_KERNEL_COLLIDE
+#undef PDB_KERNEL_EXACT_R
+#undef PDB_KERNEL_GUARDED_R
+#undef PDB_KERNEL_LANE_R
+#undef PDB_KERNEL_LANE_EXACT_R
 #ifndef PDB_FAST_BUILD   /* development builds (make dev) compile the 33-row size class only */
 #define PDB_KROWS 40
 #define PDB_KMINWAVES 5
@@ -112,6 +122,9 @@
 #define PDB_KERNEL_GUARDED pdb_step_kernel_wide
 #define PDB_KERNEL_EXACT_C pdb_contact_kernel_ctrl
 #define PDB_KERNEL_GUARDED_C pdb_contact_kernel_wide
+#define PDB_KERNEL_COLLIDE pdb_collide_kernel_wide
+#define PDB_KERNEL_EXACT_R pdb_resume_kernel_ctrl
+#define PDB_KERNEL_GUARDED_R pdb_resume_kernel_wide
 #define PDB_KNS k40
 #define PDB_CPB PDB_FIRST_CPB
 #define PDB_HELPERS 0
@@ -145,6 +158,9 @@
 #undef PDB_KERNEL_GUARDED
 #undef PDB_KERNEL_EXACT_C
 #undef PDB_KERNEL_GUARDED_C
+#undef PDB_KERNEL_COLLIDE
+#undef PDB_KERNEL_EXACT_R
+#undef PDB_KERNEL_GUARDED_R
 #endif
 #undef PDB_KMINWAVES_C
 #ifndef PDB_FAST_BUILD
@@ -231,6 +247,7 @@ struct pdb_batch {
     unsigned char* dHold = nullptr;   // [n] hold mask of pdb_step_host_held, allocated on first use
     pdb_lane_setup* dLaneSetups = nullptr;   // [n] per-lane setup rows (pdb_set_lane_setups), allocated on first use and then complete: every lane's row holds its block's values or the caller's
     pdb_lane_tune* dLaneTunes = nullptr;   // [n] per-lane tunes and reward weights (pdb_set_lane_tunes), allocated on first use; rows with valid == 0 fall back to the block
+    bool splitContact = true;            // the contact pass as the kernel pair where cars are expected in it (PDB_CONTACT_SPLIT=0: always the one kernel -- diagnostic A/B)
     pdb_dyn_state* dFresh = nullptr;     // device copy of resetTemplate (DevConst::freshState)
     pdb_dyn_state* dPartFresh[PDB_MAX_PARTS] = {nullptr, nullptr, nullptr, nullptr};   // a partition with a car block of its own: the fresh record of THAT block (ride height, pressures, fuel ...)
     pdb_contact* dContacts = nullptr;   // [n][PDB_MAX_CONTACTS]: each car's live contact joints (the first pdb_dyn_state.numContacts of its row)
@@ -396,6 +413,32 @@ static void launchTick(pdb_batch* b, hipStream_t st, int c0, int c1, pdb_step_ou
     }
     if (sampled) { (void)hipEventRecord(KS.ev[2 * KS.n + 1], st); KS.cars[KS.n] = n; ++KS.n; }
     if (!contacts) return;
+    // The contact pass, in one of two forms with the same results (step_kernel.hip.inc, pdbCollideBody): where cars are expected in it -- the hint of the last passes, or a
+    // caller's fixed grid -- the snapshot cars go through the kernel pair sized to fit beside the first pass (collide: one wave per car; resume: the first pass's workgroup
+    // shape); the one kernel follows only if a car's whole tick may have to be done again (reset mask, in-tick auto-teleport: its other list).  Where nothing has been
+    // touched lately the one kernel alone: its idle launch ends on three words, and a surprise is still served (and raises the hint).
+    const int heldNow = (b->contactGrid > 0) ? 1 : (b->hHint ? *(volatile int*)(b->hHint + q) : 0);
+    if (b->splitContact && HP.collider.enabled != 0 && heldNow > 0) {
+        const dim3 xgrid((unsigned)(n < (int)cgrid.x * PDB_CONTACT_CPB ? n : (int)cgrid.x * PDB_CONTACT_CPB))   /* one car per workgroup */, xblock(PDB_WAVE * PDB_CONTACT_WAVES);
+        switch (kind) {
+#ifndef PDB_FAST_BUILD
+        case 0: case 3: hipLaunchKernelGGL(k40c::pdb_collide_kernel_wide, xgrid, xblock, 0, st, DP, b->dTrack, CT, (k40c::RedoQueue*)Q, SN); break;
+#endif
+        default: hipLaunchKernelGGL(k33c::pdb_collide_kernel, xgrid, xblock, 0, st, DP, b->dTrack, CT, (k33c::RedoQueue*)Q, SN); break;
+        }
+        switch (kind) {
+#ifndef PDB_FAST_BUILD
+        case 0: hipLaunchKernelGGL(k40c::pdb_resume_kernel_ctrl, cgrid, cblock, 0, st, S, Aact, O, CS, DP, DK, b->dTrack, CT, (k40c::RedoQueue*)Q, n, HN, SN); break;
+        case 3: hipLaunchKernelGGL(k40c::pdb_resume_kernel_wide, cgrid, cblock, 0, st, S, Aact, O, CS, DP, DK, b->dTrack, CT, (k40c::RedoQueue*)Q, n, HN, SN); break;
+#endif
+        case 1: hipLaunchKernelGGL(k33c::pdb_resume_kernel, cgrid, cblock, 0, st, S, Aact, O, CS, DP, DK, b->dTrack, CT, (k33c::RedoQueue*)Q, n, HN, SN); break;
+        case 2: hipLaunchKernelGGL(k33c::pdb_resume_kernel_generic, cgrid, cblock, 0, st, S, Aact, O, CS, DP, DK, b->dTrack, CT, (k33c::RedoQueue*)Q, n, HN, SN); break;
+        case 4: hipLaunchKernelGGL(k33c::pdb_resume_kernel_lane_generic, cgrid, cblock, 0, st, S, Aact, O, CS, DP, DK, b->dTrack, CT, (k33c::RedoQueue*)Q, n, HN, SN); break;
+        case 5: hipLaunchKernelGGL(k33c::pdb_resume_kernel_lane, cgrid, cblock, 0, st, S, Aact, O, CS, DP, DK, b->dTrack, CT, (k33c::RedoQueue*)Q, n, HN, SN); break;
+        default: break;
+        }
+        if (!(b->resetMaskArmed || HP.autoTeleport != 0)) return;   // no car's whole tick is ever done again: the queue's other list stays empty
+    }
     switch (kind) {
 #ifndef PDB_FAST_BUILD
     case 0: hipLaunchKernelGGL(k40c::pdb_contact_kernel_ctrl, cgrid, cblock, 0, st, S, Aact, O, CS, DP, DK, b->dTrack, CT, (k40c::RedoQueue*)Q, RM, n, HN, SN); break;
@@ -488,6 +531,20 @@ pdb_batch* pdb_create(int device, int n_cars, const pdb_car_params* params, cons
     b->track.assign((const uint8_t*)track_blob, (const uint8_t*)track_blob + track_bytes);
     fillConst(b->params, b->K, action_mode);
     b->K.dt = (float)(1.0 / 333.0); b->K.fps = 1.0f / b->K.dt; b->K.dtD = 1.0 / 333.0;
+    {   // which form of the contact pass where cars are expected in it (launchTick).  The kernel pair pays where a car's collision pass is long -- its narrow phase
+        // is shared by four waves there -- and costs a launch and a trip of the snapshot through HBM where it is short: measured (profiles/r06_contact_split.txt) +3.5 % on
+        // the playground-scale meshes (obstacles of centimetre-sized triangles: grid cells with hundreds of entries), -4 % on a wall-lined road of five-metre triangles.
+        // The static proxy: the fullest cell of the collision grid.
+        const pdb_track_header* th = reinterpret_cast<const pdb_track_header*>(b->track.data());
+        int fullest = 0;
+        if (th->gridNx > 0 && th->gridNz > 0) {
+            const int32_t* gs = reinterpret_cast<const int32_t*>(b->track.data() + th->offGridStart);
+            const int64_t cells = (int64_t)th->gridNx * th->gridNz;
+            for (int64_t c = 0; c < cells; ++c) { const int e = gs[c + 1] - gs[c]; if (e > fullest) fullest = e; }
+        }
+        b->splitContact = fullest >= 48;
+    }
+    if (const char* sp = getenv("PDB_CONTACT_SPLIT")) b->splitContact = atoi(sp) != 0;   // diagnostic: 0 = the one-kernel contact pass always, 1 = the pair wherever cars are expected (tests, A/B)
     if (const char* nt = getenv("PDB_NO_TEAM")) b->K.noTeam = atoi(nt) != 0 ? 1 : 0;   // diagnostic: the per-wave form of the car waves' stage (tests, A/B)
     bool ok = true;
     ok = ok && hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking) == hipSuccess;

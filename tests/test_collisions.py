@@ -139,6 +139,38 @@ def test_contact_pass_results_do_not_depend_on_its_grid(built, grid, monkeypatch
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize('form', ['one', 'pair', 'pair_grid1'])
+@pytest.mark.parametrize('model', [AE86, 'dthwsh_mazda_rx7_fc3s_sr20'])
+def test_contact_pass_forms_agree_with_the_oracle(built, form, model, monkeypatch):
+    """the contact pass as ONE kernel (collision pass and back half of the tick by the car's wave) and as the PAIR of round 6 (collide: one car per workgroup, its
+    narrow phase shared by four waves; resume: the first pass's workgroup shape, from the snapshot the collide kernel wrote back) -- the library picks per track
+    (the fullest cell of the collision grid) and per launch (the hint); here each form is forced (PDB_CONTACT_SPLIT; a fixed grid makes the pair run on every tick, and
+    with ONE workgroup every car after the first goes through LDS blocks that have held other cars): both classes of kernel (33 and 40 rows), bit for bit the oracle"""
+    import parity_util
+    monkeypatch.setenv('PDB_CONTACT_SPLIT', '0' if form == 'one' else '1')
+    if form != 'one':
+        monkeypatch.setenv('PDB_CONTACT_GRID', '1' if form == 'pair_grid1' else '32')
+    seen = {'flag': 0, 'dmg': 0}
+
+    def on_tick(t, i, sg, sc):
+        seen['flag'] += int(sg.collisionFlag != 0)
+        seen['dmg'] += int(sg.damageZoneLevel[4] > 0)
+    worst = parity_util.run_parity(n_cars=48, ticks=1600, seed=99, track='walled', model=model, check_every=7, on_tick=on_tick)
+    assert worst == 0.0, worst
+    assert seen['flag'] > 20 and seen['dmg'] > 50, seen
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('form', ['0', '1'])
+def test_contact_pass_forms_agree_on_the_playground_scale_mesh(built, form, monkeypatch):
+    """the same on the 118 320-triangle playground (grid cells with up to 196 entries: the long narrow phases the pair is for), cars spread over the lap"""
+    monkeypatch.setenv('PDB_CONTACT_SPLIT', form)
+    h, worst, seen = _scale_run('playground', AE86, 96, 1200, 11)
+    assert worst == 0.0, worst
+    assert seen['contacts'] > 200, seen
+
+
+@pytest.mark.gpu
 def test_gpu_matches_oracle_on_the_wall_lined_road(built):
     """the synthetic mountain road with guard rails (WALL surfaces along both edges, configs[4] shape): 32 cars with constant
     actions run wide into the rails within a few seconds -- hull contacts on a curved, banked, hilly mesh, bit for bit"""

@@ -36,6 +36,15 @@ def test_first_pass_kernels_keep_six_workgroups_per_cu():
     # allocated) 56320 bytes of LDS are left -- at 58760 the bench line lost 2.3 % (round 4) without any test noticing
     for name in ('pdb_contact_kernel', 'pdb_contact_kernel_generic'):
         assert k[name]['lds'] <= 56320, (name, k[name])
+    # the contact pass as a kernel pair (round 6): the resume kernel has the first pass's workgroup shape and LDS, 120 VGPRs (the one kernel: 208) and NO spill beyond the
+    # cold teleport block's frame (held to 96 registers it spilled, and the 40-row class then faulted on the GPU); the collide kernel is one car per workgroup, four waves
+    # on its narrow phase, the car's block + the cooperative staging block in LDS
+    for name in ('pdb_resume_kernel', 'pdb_resume_kernel_generic'):
+        assert k[name]['vgprs'] <= 128 and k[name]['lds'] <= 26880 and k[name]['scratch'] <= 64, (name, k[name])
+    for name in ('pdb_resume_kernel_wide', 'pdb_resume_kernel_ctrl'):
+        assert k[name]['vgprs'] <= 128 and k[name]['lds'] <= 32000 and k[name]['scratch'] <= 64, (name, k[name])
+    for name in ('pdb_collide_kernel', 'pdb_collide_kernel_wide'):
+        assert k[name]['lds'] <= 40960 and k[name]['scratch'] == 0, (name, k[name])
     # scratch of the first pass: the cold teleport block's frame (round 2: 72 bytes).  A hot-path spill shows up as a larger frame first.
     for name in ('pdb_step_kernel', 'pdb_step_kernel_generic'):
         assert k[name]['scratch'] <= 96, (name, k[name])

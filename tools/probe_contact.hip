@@ -20,6 +20,9 @@
 #define PDB_KCLASS_LS false
 #define PDB_KERNEL_EXACT_C pdb_contact_kernel
 #define PDB_KERNEL_GUARDED_C pdb_contact_kernel_generic
+#define PDB_KERNEL_COLLIDE pdb_collide_kernel
+#define PDB_KERNEL_EXACT_R pdb_resume_kernel
+#define PDB_KERNEL_GUARDED_R pdb_resume_kernel_generic
 #define PDB_KNS k33c
 #define PDB_CPB PDB_CONTACT_CPB
 #define PDB_HELPERS 0
