@@ -301,11 +301,13 @@ typedef struct pdb_car_params {
     pdb_dyn_ctrl ctrlEbb, ctrlSteerBrake;
     /* brakes.ini [TEMPS_FRONT] + [TEMPS_REAR] (BrakeSystem.cpp:40-52,151-169): each disc's temperature follows the work done on it and the air stream,
      * and scales its brake torque through PERF_CURVE */
-    int32_t hasBrakeTemps, _padBrake;
+    int32_t hasBrakeTemps;
+    float slipEffectGainMult;      /* aero.ini [SLIPSTREAM] EFFECT_GAIN_MULT (AeroMap.cpp:25-29; SlipStream.h default 1): how strongly THIS car's wake thins the air of the cars behind it */
     pdb_brake_disc discs[4];
     /* ctrl_arb_front.ini / ctrl_arb_rear.ini (Car.cpp:158-167, AntirollBar.cpp:19-22): the bar's rate of the tick; the bars step after the drivetrain */
     pdb_dyn_ctrl ctrlArb[2];
-    int32_t numCtrlStages, _padCtrl;
+    int32_t numCtrlStages;
+    float slipSpeedFactorMult;     /* [SLIPSTREAM] SPEED_FACTOR_MULT (default 1): the wake's length = speed x 0.25 x this (Sim/SlipStream.cpp:37-47) */
     pdb_ctrl_stage ctrlStages[PDB_MAX_CTRL_STAGES];
 } pdb_car_params;
 
@@ -379,6 +381,16 @@ typedef struct pdb_dyn_state {
  * kind 0: hull vs WALL (surface.mode 28692, mu 0.25, bounce 0.01, soft_cfm 1e-4); kind 1: belly box vs TRACK (mode 28700,
  * mu 0.1, soft_erp 0.714285731, soft_cfm 0.000952380942).  A car keeps its PDB_MAX_CONTACTS deepest contact points. */
 #define PDB_MAX_CONTACTS 32
+/* A car's slipstream as its last Car::postStep left it (Sim/SlipStream.cpp:37-47 setPosition; Car.cpp:692-694): where the car was, the direction its wake points
+ * (against its velocity), the wake's length, the car's EFFECT_GAIN_MULT.  State of a multi-car simulator (pdb_set_world_size): the other cars of the world read it
+ * at the top of their next Car::step (Car::updateAirPressure, Car.cpp:557-585).  A new car's is all zero (no wake) until its first tick ends; teleports leave it alone. */
+typedef struct pdb_slip_state {
+    float pos[3];
+    float length;
+    float dir[3];
+    float effectGainMult;
+} pdb_slip_state;
+
 typedef struct pdb_contact {
     float pos[3];
     float depth;
@@ -518,6 +530,7 @@ static_assert(sizeof(pdb_car_params) == 22696, "pdb_car_params layout");
 static_assert(sizeof(pdb_dyn_state) == 2352, "pdb_dyn_state layout (multiple of 16 bytes)");
 static_assert(sizeof(pdb_step_out) == 104, "pdb_step_out layout");
 static_assert(sizeof(pdb_contact) == 32, "pdb_contact layout");
+static_assert(sizeof(pdb_slip_state) == 32, "pdb_slip_state layout");
 static_assert(sizeof(pdb_lane_setup) == 384 && sizeof(pdb_lane_wheel) == 64, "pdb_lane_setup layout");
 static_assert(sizeof(pdb_lane_tune) == 144, "pdb_lane_tune layout (a multiple of 16 bytes: it rides in the car's LDS block)");
 static_assert(sizeof(pdb_ray_rec) == 48, "pdb_ray_rec layout");

@@ -170,6 +170,14 @@ int pdb_set_contact_grid(pdb_batch* b, int workgroups);
  * e.g. to randomise the setup over the cars of a batch.  The partition's cars step, reset and teleport with it, through every
  * step entry point (the whole-batch ones then issue one launch per partition range). */
 int pdb_set_partition_params(pdb_batch* b, int part, const pdb_car_params* params);
+/* Multi-car simulators (Sim/Simulator.cpp:59-60,112-153: 1..100 cars share one Simulator; PyProjectD.cpp:219-237 addCar once per car): the batch's cars form worlds of
+ * cars_per_world consecutive lanes (a divisor of the batch's car count; partitions then cut on whole worlds).  What couples the cars of a world on this path is the
+ * slipstream -- Car::updateAirPressure (Car.cpp:557-585): the air density a car's wings and body meet is thinned by the wakes the OTHER cars of its simulator left at
+ * the end of the last tick (Sim/SlipStream.cpp).  Body contacts between cars (PhysicsEngineODE.cpp:236-241) are not built.  pdb_get_slipstreams / pdb_set_slipstreams:
+ * the wakes as state, both buffers ([0][count] then [1][count]; a car's next tick reads the one of its pdb_dyn_state.simFrame's parity) -- a new car's are zero. */
+int pdb_set_world_size(pdb_batch* b, int cars_per_world);
+int pdb_get_slipstreams(pdb_batch* b, int first, int count, pdb_slip_state* out);
+int pdb_set_slipstreams(pdb_batch* b, int first, int count, const pdb_slip_state* in);
 /* Per-LANE setup and reward weights (pdb_lane_tune, include/pdb_types.h): the reference's setCarTune / setScoringVar are per simulator, i.e. per env
  * (PyProjectD.cpp:328-365); here a lane's row overrides the eight tunes of projectd_env.py:127-130 and the scoring variables of its car block.
  * pdb_lane_tune_from_params (host library too) reads the row out of a block that went through pdb_set_car_tune / pdb_set_scoring_var;

@@ -49,6 +49,11 @@ int cpuref_last_contact_rows(void* hh, float* lambda, float* lo, float* hi, int 
     if (iterations) *iterations = w.lastLcpIterations;
     return n;
 }
+// multi-car simulators: a car's slipstream as its last tick left it; the OTHER cars' slipstreams its next tick reads (n of them, in the simulator's car order)
+void cpuref_get_slip(void* hh, pdb_slip_state* out) { *out = ((CpuRefHandle*)hh)->car.slip; }
+void cpuref_set_slip(void* hh, const pdb_slip_state* in) { ((CpuRefHandle*)hh)->car.slip = *in; }
+void cpuref_set_guid(void* hh, int guid) { ((CpuRefHandle*)hh)->car.physicsGUID = guid; }
+void cpuref_set_other_slips(void* hh, const pdb_slip_state* in, int n) { ((CpuRefHandle*)hh)->car.otherSlips.assign(in, in + n); }
 // controls-level step: steer, gas
 void cpuref_step(void* hh, float steer, float gas) {
     ((CpuRefHandle*)hh)->car.step(steer, gas, (float)(1.0 / 333.0), 1.0 / 333.0);
@@ -300,6 +305,48 @@ int cpuref_run_scenario_cb(void* hh, int sid, const char* outPath, void (*telepo
     }
     return pf.write(outPath) ? 0 : -1;
 }
+
+// A two-car scenario (oracle/scenarios.h twoCar) exactly like oracle/refharness/ref_main.cpp: two cars of one simulator -- h0 the first (at the start), h1 the second
+// (created from a record already put down kTwoCarDist ahead) -- stepped tick by tick, each reading the slipstream the OTHER's last tick left (every car of a Simulator
+// steps before any postStep: Simulator.cpp:168-201); one probe file per car
+int cpuref_run_scenario2(void* hh0, void* hh1, int sid, const char* outPath0, const char* outPath1) {
+    CpuRefHandle* h[2] = {(CpuRefHandle*)hh0, (CpuRefHandle*)hh1};
+    const auto& sc = pdoracle::kScenarios[sid];
+    if (!sc.twoCar || sc.resetEvery || sc.boostAt || sc.full) return -3;
+    for (int c = 0; c < 2; ++c) {
+        h[c]->P.acUseOnStart = sc.autoClutch; h[c]->P.acUseOnChange = sc.autoClutch; h[c]->P.autoShiftActive = sc.autoShift; h[c]->P.autoBlipActive = sc.autoBlip;
+        h[c]->P.smoothSteer = sc.rawSteer ? 0 : 1;
+        h[c]->car = cpuref::Car();
+        h[c]->car.init(&h[c]->P, &h[c]->T, h[c]->s0);
+        h[c]->car.physicsGUID = c;
+    }
+    pdoracle::ProbeFile pf[2];
+    const float dt = (float)(1.0 / 333.0); const double dtD = 1.0 / 333.0;
+    auto stepBoth = [&](float a0, float a1, float b0, float b1) {
+        const pdb_slip_state s0 = h[0]->car.slip, s1 = h[1]->car.slip;
+        h[0]->car.otherSlips.assign(1, s1); h[1]->car.otherSlips.assign(1, s0);
+        h[0]->car.step(a0, pdoracle::envGas(a1), dt, dtD);
+        h[1]->car.step(b0, pdoracle::envGas(b1), dt, dtD);
+    };
+    stepBoth(0.0f, 0.0f, 0.0f, 0.0f);   // env.reset(): the teleports (already in the records) + step([0,0])
+    for (int c = 0; c < 2; ++c) { pdoracle::Probe P; P.names = &pf[c].names; h[c]->car.fillProbe(P); pf[c].add(-1, 0.0f, 0.0f, P); }
+    for (int t = 0; t < sc.ticks; ++t) {
+        float a0, a1, b0, b1;
+        if (sc.feedback) {
+            pdb_step_out o; h[0]->car.fillStepOut(o); pdoracle::scenarioFeedback(sid, t, o.obs, a0, a1);
+            h[1]->car.fillStepOut(o); pdoracle::scenarioFeedback2(sid, t, o.obs, b0, b1);
+        } else { pdoracle::scenarioAction(sid, t, a0, a1); pdoracle::scenarioAction2(sid, t, b0, b1); }
+        stepBoth(a0, a1, b0, b1);
+        if (pdoracle::scenarioRecord(sc, t)) {
+            pdoracle::Probe P; h[0]->car.fillProbe(P); pf[0].add(t, a0, a1, P);
+            pdoracle::Probe Q; h[1]->car.fillProbe(Q); pf[1].add(t, b0, b1, Q);
+        }
+    }
+    return (pf[0].write(outPath0) && pf[1].write(outPath1)) ? 0 : -1;
+}
+int cpuref_scenario_two_car(int sid, float* dist) { const int k = pdoracle::kScenarios[sid].twoCar; if (k && dist) *dist = pdoracle::kTwoCarDist[k - 1]; return k; }
+void cpuref_scenario_action2(int sid, int tick, float* a) { pdoracle::scenarioAction2(sid, tick, a[0], a[1]); }
+void cpuref_scenario_feedback2(int sid, int tick, const float* obs, float* a) { pdoracle::scenarioFeedback2(sid, tick, obs, a[0], a[1]); }
 
 // CPU baseline: step `ncars` independent cars for `ticks` ticks with per-car constant env actions;
 // returns elapsed seconds.  threads <= 1: single thread.

@@ -24,6 +24,7 @@ struct V3 {
     V3& norm(float l) { if (l != 0.0f) { const float s = 1.0f / l; x *= s; y *= s; z *= s; } return *this; }
     V3& norm() { return norm(len()); }
     V3 get_norm() const { V3 c = *this; c.norm(); return c; }
+    V3 get_norm(float l) const { V3 c = *this; c.norm(l); return c; }
     V3 cross(const V3& v) const { return V3(y * v.z - z * v.y, z * v.x - x * v.z, x * v.y - y * v.x); }
     void store(float* p) const { p[0] = x; p[1] = y; p[2] = z; }
 };
@@ -138,6 +139,7 @@ static Hit rayCast(const TrackData& T, const V3& o, const V3& d, float maxDist) 
 // ------------------------------------------------------------------------------------------------
 void Car::init(const pdb_car_params* P_, const TrackData* T_, const pdb_dyn_state& s0) {
     P = P_; T = T_;
+    memset(&slip, 0, sizeof(slip)); otherSlips.clear(); airDensityNow = P->airDensity;
     w = pdrb::World();
     w.erp = P->worldErp; w.cfm = P->worldCfm;
     for (int k = 0; k < 3; ++k) w.gravity[k] = P->gravity[k];
@@ -955,7 +957,7 @@ static void aeroDataStep(Car& c) {
         if (fDot != 0.0f) {
             V3 vNorm = lv / sqrtf(fDot);
             const float dynamicCD = (((fabsf(vNorm.x) * P.aeroCD) * P.aeroCDX) + P.aeroCD) + ((fabsf(vNorm.y) * P.aeroCD) * P.aeroCDY);
-            const float fDrag = ((dynamicCD * fDot) * P.airDensity) * P.aeroReferenceArea;
+            const float fDrag = ((dynamicCD * fDot) * c.airDensityNow) * P.aeroReferenceArea;
             const V3 f = vNorm * -(fDrag * 0.5f);
             const float zero[3] = {0, 0, 0};
             body.addRelForceAtRelPos(&f.x, zero);
@@ -971,7 +973,7 @@ static void aeroDataStep(Car& c) {
     {
         const float fZZ = lv.z * lv.z;
         if (fZZ != 0.0f) {
-            const float fLift = (((fZZ * P.aeroCL) * P.airDensity) * P.aeroReferenceArea) * 0.5f;
+            const float fLift = (((fZZ * P.aeroCL) * c.airDensityNow) * P.aeroReferenceArea) * 0.5f;
             const float fFrontLift = fLift * P.aeroFrontShare;
             const V3 ff(0, -fFrontLift, 0);
             body.addRelForceAtRelPos(&ff.x, P.susp[0].basePosition);
@@ -1041,7 +1043,7 @@ static void wingStep(Car& c, int wi) {
         ws.cd = curve(wg.lutAOA_CD, (1.0f * angle) + off) * wg.cdGain;
         if (wg.lutGH_CD.n) ws.cd *= curve(wg.lutGH_CD, ws.groundHeight);   // Wing.cpp:134-139
         const float fDot = lv.sqlen();
-        const float fDrag = (((fDot * ws.cd) * c.P->airDensity) * wg.area) * 0.5f;
+        const float fDrag = (((fDot * ws.cd) * c.airDensityNow) * wg.area) * 0.5f;
         ws.dragKG = fDrag * 0.10197838f;
         if (fDot != 0.0f) { const V3 f = lv.get_norm() * -fDrag; body.addRelForceAtRelPos(&f.x, &pos.x); }
     }
@@ -1056,7 +1058,7 @@ static void wingStep(Car& c, int wi) {
         }
         if (wg.lutGH_CL.n) ws.cl *= curve(wg.lutGH_CL, ws.groundHeight);   // Wing.cpp:181-186
         const float fDot = (fAxis * fAxis) + (lv.z * lv.z);
-        const float fLift = (((fDot * ws.cl) * c.P->airDensity) * wg.area) * 0.5f;
+        const float fLift = (((fDot * ws.cl) * c.airDensityNow) * wg.area) * 0.5f;
         ws.liftKG = fLift * 0.10197838f;
         if (fDot != 0.0f) {
             const V3 vNorm = lv.get_norm();
@@ -1511,13 +1513,36 @@ void Car::carStep(float dt) {
     Body& body = w.bodies[PDB_BODY_CHASSIS];
     Body& tank = w.bodies[PDB_BODY_TANK];
     S.collisionFlag = 0; S.outOfTrackFlag = 0;
-    {   // ERP/CFM switch for car 0 (:426-451)
+    if (physicsGUID == 0) {   // ERP/CFM switch (:426-451): `if (!physicsGUID)` -- the first car of a simulator only
         const V3 v = getVelocity(body);
         const float fVelSq = v.sqlen();
         const float erp = (fVelSq >= 1.0f) ? 0.3f : 0.9f;
         const float cfm = 0.0000001f;
         for (int j = 0; j < Pm.numJoints; ++j)
             if (Pm.joints[j].suspErp && w.joints[j].type == pdrb::JT_DBALL) { if (erp > 0.0f) w.joints[j].erp = erp; if (cfm > 0.0f) w.joints[j].cfm = cfm; }
+    }
+    {   // Car::updateAirPressure (Car.cpp:557-585; called from Car::step, :474): SlipStream::getSlipEffect of every OTHER car of the simulator (Sim/SlipStream.cpp:15-35)
+        float fAirDensity = Pm.airDensity;
+        const float slipStreamEffectGain = 1.0f;   // Car.h:135
+        if (slipStreamEffectGain > 0.0f) {
+            const V3 vPos = getPos(body);
+            float fMinSlip = 1.0f;
+            for (const pdb_slip_state& ss : otherSlips) {
+                float fSlipE = 0;
+                V3 vDelta = vPos - V3(ss.pos);
+                const float fDeltaLen = vDelta.len();
+                if (fDeltaLen < ss.length) {
+                    vDelta.norm(fDeltaLen);
+                    const float fDot = vDelta * V3(ss.dir);
+                    if (fDot <= 0.7f) fSlipE = 0;
+                    else fSlipE = (((1.0f - (fDeltaLen / ss.length)) * (fDot - 0.7f)) * 3.3333333f) * ss.effectGainMult;
+                }
+                const float fSlip = tclamp((1.0f - (fSlipE * slipStreamEffectGain)), 0.0f, 1.0f);
+                if (fMinSlip > fSlip) fMinSlip = fSlip;
+            }
+            fAirDensity = ((fAirDensity - (fMinSlip * fAirDensity)) * (0.75f / slipStreamEffectGain)) + (fMinSlip * fAirDensity);
+        }
+        airDensityNow = fAirDensity;
     }
     controls.steer = tclamp(controls.steer, -1.0f, 1.0f);
     controls.clutch = tclamp(controls.clutch, 0.0f, 1.0f);
@@ -1784,6 +1809,15 @@ void Car::postStep(float dt) {
     const pdb_car_params& Pm = *P;
     const TrackData& Tk = *T;
     Body& body = w.bodies[PDB_BODY_CHASSIS];
+    {   // slipStream->setPosition(body position, body velocity) (Car.cpp:692-694, Sim/SlipStream.cpp:37-47; the triangle's other two corners are never read)
+        const V3 vel = getVelocity(body), pos = getPos(body);
+        const float fVelLen = vel.len();
+        const V3 dir = vel.get_norm(fVelLen) * -1.0f;
+        slip.pos[0] = pos.x; slip.pos[1] = pos.y; slip.pos[2] = pos.z;
+        slip.dir[0] = dir.x; slip.dir[1] = dir.y; slip.dir[2] = dir.z;
+        slip.length = (fVelLen * 0.25f) * Pm.slipSpeedFactorMult;
+        slip.effectGainMult = Pm.slipEffectGainMult;
+    }
     // updateTrackLocator (Car.cpp:717-771)
     for (int r = 0; r < PDB_NUM_PROBES; ++r) {
         const V3 rp(0, 0, 0), rd(Pm.probeDir[r]);
@@ -2072,7 +2106,7 @@ void Car::fillProbe(pdoracle::Probe& Pr) const {
     Pr.p3("car.lastVelocity", S.lastVelocity);
     Pr.p("car.waterT", S.waterT);
     Pr.p("car.fuel", S.fuel);
-    Pr.p("aero.airDensity", P->airDensity);
+    Pr.p("aero.airDensity", airDensityNow != 0.0f ? airDensityNow : P->airDensity);
     for (int i = 0; i < 4; ++i) {
         const pdb_tyre_state& st = S.tyre[i];
         const TyreScratch& sc = ts[i];

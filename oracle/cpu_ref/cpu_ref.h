@@ -63,6 +63,12 @@ struct Car {
     int acSeqCount = 0;
     std::vector<int> nearby;
     void (*autoTeleportHook)(pdb_dyn_state*, int mode) = nullptr;   // Car::teleportByMode on a state record (the product's pdb_teleport_by_mode)
+    // multi-car simulators: the car's own slipstream as its last postStep left it (Sim/SlipStream.cpp:37-47; zero until the first tick ends), the other cars' as THEIR last
+    // postStep left them (handed in by whoever steps the world: every car of a Simulator steps before any postStep, Simulator.cpp:168-201), the tick's air density
+    int physicsGUID = 0;   // the car's index in its simulator (Car.h physicsGUID): the first car alone switches its suspension joints' ERP by speed (Car.cpp:426)
+    pdb_slip_state slip;
+    std::vector<pdb_slip_state> otherSlips;
+    float airDensityNow = 0;
     pdcol::ContactSet contactSet;   // the engine's contactGroupDynamic for this car (S.numContacts of them are alive)
     int contactCandidates = 0;      // diagnostic: contact points the last odd frame produced, before the PDB_MAX_CONTACTS cut
 

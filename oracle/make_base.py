@@ -71,6 +71,22 @@ def make_fwd_car(base, src='ks_toyota_ae86_drift', dst='pdb_fwd_ae86'):
     open(p, 'w', newline='').write(raw.replace('TYPE=RWD', 'TYPE=FWD'))
 
 
+def make_slip_car(base, src='ks_toyota_ae86_drift', dst='pdb_slip_ae86'):
+    """No shipped car carries [SLIPSTREAM] in its aero.ini (AeroMap.cpp:25-29 reads it where it is there; SlipStream.h's defaults apply otherwise: a wake of a quarter
+    of a second's travel).  The AE86 with EFFECT_GAIN_MULT = 1.5 and SPEED_FACTOR_MULT = 4 (a wake of one second's travel) pins both, and lets two cars a few car
+    lengths apart draft each other in the two-car fixtures."""
+    s = os.path.join(REF, 'content', 'cars', src, 'data'); d = os.path.join(base, 'content', 'cars', dst, 'data')
+    if os.path.isdir(d):
+        shutil.rmtree(d)
+    shutil.copytree(s, d)
+    os.system('chmod -R u+w "%s"' % d)
+    p = os.path.join(d, 'aero.ini')
+    raw = open(p, newline='').read()
+    eol = '\r\n' if '\r\n' in raw else '\n'
+    assert 'SLIPSTREAM' not in raw
+    open(p, 'w', newline='').write(raw.rstrip('\r\n') + eol + eol.join(['', '[SLIPSTREAM]', 'EFFECT_GAIN_MULT=1.5', 'SPEED_FACTOR_MULT=4.0', '']))
+
+
 def make_cold_car(base, src='ks_mazda_rx7_tuned', dst='pdb_cold_rx7'):
     """Four branches no shipped car takes: [OVERLAP] (a torque ripple away from the ideal rpm, Engine.cpp:96-101,300-307), [THROTTLE_RESPONSE] (a second throttle curve blended in by rpm, Engine.cpp:150-154,344-366),
     [COAST_SETTINGS] (a throttle offset rising with rpm, Engine.cpp:61-67,198-207) and [EBB] (brake bias following the front axle's
@@ -346,6 +362,7 @@ def main():
     make_ctrl_inputs_cars(base)
     make_braketemp_car(base)
     make_twobox_car(base)
+    make_slip_car(base)
     gen_track.gen_flat(os.path.join(base, 'content', 'tracks', 'flat'))
     gen_track.gen_touge(os.path.join(base, 'content', 'tracks', 'touge'))
     gen_track.gen_walled(os.path.join(base, 'content', 'tracks', 'walled'))

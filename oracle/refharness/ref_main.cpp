@@ -20,15 +20,16 @@
 using namespace D;
 using pdoracle::Probe;
 
-static void fillProbe(Probe& P, Simulator* sim, Car* car) {
+static void fillProbe(Probe& P, Simulator* sim, Car* car, int carIndex = 0, int numCars = 1) {
     pdrb::World* w = ref_get_world(sim->physics.get());
     P.p("time", sim->physicsTime);
     // rigid bodies in creation order (= world order): chassis, tank, [axle], then per wheel hub (+ strut body)
     const bool legacy = car->suspensions[0]->getType() == SuspensionType::Strut && car->suspensions[2]->getType() == SuspensionType::Axle;
     const char* bn[7] = {"chassis", "tank", "axle", "hub0", "strut0", "hub1", "strut1"};
     char nm[96], bname[16];
-    for (int i = 0; i < (int)w->bodies.size(); ++i) {
-        const pdrb::Body& b = w->bodies[i];
+    const int nbCar = (int)w->bodies.size() / numCars;   // (cars of one model: the world holds their bodies car after car, in creation order)
+    for (int i = 0; i < nbCar; ++i) {
+        const pdrb::Body& b = w->bodies[carIndex * nbCar + i];
         if (!legacy) { snprintf(bname, sizeof(bname), "body%d", i); }
         const char* bni = legacy ? bn[i] : bname;
 #define bn_i bni
@@ -154,11 +155,15 @@ static void obsOf(const CarState& s, float* o) {
 struct Env {
     std::shared_ptr<Simulator> sim;
     Car* car = nullptr;
+    Car* car2 = nullptr;      // a second car in the same simulator (twoCar scenarios: PyProjectD.cpp:219-237 addCar once more)
+    float dist2 = 0.0f;
     double dt = 1.0 / 333.0;  // projectd_env.py:19
     CarControls dcontrols;    // persistent python-side object (projectd_env.py:135)
+    CarControls dcontrols2;
     bool smooth = true;       // setCarControls(sim, car, smooth, controls)
 
-    void init(const std::string& base, const std::string& track, const std::string& model, bool autoClutch = true, bool autoShift = true, bool autoBlip = true) {
+    void setupCar(Car* car, const std::string& model, bool autoClutch, bool autoShift, bool autoBlip);
+    void init(const std::string& base, const std::string& track, const std::string& model, bool autoClutch = true, bool autoShift = true, bool autoBlip = true, float secondCarAt = -1.0f) {
         // projectd_env.py:118-136, PyProjectD.cpp:111-137
         sim = std::make_shared<Simulator>();
         sim->simulatorId = 0;
@@ -166,6 +171,15 @@ struct Env {
         sim->loadTrack(strw(track));
         car = sim->addCar(strw(model));
         car->teleportByMode(TeleportMode::Start);
+        setupCar(car, model, autoClutch, autoShift, autoBlip);
+        if (secondCarAt >= 0.0f) {
+            dist2 = secondCarAt;
+            car2 = sim->addCar(strw(model));
+            car2->teleportToSpline(dist2);
+            setupCar(car2, model, autoClutch, autoShift, autoBlip);
+        }
+    }
+    void setupCarBody(Car* car, const std::string& model, bool autoClutch, bool autoShift, bool autoBlip) {
         car->teleportOnCollision = false; car->teleportOnBadLocation = false; car->teleportMode = 0;
         car->autoClutch->useAutoOnStart = autoClutch; car->autoClutch->useAutoOnChange = autoClutch;   // PyProjectD.cpp:307-317
         car->autoShift->isActive = autoShift; car->autoBlip->isActive = autoBlip;
@@ -181,12 +195,13 @@ struct Env {
             {"StallPenalty", 0.0f}};
         for (auto& v : svars) car->scoring->config->setVar(v.first, v.second);
     }
-    void step(float a0, float a1) {
+    void step(float a0, float a1, float b0 = 0.0f, float b1 = 0.0f) {
         // projectd_env.py:157-171, PyProjectD.cpp:160-180,297-305
         dcontrols.steer = a0;
         dcontrols.gas = pdoracle::envGas(a1);
         car->controls = dcontrols;
         car->smoothSteer = smooth;
+        if (car2) { dcontrols2.steer = b0; dcontrols2.gas = pdoracle::envGas(b1); car2->controls = dcontrols2; car2->smoothSteer = smooth; }
         sim->step((float)dt, sim->physicsTime, sim->gameTime);
         sim->physicsTime += dt;
         sim->gameTime += dt;
@@ -204,9 +219,11 @@ struct Env {
     void reset() {
         // projectd_env.py:216-227
         car->teleportByMode(TeleportMode::Start);
+        if (car2) car2->teleportToSpline(dist2);
         step(0.0f, 0.0f);
     }
 };
+void Env::setupCar(Car* c, const std::string& model, bool autoClutch, bool autoShift, bool autoBlip) { setupCarBody(c, model, autoClutch, autoShift, autoBlip); }
 
 int main(int argc, char** argv) {
     if (argc < 4) { fprintf(stderr, "usage: %s <basePath> <track> <outDir> [car] [-v]\n", argv[0]); return 2; }
@@ -220,19 +237,21 @@ int main(int argc, char** argv) {
             Env env;
             const std::string track = sc.track;
             if (!only.empty() && only != track) continue;
-            env.init(base, track, sc.car ? std::string(sc.car) : model, sc.autoClutch != 0, sc.autoShift != 0, sc.autoBlip != 0);
+            env.init(base, track, sc.car ? std::string(sc.car) : model, sc.autoClutch != 0, sc.autoShift != 0, sc.autoBlip != 0, sc.twoCar ? pdoracle::kTwoCarDist[sc.twoCar - 1] : -1.0f);
             env.smooth = sc.rawSteer == 0;
             ref_set_collide(env.sim->physics.get(), sc.collide != 0);
             if (sc.autoTele) { env.car->teleportOnCollision = sc.autoTele & 1; env.car->teleportOnBadLocation = (sc.autoTele >> 1) & 1; env.car->teleportMode = (sc.autoTele >> 2) & 3; }   // setCarAutoTeleport, PyProjectD.cpp:286-295
             ref_msvc_srand(1);   // every scenario starts like a fresh process
             if (sc.scoringSet) for (int i = 0; i < pdoracle::kNumScoringSetA; ++i) env.car->scoring->config->setVar(pdoracle::kScoringSetA[i].name, pdoracle::kScoringSetA[i].value);   // PyProjectD.cpp:347-355
             if (sc.tuneSet) for (int i = 0; i < pdoracle::kNumTuneSetA; ++i) env.car->setup->setTune(pdoracle::kTuneSetA[i].name, pdoracle::kTuneSetA[i].value);   // PyProjectD.cpp:328-335
-            pdoracle::ProbeFile pf;
+            pdoracle::ProbeFile pf, pf2;
+            const int nCars = sc.twoCar ? 2 : 1;
             env.reset();
             {
                 Probe P; P.names = &pf.names;
-                fillProbe(P, env.sim.get(), env.car);
+                fillProbe(P, env.sim.get(), env.car, 0, nCars);
                 pf.add(-1, 0.0f, 0.0f, P);
+                if (sc.twoCar) { Probe Q; Q.names = &pf2.names; fillProbe(Q, env.sim.get(), env.car2, 1, nCars); pf2.add(-1, 0.0f, 0.0f, Q); }
             }
             for (int t = 0; t < sc.ticks; ++t) {
                 if (sc.resetEvery && t > 0 && t % sc.resetEvery == 0) {
@@ -251,11 +270,16 @@ int main(int argc, char** argv) {
                     pdrb::World* w = ref_get_world(env.sim->physics.get());
                     for (auto& b : w->bodies) b.lvel[2] = 50.0f;
                 }
-                float a0, a1;
+                float a0, a1, b0 = 0.0f, b1 = 0.0f;
                 if (sc.feedback) {
                     float obs[24]; obsOf(*env.car->state, obs);
                     pdoracle::scenarioFeedback(sid, t, obs, a0, a1);
-                    env.step(a0, a1);
+                    if (sc.twoCar) { float obs2[24]; obsOf(*env.car2->state, obs2); pdoracle::scenarioFeedback2(sid, t, obs2, b0, b1); }
+                    env.step(a0, a1, b0, b1);
+                } else if (sc.twoCar) {
+                    pdoracle::scenarioAction(sid, t, a0, a1);
+                    pdoracle::scenarioAction2(sid, t, b0, b1);
+                    env.step(a0, a1, b0, b1);
                 } else if (sc.full) {
                     pdoracle::Ctl c; pdoracle::scenarioControls(sid, t, c);
                     a0 = c.steer; a1 = c.gas;
@@ -266,13 +290,18 @@ int main(int argc, char** argv) {
                 }
                 if (pdoracle::scenarioRecord(sc, t)) {
                     Probe P;
-                    fillProbe(P, env.sim.get(), env.car);
+                    fillProbe(P, env.sim.get(), env.car, 0, nCars);
                     pf.add(t, a0, a1, P);
+                    if (sc.twoCar) { Probe Q; fillProbe(Q, env.sim.get(), env.car2, 1, nCars); pf2.add(t, b0, b1, Q); }
                 }
             }
             const std::string path = outDir + "/" + track + "_" + sc.name + ".bin";
             if (!pf.write(path.c_str())) { fprintf(stderr, "cannot write %s\n", path.c_str()); return 1; }
             fprintf(stderr, "wrote %s: %d records x %d fields\n", path.c_str(), (int)pf.ticks.size(), pf.nfields);
+            if (sc.twoCar) {
+                const std::string path2 = outDir + "/" + track + "_" + sc.name + "_b.bin";
+                if (!pf2.write(path2.c_str())) { fprintf(stderr, "cannot write %s\n", path2.c_str()); return 1; }
+            }
         }
     } catch (const std::exception& ex) {
         fprintf(stderr, "EXCEPTION: %s\n", ex.what());

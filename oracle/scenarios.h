@@ -19,7 +19,9 @@ struct Scenario { const char* name; int ticks; int denseTicks; int stride; int f
                                    (teleportCarToPits); 3: to the chassis' position + kTeleLoc[k % 4] (teleportCarToLocation = Car::forcePosition) */
                   int scoringSet; /* kScoringSetA through setScoringVar: every reward weight and threshold non-default and non-zero */
                   int boostAt; /* before this tick every body's linear velocity z is set to 50 m/s (180 km/h); 0 = never */
-                  int autoTele; /* setCarAutoTeleport: bit 0 on collision, bit 1 on bad location, bits 2-3 mode (0 Start, 1 Nearest, 2 Random) */ };
+                  int autoTele; /* setCarAutoTeleport: bit 0 on collision, bit 1 on bad location, bits 2-3 mode (0 Start, 1 Nearest, 2 Random) */
+                  int twoCar; /* a second car of the same model in the same simulator (Simulator::addCar twice), put down kTwoCarDist[twoCar - 1] along the spline ahead of the first;
+                                 its script: scenarioAction2 / scenarioFeedback2; its records go to a second probe file (<track>_<name>_b) */ };
 
 static const Scenario kScenarios[] = {
     {"idle", 600, 200, 10, 0, 1, 1, 1, "flat", 0, nullptr, 0, 0, 0, 0, 0, 0, 0},
@@ -116,8 +118,15 @@ static const Scenario kScenarios[] = {
     // on what the ray from 10 m above the point meets (or left at the point's height when it meets nothing: the last offset leaves the mountain road)
     {"locations", 3600, 300, 10, 0, 1, 1, 1, "touge", 1, nullptr, 0, 0, 800, 0, 3, 0, 0},
     {"locations_fc3s", 2400, 300, 10, 0, 1, 1, 1, "flat", 0, "dthwsh_mazda_rx7_fc3s_sr20", 0, 0, 550, 0, 3, 0, 0},
+    // two cars in one simulator (cfg/sim.ini ships MAX_CARS = 2): Car::updateAirPressure (Car.cpp:557-585) thins the air a car meets by the wakes of the OTHER cars
+    // (Sim/SlipStream.cpp), as their last Car::postStep left them.  On a derived car whose aero.ini carries [SLIPSTREAM] (EFFECT_GAIN_MULT 1.5, SPEED_FACTOR_MULT 4: no
+    // shipped car has the section): on the plane the car behind, flat out and weaving a little, closes on the slower car ahead through its wake, drives through it (the
+    // harness's engine collides cars with the track only) and tows it in turn; the same with two stock AE86 (SlipStream.h's defaults: a wake of a quarter of a second's travel)
+    {"twocar_draft", 4200, 300, 10, 0, 1, 1, 1, "flat", 0, "pdb_slip_ae86", 0, 0, 0, 0, 0, 0, 0, 0, 1},
+    {"twocar_stock", 4200, 300, 10, 0, 1, 1, 1, "flat", 0, nullptr, 0, 0, 0, 0, 0, 0, 0, 0, 1},
 };
-static const int kNumScenarios = 54;
+static const int kNumScenarios = 56;
+static const float kTwoCarDist[2] = {0.0034f, 0.0035f};
 static const float kTeleDist[4] = {0.13f, 0.41f, 0.77f, 0.95f};
 static const int kTelePit[5] = {0, 2, 99, 1, 3};
 static const float kTeleLoc[4][3] = {{0.7f, 5.0f, -0.4f}, {-1.1f, 0.3f, 0.9f}, {0.0f, 12.0f, 0.0f}, {30.0f, 2.0f, 30.0f}};
@@ -163,6 +172,16 @@ inline void scenarioFeedback(int sid, int tick, const float* obs, float& a0, flo
     a0 = s; a1 = g;
 }
 
+// the second car's scripts (twoCar scenarios)
+inline void scenarioAction2(int sid, int tick, float& a0, float& a1) { (void)sid; (void)tick; a0 = 0.0f; a1 = -0.5f; }   // straight on, a third of the throttle
+inline void scenarioFeedback2(int sid, int tick, const float* obs, float& a0, float& a1) {
+    scenarioFeedback(sid, tick, obs, a0, a1);
+    float g = 0.3f * (9.0f - obs[2]);   // three m/s slower than the first car's law: the car behind closes in
+    if (g < -1.0f) g = -1.0f;
+    if (g > 1.0f) g = 1.0f;
+    a1 = g;
+}
+
 struct Ctl { float steer, clutch, brake, handBrake, gas; int requestedGearIndex, gearUp, gearDn; };
 
 inline void scenarioAction(int sid, int tick, float& a0, float& a1) {
@@ -173,6 +192,7 @@ inline void scenarioAction(int sid, int tick, float& a0, float& a1) {
     case 2: a0 = 0.35f; a1 = 0.2f; break;
     case 30: case 32: a0 = 0.04f; a1 = 0.8f; break;
     case 31: case 34: a0 = 0.0f; a1 = 1.0f; break;
+    case 54: case 55: a0 = (float)(0.012 * cos(6.283185307179586 * t / 3.0)); a1 = 1.0f; break;   // `twocar_*`, the car behind: flat out, weaving a little about the line
     default:   // slalom (3), the rx7 run (7), the fc3s run (9)
         a0 = (float)(0.4 * sin(6.283185307179586 * t / 2.0));
         a1 = (float)(0.6 * sin(6.283185307179586 * t / 5.0 + 1.0));

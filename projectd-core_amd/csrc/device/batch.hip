@@ -247,6 +247,7 @@ struct pdb_batch {
     unsigned char* dHold = nullptr;   // [n] hold mask of pdb_step_host_held, allocated on first use
     pdb_lane_setup* dLaneSetups = nullptr;   // [n] per-lane setup rows (pdb_set_lane_setups), allocated on first use and then complete: every lane's row holds its block's values or the caller's
     pdb_lane_tune* dLaneTunes = nullptr;   // [n] per-lane tunes and reward weights (pdb_set_lane_tunes), allocated on first use; rows with valid == 0 fall back to the block
+    pdb_slip_state* dSlip = nullptr;     // [2][n]: the cars' slipstreams (pdb_set_world_size; DevConst::slip)
     bool splitContact = true;            // the contact pass as the kernel pair where cars are expected in it (PDB_CONTACT_SPLIT=0: always the one kernel -- diagnostic A/B)
     pdb_dyn_state* dFresh = nullptr;     // device copy of resetTemplate (DevConst::freshState)
     pdb_dyn_state* dPartFresh[PDB_MAX_PARTS] = {nullptr, nullptr, nullptr, nullptr};   // a partition with a car block of its own: the fresh record of THAT block (ride height, pressures, fuel ...)
@@ -306,7 +307,8 @@ static int joinParts(pdb_batch* b) {
 static int partFirst(const pdb_batch* b, int p) {   // boundaries on whole workgroups
     if (p >= b->parts) return b->n;
     const long long raw = (long long)b->n * p / b->parts;
-    return (int)(raw / PDB_CPB * PDB_CPB);
+    const int unit = PDB_CPB * (b->K.worldSize > 1 ? b->K.worldSize : 1);   // ... and, in a batch of multi-car simulators, on whole worlds
+    return (int)(raw / unit * unit);
 }
 
 static void fillConst(const pdb_car_params& P, DevConst& K, int actionMode) {
@@ -478,6 +480,7 @@ static int pushK(pdb_batch* b, hipStream_t st, bool async) {
         K.laneTunes = b->K.laneTunes ? b->K.laneTunes + c0 : nullptr;
         K.laneSetups = b->K.laneSetups ? b->K.laneSetups + c0 : nullptr;
         K.holdMask = b->K.holdMask ? b->K.holdMask + c0 : nullptr;
+        K.worldSize = b->K.worldSize; K.slipStride = b->K.slipStride; K.slip = b->K.slip ? b->K.slip + c0 : nullptr;
         K.dt = b->K.dt; K.fps = b->K.fps; K.dtD = b->K.dtD; K.stuckTimeout = b->K.stuckTimeout; K.wantCarState = b->K.wantCarState; K.stamps = b->K.stamps; K.stampCars = b->K.stampCars;
         K.envHitPenalty = b->K.envHitPenalty; K.envOffPenalty = b->K.envOffPenalty; K.envStuckPenalty = b->K.envStuckPenalty; K.envLowReward = b->K.envLowReward;
         K.envMode = b->K.envMode; K.envTermHit = b->K.envTermHit; K.envTermOff = b->K.envTermOff; K.envTermStuck = b->K.envTermStuck;
@@ -607,7 +610,7 @@ void pdb_destroy(pdb_batch* b) {
     commFree(b);
     if (b->graphExec) (void)hipGraphExecDestroy(b->graphExec);
     if (b->stream) (void)hipStreamSynchronize(b->stream);
-    (void)hipFree(b->dStates); (void)hipFree(b->dActions); (void)hipFree(b->dOut); (void)hipFree(b->dCarStates); (void)hipFree(b->dParams); (void)hipFree(b->dK); (void)hipFree(b->dTrack); (void)hipFree(b->dContacts); (void)hipFree(b->dFresh); for (int p = 0; p < PDB_MAX_PARTS; ++p) (void)hipFree(b->dPartFresh[p]); (void)hipFree(b->dResetMask); (void)hipFree(b->dResetScratch);
+    (void)hipFree(b->dStates); (void)hipFree(b->dActions); (void)hipFree(b->dOut); (void)hipFree(b->dCarStates); (void)hipFree(b->dParams); (void)hipFree(b->dK); (void)hipFree(b->dTrack); (void)hipFree(b->dContacts); (void)hipFree(b->dSlip); (void)hipFree(b->dFresh); for (int p = 0; p < PDB_MAX_PARTS; ++p) (void)hipFree(b->dPartFresh[p]); (void)hipFree(b->dResetMask); (void)hipFree(b->dResetScratch);
     if (b->hHint) (void)hipHostFree(b->hHint);
     if (b->hActions) (void)hipHostFree(b->hActions);
     if (b->hOut) (void)hipHostFree(b->hOut);
@@ -854,6 +857,38 @@ int pdb_set_lane_setups(pdb_batch* b, int first, int count, const pdb_lane_setup
     if (count == 0) return PDB_OK;
     if (rows) HIPCHK(hipMemcpy(b->dLaneSetups + first, rows, sizeof(pdb_lane_setup) * (size_t)count, hipMemcpyHostToDevice));
     else if (int rcd = laneSetupDefaults(b, first, count)) return rcd;
+    return PDB_OK;
+}
+// Multi-car simulators (reference Sim/Simulator.cpp:59-60,112-153: 1..100 cars share a Simulator; cfg/sim.ini ships MAX_CARS = 2): the batch's cars form worlds of
+// `cars_per_world` consecutive lanes.  What couples the cars of a world on this path is the slipstream (Car::updateAirPressure, Car.cpp:557-585: the air a car meets is
+// thinned by the wakes of the others); body contacts between cars are not built.
+int pdb_set_world_size(pdb_batch* b, int cars_per_world) {
+    if (!b || cars_per_world < 1 || cars_per_world > 100 || b->n % cars_per_world != 0) { pdb::setError("pdb_set_world_size: 1..100 cars per world, a divisor of the batch's car count"); return PDB_ERR_ARG; }
+    if (int rcj = joinParts(b)) return rcj;
+    for (int p = 0; p < PDB_MAX_PARTS; ++p) if (b->partStream[p]) HIPCHK(hipStreamSynchronize(b->partStream[p]));
+    HIPCHK(hipStreamSynchronize(b->stream));
+    if (cars_per_world > 1 && !b->dSlip) {
+        HIPCHK(hipMalloc(&b->dSlip, sizeof(pdb_slip_state) * 2 * (size_t)b->n));
+        HIPCHK(hipMemset(b->dSlip, 0, sizeof(pdb_slip_state) * 2 * (size_t)b->n));   // a new car has no wake (SlipStream.h: length 0) until its first tick ends
+    }
+    b->K.worldSize = cars_per_world; b->K.slipStride = b->n; b->K.slip = cars_per_world > 1 ? b->dSlip : nullptr;
+    if (b->graphExec) { (void)hipGraphExecDestroy(b->graphExec); b->graphExec = nullptr; b->graphTicks = 0; }
+    return pushK(b, b->stream, false);   // (the partitions' boundaries move to whole worlds: partFirst)
+}
+// the slipstreams as state (a snapshot that must replay bit for bit carries them next to the records): both buffers, [0][count] then [1][count] -- a car's next tick reads
+// the one of its frame counter's parity (pdb_dyn_state.simFrame & 1)
+int pdb_get_slipstreams(pdb_batch* b, int first, int count, pdb_slip_state* out) {
+    if (!b || !out || first < 0 || count < 0 || first + count > b->n || !b->dSlip) { pdb::setError("pdb_get_slipstreams: bad range, or not a batch of multi-car simulators"); return PDB_ERR_ARG; }
+    if (int rcj = joinParts(b)) return rcj;
+    HIPCHK(hipStreamSynchronize(b->stream));
+    for (int k = 0; k < 2; ++k) HIPCHK(hipMemcpy(out + (size_t)k * count, b->dSlip + (size_t)k * b->n + first, sizeof(pdb_slip_state) * (size_t)count, hipMemcpyDeviceToHost));
+    return PDB_OK;
+}
+int pdb_set_slipstreams(pdb_batch* b, int first, int count, const pdb_slip_state* in) {
+    if (!b || !in || first < 0 || count < 0 || first + count > b->n || !b->dSlip) { pdb::setError("pdb_set_slipstreams: bad range, or not a batch of multi-car simulators"); return PDB_ERR_ARG; }
+    if (int rcj = joinParts(b)) return rcj;
+    HIPCHK(hipStreamSynchronize(b->stream));
+    for (int k = 0; k < 2; ++k) HIPCHK(hipMemcpy(b->dSlip + (size_t)k * b->n + first, in + (size_t)k * count, sizeof(pdb_slip_state) * (size_t)count, hipMemcpyHostToDevice));
     return PDB_OK;
 }
 int pdb_set_env(pdb_batch* b, const pdb_env_config* cfg) {

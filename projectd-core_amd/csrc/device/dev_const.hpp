@@ -32,6 +32,11 @@ struct DevConst {
     const pdb_lane_setup* laneSetups;     // [cars of the batch] or null: pdb_set_lane_setups (read by the kernel pair compiled for it only)
     const unsigned char* holdMask;        // [cars of the batch] or null: cars whose byte is non-zero sit this launch out (pdb_step_host_held: the reset tick of the lanes whose episode just ended)
     const pdb_dyn_state* freshState;      // the record of a fresh car at the start pose (device memory): env mode re-creates a car whose pose is no longer finite from it
+    // multi-car simulators (pdb_set_world_size): a world = worldSize consecutive cars that share one Simulator in the reference; their only coupling on this path is the
+    // slipstream (Car::updateAirPressure).  slip: [2][slipStride] -- a tick reads the buffer of its frame's parity (what the cars' last postStep left) and writes the other
+    int worldSize;
+    int slipStride;
+    pdb_slip_state* slip;
     unsigned long long* stamps;   // diagnostic build only (-DPDB_STAMPS): [car][32] shader-clock stamps of the first pass, then [stampCars + car][32] of the contact pass
     int stampCars;
     int noTeam;   // diagnostic (PDB_NO_TEAM in the environment at pdb_create): the car waves each walk their own car's joint rows, bars, wings ... as before round 5 (the form a model with more than 21 joints takes)

@@ -721,6 +721,9 @@ void buildCarModel(const std::string& basePathIn, const std::string& modelName, 
     {
         Ini aero(dataPath + "aero.ini");
         if (!aero.ready) throw std::runtime_error("pdb: aero.ini not found");
+        // [SLIPSTREAM] (AeroMap.cpp:25-29; no shipped car carries it: SlipStream.h's defaults then)
+        P.slipEffectGainMult = 1.0f; P.slipSpeedFactorMult = 1.0f;
+        if (aero.hasSection("SLIPSTREAM")) { P.slipEffectGainMult = aero.getFloat("SLIPSTREAM", "EFFECT_GAIN_MULT"); P.slipSpeedFactorMult = aero.getFloat("SLIPSTREAM", "SPEED_FACTOR_MULT"); }
         const int aver = aero.getInt("HEADER", "VERSION");
         int n = 0;
         for (int pass = 0; pass < 2; ++pass)

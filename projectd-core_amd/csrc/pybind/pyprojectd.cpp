@@ -4,8 +4,8 @@
 // (reference src/PyProjectD/PyProjectD.cpp:515-640), so pyprojectd/projectd_env.py runs against it unchanged:
 //   * creators return -1 on failure and log; everything else silently ignores unknown ids (:74-109)
 //   * nothing throws into python; the GIL is never released
-//   * a simulator holds one track and ONE car (what every env does, projectd_env.py:118-121); it is one lane of a
-//     device batch.  The classic per-simulator calls drive a 1-car batch; createBatch() widens a configured simulator
+//   * a simulator holds one track and its cars (one in every env: projectd_env.py:118-121; up to cfg/sim.ini's MAX_CARS of one model, coupled through the
+//     slipstream -- no body contacts between cars); they are the lanes of one world of a device batch.  The classic per-simulator calls drive a 1-car batch; createBatch() widens a configured simulator
 //     into N identical lanes stepped by one kernel launch (stepBatch), which is the point of this build.
 // The playground / window functions (:600-640) exist and do nothing: rendering is outside the hot path.
 #include <pybind11/pybind11.h>
@@ -59,14 +59,27 @@ void logf(const char* fmt, ...) {
     else if (getenv("PDB_VERBOSE")) fprintf(stderr, "%s\n", buf);
 }
 
+// A car of a simulator beyond the first (Simulator::addCar again: cfg/sim.ini MAX_CARS, 1..100; PyProjectD.cpp:219-237).  The cars of a simulator are the lanes of ONE
+// world of its device batch (pdb_set_world_size): same model, each with its own block where its tunes / scoring variables / assists differ (per-lane rows), coupled through
+// the slipstream.  Body contacts between cars are not built.
+struct ExtraCar {
+    pdb_car_params P{};
+    pdb_dyn_state S{};
+    pdb_contact contacts[PDB_MAX_CONTACTS] = {};
+    CarControls controls;
+    CarState state;
+};
 struct Sim {
     int id = 0;
     std::string base, trackName, model;
     std::vector<uint8_t> track;
     bool hasCar = false;
-    pdb_car_params P{};
+    pdb_car_params P{};           // car 0
     pdb_dyn_state S{};            // host copy; authoritative while batch == nullptr
-    pdb_batch* batch = nullptr;   // 1-car device batch, created at the first step
+    std::vector<std::unique_ptr<ExtraCar>> more;   // cars 1 ..
+    std::vector<pdb_slip_state> slips;             // [2][cars]: the cars' wakes (state of a multi-car simulator), host copy
+    int maxCars = 1;              // cfg/sim.ini [SIM] MAX_CARS, clamped to 1..100 (Simulator.cpp:59-60)
+    pdb_batch* batch = nullptr;   // device batch of the simulator's cars (one world), created at the first step
     bool paramsDirty = false;
     CarControls controls;
     CarState state;
@@ -74,43 +87,62 @@ struct Sim {
     int device = 0;
     ~Sim() { if (batch) pdb_destroy(batch); }
 
-    pdb_contact contacts[PDB_MAX_CONTACTS] = {};   // the car's live contact joints (the first S.numContacts): they move with the record
-    bool pullState() { return !batch || (pdb_get_state(batch, 0, 1, &S) == PDB_OK && pdb_get_contacts(batch, 0, 1, contacts) == PDB_OK); }
-    bool pushState() { return !batch || (pdb_set_state(batch, 0, 1, &S) == PDB_OK && pdb_set_contacts(batch, 0, 1, contacts) == PDB_OK); }
+    pdb_contact contacts[PDB_MAX_CONTACTS] = {};   // car 0's live contact joints (the first S.numContacts): they move with the record
+    int numCars() const { return hasCar ? 1 + (int)more.size() : 0; }
+    pdb_car_params& carP(int c) { return c == 0 ? P : more[(size_t)c - 1]->P; }
+    pdb_dyn_state& carS(int c) { return c == 0 ? S : more[(size_t)c - 1]->S; }
+    pdb_contact* carContacts(int c) { return c == 0 ? contacts : more[(size_t)c - 1]->contacts; }
+    CarControls& carControls(int c) { return c == 0 ? controls : more[(size_t)c - 1]->controls; }
+    CarState& carState(int c) { return c == 0 ? state : more[(size_t)c - 1]->state; }
+    bool pullState() {
+        if (!batch) return true;
+        const int n = numCars();
+        for (int c = 0; c < n; ++c)
+            if (pdb_get_state(batch, c, 1, &carS(c)) != PDB_OK || pdb_get_contacts(batch, c, 1, carContacts(c)) != PDB_OK) return false;
+        if (n > 1) { slips.resize(2 * (size_t)n); if (pdb_get_slipstreams(batch, 0, n, slips.data()) != PDB_OK) return false; }
+        return true;
+    }
+    bool pushState() {
+        if (!batch) return true;
+        const int n = numCars();
+        for (int c = 0; c < n; ++c)
+            if (pdb_set_state(batch, c, 1, &carS(c)) != PDB_OK || pdb_set_contacts(batch, c, 1, carContacts(c)) != PDB_OK) return false;
+        if (n > 1 && slips.size() == 2 * (size_t)n && pdb_set_slipstreams(batch, 0, n, slips.data()) != PDB_OK) return false;
+        return true;
+    }
     bool ensureBatch() {
         if (batch && paramsDirty) { pullState(); pdb_destroy(batch); batch = nullptr; }
         if (!batch) {
-            batch = pdb_create(device, 1, &P, track.data(), track.size(), PDB_ACTION_FULL);
+            const int n = numCars();
+            batch = pdb_create(device, n, &P, track.data(), track.size(), PDB_ACTION_FULL);
             if (!batch) { logf("EXCEPTION: %s", pdb_last_error()); return false; }
+            if (n > 1) {
+                if (pdb_set_world_size(batch, n) != PDB_OK) { logf("EXCEPTION: %s", pdb_last_error()); return false; }
+                for (int c = 1; c < n; ++c) {   // a car whose block differs from car 0's (its own setCarTune / setScoringVar calls): its lane's rows
+                    if (memcmp(&carP(c), &P, sizeof(P)) == 0) continue;
+                    pdb_lane_tune lt; pdb_lane_setup ls;
+                    if (pdb_lane_tune_from_params(&carP(c), &lt) != PDB_OK || pdb_set_lane_tunes(batch, c, 1, &lt) != PDB_OK ||
+                        pdb_lane_setup_from_params(&carP(c), &ls) != PDB_OK || pdb_set_lane_setups(batch, c, 1, &ls) != PDB_OK) { logf("EXCEPTION: %s", pdb_last_error()); return false; }
+                }
+            }
             if (!pushState()) { logf("EXCEPTION: %s", pdb_last_error()); return false; }
         }
         paramsDirty = false;
         return true;
     }
-    void teleportSpline(float d) {
-        if (!hasCar || track.empty()) return;
+    template <class F> void editState(int c, F f) {   // a host-side edit of one car's record (teleports): pull, edit, push
+        if (!hasCar || track.empty() || c < 0 || c >= numCars()) return;
         pullState();
-        if (pdb_teleport_to_spline(&P, track.data(), d, &S) != PDB_OK) logf("EXCEPTION: %s", pdb_last_error());
+        if (f(&carP(c), &carS(c)) != PDB_OK) logf("EXCEPTION: %s", pdb_last_error());
         pushState();
     }
-    void teleportPit(int pitId) {   // Car::teleportToPits (Car.cpp:1316-1323): an id outside pits.ini's list leaves the car alone
-        if (!hasCar || track.empty()) return;
-        pullState();
-        if (pdb_teleport_to_pit(&P, track.data(), pitId, &S) != PDB_OK) logf("EXCEPTION: %s", pdb_last_error());
-        pushState();
-    }
-    void teleportLocation(float x, float y, float z) {   // Car::forcePosition (Car.cpp:1240-1272)
-        if (!hasCar || track.empty()) return;
-        pullState();
-        if (pdb_teleport_to_location(&P, track.data(), x, y, z, &S) != PDB_OK) logf("EXCEPTION: %s", pdb_last_error());
-        pushState();
-    }
-    void teleportByMode(int mode) {   // Car::teleportByMode (Car.cpp:1320-1336); Random draws from the car's own C-runtime rand() state
-        if (!hasCar || track.empty() || mode < 0 || mode > 2) return;
-        pullState();
-        if (pdb_teleport_by_mode(&P, track.data(), mode, &S) != PDB_OK) logf("EXCEPTION: %s", pdb_last_error());
-        pushState();
-    }
+    void teleportSpline(int c, float d) { editState(c, [&](pdb_car_params* p, pdb_dyn_state* st) { return pdb_teleport_to_spline(p, track.data(), d, st); }); }
+    // Car::teleportToPits (Car.cpp:1316-1323): an id outside pits.ini's list leaves the car alone
+    void teleportPit(int c, int pitId) { editState(c, [&](pdb_car_params* p, pdb_dyn_state* st) { return pdb_teleport_to_pit(p, track.data(), pitId, st); }); }
+    // Car::forcePosition (Car.cpp:1240-1272)
+    void teleportLocation(int c, float x, float y, float z) { editState(c, [&](pdb_car_params* p, pdb_dyn_state* st) { return pdb_teleport_to_location(p, track.data(), x, y, z, st); }); }
+    // Car::teleportByMode (Car.cpp:1320-1336); Random draws from the car's own C-runtime rand() state
+    void teleportByMode(int c, int mode) { if (mode < 0 || mode > 2) return; editState(c, [&](pdb_car_params* p, pdb_dyn_state* st) { return pdb_teleport_by_mode(p, track.data(), mode, st); }); }
 };
 
 struct Batch {
@@ -125,7 +157,7 @@ std::unordered_map<int, std::shared_ptr<Batch>> g_batches;
 int g_uniqSimId = 0, g_uniqBatchId = 0;
 
 Sim* getSim(int simId) { auto it = g_sims.find(simId); return it == g_sims.end() ? nullptr : it->second.get(); }
-Sim* getCarSim(int simId, int carId) { Sim* s = getSim(simId); return (s && s->hasCar && carId == 0) ? s : nullptr; }
+Sim* getCarSim(int simId, int carId) { Sim* s = getSim(simId); return (s && s->hasCar && carId >= 0 && carId < s->numCars()) ? s : nullptr; }
 Batch* getBatch(int id) { auto it = g_batches.find(id); return it == g_batches.end() ? nullptr : it->second.get(); }
 
 // ---- logging / seed (:50-68) ----
@@ -139,7 +171,7 @@ void writeLog(const std::string& msg) { logf("%s", msg.c_str()); }
 
 void setSeed(unsigned int seed) {
     g_seed = seed;
-    for (auto& kv : g_sims) { Sim* s = kv.second.get(); if (s->hasCar) { s->pullState(); s->S.randState = (int32_t)seed; s->pushState(); } }
+    for (auto& kv : g_sims) { Sim* s = kv.second.get(); if (s->hasCar) { s->pullState(); for (int c = 0; c < s->numCars(); ++c) s->carS(c).randState = (int32_t)seed; s->pushState(); } }
 }
 // ---- simulator (:111-180) ----
 int createSimulator(const std::string& basePath) {
@@ -147,6 +179,14 @@ int createSimulator(const std::string& basePath) {
     if (!ini.good()) { logf("EXCEPTION: cannot open %s/cfg/sim.ini", basePath.c_str()); return -1; }
     auto s = std::make_shared<Sim>();
     s->base = basePath;
+    {   // [SIM] MAX_CARS (Simulator.cpp:59-60: clamped to 1..100; the shipped cfg/sim.ini says 2)
+        std::string line; bool inSim = false;
+        while (std::getline(ini, line)) {
+            if (!line.empty() && line.back() == '\r') line.pop_back();
+            if (!line.empty() && line[0] == '[') inSim = line.rfind("[SIM]", 0) == 0;
+            else if (inSim && line.rfind("MAX_CARS=", 0) == 0) { const int v = atoi(line.c_str() + 9); s->maxCars = v < 1 ? 1 : (v > 100 ? 100 : v); }
+        }
+    }
     if (const char* d = getenv("PDB_DEVICE")) s->device = atoi(d);
     std::lock_guard<std::mutex> g(g_lock);
     s->id = g_uniqSimId++;
@@ -161,12 +201,19 @@ void stepSimulator(int simId, double dt) {
     Sim* s = getSim(simId);
     if (!s || !s->hasCar) return;
     if (!s->ensureBatch()) return;
-    const CarControls& c = s->controls;
-    const float a[8] = {c.steer, c.clutch, c.brake, c.handBrake, c.gas, (float)c.requestedGearIndex, (float)(c.gearUp != 0), (float)(c.gearDn != 0)};
-    pdb_step_out o;
-    if (pdb_step_host(s->batch, a, (float)dt, &o) != PDB_OK) { logf("EXCEPTION: %s", pdb_last_error()); return; }
-    pdb_car_state cs;
-    if (pdb_get_car_state(s->batch, 0, 1, &cs) == PDB_OK) { memcpy(&s->state, &cs, sizeof(cs)); s->state.carId = 0; s->state.simId = s->id; }
+    const int n = s->numCars();
+    std::vector<float> a(8 * (size_t)n);
+    for (int k = 0; k < n; ++k) {
+        const CarControls& c = s->carControls(k);
+        const float row[8] = {c.steer, c.clutch, c.brake, c.handBrake, c.gas, (float)c.requestedGearIndex, (float)(c.gearUp != 0), (float)(c.gearDn != 0)};
+        memcpy(&a[8 * (size_t)k], row, sizeof(row));
+    }
+    std::vector<pdb_step_out> o((size_t)n);
+    if (pdb_step_host(s->batch, a.data(), (float)dt, o.data()) != PDB_OK) { logf("EXCEPTION: %s", pdb_last_error()); return; }
+    for (int k = 0; k < n; ++k) {
+        pdb_car_state cs;
+        if (pdb_get_car_state(s->batch, k, 1, &cs) == PDB_OK) { CarState& st = s->carState(k); memcpy(&st, &cs, sizeof(cs)); st.carId = k; st.simId = s->id; }
+    }
     s->physicsTime += dt;   // (setCarAutoTeleport: the teleport happens inside the tick, in the kernel, like ScoringSystem.cpp:194-226)
 }
 
@@ -181,7 +228,8 @@ void loadTrack(int simId, const std::string& trackName) {
     pdb_free(blob);
     s->trackName = trackName;
     if (s->batch) { pdb_destroy(s->batch); s->batch = nullptr; }
-    if (s->hasCar && pdb_initial_state(&s->P, s->track.data(), &s->S) != PDB_OK) logf("EXCEPTION: %s", pdb_last_error());
+    for (int c = 0; c < s->numCars(); ++c) if (pdb_initial_state(&s->carP(c), s->track.data(), &s->carS(c)) != PDB_OK) logf("EXCEPTION: %s", pdb_last_error());
+    s->slips.clear();
 }
 void unloadTrack(int simId) { Sim* s = getSim(simId); if (!s) return; if (s->batch) { pdb_destroy(s->batch); s->batch = nullptr; } s->track.clear(); s->trackName.clear(); }
 
@@ -190,48 +238,76 @@ int addCar(int simId, const std::string& modelName) {
     logf("[PY] addCar simId=%d modelName=%s", simId, modelName.c_str());
     Sim* s = getSim(simId);
     if (!s) return -1;
-    if (s->hasCar) { logf("EXCEPTION: one car per simulator in the batched build (cars never interact across envs)"); return -1; }
     if (s->track.empty()) { logf("EXCEPTION: addCar needs a loaded track"); return -1; }
+    if (s->hasCar) {   // another car of the same simulator: the next lane of its world
+        if (s->numCars() >= s->maxCars) { logf("EXCEPTION: addCar: the simulator is full (cfg/sim.ini MAX_CARS = %d)", s->maxCars); return -1; }
+        if (modelName != s->model) { logf("EXCEPTION: addCar: the cars of one simulator share a model in this build (%s)", s->model.c_str()); return -1; }
+        auto e = std::make_unique<ExtraCar>();
+        if (pdb_build_car_model(s->base.c_str(), modelName.c_str(), &e->P) != PDB_OK) { logf("EXCEPTION: %s", pdb_last_error()); return -1; }
+        if (pdb_initial_state(&e->P, s->track.data(), &e->S) != PDB_OK) { logf("EXCEPTION: %s", pdb_last_error()); return -1; }
+        e->S.randState = (int32_t)g_seed;
+        s->pullState();
+        if (s->batch) { pdb_destroy(s->batch); s->batch = nullptr; }
+        s->more.push_back(std::move(e));
+        {   // the wakes: the cars there keep theirs, the new car has none yet (SlipStream.h: length 0)
+            const int n = s->numCars(), old = n - 1;
+            std::vector<pdb_slip_state> sl(2 * (size_t)n);
+            memset(sl.data(), 0, sizeof(pdb_slip_state) * sl.size());
+            if (s->slips.size() == 2 * (size_t)old) for (int k = 0; k < 2; ++k) for (int c = 0; c < old; ++c) sl[(size_t)k * n + c] = s->slips[(size_t)k * old + c];
+            s->slips.swap(sl);
+        }
+        return s->numCars() - 1;
+    }
     if (pdb_build_car_model(s->base.c_str(), modelName.c_str(), &s->P) != PDB_OK) { logf("EXCEPTION: %s", pdb_last_error()); return -1; }
     if (pdb_initial_state(&s->P, s->track.data(), &s->S) != PDB_OK) { logf("EXCEPTION: %s", pdb_last_error()); return -1; }
     s->S.randState = (int32_t)g_seed;
     s->model = modelName; s->hasCar = true;
     return 0;
 }
-void removeCar(int simId, int carId) { Sim* s = getCarSim(simId, carId); if (!s) return; if (s->batch) { pdb_destroy(s->batch); s->batch = nullptr; } s->hasCar = false; }
-void teleportCarToLocation(int simId, int carId, float x, float y, float z) { if (Sim* s = getCarSim(simId, carId)) s->teleportLocation(x, y, z); }
-void teleportCarToPits(int simId, int carId, int pitId) { if (Sim* s = getCarSim(simId, carId)) s->teleportPit(pitId); }
-void teleportCarToSpline(int simId, int carId, float d) { if (Sim* s = getCarSim(simId, carId)) s->teleportSpline(d); }
-void teleportCarByMode(int simId, int carId, int mode) { if (Sim* s = getCarSim(simId, carId)) s->teleportByMode(mode); }
+void removeCar(int simId, int carId) {
+    Sim* s = getCarSim(simId, carId);
+    if (!s) return;
+    s->pullState();
+    if (s->batch) { pdb_destroy(s->batch); s->batch = nullptr; }
+    if (carId == 0) {   // the next car, if any, becomes the simulator's first
+        if (s->more.empty()) s->hasCar = false;
+        else { ExtraCar& e = *s->more[0]; s->P = e.P; s->S = e.S; memcpy(s->contacts, e.contacts, sizeof(s->contacts)); s->controls = e.controls; s->state = e.state; s->more.erase(s->more.begin()); }
+    } else s->more.erase(s->more.begin() + (carId - 1));
+    s->slips.clear();   // (the wakes start afresh)
+}
+void teleportCarToLocation(int simId, int carId, float x, float y, float z) { if (Sim* s = getCarSim(simId, carId)) s->teleportLocation(carId, x, y, z); }
+void teleportCarToPits(int simId, int carId, int pitId) { if (Sim* s = getCarSim(simId, carId)) s->teleportPit(carId, pitId); }
+void teleportCarToSpline(int simId, int carId, float d) { if (Sim* s = getCarSim(simId, carId)) s->teleportSpline(carId, d); }
+void teleportCarByMode(int simId, int carId, int mode) { if (Sim* s = getCarSim(simId, carId)) s->teleportByMode(carId, mode); }
 void setCarAutoTeleport(int simId, int carId, bool collision, bool badLoc, int mode) {
-    if (Sim* s = getCarSim(simId, carId)) { if (pdb_set_auto_teleport(&s->P, collision, badLoc, mode) == PDB_OK) s->paramsDirty = true; }
+    if (Sim* s = getCarSim(simId, carId)) { if (pdb_set_auto_teleport(&s->carP(carId), collision, badLoc, mode) == PDB_OK) s->paramsDirty = true; }
 }
 void setCarControls(int simId, int carId, bool smooth, const CarControls& controls) {
     Sim* s = getCarSim(simId, carId);
     if (!s) return;
-    s->controls = controls;
-    if ((s->P.smoothSteer != 0) != smooth) { s->P.smoothSteer = smooth ? 1 : 0; s->paramsDirty = true; }
+    s->carControls(carId) = controls;
+    if ((s->carP(carId).smoothSteer != 0) != smooth) { s->carP(carId).smoothSteer = smooth ? 1 : 0; s->paramsDirty = true; }
 }
 void setCarAssists(int simId, int carId, bool autoClutch, bool autoShift, bool autoBlip) {
-    if (Sim* s = getCarSim(simId, carId)) { pdb_set_assists(&s->P, autoClutch, autoShift, autoBlip, s->P.smoothSteer); s->paramsDirty = true; }
+    if (Sim* s = getCarSim(simId, carId)) { pdb_set_assists(&s->carP(carId), autoClutch, autoShift, autoBlip, s->carP(carId).smoothSteer); s->paramsDirty = true; }
 }
-void getCarState(int simId, int carId, CarState& state) { if (Sim* s = getCarSim(simId, carId)) state = s->state; }
+void getCarState(int simId, int carId, CarState& state) { if (Sim* s = getCarSim(simId, carId)) state = s->carState(carId); }
 void setCarTune(int simId, int carId, const std::string& name, float value) {
     if (Sim* s = getCarSim(simId, carId)) {
-        if (pdb_set_car_tune(&s->P, s->base.c_str(), s->model.c_str(), name.c_str(), value, 0) != PDB_OK) logf("EXCEPTION: %s", pdb_last_error());
+        if (pdb_set_car_tune(&s->carP(carId), s->base.c_str(), s->model.c_str(), name.c_str(), value, 0) != PDB_OK) logf("EXCEPTION: %s", pdb_last_error());
         s->paramsDirty = true;
     }
 }
 void setCarRawTune(int simId, int carId, const std::string& name, float value) {
     if (Sim* s = getCarSim(simId, carId)) {
-        if (pdb_set_car_tune(&s->P, s->base.c_str(), s->model.c_str(), name.c_str(), value, 1) != PDB_OK) logf("EXCEPTION: %s", pdb_last_error());
+        if (pdb_set_car_tune(&s->carP(carId), s->base.c_str(), s->model.c_str(), name.c_str(), value, 1) != PDB_OK) logf("EXCEPTION: %s", pdb_last_error());
         s->paramsDirty = true;
     }
 }
 void setScoringVar(int simId, int carId, const std::string& name, float w) {
-    if (Sim* s = getCarSim(simId, carId)) { pdb_set_scoring_var(&s->P, name.c_str(), w); s->paramsDirty = true; }
+    if (Sim* s = getCarSim(simId, carId)) { pdb_set_scoring_var(&s->carP(carId), name.c_str(), w); s->paramsDirty = true; }
 }
-float getScoringVar(int simId, int carId, const std::string& name) { Sim* s = getCarSim(simId, carId); return s ? pdb_get_scoring_var(&s->P, name.c_str()) : 0.0f; }
+float getScoringVar(int simId, int carId, const std::string& name) { Sim* s = getCarSim(simId, carId); return s ? pdb_get_scoring_var(&s->carP(carId), name.c_str()) : 0.0f; }
 
 // ---- vectorised extension: one lane of a batch takes the setup and the reward weights of a simulator (the reference's setCarTune / setScoringVar
 //      are per simulator, i.e. per env: configure a simulator with them, then hand its values to the lanes that should drive that setup) ----
@@ -241,6 +317,7 @@ bool setBatchLaneSetup(int batchId, int lane, int simId);
 int createBatch(int simId, int nCars, int device) {
     Sim* s = getSim(simId);
     if (!s || !s->hasCar || nCars <= 0) { logf("EXCEPTION: createBatch needs a simulator with a track and a car"); return -1; }
+    if (s->numCars() > 1) { logf("EXCEPTION: createBatch widens a ONE-car simulator into lanes (a multi-car simulator steps its own world through stepSimulator)"); return -1; }
     auto B = std::make_shared<Batch>();
     B->b = pdb_create(device, nCars, &s->P, s->track.data(), s->track.size(), PDB_ACTION_ENV);
     if (!B->b) { logf("EXCEPTION: %s", pdb_last_error()); return -1; }

@@ -96,7 +96,7 @@ class CarParams(C.Structure):
         [('upshiftProfile', Curve), ('downshiftProfile', Curve), ('blipProfile', Curve), ('blipPerformTime', C.c_double), ('asChangeUpRpm', C.c_int32), ('asChangeDnRpm', C.c_int32),
          ('asSlipThreshold', C.c_float), ('asGasCutoffTime', C.c_float), ('smoothSteer', C.c_int32), ('patchConnCount', C.c_int8 * 36), ('patchConn', (C.c_int8 * 4) * 36),
          ('scoring', Scoring), ('collider', Collider), ('throttleCurveMax', Curve), ('throttleMaxRef', C.c_float), ('gasCoastOffset', C.c_float),
-         ('coastEntryRpm', C.c_int32), ('ebbInternal', C.c_int32), ('ebbFrontMultiplier', C.c_float), ('overlapFreq', C.c_float), ('overlapGain', C.c_float), ('overlapIdealRPM', C.c_float), ('wingGroundEffect', C.c_int32)] + [(k, C.c_float) for k in ('aeroReferenceArea', 'aeroFrontShare', 'aeroCD', 'aeroCL', 'aeroCDX', 'aeroCDY', 'aeroCDA')] + [('numWingCtrl', C.c_int32), ('wingCtrl', WingCtrl * 4), ('ctrlDiffLock', DynCtrl), ('ctrlTurboBoost', DynCtrl * 3), ('ctrlWastegate', DynCtrl * 3), ('ctrlEbb', DynCtrl), ('ctrlSteerBrake', DynCtrl), ('hasBrakeTemps', C.c_int32), ('_padBrake', C.c_int32), ('discs', BrakeDisc * 4), ('ctrlArb', DynCtrl * 2), ('numCtrlStages', C.c_int32), ('_padCtrl', C.c_int32), ('ctrlStages', CtrlStage * 8)]
+         ('coastEntryRpm', C.c_int32), ('ebbInternal', C.c_int32), ('ebbFrontMultiplier', C.c_float), ('overlapFreq', C.c_float), ('overlapGain', C.c_float), ('overlapIdealRPM', C.c_float), ('wingGroundEffect', C.c_int32)] + [(k, C.c_float) for k in ('aeroReferenceArea', 'aeroFrontShare', 'aeroCD', 'aeroCL', 'aeroCDX', 'aeroCDY', 'aeroCDA')] + [('numWingCtrl', C.c_int32), ('wingCtrl', WingCtrl * 4), ('ctrlDiffLock', DynCtrl), ('ctrlTurboBoost', DynCtrl * 3), ('ctrlWastegate', DynCtrl * 3), ('ctrlEbb', DynCtrl), ('ctrlSteerBrake', DynCtrl), ('hasBrakeTemps', C.c_int32), ('slipEffectGainMult', C.c_float), ('discs', BrakeDisc * 4), ('ctrlArb', DynCtrl * 2), ('numCtrlStages', C.c_int32), ('slipSpeedFactorMult', C.c_float), ('ctrlStages', CtrlStage * 8)]
 class BodyState(C.Structure):
     _fields_ = [('pos', C.c_float * 3), ('q', C.c_float * 4), ('R', C.c_float * 9), ('lvel', C.c_float * 3), ('avel', C.c_float * 3)]
 class TyreState(C.Structure):
@@ -153,6 +153,8 @@ class TrackHeader(C.Structure):   # pdb_track_header (version 6)
                [('rayNx', C.c_int32), ('rayNz', C.c_int32), ('rayMinX', C.c_float), ('rayMinZ', C.c_float), ('rayCell', C.c_float), ('_rayPad', C.c_float)] + \
                [(n, C.c_uint64) for n in ('offRayStart', 'offRayRecs', 'offFatGridRec', 'offFatSeg')] + \
                [('numPits', C.c_int32), ('_pitPad', C.c_int32), ('offPits', C.c_uint64)]
+class SlipState(C.Structure):   # pdb_slip_state
+    _fields_ = [('pos', C.c_float * 3), ('length', C.c_float), ('dir', C.c_float * 3), ('effectGainMult', C.c_float)]
 class StepOut(C.Structure):
     _fields_ = [('obs', C.c_float * 24), ('reward', C.c_float), ('flags', C.c_int32)]
 
@@ -172,6 +174,9 @@ def load_product(host_only=False):
     lib.pdb_set_scoring_var.argtypes = [C.c_void_p, C.c_char_p, C.c_float]
     lib.pdb_teleport_to_spline.argtypes = [C.c_void_p, C.c_void_p, C.c_float, C.c_void_p]
     lib.pdb_teleport_by_mode.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
+    if not host_only:
+        lib.pdb_set_world_size.argtypes = [C.c_void_p, C.c_int]
+        lib.pdb_get_slipstreams.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]; lib.pdb_set_slipstreams.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]
     lib.pdb_teleport_to_pit.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
     lib.pdb_teleport_to_location.argtypes = [C.c_void_p, C.c_void_p, C.c_float, C.c_float, C.c_float, C.c_void_p]
     lib.pdb_track_num_pits.argtypes = [C.c_void_p]

@@ -75,6 +75,21 @@ class Batch:
         """one tick of one partition on its own stream (nothing forked or joined)"""
         self._chk(self.lib.pdb_step_partition(self.h, C.c_float(SIM_DT), part, C.c_void_p(out_ptr) if out_ptr else None))
 
+    def set_world_size(self, cars_per_world):
+        """multi-car simulators: worlds of `cars_per_world` consecutive lanes (coupled through the slipstream: Car::updateAirPressure)"""
+        self._chk(self.lib.pdb_set_world_size(self.h, int(cars_per_world)))
+
+    def get_slipstreams(self):
+        """-> (SlipState * n, SlipState * n): the two buffers of the cars' wakes (a car's next tick reads the one of its simFrame's parity)"""
+        buf = (pc.SlipState * (2 * self.n))()
+        self._chk(self.lib.pdb_get_slipstreams(self.h, 0, self.n, buf))
+        return [(pc.SlipState * self.n).from_buffer(buf, 0), (pc.SlipState * self.n).from_buffer(buf, C.sizeof(pc.SlipState) * self.n)]
+
+    def set_slipstreams(self, both):
+        buf = (pc.SlipState * (2 * self.n))()
+        C.memmove(buf, both[0], C.sizeof(pc.SlipState) * self.n); C.memmove(C.byref(buf, C.sizeof(pc.SlipState) * self.n), both[1], C.sizeof(pc.SlipState) * self.n)
+        self._chk(self.lib.pdb_set_slipstreams(self.h, 0, self.n, buf))
+
     def host_mirrors(self):
         """numpy views of the library's page-locked host mirrors: actions float32[n, stride], outputs (structured pdb_step_out)[n]"""
         pa = self.lib.pdb_host_actions(self.h); po = self.lib.pdb_host_out(self.h)

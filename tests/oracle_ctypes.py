@@ -41,6 +41,12 @@ def load_oracle(portable_math=False):
     lib.cpuref_scenario_fields.argtypes = [C.c_int, C.c_void_p]
     lib.cpuref_scenario_teledist.restype = C.c_float; lib.cpuref_scenario_teledist.argtypes = [C.c_int]
     lib.cpuref_scenario_teleport.argtypes = [C.c_int, C.c_int, C.c_void_p]
+    lib.cpuref_run_scenario2.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_char_p, C.c_char_p]
+    lib.cpuref_scenario_two_car.argtypes = [C.c_int, C.c_void_p]
+    lib.cpuref_scenario_action2.argtypes = [C.c_int, C.c_int, C.c_void_p]; lib.cpuref_scenario_feedback2.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+    for f in ('cpuref_get_slip', 'cpuref_set_slip'):
+        getattr(lib, f).argtypes = [C.c_void_p, C.c_void_p]
+    lib.cpuref_set_other_slips.argtypes = [C.c_void_p, C.c_void_p, C.c_int]; lib.cpuref_set_guid.argtypes = [C.c_void_p, C.c_int]
     lib.cpuref_scenario_action.argtypes = [C.c_int, C.c_int, C.c_void_p]
     lib.cpuref_scenario_feedback.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_void_p]
     lib.cpuref_run_scenario.argtypes = [C.c_void_p, C.c_int, C.c_char_p]

@@ -222,7 +222,7 @@ def run_parity(n_cars=8, ticks=200, seed=1234, resync=False, verbose=False, chec
 
 
 def run_replicated(n_cars, distinct, ticks, track, model='ks_toyota_ae86_drift', seed=7, spread=(0.0, 1.0), check_every=50, partitions=None, threads=8,
-                   law=None, resets=None, verbose=False, lane_params_fn=None):
+                   law=None, resets=None, verbose=False, lane_params_fn=None, host_pipeline=False):
     """Full-size parity by replication (BASELINE's car counts, the oracle at `distinct` cars): `distinct` different (start point on the lap, input) pairs tiled over
     a batch of n_cars.  Size-independent properties, checked every `check_every` ticks and at the end:
       (1) every replica of a representative holds the byte-identical record AND the byte-identical live contact joints wherever it sits in the batch (any
@@ -233,6 +233,9 @@ def run_replicated(n_cars, distinct, ticks, track, model='ks_toyota_ae86_drift',
     pdb_step_host returns, for the oracle from cpuref_get_out -- so equal observations give equal actions.
     resets=(bits, mode): the env's episode rule on the host (projectd_env.py:173-227 without the reward sums): a car whose output flags meet `bits` is teleported by
     Car::teleportByMode(mode) before its next tick, which it takes with the zero action; GPU: pdb_reset_mode, oracle: the product's host function on the oracle's record.
+    host_pipeline (with a law and partitions): the GPU batch is fed the way BASELINE configs[4] words it -- "actions fed from host", every tick -- through the library's
+    pipelined form: the law's rows go into the page-locked action mirror, every partition's upload + tick + download is enqueued on its own stream
+    (pdb_step_host_partition), and the rows are read out of the output mirror as each partition's download lands (pdb_wait_host_partition).
     lane_params_fn(k, Pk): representative k's own copy of the car block (tunes, scoring variables): the oracle steps it with that block, the GPU batch carries it as the
     rows of its replicas' lanes (pdb_set_lane_tunes + pdb_set_lane_setups).
     Returns dict(worst, max_in_contact (cars with live joints at a check, over the whole batch), contact_checks, resets)."""
@@ -333,8 +336,19 @@ def run_replicated(n_cars, distinct, ticks, track, model='ks_toyota_ae86_drift',
                         assert lib.pdb_teleport_by_mode(C.byref(P), trk, mode, C.byref(s)) == 0
                         orc.cpuref_set_state(hs[k], C.byref(s)); ao[k] = 0.0
                         res['resets'] += 1
-                out = b.step_host(ag)
-                list(pool.map(lambda k: orc.cpuref_step_env(hs[k], float(ao[k, 0]), float(ao[k, 1])), range(distinct)))
+                if host_pipeline:
+                    assert partitions and resets is None
+                    ha, ho = b.host_mirrors()
+                    ha[:, :2] = ag
+                    for p in range(partitions):
+                        b.step_host_partition(p)
+                    list(pool.map(lambda k: orc.cpuref_step_env(hs[k], float(ao[k, 0]), float(ao[k, 1])), range(distinct)))   # (the oracle steps while the partitions' ticks are in flight)
+                    for p in range(partitions):
+                        b.wait_host_partition(p)
+                    out = {'obs': np.array(ho['obs']), 'flags': np.array(ho['flags'])}
+                else:
+                    out = b.step_host(ag)
+                    list(pool.map(lambda k: orc.cpuref_step_env(hs[k], float(ao[k, 0]), float(ao[k, 1])), range(distinct)))
                 obs_g = np.array(out['obs'], dtype=np.float32); fg = np.array(out['flags'])
                 if n_cars % distinct == 0:
                     assert (obs_g.reshape(-1, distinct, 24).view(np.uint32) == obs_g[:distinct].view(np.uint32)).all() and (fg.reshape(-1, distinct) == fg[:distinct]).all(), 'tick %d: a replica\'s output row differs' % t

@@ -87,8 +87,64 @@ def setup(orc, hostlib, sid, base_dir):
     f = (C.c_int * 8)(); orc.cpuref_scenario_fields(sid, f)
     S0 = pc.DynState()
     assert hostlib.pdb_initial_state(C.byref(P), blob, C.byref(S0)) == 0
+    d2 = C.c_float()
+    two = orc.cpuref_scenario_two_car(sid, C.byref(d2))
+    S1 = None
+    if two:   # a second car of the same model in the same simulator, put down ahead of the first (teleportCarToSpline)
+        S1 = pc.DynState()
+        assert hostlib.pdb_initial_state(C.byref(P), blob, C.byref(S1)) == 0
+        assert hostlib.pdb_teleport_to_spline(C.byref(P), blob, d2, C.byref(S1)) == 0
     return dict(sid=sid, name=name, track=track, model=model, P=P, blob=blob, S0=S0, ticks=ticks.value, full=full.value,
-                reset_every=f[0], tele_dist=f[1], boost_at=f[2], feedback=f[3], auto_tele=f[5])
+                reset_every=f[0], tele_dist=f[1], boost_at=f[2], feedback=f[3], auto_tele=f[5], two_car=two, S1=S1)
+
+
+def run_two_car_script(orc, sc, out0, out1):
+    """a twoCar scenario through the oracle exactly like the reference-TU harness ran it: two probe files"""
+    P, blob = sc['P'], sc['blob']
+    h0 = orc.cpuref_create(C.byref(P), blob, len(blob), C.byref(sc['S0'])); h1 = orc.cpuref_create(C.byref(P), blob, len(blob), C.byref(sc['S1']))
+    try:
+        assert orc.cpuref_run_scenario2(h0, h1, sc['sid'], out0.encode(), out1.encode()) == 0
+    finally:
+        orc.cpuref_destroy(h0); orc.cpuref_destroy(h1)
+
+
+def drive_two_cars(orc, sc, batch=None, max_ticks=None, on_tick=None):
+    """Step two oracle cars of one simulator -- and a GPU batch of two lanes forming one world (pdb_set_world_size(2)), if given -- through a twoCar scenario:
+    each car's tick reads the slipstream the OTHER's last tick left.  on_tick(t, (h0, h1), batch) after every tick."""
+    P, blob, sid = sc['P'], sc['blob'], sc['sid']
+    hs = [orc.cpuref_create(C.byref(P), blob, len(blob), C.byref(sc['S0'])), orc.cpuref_create(C.byref(P), blob, len(blob), C.byref(sc['S1']))]
+    orc.cpuref_set_guid(hs[1], 1)   # the second car of the simulator (Car.h physicsGUID)
+    slips = (pc.SlipState * 2)()
+
+    def step_both(a):   # a: float32[2][2]
+        for c in range(2):
+            orc.cpuref_get_slip(hs[c], C.byref(slips[c]))
+        for c in range(2):
+            orc.cpuref_set_other_slips(hs[c], C.byref(slips[1 - c]), 1)
+        for c in range(2):
+            orc.cpuref_step_env(hs[c], float(a[c, 0]), float(a[c, 1]))
+        if batch is not None:
+            batch.step_host(a)
+    a = np.zeros((2, 2), np.float32)
+    step_both(a)
+    if on_tick is not None:
+        on_tick(-1, hs, batch)
+    n = sc['ticks'] if max_ticks is None else min(sc['ticks'], max_ticks)
+    o = pc.StepOut(); a2 = (C.c_float * 2)()
+    try:
+        for t in range(n):
+            if sc['feedback']:
+                for c, fn in ((0, orc.cpuref_scenario_feedback), (1, orc.cpuref_scenario_feedback2)):
+                    orc.cpuref_get_out(hs[c], C.byref(o)); obs = (C.c_float * 24)(*o.obs); fn(sid, t, obs, a2); a[c] = (a2[0], a2[1])
+            else:
+                orc.cpuref_scenario_action(sid, t, a2); a[0] = (a2[0], a2[1])
+                orc.cpuref_scenario_action2(sid, t, a2); a[1] = (a2[0], a2[1])
+            step_both(a)
+            if on_tick is not None:
+                on_tick(t, hs, batch)
+    finally:
+        for h in hs:
+            orc.cpuref_destroy(h)
 
 
 def drive(orc, hostlib, sc, batch=None, max_ticks=None, on_tick=None):

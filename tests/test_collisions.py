@@ -262,3 +262,28 @@ def test_full_size_contact_batches_by_replication(built, track, model, parts):
     print('%s: worst %.3e, up to %d of 8192 cars with live contact joints at a check, %d representative checks with live joints' % (track, r['worst'], r['max_in_contact'], r['contact_checks']))
     assert r['worst'] == 0.0, r
     assert r['max_in_contact'] >= 512 and r['contact_checks'] >= 10, r
+
+
+@pytest.mark.gpu
+def test_host_fed_policy_at_full_size_by_replication(built):
+    """BASELINE configs[4] as worded on one GPU's shard: 8192 cars on the reference's driftplayground (walls), "SAC-policy actions fed from host" every tick -- observations
+    down, a float32 24-256-256-2 MLP (the bench's fixed random actor, seed 4567) on the host, actions up -- through the library's pipelined form over three free-running
+    partitions (pdb_step_host_partition / pdb_wait_host_partition).  32 representatives tiled 256 times: every replica's output row equal to its representative's every
+    tick, every replica's record and live contact joints byte-identical at every check, the representatives equal to the oracle fed the same law."""
+    import parity_util
+    rs = np.random.RandomState(4567)
+    w1 = (rs.randn(24, 256) / 24 ** 0.5).astype(np.float32); w2 = (rs.randn(256, 256) / 16.0).astype(np.float32); w3 = (rs.randn(256, 2) / 16.0).astype(np.float32)
+    b3 = np.array([0.0, 0.5], np.float32)
+    import projectd_env
+    scale = (1.0 / projectd_env.obs_bounds(projectd_env.EnvConfig())[1]).astype(np.float32)
+
+    def law(obs, t, ids):   # float32 throughout, the same shapes for both sides (the law sees the representatives' rows only)
+        h = np.tanh((obs * scale) @ w1, dtype=np.float32)
+        h = np.tanh(h @ w2, dtype=np.float32)
+        a = np.tanh(h @ w3 + b3, dtype=np.float32)
+        a[:, 0] += np.float32(0.7) * ((ids % 3) - 1).astype(np.float32)   # an untrained actor that also pulls two thirds of the cars to one side or the other: they meet the walls
+        a[:, 1] += np.float32(0.5)
+        return np.clip(a, -1.0, 1.0).astype(np.float32)
+    r = parity_util.run_replicated(8192, 32, 1200, 'driftplayground', law=law, partitions=3, check_every=100, host_pipeline=True)
+    assert r['worst'] == 0.0, r
+    assert r['max_in_contact'] >= 256 and r['contact_checks'] > 0, r   # cars really were leaning on the walls while the policy drove them

@@ -71,7 +71,12 @@ def test_error_convention(pd, base):
     assert pd.addCar(sim, 'no_such_car') == -1
     car = pd.addCar(sim, 'ks_toyota_ae86_drift')
     assert car == 0
-    assert pd.addCar(sim, 'ks_toyota_ae86_drift') == -1          # one car per simulator in the batched build
+    assert pd.addCar(sim, 'ks_toyota_ae86_drift') == 1           # a second car of the simulator (cfg/sim.ini MAX_CARS = 2) ...
+    assert pd.addCar(sim, 'ks_toyota_ae86_drift') == -1          # ... and the simulator is full
+    pd.removeCar(sim, 1)
+    assert pd.addCar(sim, 'no_such_car') == -1
+    assert pd.addCar(sim, 'ks_toyota_ae86_drift') == 1
+    pd.removeCar(sim, 1)
     pd.setScoringVar(sim, car, 'TravelBonus', 0.25)
     assert pd.getScoringVar(sim, car, 'TravelBonus') == 0.25
     assert pd.getScoringVar(sim, car, 'NoSuchVar') == 0.0
@@ -190,6 +195,56 @@ def test_teleports_to_pits_and_locations_through_the_module(pd, built):
         assert abs(st.bodyPos.x - x) < 0.05 and abs(st.bodyPos.z - z) < 0.05
         run(150)
     orc.cpuref_destroy(h); pd.destroySimulator(sim)
+
+
+@pytest.mark.gpu
+def test_two_cars_in_one_simulator_through_the_module(pd, built):
+    """Simulator::addCar twice (PyProjectD.cpp:219-237; cfg/sim.ini MAX_CARS = 2): the second car is put down 10 m ahead on the plane, the first closes in flat out
+    through its wake -- Car::updateAirPressure / Sim/SlipStream.cpp, pinned to the reference TUs by the twocar_* goldens -- and every CarState of both cars equals two
+    oracle cars that exchange their wakes every tick; the air really is thinner for the car behind (its drag drops: it ends up faster than it would alone)."""
+    import synthetic_tracks, pdbatch, pdb_ctypes as pc, oracle_ctypes
+    base = tempfile.mkdtemp(prefix='pdb_two_')
+    synthetic_tracks.make_base(base, tracks=('flat',)); synthetic_tracks.install_packed_car(base)
+    sim = pd.createSimulator(base); pd.loadTrack(sim, 'flat')
+    assert pd.addCar(sim, 'ks_toyota_ae86_drift') == 0 and pd.addCar(sim, 'ks_toyota_ae86_drift') == 1
+    pd.teleportCarToSpline(sim, 1, 0.0034)
+    lib = pc.load_product(); orc = oracle_ctypes.load_oracle(True)
+    P = pdbatch.packed_params(); trk = pc.build_track(lib, base, 'flat')
+    S = [pc.DynState(), pc.DynState()]
+    for c in range(2):
+        assert lib.pdb_initial_state(C.byref(P), trk, C.byref(S[c])) == 0
+    assert lib.pdb_teleport_to_spline(C.byref(P), trk, C.c_float(0.0034), C.byref(S[1])) == 0
+    hs = [orc.cpuref_create(C.byref(P), trk, len(trk), C.byref(S[c])) for c in range(2)]
+    orc.cpuref_set_guid(hs[1], 1)
+    solo = orc.cpuref_create(C.byref(P), trk, len(trk), C.byref(S[0]))   # the first car alone, same inputs: no wake to run in
+    ctl = [pd.CarControls(), pd.CarControls()]
+    ctl[0].gas = 1.0; ctl[1].gas = 0.3
+    a8 = [np.array([0, 0, 0, 0, 1.0, -1, 0, 0], np.float32), np.array([0, 0, 0, 0, 0.3, -1, 0, 0], np.float32)]
+    st = pd.CarState(); cs = pc.CarState(); slips = (pc.SlipState * 2)()
+    for t in range(3600):
+        for c in range(2):
+            pd.setCarControls(sim, c, True, ctl[c])
+        pd.stepSimulator(sim, 1.0 / 333.0)
+        for c in range(2):
+            orc.cpuref_get_slip(hs[c], C.byref(slips[c]))
+        for c in range(2):
+            orc.cpuref_set_other_slips(hs[c], C.byref(slips[1 - c]), 1)
+        for c in range(2):
+            orc.cpuref_step_controls(hs[c], a8[c].ctypes.data_as(C.c_void_p))
+        orc.cpuref_step_controls(solo, a8[0].ctypes.data_as(C.c_void_p))
+        if t % 5 == 0 or t > 3590:
+            for c in range(2):
+                pd.getCarState(sim, c, st); orc.cpuref_get_car_state(hs[c], C.byref(cs))
+                assert st.carId == c
+                for f in ('bodyPos', 'velocity', 'localAngularVelocity'):
+                    v = getattr(st, f)
+                    assert (np.float32(v.x), np.float32(v.y), np.float32(v.z)) == tuple(np.float32(x) for x in getattr(cs, f)), (t, c, f)
+                assert np.float32(st.engineRPM) == np.float32(cs.engineRPM) and st.gear == cs.gear, (t, c)
+    pd.getCarState(sim, 0, st); orc.cpuref_get_car_state(solo, C.byref(cs))
+    assert st.speedMS > cs.speedMS, (st.speedMS, cs.speedMS)   # the tow: a little faster than the same car with the same inputs alone
+    for h in hs + [solo]:
+        orc.cpuref_destroy(h)
+    pd.destroySimulator(sim)
 
 
 @pytest.mark.gpu

@@ -17,7 +17,7 @@ from conftest import load_golden
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..', 'oracle'))
 import probe_io  # noqa: E402
 
-NSC = 54
+NSC = 56
 INT_LIKE = ('gear', 'Gear', 'Id', 'Flag', 'flag', 'isLocked', 'limiterOn', 'sleepingFrames', 'Counter', 'drifting', 'driftExtreme', 'driftInvalid', 'acSeq', 'clutchOpenState', 'surface')
 
 
@@ -29,6 +29,16 @@ def test_portable_math_oracle_stays_on_the_reference_trajectories(built, hostlib
     except SU.Skip as e:
         pytest.skip(str(e))
     g = load_golden(sc['track'] + '_' + sc['name'])
+    if sc['two_car']:   # two cars of one simulator: both cars' probe files, the same windows
+        with tempfile.TemporaryDirectory() as d:
+            outs = [os.path.join(d, 'a.bin'), os.path.join(d, 'b.bin')]
+            SU.run_two_car_script(orc, sc, outs[0], outs[1])
+            for o, suf in zip(outs, ('', '_b')):
+                p = probe_io.load(o); gg = load_golden(sc['track'] + '_' + sc['name'] + suf)
+                good, good_int, first = held_records(p['data'], gg['data'], gg['names'])
+                print('%s%s: within 1e-4 for the first %d records (integers %d)' % (sc['name'], suf, good, good_int))
+                assert good >= 4 and good_int >= 4, (sc['name'] + suf, good, good_int, first)
+        return
     h = orc.cpuref_create(C.byref(sc['P']), sc['blob'], len(sc['blob']), C.byref(sc['S0']))
     P, blob = sc['P'], sc['blob']
 
@@ -153,6 +163,27 @@ def test_every_scenario_gpu_equals_the_portable_oracle(built, sid):
         sc = SU.setup(orc, hostlib, sid, base)
     except SU.Skip as e:
         pytest.skip(str(e))
+    if sc['two_car']:   # one world of two lanes (pdb_set_world_size): each car's record against its oracle car, and the wakes the kernels left against the oracle's
+        b = pdbatch.Batch(2, sc['P'], sc['blob'], device=0, action_mode=1)
+        b.set_world_size(2)
+        b.set_state((pc.DynState * 2)(sc['S0'], sc['S1']))
+        seen = {'thin': 0}
+
+        def on_tick2(t, hs, batch):
+            if t % 7 and t != sc['ticks'] - 1:
+                return
+            st = batch.get_state(); sl = batch.get_slipstreams()
+            for c in range(2):
+                so = pc.DynState(); orc.cpuref_get_state(hs[c], C.byref(so))
+                rel, name, vg, vc, bad_int = parity_util.compare_states(st[c], so)
+                assert not bad_int and rel == 0.0, (sc['name'], t, c, name, vg, vc, bad_int[:4])
+                ss = pc.SlipState(); orc.cpuref_get_slip(hs[c], C.byref(ss))
+                assert bytes(ss) == bytes(sl[st[c].simFrame & 1][c]), (sc['name'], t, c)
+        try:
+            SU.drive_two_cars(orc, sc, batch=b, max_ticks=3000, on_tick=on_tick2)
+        finally:
+            b.close()
+        return
     b = pdbatch.Batch(1, sc['P'], sc['blob'], device=0, action_mode=2 if sc['full'] else 1)
     b.set_state((pc.DynState * 1)(sc['S0']))
     worst = [0.0]
@@ -203,6 +234,8 @@ def test_gpu_car_state_stays_on_the_reference_trajectories(built, sid):
         sc = SU.setup(orc, hostlib, sid, base)
     except SU.Skip as e:
         pytest.skip(str(e))
+    if sc['two_car']:
+        pytest.skip('two-car simulators: the GPU is held against the oracle car by car (test_every_scenario_gpu_equals_the_portable_oracle), the oracle against the goldens')
     g = load_golden(sc['track'] + '_' + sc['name'])
     cols = [i for i, n in enumerate(g['names']) if n.startswith('cs.')]
     names = [g['names'][i] for i in cols]
@@ -287,6 +320,8 @@ def test_one_tick_from_every_state_of_the_reference_trajectory(built, hostlib, b
         sc = SU.setup(glibc, hostlib, sid, base_dir)
     except SU.Skip as e:
         pytest.skip(str(e))
+    if sc['two_car']:
+        pytest.skip('two-car simulators: the single-car bridge does not apply (the cars exchange their wakes every tick); GPU = oracle car by car, oracle = goldens')
     P, blob = sc['P'], sc['blob']
 
     def _tele_mode(state_ptr, mode):
@@ -340,6 +375,8 @@ def test_gpu_one_tick_from_every_state_of_the_reference_trajectory(built, sid):
         sc = SU.setup(glibc, hostlib, sid, base)
     except SU.Skip as e:
         pytest.skip(str(e))
+    if sc['two_car']:
+        pytest.skip('two-car simulators: the single-car bridge does not apply (the cars exchange their wakes every tick); GPU = oracle car by car, oracle = goldens')
     b = pdbatch.Batch(1, sc['P'], sc['blob'], device=0, action_mode=2 if sc['full'] else 1)
     b.set_state((pc.DynState * 1)(sc['S0']))
     over, ints, n = [], [], [0]

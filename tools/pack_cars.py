@@ -11,7 +11,7 @@ lib = pc.load_product(host_only=True)
 out = os.path.join(ROOT, 'projectd-core_amd', 'data')
 os.makedirs(out, exist_ok=True)
 DERIVED = os.path.join(ROOT, 'oracle', '_ref', 'base')   # cars derived for the fixtures (oracle/make_base.py): the multilink Supra, the RX-7 with heave springs
-models = [(REF, m) for m in sorted(os.listdir(os.path.join(REF, 'content', 'cars')))] + [(DERIVED, 'pdb_ml_supra'), (DERIVED, 'pdb_heave_rx7'), (DERIVED, 'pdb_fwd_ae86'), (DERIVED, 'pdb_cold_rx7'), (DERIVED, 'pdb_curves_ae86'), (DERIVED, 'pdb_gh_fc3s'), (DERIVED, 'pdb_aerodata_ae86'), (DERIVED, 'pdb_wingctrl_fc3s'), (DERIVED, 'pdb_dynctrl_supra'), (DERIVED, 'pdb_dynctrl_ae86'), (DERIVED, 'pdb_brakectrl_rx7'), (DERIVED, 'pdb_ctrlin_a_ae86'), (DERIVED, 'pdb_ctrlin_b_ae86'), (DERIVED, 'pdb_braketemp_rx7'), (DERIVED, 'pdb_wingctrl2_fc3s'), (DERIVED, 'pdb_twobox_ae86')]
+models = [(REF, m) for m in sorted(os.listdir(os.path.join(REF, 'content', 'cars')))] + [(DERIVED, 'pdb_ml_supra'), (DERIVED, 'pdb_heave_rx7'), (DERIVED, 'pdb_fwd_ae86'), (DERIVED, 'pdb_cold_rx7'), (DERIVED, 'pdb_curves_ae86'), (DERIVED, 'pdb_gh_fc3s'), (DERIVED, 'pdb_aerodata_ae86'), (DERIVED, 'pdb_wingctrl_fc3s'), (DERIVED, 'pdb_dynctrl_supra'), (DERIVED, 'pdb_dynctrl_ae86'), (DERIVED, 'pdb_brakectrl_rx7'), (DERIVED, 'pdb_ctrlin_a_ae86'), (DERIVED, 'pdb_ctrlin_b_ae86'), (DERIVED, 'pdb_braketemp_rx7'), (DERIVED, 'pdb_wingctrl2_fc3s'), (DERIVED, 'pdb_twobox_ae86'), (DERIVED, 'pdb_slip_ae86')]
 for REFB, m in models:
     P = pc.CarParams()
     if lib.pdb_build_car_model(REFB.encode(), m.encode(), C.byref(P)) != 0:

@@ -21,6 +21,8 @@ timeout 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -o 
 timeout 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -o run -- python3 bench.py --steps 100 --warmup 20 $ARGS > $OUT/pmc_write.log 2>&1
 timeout 300 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_SMEM SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY --output-format csv -d $OUT/pmc_sq1 -o run -- python3 bench.py --steps 100 --warmup 20 $ARGS > $OUT/pmc_sq1.log 2>&1
 timeout 300 rocprofv3 --pmc SQ_WAVES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_LDS_BANK_CONFLICT SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $OUT/pmc_sq2 -o run -- python3 bench.py --steps 100 --warmup 20 $ARGS > $OUT/pmc_sq2.log 2>&1
+# round 6: where the issue-stalled share comes from (24 % on ek_akina against 7 % on the plane): waits for LDS results and vector-memory reads
+timeout 300 rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_SCA SQ_INST_CYCLES_VMEM_RD SQ_INSTS_FLAT --output-format csv -d $OUT/pmc_sq3 -o run -- python3 bench.py --steps 100 --warmup 20 $ARGS > $OUT/pmc_sq3.log 2>&1
 # issue model: measured cycles per wave-instruction (tools/issue_rate.hip), plain and under the SQ counters
 if [ -x tools/issue_rate ] && [ "${PDB_PROFILE_ISSUE:-0}" = "1" ]; then
   timeout 300 tools/issue_rate > $OUT/issue_rate.txt 2>&1

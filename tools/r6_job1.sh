@@ -1,0 +1,9 @@
+# round 6 GPU job: occupancy curve, rocprofv3 kernel stats + PMC passes of the headline and of configs[1], the driver's own bench command; small summaries only come back
+mkdir -p gpurun_out/r06_profiles
+python3 tools/occupancy_curve.py > gpurun_out/r06_profiles/r06_occupancy_curve.txt 2>&1
+bash tools/profile_round.sh r06 > gpurun_out/r06_profile_round.log 2>&1
+bash tools/profile_round.sh r06_flat flat --workload flat > gpurun_out/r06_flat_profile_round.log 2>&1
+cp profiles/r06_* gpurun_out/r06_profiles/ 2>/dev/null
+for t in r06 r06_flat; do cp gpurun_out/$t/bench.json gpurun_out/r06_profiles/${t}_bench_3000.json 2>/dev/null; rm -rf gpurun_out/$t; done
+python bench.py --gpus 1 --steps 20 --warmup 5 > gpurun_out/r06_profiles/r06_bench_driver.json 2> gpurun_out/r06_bench_driver.err
+ls -la gpurun_out/r06_profiles

@@ -51,7 +51,7 @@ if ks:
             summary['rocprof_calls'] = int(r['Calls'])
 # counters: average per dispatch of the step kernel
 cnt = {}
-for d in ('pmc_fetch', 'pmc_write', 'pmc_sq1', 'pmc_sq2'):
+for d in ('pmc_fetch', 'pmc_write', 'pmc_sq1', 'pmc_sq2', 'pmc_sq3'):
     acc = {}
     for r in rows(d + '/**/*counter_collection.csv'):
         if KERNEL not in r['Kernel_Name']:
