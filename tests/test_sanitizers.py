@@ -61,6 +61,38 @@ DRIVER = textwrap.dedent('''
             orc.cpuref_set_state(h, C.byref(S))
     orc.cpuref_destroy(h)
     assert contacts > 0
+    # round 6: pit boxes and location teleports (every box of the mountain road's pits.ini, ids outside the list, a point with nothing under it), and two oracle
+    # cars exchanging their wakes (cpuref_get_slip / cpuref_set_other_slips)
+    host.pdb_teleport_to_pit.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
+    host.pdb_teleport_to_location.argtypes = [C.c_void_p, C.c_void_p, C.c_float, C.c_float, C.c_float, C.c_void_p]
+    host.pdb_track_num_pits.argtypes = [C.c_void_p]; host.pdb_track_pit.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+    trk = blobs['touge']
+    np_ = host.pdb_track_num_pits(trk); assert np_ == 5
+    S = pc.DynState(); assert host.pdb_initial_state(C.byref(P), trk, C.byref(S)) == 0
+    m = (C.c_float * 16)()
+    for pit in (-3, 0, 1, 2, 3, 4, 5, 1000):
+        assert host.pdb_teleport_to_pit(C.byref(P), trk, pit, C.byref(S)) == 0
+        assert (host.pdb_track_pit(trk, pit, m) == 0) == (0 <= pit < np_)
+    for xyz in ((S.body[0].pos[0] + 1.0, S.body[0].pos[1] + 3.0, S.body[0].pos[2] - 2.0), (1.0e4, 50.0, -1.0e4)):
+        assert host.pdb_teleport_to_location(C.byref(P), trk, C.c_float(xyz[0]), C.c_float(xyz[1]), C.c_float(xyz[2]), C.byref(S)) == 0
+    trk = blobs['flat']
+    Sa = pc.DynState(); Sb = pc.DynState()
+    assert host.pdb_initial_state(C.byref(P), trk, C.byref(Sa)) == 0 and host.pdb_initial_state(C.byref(P), trk, C.byref(Sb)) == 0
+    assert host.pdb_teleport_to_spline(C.byref(P), trk, C.c_float(0.0034), C.byref(Sb)) == 0
+    for f in ('cpuref_get_slip', 'cpuref_set_slip'):
+        getattr(orc, f).argtypes = [C.c_void_p, C.c_void_p]
+    orc.cpuref_set_other_slips.argtypes = [C.c_void_p, C.c_void_p, C.c_int]; orc.cpuref_set_guid.argtypes = [C.c_void_p, C.c_int]
+    hs = [orc.cpuref_create(C.byref(P), trk, len(trk), C.byref(Sa)), orc.cpuref_create(C.byref(P), trk, len(trk), C.byref(Sb))]
+    orc.cpuref_set_guid(hs[1], 1)
+    sl = (pc.SlipState * 2)()
+    for t in range(600):
+        for c in range(2):
+            orc.cpuref_get_slip(hs[c], C.byref(sl[c]))
+        for c in range(2):
+            orc.cpuref_set_other_slips(hs[c], C.byref(sl[1 - c]), 1)
+        orc.cpuref_step_env(hs[0], 0.0, 1.0); orc.cpuref_step_env(hs[1], 0.0, -0.5)
+    for h in hs:
+        orc.cpuref_destroy(h)
     print('sanitized run ok, contact ticks', contacts)
 ''')
 
