@@ -174,7 +174,7 @@ def load_product(host_only=False):
     lib.pdb_set_scoring_var.argtypes = [C.c_void_p, C.c_char_p, C.c_float]
     lib.pdb_teleport_to_spline.argtypes = [C.c_void_p, C.c_void_p, C.c_float, C.c_void_p]
     lib.pdb_teleport_by_mode.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
-    if not host_only:
+    if not host_only and hasattr(lib, 'pdb_set_world_size'):   # (a library variant built before round 6 has none: tools/ A/B runs)
         lib.pdb_set_world_size.argtypes = [C.c_void_p, C.c_int]
         lib.pdb_get_slipstreams.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]; lib.pdb_set_slipstreams.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]
     lib.pdb_teleport_to_pit.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]

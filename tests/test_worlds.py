@@ -9,10 +9,10 @@ import oracle_ctypes
 from conftest import car_params
 
 
-def _world_run(G, worlds, ticks, partitions=None, model='pdb_slip_ae86', check_every=50, seed=5):
+def _world_run(G, worlds, ticks, partitions=None, model='pdb_slip_ae86', check_every=50, seed=5, track='flat', steer=0.01):
     import pdbatch, parity_util
     n = G * worlds
-    P = car_params(model); trk = pdbatch.synthetic_track('flat')
+    P = car_params(model); trk = pdbatch.synthetic_track(track)
     lib = pc.load_product(); orc = oracle_ctypes.load_oracle(portable_math=True)
     S0 = pc.DynState(); assert lib.pdb_initial_state(C.byref(P), trk, C.byref(S0)) == 0
     init = (pc.DynState * n)()
@@ -32,7 +32,7 @@ def _world_run(G, worlds, ticks, partitions=None, model='pdb_slip_ae86', check_e
         orc.cpuref_set_guid(hs[i], i % G)
     rs = np.random.RandomState(seed)
     acts = np.zeros((n, 2), np.float32)
-    acts[:, 0] = rs.uniform(-0.01, 0.01, n)
+    acts[:, 0] = rs.uniform(-steer, steer, n)
     acts[:, 1] = np.where(np.arange(n) % G == 0, 1.0, rs.uniform(-0.6, 0.2, n))   # a world's first car (the one behind) flat out, the others slower: it runs through their wakes
     slips = (pc.SlipState * n)(); others = (pc.SlipState * max(1, G - 1))()
     thinned = 0
@@ -75,6 +75,20 @@ def test_worlds_equal_the_oracle_car_by_car(built, G, worlds, partitions):
     b.close()
     for h in hs:
         orc.cpuref_destroy(h)
+
+
+@pytest.mark.gpu
+def test_worlds_through_the_contact_pass(built):
+    """two-car worlds on the walled strip, steered into the side walls and the cross wall: the cars that touch something take their ticks in the contact pass (one
+    kernel or the pair), the others in the first pass -- whichever pass stores a car's record leaves its wake too; records, live contact counts and wakes bit for bit"""
+    b, hs, orc = _world_run(2, 12, 1800, model='ks_toyota_ae86_drift', track='walled', steer=0.12, check_every=30)
+    try:
+        st = b.get_state()
+        assert sum(1 for i in range(24) if st[i].damageZoneLevel[4] > 0) >= 6   # cars really did hit the walls
+    finally:
+        b.close()
+        for h in hs:
+            orc.cpuref_destroy(h)
 
 
 @pytest.mark.gpu
