@@ -53,7 +53,10 @@
 #define PDB_KMINWAVES_C 2
 #endif
 #define PDB_KROWS 33
-#define PDB_KMINWAVES 6
+#ifndef PDB_KMINWAVES33
+#define PDB_KMINWAVES33 6
+#endif
+#define PDB_KMINWAVES PDB_KMINWAVES33
 #define PDB_KERNEL_EXACT pdb_step_kernel
 #define PDB_KSLOT0_EXACT true    /* the class's first kernel pair: exactly 33 rows, no run-time row guards */
 #define PDB_KSLOT0_CTRL false
