@@ -422,6 +422,7 @@ static void launchTick(pdb_batch* b, hipStream_t st, int c0, int c1, pdb_step_ou
     // caller's fixed grid -- the snapshot cars go through the kernel pair sized to fit beside the first pass (collide: one wave per car; resume: the first pass's workgroup
     // shape); the one kernel follows only if a car's whole tick may have to be done again (reset mask, in-tick auto-teleport: its other list).  Where nothing has been
     // touched lately the one kernel alone: its idle launch ends on three words, and a surprise is still served (and raises the hint).
+    // (A launch recorded into a graph keeps the form chosen at capture: a caller that captures pdb_step_partition asks for a fixed grid, pdb_set_contact_grid, and so for the pair.)
     const int heldNow = (b->contactGrid > 0) ? 1 : (b->hHint ? *(volatile int*)(b->hHint + q) : 0);
     if (b->splitContact && HP.collider.enabled != 0 && heldNow > 0) {
         const dim3 xgrid((unsigned)(n < (int)cgrid.x * PDB_CONTACT_CPB ? n : (int)cgrid.x * PDB_CONTACT_CPB))   /* one car per workgroup */, xblock(PDB_WAVE * PDB_CONTACT_WAVES);
@@ -874,6 +875,7 @@ int pdb_set_world_size(pdb_batch* b, int cars_per_world) {
         HIPCHK(hipMalloc(&b->dSlip, sizeof(pdb_slip_state) * 2 * (size_t)b->n));
         HIPCHK(hipMemset(b->dSlip, 0, sizeof(pdb_slip_state) * 2 * (size_t)b->n));   // a new car has no wake (SlipStream.h: length 0) until its first tick ends
     }
+    if (b->parts > 1 && cars_per_world != (b->K.worldSize > 1 ? b->K.worldSize : 1)) commFree(b);   // the partitions' cuts move to whole worlds: their communicators' ranges are the old cut's (pdb_comm_init again)
     b->K.worldSize = cars_per_world; b->K.slipStride = b->n; b->K.slip = cars_per_world > 1 ? b->dSlip : nullptr;
     if (b->graphExec) { (void)hipGraphExecDestroy(b->graphExec); b->graphExec = nullptr; b->graphTicks = 0; }
     return pushK(b, b->stream, false);   // (the partitions' boundaries move to whole worlds: partFirst)
