@@ -214,7 +214,17 @@ def measure(args, world, rank, local_rank, dist, want_cpu=False):
         s_cf = torch.from_numpy(cf).to(dev)
         s_tab = torch.matmul(s_sc, s_cf).contiguous()   # [T_per, n, 2]
 
+    # Round 6: the linear laws run inside the tick's own launches (pdb_set_law: a = bias + obs @ W where the kernel writes the observation row; the scripted law's per-tick
+    # bias is row `lawTick` of the same table) -- no launch between two ticks of a stream.  --no-device-law: the torch launch of rounds 1-5 (different rounding of the 24-term sum)
+    device_law = policy in ('scripted', 'feedback') and not args.no_device_law and not do_scatter
+    if device_law and policy == 'scripted':
+        b.set_law(sw, table_device_ptr=s_tab.data_ptr(), period=T_per)
+    elif device_law:
+        b.set_law(fw, bias0=np.array([0.0, 0.3 * 12.0], np.float32))
+
     def policy_step(o, a, p=4, f=0):
+        if device_law:
+            return
         if policy == 'scripted':
             c = a.shape[0]
             torch.addmm(s_tab[site_tick[p] % T_per][f:f + c], o[:, :24], s_w, out=a)
@@ -279,7 +289,7 @@ def measure(args, world, rank, local_rank, dist, want_cpu=False):
         if gather.active and not args.ring_fork:
             ring_streams.extend(part_st)
         graphs = {}; plain_done = set(); graph_pool = [None] * args.partitions
-        use_graph = not args.no_graph_policy and policy in ('feedback', 'mlp') and n < 8192 and not gather.active   # (from 8192 cars up a graph launch costs the host more than the launches it replaces: 54 against 57 M on the 16384-car headline)
+        use_graph = not args.no_graph_policy and policy in ('feedback', 'mlp') and n < 8192 and not gather.active and not (device_law and args.graph_policy_only)   # (from 8192 cars up a graph launch costs the host more than the launches it replaces: 54 against 57 M on the 16384-car headline)
         part_graph = graphs if use_graph else None
         part_graph_whole = use_graph and n < 8192 and not gather.active and not args.graph_policy_only
         if part_graph_whole:
@@ -458,7 +468,8 @@ def measure(args, world, rank, local_rank, dist, want_cpu=False):
             kernel_us = tick_us; k_src = "HIP events around the launch site's whole ticks (first pass + contact pass + gaps)"
         achieved = B_ALG * launch_cars / (kernel_us * 1e-6) / 1e9
         hdr = pc.TrackHeader.from_buffer_copy(trk[:C.sizeof(pc.TrackHeader)])
-        pol = {'constant': "per-car constant random actions", 'scripted': "scripted gas 0.6+0.4sin(2pi t/7s+phi_i) + P-steer, on the GPU every tick", 'feedback': "probe-feedback law on the GPU",
+        pol = {'constant': "per-car constant random actions", 'scripted': "scripted gas 0.6+0.4sin(2pi t/7s+phi_i) + P-steer, " + ("evaluated by the tick's own launches (pdb_set_law)" if device_law else "a torch launch behind every tick"),
+               'feedback': "probe-feedback law " + ("evaluated by the tick's own launches (pdb_set_law)" if device_law else "on the GPU (a torch launch behind every tick)"),
                'mlp': "24-256-256-2 MLP on the GPU", 'host': "probe-feedback law on the HOST, pipelined", 'host_sync': "probe-feedback law on the HOST, synchronous",
                'host_mlp': "24-256-256-2 MLP on the HOST, pipelined", 'random': "fresh random actions every tick"}[policy]
         where = ("reference %s spline (%d pts) as a road ribbon" % (args.workload, hdr.numFat)) if args.workload in ('ek_akina', 'ks_nordschleife') else \
@@ -561,6 +572,7 @@ def parser():
     ap.add_argument('--library-exchange', action='store_true', help='N > 1: the per-partition exchange through the library\'s own RCCL communicators (pdb_step_exchange_partition); default with one rank, opt-in with more')
     ap.add_argument('--graph-policy-only', action='store_true', help='per-partition loops below 8192 cars: only the policy in the captured graph, the tick as plain launches (A/B)')
     ap.add_argument('--graph-contact-grid', type=int, default=96, help='workgroups of the contact pass inside a captured per-partition tick')
+    ap.add_argument('--no-device-law', action='store_true', help='scripted / feedback policies: the law as a torch launch behind every tick (rounds 1-5) instead of the device law, pdb_set_law (A/B)')
     ap.add_argument('--no-graph-policy', action='store_true', help='per-partition policy loops: the policy as plain torch launches instead of one captured graph per partition (A/B)')
     ap.add_argument('--ring-fork', action='store_true', help='ring mode: every ring starts behind the batch stream (the older form; A/B)')
     ap.add_argument('--torch-exchange', action='store_true', help='the per-partition exchange (--scatter-actions with --gather-ticks 1) through torch.distributed instead of the library\'s own RCCL communicators (A/B)')

@@ -368,7 +368,8 @@ typedef struct pdb_dyn_state {
                               * projectd_env.py:216-227); 2 = reset tick whose teleport the caller has already done (the record stays as the caller left it);
                               * 3 = the episode ended because the record is no longer finite: the next tick re-creates it from a fresh record, then goes on as 1 */
     int32_t envStepId;       /* env mode: ticks since the episode's reset tick (projectd_env.py step_id) */
-    int32_t _pad[1];         /* record size is a multiple of 16 bytes (coalesced 16-byte-per-lane copies) */
+    int32_t lawTick;         /* pdb_set_law: the row of the law's bias table this car's next write-out takes (wraps at the table's period); 0 and untouched without a law.
+                              * Not reference state (it also keeps the record a multiple of 16 bytes: coalesced 16-byte-per-lane copies) */
     float suspTravel[4];     /* ISuspension status.travel of the last suspension step (read by controllers: the brake system's before this tick's step, the others after it) */
     float brakeDiscT[4];     /* BrakeDisc::t (BrakeSystem.cpp:151-169): 0 at creation, the ambient temperature after Car::reset */
     float ctrlValue[PDB_MAX_CTRL_STAGES];   /* DynamicControllerStage::currentValue of the car's controller stages (never reset, as in the reference) */

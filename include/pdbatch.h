@@ -178,6 +178,15 @@ int pdb_set_partition_params(pdb_batch* b, int part, const pdb_car_params* param
 int pdb_set_world_size(pdb_batch* b, int cars_per_world);
 int pdb_get_slipstreams(pdb_batch* b, int first, int count, pdb_slip_state* out);
 int pdb_set_slipstreams(pdb_batch* b, int first, int count, const pdb_slip_state* in);
+/* The device law: the NEXT tick's two action components (steer, throttle: the action modes with two floats a car) worked out by the tick's own launches, where they
+ * write the car's observation row:   a[c] = bias[c] + sum_{k < 24} obs[k] * weights[k][c]   (the 24 products as the leaves of a balanced binary tree over 32 slots
+ * in slot order; IEEE single, no fused operations) -- scripted input streams (BASELINE configs[2]: bias = row pdb_dyn_state.lawTick of `table`, [period][n_cars][2]
+ * floats, the car's row counter advancing by one a tick and wrapping at `period`) and linear feedback laws of the observation (table == NULL: bias = bias0, or zero)
+ * then cost a stepping stream no launch between two ticks.  The reference has no counterpart: there the actions come from the caller through
+ * setCarControls (PyProjectD.cpp:297-305) every tick, and they still can -- the law only WRITES the batch's action buffer (pdb_actions_device), after the tick has read it;
+ * the env mode's reset tick still steps with the zero action (projectd_env.py:222).  weights: [24][2] floats on the host (NULL: no law, the default); bias0: 2 floats
+ * on the host or NULL; table: on the host (copied) or, with table_on_device != 0, device memory the caller keeps alive and may rewrite between ticks. */
+int pdb_set_law(pdb_batch* b, const float* weights, const float* bias0, const float* table, int period, int table_on_device);
 /* Per-LANE setup and reward weights (pdb_lane_tune, include/pdb_types.h): the reference's setCarTune / setScoringVar are per simulator, i.e. per env
  * (PyProjectD.cpp:328-365); here a lane's row overrides the eight tunes of projectd_env.py:127-130 and the scoring variables of its car block.
  * pdb_lane_tune_from_params (host library too) reads the row out of a block that went through pdb_set_car_tune / pdb_set_scoring_var;

@@ -249,6 +249,7 @@ struct pdb_batch {
     bool resetMaskArmed = false;     // pdb_reset_mask_device was asked for: the step kernels look at the mask
     unsigned char* dHold = nullptr;   // [n] hold mask of pdb_step_host_held, allocated on first use
     pdb_lane_setup* dLaneSetups = nullptr;   // [n] per-lane setup rows (pdb_set_lane_setups), allocated on first use and then complete: every lane's row holds its block's values or the caller's
+    float* dLawBias = nullptr;             // pdb_set_law's bias table where the library holds the copy (a caller's device table is used in place)
     pdb_lane_tune* dLaneTunes = nullptr;   // [n] per-lane tunes and reward weights (pdb_set_lane_tunes), allocated on first use; rows with valid == 0 fall back to the block
     pdb_slip_state* dSlip = nullptr;     // [2][n]: the cars' slipstreams (pdb_set_world_size; DevConst::slip)
     bool splitContact = true;            // the contact pass as the kernel pair where cars are expected in it (PDB_CONTACT_SPLIT=0: always the one kernel -- diagnostic A/B)
@@ -485,6 +486,8 @@ static int pushK(pdb_batch* b, hipStream_t st, bool async) {
         K.laneSetups = b->K.laneSetups ? b->K.laneSetups + c0 : nullptr;
         K.holdMask = b->K.holdMask ? b->K.holdMask + c0 : nullptr;
         K.worldSize = b->K.worldSize; K.slipStride = b->K.slipStride; K.slip = b->K.slip ? b->K.slip + c0 : nullptr;
+        K.lawPeriod = b->K.lawPeriod; K.lawStride = b->K.lawStride; K.lawBias = b->K.lawBias ? b->K.lawBias + 2 * (size_t)c0 : nullptr;
+        memcpy(K.lawBias0, b->K.lawBias0, sizeof(K.lawBias0)); memcpy(K.lawW, b->K.lawW, sizeof(K.lawW));
         K.dt = b->K.dt; K.fps = b->K.fps; K.dtD = b->K.dtD; K.stuckTimeout = b->K.stuckTimeout; K.wantCarState = b->K.wantCarState; K.stamps = b->K.stamps; K.stampCars = b->K.stampCars;
         K.envHitPenalty = b->K.envHitPenalty; K.envOffPenalty = b->K.envOffPenalty; K.envStuckPenalty = b->K.envStuckPenalty; K.envLowReward = b->K.envLowReward;
         K.envMode = b->K.envMode; K.envTermHit = b->K.envTermHit; K.envTermOff = b->K.envTermOff; K.envTermStuck = b->K.envTermStuck;
@@ -622,6 +625,7 @@ void pdb_destroy(pdb_batch* b) {
     for (int q = 0; q <= PDB_MAX_PARTS; ++q) for (hipEvent_t e : b->samples[q].ev) if (e) (void)hipEventDestroy(e);
     (void)hipFree(b->dSnap);
     (void)hipFree(b->dLaneTunes);
+    (void)hipFree(b->dLawBias);
     (void)hipFree(b->dLaneSetups);
     (void)hipFree(b->dHold);
     for (int q = 0; q < PDB_MAX_PARTS; ++q) { (void)hipFree(b->dPartParams[q]); (void)hipFree(b->dPartK[q]); }
@@ -862,6 +866,33 @@ int pdb_set_lane_setups(pdb_batch* b, int first, int count, const pdb_lane_setup
     if (rows) HIPCHK(hipMemcpy(b->dLaneSetups + first, rows, sizeof(pdb_lane_setup) * (size_t)count, hipMemcpyHostToDevice));
     else if (int rcd = laneSetupDefaults(b, first, count)) return rcd;
     return PDB_OK;
+}
+// The device law: the next tick's steer / throttle components worked out by the tick's own launches from the observation row they write (step_kernel.hip.inc, phase 7),
+// a[c] = bias[c] + sum_k obs[k] * weights[k][c] -- scripted input streams (a per-car, per-tick table of biases with a period) and linear feedback laws of the observation
+// (projectd_env.py's 24 slots) without a policy launch between two ticks.  The action buffer stays the caller's to read (pdb_actions_device) and to overwrite.
+int pdb_set_law(pdb_batch* b, const float* weights, const float* bias0, const float* table, int period, int table_on_device) {
+    if (!b) { pdb::setError("pdb_set_law: no batch"); return PDB_ERR_ARG; }
+    if (weights && b->K.actionMode == PDB_ACTION_FULL) { pdb::setError("pdb_set_law: the law writes two action components; this batch takes all eight controls"); return PDB_ERR_ARG; }
+    if (weights && table && period < 1) { pdb::setError("pdb_set_law: a bias table needs a period of at least one row"); return PDB_ERR_ARG; }
+    if (int rcj = joinParts(b)) return rcj;
+    for (int p = 0; p < PDB_MAX_PARTS; ++p) if (b->partStream[p]) HIPCHK(hipStreamSynchronize(b->partStream[p]));
+    HIPCHK(hipStreamSynchronize(b->stream));
+    if (b->graphExec) { (void)hipGraphExecDestroy(b->graphExec); b->graphExec = nullptr; b->graphTicks = 0; }
+    (void)hipFree(b->dLawBias); b->dLawBias = nullptr;
+    b->K.lawPeriod = 0; b->K.lawStride = 0; b->K.lawBias = nullptr; b->K.lawBias0[0] = 0.0f; b->K.lawBias0[1] = 0.0f; memset(b->K.lawW, 0, sizeof(b->K.lawW));
+    if (weights) {
+        memcpy(b->K.lawW, weights, sizeof(b->K.lawW));
+        if (bias0) { b->K.lawBias0[0] = bias0[0]; b->K.lawBias0[1] = bias0[1]; }
+        b->K.lawPeriod = table ? period : 1; b->K.lawStride = b->n;
+        if (table && table_on_device) b->K.lawBias = table;
+        else if (table) {
+            const size_t bytes = sizeof(float) * 2 * (size_t)b->n * (size_t)period;
+            if (hipMalloc(&b->dLawBias, bytes) != hipSuccess) { b->dLawBias = nullptr; b->K.lawPeriod = 0; (void)pushK(b, b->stream, false); pdb::setError("pdb_set_law: out of device memory for the bias table"); return PDB_ERR_HIP; }
+            HIPCHK(hipMemcpy(b->dLawBias, table, bytes, hipMemcpyHostToDevice));
+            b->K.lawBias = b->dLawBias;
+        }
+    }
+    return pushK(b, b->stream, false);
 }
 // Multi-car simulators (reference Sim/Simulator.cpp:59-60,112-153: 1..100 cars share a Simulator; cfg/sim.ini ships MAX_CARS = 2): the batch's cars form worlds of
 // `cars_per_world` consecutive lanes.  What couples the cars of a world on this path is the slipstream (Car::updateAirPressure, Car.cpp:557-585: the air a car meets is

@@ -39,6 +39,14 @@ struct DevConst {
     pdb_slip_state* slip;
     unsigned long long* stamps;   // diagnostic build only (-DPDB_STAMPS): [car][32] shader-clock stamps of the first pass, then [stampCars + car][32] of the contact pass
     int stampCars;
+    // device law (pdb_set_law): the NEXT tick's two action components evaluated where the tick writes its observation row out -- a[c] = bias[c] + sum_k obs[k] * lawW[k][c],
+    // the 24 products summed as the leaves of waveSumF's balanced tree in slot order; bias = lawBias0, or row (record.lawTick) of the table lawBias ([lawPeriod][lawStride cars][2],
+    // offset to the launch's first car).  A scripted input stream or a linear feedback law then costs the stream no launch of its own.  lawPeriod == 0: no law (the caller writes the actions)
+    int lawPeriod;
+    int lawStride;
+    const float* lawBias;
+    float lawBias0[2];
+    float lawW[2 * 24];
     int noTeam;   // diagnostic (PDB_NO_TEAM in the environment at pdb_create): the car waves each walk their own car's joint rows, bars, wings ... as before round 5 (the form a model with more than 21 joints takes)
 };
 

@@ -118,7 +118,7 @@ class DynState(C.Structure):
         [(n, C.c_int32) for n in ('oldPointId', 'oldSplinePointId', 'drifting', 'driftExtreme', 'driftInvalid', 'driftComboCounter', 'collisionFlag', 'oldCollisionFlag',
                                   'outOfTrackFlag')] + \
         [('gasUsage', C.c_float), ('locClutch', C.c_float), ('turboRotation', C.c_float * 3), ('simFrame', C.c_int32), ('damageChanged', C.c_int32),
-         ('damageZoneLevel', C.c_float * 5), ('numContacts', C.c_int32), ('randState', C.c_int32), ('envPending', C.c_int32), ('envStepId', C.c_int32), ('_pad', C.c_int32 * 1), ('suspTravel', C.c_float * 4), ('brakeDiscT', C.c_float * 4), ('ctrlValue', C.c_float * 8), ('wingCtrlOut', C.c_float * 4)]
+         ('damageZoneLevel', C.c_float * 5), ('numContacts', C.c_int32), ('randState', C.c_int32), ('envPending', C.c_int32), ('envStepId', C.c_int32), ('lawTick', C.c_int32), ('suspTravel', C.c_float * 4), ('brakeDiscT', C.c_float * 4), ('ctrlValue', C.c_float * 8), ('wingCtrlOut', C.c_float * 4)]
 assert C.sizeof(DynState) % 16 == 0
 MAX_CONTACTS = 32
 class Contact(C.Structure):   # pdb_contact
@@ -206,6 +206,8 @@ def load_product(host_only=False):
             lib.pdb_set_contact_grid.argtypes = [C.c_void_p, C.c_int]
         if hasattr(lib, 'pdb_set_lane_tunes'):
             lib.pdb_set_lane_tunes.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+        if hasattr(lib, 'pdb_set_law'):
+            lib.pdb_set_law.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int]
         if hasattr(lib, 'pdb_set_lane_setups'):
             lib.pdb_set_lane_setups.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]
         lib.pdb_actions_device.restype = C.c_void_p; lib.pdb_actions_device.argtypes = [C.c_void_p]

@@ -219,6 +219,27 @@ class Batch:
         """0 = the contact pass's grid follows the load (default); > 0 = fixed (for launches recorded into a caller's graph)"""
         self._chk(self.lib.pdb_set_contact_grid(self.h, int(workgroups)))
 
+    def set_law(self, weights, bias0=None, table=None, table_device_ptr=None, period=0):
+        """the device law (pdb_set_law): the next tick's two action components evaluated by the tick's own launches, a = bias + obs[:24] @ weights (float32, the products
+        summed as a balanced binary tree over 32 slots); bias = bias0 [2], or row pdb_dyn_state.lawTick of `table` [period, n, 2] (a numpy array: copied to the
+        device) / of the device memory at table_device_ptr (period rows; the caller keeps it alive).  weights=None removes the law"""
+        import numpy as np
+        if weights is None:
+            self._chk(self.lib.pdb_set_law(self.h, None, None, None, 0, 0)); return
+        w = np.ascontiguousarray(weights, dtype=np.float32)
+        assert w.shape == (24, 2)
+        b0 = None if bias0 is None else np.ascontiguousarray(bias0, dtype=np.float32)
+        assert b0 is None or b0.shape == (2,)
+        b0p = None if b0 is None else b0.ctypes.data_as(C.c_void_p)
+        if table_device_ptr is not None:
+            self._chk(self.lib.pdb_set_law(self.h, w.ctypes.data_as(C.c_void_p), b0p, C.c_void_p(int(table_device_ptr)), int(period), 1))
+        elif table is not None:
+            t = np.ascontiguousarray(table, dtype=np.float32)
+            assert t.ndim == 3 and t.shape[1:] == (self.n, 2)
+            self._chk(self.lib.pdb_set_law(self.h, w.ctypes.data_as(C.c_void_p), b0p, t.ctypes.data_as(C.c_void_p), t.shape[0], 0))
+        else:
+            self._chk(self.lib.pdb_set_law(self.h, w.ctypes.data_as(C.c_void_p), b0p, None, 0, 0))
+
     def set_lane_tunes(self, blocks, first=0):
         """per-lane setup and reward weights (PyProjectD.cpp:328-365 is per simulator = per env): lane first + i takes the eight env tunes
         (FRONT_BIAS, DIFF_POWER, DIFF_COAST, FINAL_RATIO, PRESSURE_*) and the scoring variables of blocks[i], a pdb_car_params that went

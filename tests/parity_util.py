@@ -17,7 +17,7 @@ def _leaves():
     def walk(prefix, dt, off):
         if dt.names:
             for n in dt.names:
-                if n.startswith('_pad'):
+                if n.startswith('_pad') or n == 'lawTick':   # (lawTick: the device law's row counter, pdb_set_law -- not reference state; tests/test_device_law.py checks it)
                     continue
                 walk(prefix + '.' + n if prefix else n, dt.fields[n][0], off + dt.fields[n][1])
         elif dt.subdtype:
