@@ -411,7 +411,7 @@ def measure(args, world, rank, local_rank, dist, want_cpu=False):
     regions = []          # (wall seconds (max over ranks), event ms on the batch stream, partition-0 event ms, cars per launch)
     total = 0.0
     # the dominant kernel's own duration, live: HIP events around every k-th first-pass launch of every launch site, on the stream it is launched on
-    sample_every = max(4, args.steps // 16)
+    sample_every = args.sample_every if args.sample_every is not None else max(4, args.steps // 16)
     can_sample = hasattr(lib, 'pdb_sample_kernel') and not (part_loops and part_graph is not None and part_graph_whole)   # (launches replayed from a graph pass no event)
     k_us = 0.0; k_n = 0; k_cars = 0.0
     if can_sample:
@@ -549,6 +549,7 @@ def parser():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=3000)
     ap.add_argument('--warmup', type=int, default=333)
+    ap.add_argument('--sample-every', type=int, default=None, help='HIP events around every k-th first-pass launch of every launch site (default max(4, steps // 16); 0: none, the roofline block then falls back to the whole tick)')
     ap.add_argument('--settle', type=int, default=None, help='ticks of state preparation before warm-up (cars come off their springs and get rolling); neither warm-up nor timed')
     ap.add_argument('--cars', type=int, default=None, help='cars per GPU (default: 16384 for the headline workload, 4096 with an explicit --workload)')
     ap.add_argument('--no-cpu-baseline', action='store_true')

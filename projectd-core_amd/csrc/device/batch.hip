@@ -164,11 +164,99 @@
 #undef PDB_KERNEL_COLLIDE
 #undef PDB_KERNEL_EXACT_R
 #undef PDB_KERNEL_GUARDED_R
+/* exact-row class: the 26-row cars (no run-time row guards, the per-car LDS block sized for 26 rows) */
+#define PDB_KROWS 26
+#define PDB_KMINWAVES 6
+#define PDB_KERNEL_EXACT pdb_step_kernel_r26
+#define PDB_KSLOT0_EXACT true
+#define PDB_KSLOT0_CTRL false
+#define PDB_KCLASS_LS false
+#define PDB_KERNEL_EXACT_C pdb_contact_kernel_r26
+#define PDB_KERNEL_COLLIDE pdb_collide_kernel_r26
+#define PDB_KERNEL_EXACT_R pdb_resume_kernel_r26
+#define PDB_KNS k26
+#define PDB_CPB PDB_FIRST_CPB
+#define PDB_HELPERS 0
+#define PDB_SOLO 0
+#define PDB_FIRST_ONLY
+#include "step_kernel.hip.inc"
+#undef PDB_FIRST_ONLY
+#undef PDB_SOLO
+#undef PDB_HELPERS
+#undef PDB_CPB
+#undef PDB_BLOCK_THREADS
+#undef PDB_KNS
+#define PDB_KNS k26c
+#define PDB_CPB PDB_CONTACT_CPB
+#define PDB_HELPERS PDB_CONTACT_HELPERS
+#define PDB_SOLO PDB_CONTACT_SOLO
+#define PDB_CONTACT_ONLY
+#include "step_kernel.hip.inc"
+#undef PDB_CONTACT_ONLY
+#undef PDB_SOLO
+#undef PDB_HELPERS
+#undef PDB_CPB
+#undef PDB_BLOCK_THREADS
+#undef PDB_KNS
+#undef PDB_KROWS
+#undef PDB_KMINWAVES
+#undef PDB_KERNEL_EXACT
+#undef PDB_KSLOT0_EXACT
+#undef PDB_KSLOT0_CTRL
+#undef PDB_KCLASS_LS
+#undef PDB_KERNEL_EXACT_C
+#undef PDB_KERNEL_COLLIDE
+#undef PDB_KERNEL_EXACT_R
+/* exact-row class: the 38-row cars (no run-time row guards, the per-car LDS block sized for 38 rows) */
+#define PDB_KROWS 38
+#define PDB_KMINWAVES 5
+#define PDB_KERNEL_EXACT pdb_step_kernel_r38
+#define PDB_KSLOT0_EXACT true
+#define PDB_KSLOT0_CTRL false
+#define PDB_KCLASS_LS true
+#define PDB_KERNEL_EXACT_C pdb_contact_kernel_r38
+#define PDB_KERNEL_COLLIDE pdb_collide_kernel_r38
+#define PDB_KERNEL_EXACT_R pdb_resume_kernel_r38
+#define PDB_KNS k38
+#define PDB_CPB PDB_FIRST_CPB
+#define PDB_HELPERS 0
+#define PDB_SOLO 0
+#define PDB_FIRST_ONLY
+#include "step_kernel.hip.inc"
+#undef PDB_FIRST_ONLY
+#undef PDB_SOLO
+#undef PDB_HELPERS
+#undef PDB_CPB
+#undef PDB_BLOCK_THREADS
+#undef PDB_KNS
+#define PDB_KNS k38c
+#define PDB_CPB PDB_CONTACT_CPB
+#define PDB_HELPERS PDB_CONTACT_HELPERS
+#define PDB_SOLO PDB_CONTACT_SOLO
+#define PDB_CONTACT_ONLY
+#include "step_kernel.hip.inc"
+#undef PDB_CONTACT_ONLY
+#undef PDB_SOLO
+#undef PDB_HELPERS
+#undef PDB_CPB
+#undef PDB_BLOCK_THREADS
+#undef PDB_KNS
+#undef PDB_KROWS
+#undef PDB_KMINWAVES
+#undef PDB_KERNEL_EXACT
+#undef PDB_KSLOT0_EXACT
+#undef PDB_KSLOT0_CTRL
+#undef PDB_KCLASS_LS
+#undef PDB_KERNEL_EXACT_C
+#undef PDB_KERNEL_COLLIDE
+#undef PDB_KERNEL_EXACT_R
+#define PDB_EXACT_CLASSES 1
 #endif
 #undef PDB_KMINWAVES_C
 #ifndef PDB_FAST_BUILD
 static constexpr size_t kSnapStrideWide = k40::kSnapStride;
 static_assert(k40::kSnapStride >= k33::kSnapStride && k33::kSnapStride == k33c::kSnapStride && k40::kSnapStride == k40c::kSnapStride, "snapshot slots");
+static_assert(k40::kSnapStride >= k38::kSnapStride && k40::kSnapStride >= k26::kSnapStride && k26::kSnapStride == k26c::kSnapStride && k38::kSnapStride == k38c::kSnapStride, "snapshot slots of the exact-row classes");
 #else
 static constexpr size_t kSnapStrideWide = k33::kSnapStride;
 #endif
@@ -249,6 +337,7 @@ struct pdb_batch {
     bool resetMaskArmed = false;     // pdb_reset_mask_device was asked for: the step kernels look at the mask
     unsigned char* dHold = nullptr;   // [n] hold mask of pdb_step_host_held, allocated on first use
     pdb_lane_setup* dLaneSetups = nullptr;   // [n] per-lane setup rows (pdb_set_lane_setups), allocated on first use and then complete: every lane's row holds its block's values or the caller's
+    bool noExactClasses = false;
     float* dLawBias = nullptr;             // pdb_set_law's bias table where the library holds the copy (a caller's device table is used in place)
     pdb_lane_tune* dLaneTunes = nullptr;   // [n] per-lane tunes and reward weights (pdb_set_lane_tunes), allocated on first use; rows with valid == 0 fall back to the block
     pdb_slip_state* dSlip = nullptr;     // [2][n]: the cars' slipstreams (pdb_set_world_size; DevConst::slip)
@@ -401,7 +490,11 @@ static void launchTick(pdb_batch* b, hipStream_t st, int c0, int c1, pdb_step_ou
     const dim3 grid(nblk), block(PDB_BLOCK_THREADS), cblock(PDB_WAVE * PDB_CONTACT_WAVES), cgrid(((n + PDB_CONTACT_CPB - 1) / PDB_CONTACT_CPB) < cg ? ((n + PDB_CONTACT_CPB - 1) / PDB_CONTACT_CPB) : cg);
     // a car with DynamicController files goes through the kernel pair compiled with the controllers' call sites (40-row class, row-guarded: any car)
     const bool ctrl = HP.numCtrlStages != 0 || HP.hasBrakeTemps != 0;
-    const int kind = ctrl ? 0 : (m > 33 ? 3 : (b->dLaneSetups ? (m == 33 ? 5 : 4) : (m == 33 ? 1 : 2)));   // (4: the 33-row class's kernel pair compiled for the per-lane setup table; the 40-row class tests for the table at run time)
+#ifdef PDB_EXACT_CLASSES   /* 6 / 7: the classes compiled for exactly 26 / 38 rows (the other shipped cars: double wishbones all round with and without a multilink-style rear) */
+    const int kind = ctrl ? 0 : (m > 33 ? ((m == 38 && !b->noExactClasses) ? 7 : 3) : (b->dLaneSetups ? (m == 33 ? 5 : 4) : (m == 33 ? 1 : ((m == 26 && !b->noExactClasses) ? 6 : 2))));
+#else
+    const int kind = ctrl ? 0 : (m > 33 ? 3 : (b->dLaneSetups ? (m == 33 ? 5 : 4) : (m == 33 ? 1 : 2)));
+#endif   // (4: the 33-row class's kernel pair compiled for the per-lane setup table; the 40-row class tests for the table at run time)
     // measurement (pdb_sample_kernel): HIP events around every k-th first-pass launch of this site, on the stream it is launched on
     KernelSamples& KS = b->samples[q];
     const bool sampled = b->sampleEvery > 0 && !b->capturing && KS.ev[0] && (KS.tick++ % b->sampleEvery) == 0 && KS.n < PDB_KERNEL_SAMPLES;
@@ -409,6 +502,8 @@ static void launchTick(pdb_batch* b, hipStream_t st, int c0, int c1, pdb_step_ou
     switch (kind) {
 #ifndef PDB_FAST_BUILD
     case 0: hipLaunchKernelGGL(k40::pdb_step_kernel_ctrl, grid, block, 0, st, S, Aact, O, CS, DP, DK, b->dTrack, (k40::RedoQueue*)Q, RM, n, SN); break;
+    case 6: hipLaunchKernelGGL(k26::pdb_step_kernel_r26, grid, block, 0, st, S, Aact, O, CS, DP, DK, b->dTrack, (k26::RedoQueue*)Q, RM, n, SN); break;
+    case 7: hipLaunchKernelGGL(k38::pdb_step_kernel_r38, grid, block, 0, st, S, Aact, O, CS, DP, DK, b->dTrack, (k38::RedoQueue*)Q, RM, n, SN); break;
     case 3: hipLaunchKernelGGL(k40::pdb_step_kernel_wide, grid, block, 0, st, S, Aact, O, CS, DP, DK, b->dTrack, (k40::RedoQueue*)Q, RM, n, SN); break;
 #endif
     case 1: hipLaunchKernelGGL(k33::pdb_step_kernel, grid, block, 0, st, S, Aact, O, CS, DP, DK, b->dTrack, (k33::RedoQueue*)Q, RM, n, SN); break;
@@ -430,6 +525,8 @@ static void launchTick(pdb_batch* b, hipStream_t st, int c0, int c1, pdb_step_ou
         switch (kind) {
 #ifndef PDB_FAST_BUILD
         case 0: case 3: hipLaunchKernelGGL(k40c::pdb_collide_kernel_wide, xgrid, xblock, 0, st, DP, b->dTrack, CT, (k40c::RedoQueue*)Q, SN); break;
+        case 6: hipLaunchKernelGGL(k26c::pdb_collide_kernel_r26, xgrid, xblock, 0, st, DP, b->dTrack, CT, (k26c::RedoQueue*)Q, SN); break;
+        case 7: hipLaunchKernelGGL(k38c::pdb_collide_kernel_r38, xgrid, xblock, 0, st, DP, b->dTrack, CT, (k38c::RedoQueue*)Q, SN); break;
 #endif
         default: hipLaunchKernelGGL(k33c::pdb_collide_kernel, xgrid, xblock, 0, st, DP, b->dTrack, CT, (k33c::RedoQueue*)Q, SN); break;
         }
@@ -437,6 +534,8 @@ static void launchTick(pdb_batch* b, hipStream_t st, int c0, int c1, pdb_step_ou
 #ifndef PDB_FAST_BUILD
         case 0: hipLaunchKernelGGL(k40c::pdb_resume_kernel_ctrl, cgrid, cblock, 0, st, S, Aact, O, CS, DP, DK, b->dTrack, CT, (k40c::RedoQueue*)Q, n, HN, SN); break;
         case 3: hipLaunchKernelGGL(k40c::pdb_resume_kernel_wide, cgrid, cblock, 0, st, S, Aact, O, CS, DP, DK, b->dTrack, CT, (k40c::RedoQueue*)Q, n, HN, SN); break;
+        case 6: hipLaunchKernelGGL(k26c::pdb_resume_kernel_r26, cgrid, cblock, 0, st, S, Aact, O, CS, DP, DK, b->dTrack, CT, (k26c::RedoQueue*)Q, n, HN, SN); break;
+        case 7: hipLaunchKernelGGL(k38c::pdb_resume_kernel_r38, cgrid, cblock, 0, st, S, Aact, O, CS, DP, DK, b->dTrack, CT, (k38c::RedoQueue*)Q, n, HN, SN); break;
 #endif
         case 1: hipLaunchKernelGGL(k33c::pdb_resume_kernel, cgrid, cblock, 0, st, S, Aact, O, CS, DP, DK, b->dTrack, CT, (k33c::RedoQueue*)Q, n, HN, SN); break;
         case 2: hipLaunchKernelGGL(k33c::pdb_resume_kernel_generic, cgrid, cblock, 0, st, S, Aact, O, CS, DP, DK, b->dTrack, CT, (k33c::RedoQueue*)Q, n, HN, SN); break;
@@ -450,6 +549,8 @@ static void launchTick(pdb_batch* b, hipStream_t st, int c0, int c1, pdb_step_ou
 #ifndef PDB_FAST_BUILD
     case 0: hipLaunchKernelGGL(k40c::pdb_contact_kernel_ctrl, cgrid, cblock, 0, st, S, Aact, O, CS, DP, DK, b->dTrack, CT, (k40c::RedoQueue*)Q, RM, n, HN, SN); break;
     case 3: hipLaunchKernelGGL(k40c::pdb_contact_kernel_wide, cgrid, cblock, 0, st, S, Aact, O, CS, DP, DK, b->dTrack, CT, (k40c::RedoQueue*)Q, RM, n, HN, SN); break;
+    case 6: hipLaunchKernelGGL(k26c::pdb_contact_kernel_r26, cgrid, cblock, 0, st, S, Aact, O, CS, DP, DK, b->dTrack, CT, (k26c::RedoQueue*)Q, RM, n, HN, SN); break;
+    case 7: hipLaunchKernelGGL(k38c::pdb_contact_kernel_r38, cgrid, cblock, 0, st, S, Aact, O, CS, DP, DK, b->dTrack, CT, (k38c::RedoQueue*)Q, RM, n, HN, SN); break;
 #endif
     case 1: hipLaunchKernelGGL(k33c::pdb_contact_kernel, cgrid, cblock, 0, st, S, Aact, O, CS, DP, DK, b->dTrack, CT, (k33c::RedoQueue*)Q, RM, n, HN, SN); break;
     case 2: hipLaunchKernelGGL(k33c::pdb_contact_kernel_generic, cgrid, cblock, 0, st, S, Aact, O, CS, DP, DK, b->dTrack, CT, (k33c::RedoQueue*)Q, RM, n, HN, SN); break;
@@ -555,6 +656,7 @@ pdb_batch* pdb_create(int device, int n_cars, const pdb_car_params* params, cons
         b->splitContact = fullest >= 48;
     }
     if (const char* sp = getenv("PDB_CONTACT_SPLIT")) b->splitContact = atoi(sp) != 0;   // diagnostic: 0 = the one-kernel contact pass always, 1 = the pair wherever cars are expected (tests, A/B)
+    if (const char* ne = getenv("PDB_NO_EXACT_CLASSES")) b->noExactClasses = atoi(ne) != 0;   // diagnostic: the 26- / 38-row cars through the row-guarded kernels of the 33- / 40-row classes, as before round 6 (tests, A/B)
     if (const char* nt = getenv("PDB_NO_TEAM")) b->K.noTeam = atoi(nt) != 0 ? 1 : 0;   // diagnostic: the per-wave form of the car waves' stage (tests, A/B)
     bool ok = true;
     ok = ok && hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking) == hipSuccess;

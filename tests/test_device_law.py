@@ -141,6 +141,19 @@ def test_device_law_refusals_and_removal(built):
         b.step(3); b.sync()
         a1 = _download(b.actions_device_ptr(), 64).view(np.float32).reshape(8, 2)
         assert not np.array_equal(a1, a) and np.isfinite(a1).all()
+        # a record whose row counter lies past the table's period (it came in through pdb_set_state): row 0, then on from there
+        tab = np.random.RandomState(9).uniform(-0.2, 0.2, (3, 8, 2)).astype(np.float32)
+        b.set_law(W, table=tab)
+        st = b.get_state()
+        for s_ in st:
+            s_.lawTick = 99
+        b.set_state(st)
+        b.step(1); b.sync()
+        og = _download(b.out_device_ptr(), 8 * C.sizeof(pc.StepOut)).view(np.dtype(pc.StepOut))
+        want = law_host(np.ascontiguousarray(og['obs']), W, tab[0])
+        got = _download(b.actions_device_ptr(), 64).view(np.float32).reshape(8, 2)
+        assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+        assert all(s_.lawTick == 1 for s_ in b.get_state())
         b.set_law(None)                                      # the caller's actions stand again
         b.upload_actions(a)
         b.step(3); b.sync()

@@ -225,9 +225,19 @@ def test_cars_with_dynamic_controllers(built, model):
 @pytest.mark.parametrize('model', ['ks_mazda_rx7_tuned', 'ks_toyota_supra_mkiv_drift', 'dthwsh_mazda_rx7_fc3s_sr20', 'gravygarage_street_ae86_readie', 'pdb_ml_supra', 'pdb_fwd_ae86'])
 def test_double_wishbone_turbo_cars(built, model):
     """the other four cars the reference ships: double wishbones on all four wheels (6 bodies, 21 joints, 26 rows -> the
-    row-guarded kernel), or struts in front and double wishbones behind (8 bodies, 38 rows -> the 40-row LDS size class);
+    class compiled for exactly 26 rows), or struts in front and double wishbones behind (8 bodies, 38 rows -> the class compiled for exactly 38);
     one / two turbos, 5 / 6 forward gears, up to 5 wings; and the derived multilink car (reference SuspensionML front and rear).  32 cars x 1200 ticks, random constant actions."""
     worst = parity_util.run_parity(n_cars=32, ticks=1200, seed=21, resync=False, verbose=True, check_every=20, model=model)
+    assert worst == 0.0
+
+
+@pytest.mark.parametrize('model', ['ks_mazda_rx7_tuned', 'dthwsh_mazda_rx7_fc3s_sr20'])
+def test_row_guarded_kernels_for_the_26_and_38_row_cars(built, monkeypatch, model):
+    """since round 6 the 26- and 38-row cars step through kernel classes compiled for exactly their row counts (test_double_wishbone_turbo_cars and every other
+    test with these cars); PDB_NO_EXACT_CLASSES=1 routes them through the row-guarded kernels of the 33- / 40-row classes as before -- the form any OTHER row count
+    still takes -- which must give the same bits"""
+    monkeypatch.setenv('PDB_NO_EXACT_CLASSES', '1')
+    worst = parity_util.run_parity(n_cars=32, ticks=600, seed=23, resync=False, verbose=True, check_every=20, model=model)
     assert worst == 0.0
 
 

@@ -50,6 +50,15 @@ def test_first_pass_kernels_keep_six_workgroups_per_cu():
         assert k[name]['scratch'] <= 96, (name, k[name])
     for name in ('pdb_step_kernel_wide', 'pdb_step_kernel_ctrl'):   # 40-row cars: five workgroups (96 VGPRs, 29.9 KB)
         assert k[name]['vgprs'] <= 96 and k[name]['lds'] <= 32000, (name, k[name])
+    # round 6: the classes compiled for exactly 26 / 38 rows (the other four shipped cars): the 26-row class keeps six workgroups per CU, the 38-row class five like the 40-row one
+    assert k['pdb_step_kernel_r26']['vgprs'] <= 80 and k['pdb_step_kernel_r26']['lds'] <= 26880 and k['pdb_step_kernel_r26']['occupancy'] >= 6 and k['pdb_step_kernel_r26']['scratch'] <= 96, k['pdb_step_kernel_r26']
+    assert k['pdb_step_kernel_r38']['vgprs'] <= 96 and k['pdb_step_kernel_r38']['lds'] <= 32000, k['pdb_step_kernel_r38']
+    for name in ('pdb_resume_kernel_r26', 'pdb_resume_kernel_r38'):
+        assert k[name]['vgprs'] <= 128 and k[name]['lds'] <= 32000 and k[name]['scratch'] <= 64, (name, k[name])
+    for name in ('pdb_contact_kernel_r26', 'pdb_contact_kernel_r38'):
+        assert k[name]['vgprs'] <= 256 and k[name]['occupancy'] >= 2 and k[name]['lds'] <= 65536 and k[name]['scratch'] <= 128, (name, k[name])
+    for name in ('pdb_collide_kernel_r26', 'pdb_collide_kernel_r38'):
+        assert k[name]['lds'] <= 40960 and k[name]['scratch'] == 0, (name, k[name])
 
 
 COLD_BLOCKS = ('teleportByModeT', 'wingStepGroundEffect')   # the env's reset tick (inlined teleport) and the wings of a car with ground-effect LUTs
