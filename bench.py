@@ -233,12 +233,16 @@ def measure(args, world, rank, local_rank, dist, want_cpu=False):
         if policy == 'feedback':   # oracle/scenarios.h scenarioFeedback (a linear law of the observation, clamped) as one addmm; the clamp is the pre-step's (above)
             torch.addmm(fb_b, o[:, :24], fb_w, out=a)
         elif policy == 'mlp':      # obs -> normalise -> 256 -> 256 -> 2, tanh-squashed like SAC's actor mean (hyperparams/sac.yml net_arch)
-            # six launches: three GEMMs with their bias (addmm), two ReLUs and the tanh in place, hidden layers in buffers kept per row count
+            # four launches: three GEMMs with their bias, the hidden layers' ReLU in the GEMM's epilogue, the tanh in place; hidden layers in buffers kept per row count
             c = a.shape[0]
             if c not in h1_buf:
                 h1_buf[c] = torch.empty(c, 256, device=dev); h2_buf[c] = torch.empty(c, 256, device=dev)
-            h1 = torch.addmm(b1, o[:, :24], w1, out=h1_buf[c]).relu_()
-            h2 = torch.addmm(b2, h1, w2, out=h2_buf[c]).relu_()
+            if not args.mlp_plain_relu:   # the hidden layers' ReLU as the GEMM's epilogue (torch._addmm_activation: hipBLASLt's fused form where the build has it): four launches
+                h1 = torch._addmm_activation(b1, o[:, :24], w1, use_gelu=False, out=h1_buf[c])
+                h2 = torch._addmm_activation(b2, h1, w2, use_gelu=False, out=h2_buf[c])
+            else:
+                h1 = torch.addmm(b1, o[:, :24], w1, out=h1_buf[c]).relu_()
+                h2 = torch.addmm(b2, h1, w2, out=h2_buf[c]).relu_()
             torch.addmm(b3, h2, w3, out=a).tanh_()
         elif policy == 'random':   # fresh uniform actions every tick (an untrained agent: ends episodes quickly)
             a.uniform_(-1.0, 1.0)
@@ -573,6 +577,8 @@ def parser():
     ap.add_argument('--library-exchange', action='store_true', help='N > 1: the per-partition exchange through the library\'s own RCCL communicators (pdb_step_exchange_partition); default with one rank, opt-in with more')
     ap.add_argument('--graph-policy-only', action='store_true', help='per-partition loops below 8192 cars: only the policy in the captured graph, the tick as plain launches (A/B)')
     ap.add_argument('--graph-contact-grid', type=int, default=96, help='workgroups of the contact pass inside a captured per-partition tick')
+    ap.add_argument('--mlp-plain-relu', action='store_true', help='mlp policy: the hidden layers as addmm + relu_ (six launches a tick, rounds 3-5) instead of torch._addmm_activation (ReLU in the GEMM epilogue: four) (A/B)')
+    ap.add_argument('--mlp-fused-relu', action='store_true', help=argparse.SUPPRESS)   # (the default since round 6)
     ap.add_argument('--no-device-law', action='store_true', help='scripted / feedback policies: the law as a torch launch behind every tick (rounds 1-5) instead of the device law, pdb_set_law (A/B)')
     ap.add_argument('--no-graph-policy', action='store_true', help='per-partition policy loops: the policy as plain torch launches instead of one captured graph per partition (A/B)')
     ap.add_argument('--ring-fork', action='store_true', help='ring mode: every ring starts behind the batch stream (the older form; A/B)')
