@@ -293,7 +293,7 @@ def measure(args, world, rank, local_rank, dist, want_cpu=False):
         if gather.active and not args.ring_fork:
             ring_streams.extend(part_st)
         graphs = {}; plain_done = set(); graph_pool = [None] * args.partitions
-        use_graph = not args.no_graph_policy and policy in ('feedback', 'mlp') and n < 8192 and not gather.active and not (device_law and args.graph_policy_only)   # (from 8192 cars up a graph launch costs the host more than the launches it replaces: 54 against 57 M on the 16384-car headline)
+        use_graph = not args.no_graph_policy and policy in ('feedback', 'mlp') and n < args.graph_max_cars and not gather.active and not (device_law and args.graph_policy_only)   # (from 8192 cars up a graph launch costs the host more than the launches it replaces: 54 against 57 M on the 16384-car headline)
         part_graph = graphs if use_graph else None
         part_graph_whole = use_graph and n < 8192 and not gather.active and not args.graph_policy_only
         if part_graph_whole:
@@ -580,6 +580,7 @@ def parser():
     ap.add_argument('--mlp-plain-relu', action='store_true', help='mlp policy: the hidden layers as addmm + relu_ (six launches a tick, rounds 3-5) instead of torch._addmm_activation (ReLU in the GEMM epilogue: four) (A/B)')
     ap.add_argument('--mlp-fused-relu', action='store_true', help=argparse.SUPPRESS)   # (the default since round 6)
     ap.add_argument('--no-device-law', action='store_true', help='scripted / feedback policies: the law as a torch launch behind every tick (rounds 1-5) instead of the device law, pdb_set_law (A/B)')
+    ap.add_argument('--graph-max-cars', type=int, default=8192, help='per-partition policy loops: captured graphs below this many cars per GPU (the whole tick below 8192 in any case; above, with --graph-policy-only, the policy launches alone) (A/B)')
     ap.add_argument('--no-graph-policy', action='store_true', help='per-partition policy loops: the policy as plain torch launches instead of one captured graph per partition (A/B)')
     ap.add_argument('--ring-fork', action='store_true', help='ring mode: every ring starts behind the batch stream (the older form; A/B)')
     ap.add_argument('--torch-exchange', action='store_true', help='the per-partition exchange (--scatter-actions with --gather-ticks 1) through torch.distributed instead of the library\'s own RCCL communicators (A/B)')

@@ -52,6 +52,9 @@
 #ifndef PDB_KMINWAVES_C
 #define PDB_KMINWAVES_C 2
 #endif
+#ifndef PDB_COLLIDE_NW   /* waves of the collide kernel's one-car workgroup (its narrow phase is shared by all of them; the GPU is mostly empty while it runs) */
+#define PDB_COLLIDE_NW PDB_CONTACT_WAVES
+#endif
 #define PDB_KROWS 33
 #ifndef PDB_KMINWAVES33
 #define PDB_KMINWAVES33 6
@@ -521,7 +524,7 @@ static void launchTick(pdb_batch* b, hipStream_t st, int c0, int c1, pdb_step_ou
     // (A launch recorded into a graph keeps the form chosen at capture: a caller that captures pdb_step_partition asks for a fixed grid, pdb_set_contact_grid, and so for the pair.)
     const int heldNow = (b->contactGrid > 0) ? 1 : (b->hHint ? *(volatile int*)(b->hHint + q) : 0);
     if (b->splitContact && HP.collider.enabled != 0 && heldNow > 0) {
-        const dim3 xgrid((unsigned)(n < (int)cgrid.x * PDB_CONTACT_CPB ? n : (int)cgrid.x * PDB_CONTACT_CPB))   /* one car per workgroup */, xblock(PDB_WAVE * PDB_CONTACT_WAVES);
+        const dim3 xgrid((unsigned)(n < (int)cgrid.x * PDB_CONTACT_CPB ? n : (int)cgrid.x * PDB_CONTACT_CPB))   /* one car per workgroup */, xblock(PDB_WAVE * PDB_COLLIDE_NW);
         switch (kind) {
 #ifndef PDB_FAST_BUILD
         case 0: case 3: hipLaunchKernelGGL(k40c::pdb_collide_kernel_wide, xgrid, xblock, 0, st, DP, b->dTrack, CT, (k40c::RedoQueue*)Q, SN); break;

@@ -160,3 +160,48 @@ def test_device_law_refusals_and_removal(built):
         assert np.array_equal(_download(b.actions_device_ptr(), 64).view(np.float32).reshape(8, 2), a)
     finally:
         b.close()
+
+
+def test_device_law_through_the_env_loop_in_the_kernel(built):
+    """bench.py's headline regime: the law AND the env's episode rules (pdb_set_env: terminations, the reset tick's teleport to a random point and its zero action)
+    inside the tick's launches.  Against a second batch with the same env mode that is FED the same law from the host (law_host on the rows pdb_step_host returns):
+    every output row, flag and reward every tick, every record at the checks -- over many episode ends (half the cars creep and get `stuck` after 0.4 s, the others
+    are steered into the walls of the strip), three free-running partitions on the law's side."""
+    import pdbatch, projectd_env
+    n, ticks, period = 48, 900, 5
+    P = pdbatch.packed_params('ks_toyota_ae86_drift.env'); trk = pdbatch.synthetic_track('walled')
+    W = np.zeros((24, 2), np.float32)
+    W[20, 0] = -0.01; W[21, 0] = 0.01; W[2, 1] = -0.002                       # a weak feedback on top of the table
+    r = np.random.RandomState(8)
+    table = np.zeros((period, n, 2), np.float32)
+    table[:, 0::2, 1] = -1.0                                                  # gas 0.1: creeps, no new track point within 0.4 s
+    table[:, 1::2, 1] = 1.0; table[:, 1::2, 0] = np.where(np.arange(n // 2) % 2 == 0, 0.06, -0.06)[None, :]   # full throttle into a side wall
+    table += r.uniform(-0.01, 0.01, table.shape).astype(np.float32)
+    cfg = projectd_env.EnvConfig(teleport_mode=2, stuck_timeout=0.4, terminate_low_reward=-1.0e9)
+    bl = pdbatch.Batch(n, P, trk, device=0, action_mode=1); bh = pdbatch.Batch(n, P, trk, device=0, action_mode=1)
+    nb_out = C.sizeof(pc.StepOut)
+    try:
+        for b in (bl, bh):
+            b.set_env(cfg)
+        bl.set_partitions(3)
+        bl.set_law(W, table=table)
+        a = np.zeros((n, 2), np.float32)
+        bl.upload_actions(a)
+        ends = 0
+        for t in range(ticks):
+            bl.step_ring(1, join=True); bl.sync()
+            oh = bh.step_host(a)
+            ol = _download(bl.out_device_ptr(), n * nb_out).view(np.dtype(pc.StepOut))
+            assert ol.tobytes() == np.asarray(oh).tobytes(), (t, np.argwhere(np.asarray(ol['flags']) != np.asarray(oh['flags']))[:4])
+            ends += int(((np.asarray(oh['flags']) & 8) != 0).sum())
+            a = law_host(np.ascontiguousarray(oh['obs']), W, table[t % period])
+            assert np.array_equal(_download(bl.actions_device_ptr(), n * 8).view(np.uint32), a.view(np.uint32).ravel()), t
+            if t % 50 == 49 or t == ticks - 1:
+                sl, sh = bl.get_state(), bh.get_state()
+                for i in range(n):
+                    rel, name, vg, vc, bad_int = parity_util.compare_states(sl[i], sh[i])
+                    assert not bad_int and rel == 0.0, (t, i, name, vg, vc, bad_int[:3])
+                    assert sl[i].lawTick == (t + 1) % period and sh[i].lawTick == 0
+        assert ends >= 40, ends
+    finally:
+        bl.close(); bh.close()
