@@ -79,12 +79,16 @@ def test_no_scratch_instruction_on_the_first_pass_hot_path():
                 h.update(open(os.path.join(dp, f), 'rb').read())
     for f in ('pdb_types.h', 'pdbatch.h'):
         h.update(open(os.path.join(root, 'include', f), 'rb').read())
+    h.update(open(os.path.join(root, 'tools', 'isa_callsite_profile.py'), 'rb').read())   # (its compile flags are part of what the cached object is)
     cache = os.path.join(tempfile.gettempdir(), 'pdb_isa_' + h.hexdigest()[:16])
     os.makedirs(cache, exist_ok=True)
     r = subprocess.run([sys.executable, os.path.join(root, 'tools', 'isa_callsite_profile.py'), 'pdb_step_kernel', 'scratchlist'],
                        env=dict(os.environ, PDB_ISA_TMP=cache), capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [l for l in r.stdout.split('\n') if re.match(r'^\s*[0-9a-f]+ scratch_', l)]
-    assert lines, 'the cold teleport block is known to spill: no scratch instruction at all means the listing broke'
+    if not lines:   # since the SLP vectorizer is off (round 6) the 33-row first pass has no scratch frame at all: then the compiler's own report has to say so too
+        assert 'pdb_step_kernel: ' in r.stdout, r.stdout[-500:]       # (the listing itself is there)
+        assert os.path.exists(REPORT) and kernels()['pdb_step_kernel']['scratch'] == 0, 'no scratch instruction listed, yet the build reports a scratch frame'
+        return
     hot = [l for l in lines if not any(c in l for c in COLD_BLOCKS)]
     assert not hot, 'scratch traffic on the hot path of pdb_step_kernel:\n' + '\n'.join(hot[:20])

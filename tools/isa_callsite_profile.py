@@ -19,7 +19,7 @@ tmp = os.environ.get('PDB_ISA_TMP') or tempfile.mkdtemp(prefix='pdb_isa_')   # P
 csrc = os.path.join(ROOT, 'projectd-core_amd', 'csrc')
 obj, co = os.path.join(tmp, 'k.o'), os.path.join(tmp, 'k.co')
 if not os.path.exists(obj):
-  subprocess.check_call(['/opt/rocm/bin/hipcc', '--offload-arch=gfx950', '-std=c++17', '-O3', '-ffp-contract=off', '-fno-fast-math', '-fPIC', '-g', '-DPDB_FAST_BUILD', '-mllvm', '-disable-machine-licm',
+  subprocess.check_call(['/opt/rocm/bin/hipcc', '--offload-arch=gfx950', '-std=c++17', '-O3', '-ffp-contract=off', '-fno-fast-math', '-fPIC', '-g', '-DPDB_FAST_BUILD', '-mllvm', '-disable-machine-licm', '-fno-slp-vectorize',
                        '-I' + os.path.join(ROOT, 'include'), '-I' + os.path.join(csrc, 'host'), '-I' + os.path.join(csrc, 'device'),
                        '--cuda-device-only', '-c', os.path.join(csrc, 'device', 'batch.hip'), '-o', obj])
 subprocess.check_call([LLVM + '/clang-offload-bundler', '--unbundle', '--type=o', '--input=' + obj, '--targets=hipv4-amdgcn-amd-amdhsa--gfx950', '--output=' + co])
