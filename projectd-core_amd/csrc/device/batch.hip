@@ -493,10 +493,13 @@ static void launchTick(pdb_batch* b, hipStream_t st, int c0, int c1, pdb_step_ou
     const dim3 grid(nblk), block(PDB_BLOCK_THREADS), cblock(PDB_WAVE * PDB_CONTACT_WAVES), cgrid(((n + PDB_CONTACT_CPB - 1) / PDB_CONTACT_CPB) < cg ? ((n + PDB_CONTACT_CPB - 1) / PDB_CONTACT_CPB) : cg);
     // a car with DynamicController files goes through the kernel pair compiled with the controllers' call sites (40-row class, row-guarded: any car)
     const bool ctrl = HP.numCtrlStages != 0 || HP.hasBrakeTemps != 0;
+    // the exact-row kernels hold the team form of the car waves' stage only (step_kernel.hip.inc): a model with more joints than a car's share of the wave's lanes, or a batch
+    // created under PDB_NO_TEAM, steps through the row-guarded kernels
+    const bool teamOk = HP.numJoints <= PDB_WAVE / PDB_FIRST_CPB && b->K.noTeam == 0;
 #ifdef PDB_EXACT_CLASSES   /* 6 / 7: the classes compiled for exactly 26 / 38 rows (the other shipped cars: double wishbones all round with and without a multilink-style rear) */
-    const int kind = ctrl ? 0 : (m > 33 ? ((m == 38 && !b->noExactClasses) ? 7 : 3) : (b->dLaneSetups ? (m == 33 ? 5 : 4) : (m == 33 ? 1 : ((m == 26 && !b->noExactClasses) ? 6 : 2))));
+    const int kind = ctrl ? 0 : (m > 33 ? ((m == 38 && !b->noExactClasses && teamOk) ? 7 : 3) : (b->dLaneSetups ? ((m == 33 && teamOk) ? 5 : 4) : ((m == 33 && teamOk) ? 1 : ((m == 26 && !b->noExactClasses && teamOk) ? 6 : 2))));
 #else
-    const int kind = ctrl ? 0 : (m > 33 ? 3 : (b->dLaneSetups ? (m == 33 ? 5 : 4) : (m == 33 ? 1 : 2)));
+    const int kind = ctrl ? 0 : (m > 33 ? 3 : (b->dLaneSetups ? ((m == 33 && teamOk) ? 5 : 4) : ((m == 33 && teamOk) ? 1 : 2)));
 #endif   // (4: the 33-row class's kernel pair compiled for the per-lane setup table; the 40-row class tests for the table at run time)
     // measurement (pdb_sample_kernel): HIP events around every k-th first-pass launch of this site, on the stream it is launched on
     KernelSamples& KS = b->samples[q];
