@@ -216,7 +216,10 @@ def measure(args, world, rank, local_rank, dist, want_cpu=False):
 
     # Round 6: the linear laws run inside the tick's own launches (pdb_set_law: a = bias + obs @ W where the kernel writes the observation row; the scripted law's per-tick
     # bias is row `lawTick` of the same table) -- no launch between two ticks of a stream.  --no-device-law: the torch launch of rounds 1-5 (different rounding of the 24-term sum)
-    device_law = policy in ('scripted', 'feedback') and not args.no_device_law and not do_scatter
+    # Measured on the round's final build (profiles/r06_law_ab.txt): the legs bound by a partition's chain gain 4-7 % from the law (4096-car env loop, 16384 cars on the mountain road /
+    # nordring with the feedback law); the 16384-car headline, where three partitions saturate the GPU's issue slots, is 1.5-2 % FASTER with the torch launch between a partition's ticks
+    # (it keeps the partitions' first passes apart: 128 against 150 us per launch).  So: the feedback law on the device by default, the scripted headline as a torch launch; --device-law / --no-device-law force a form
+    device_law = policy in ('scripted', 'feedback') and (policy == 'feedback' or args.device_law) and not args.no_device_law and not do_scatter
     if device_law and policy == 'scripted':
         b.set_law(sw, table_device_ptr=s_tab.data_ptr(), period=T_per)
     elif device_law:
@@ -579,6 +582,7 @@ def parser():
     ap.add_argument('--graph-contact-grid', type=int, default=96, help='workgroups of the contact pass inside a captured per-partition tick')
     ap.add_argument('--mlp-plain-relu', action='store_true', help='mlp policy: the hidden layers as addmm + relu_ (six launches a tick, rounds 3-5) instead of torch._addmm_activation (ReLU in the GEMM epilogue: four) (A/B)')
     ap.add_argument('--mlp-fused-relu', action='store_true', help=argparse.SUPPRESS)   # (the default since round 6)
+    ap.add_argument('--device-law', action='store_true', help='scripted policy: the law evaluated by the tick\'s own launches (pdb_set_law) instead of the torch launch behind every tick (the default for the feedback policy) (A/B)')
     ap.add_argument('--no-device-law', action='store_true', help='scripted / feedback policies: the law as a torch launch behind every tick (rounds 1-5) instead of the device law, pdb_set_law (A/B)')
     ap.add_argument('--graph-max-cars', type=int, default=8192, help='per-partition policy loops: captured graphs below this many cars per GPU (the whole tick below 8192 in any case; above, with --graph-policy-only, the policy launches alone) (A/B)')
     ap.add_argument('--no-graph-policy', action='store_true', help='per-partition policy loops: the policy as plain torch launches instead of one captured graph per partition (A/B)')

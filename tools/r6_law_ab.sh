@@ -14,8 +14,8 @@ for l in sys.stdin:
 for r in $(seq $R); do
   for v in law torch; do
     X=""; [ $v = torch ] && X="--no-device-law"
-    leg $v headline_1500 --steps 1500 --warmup 200 $X
-    leg $v headline_driver --steps 20 --warmup 5 $X
+    D=""; [ $v = law ] && D="--device-law"; leg $v headline_1500 --steps 1500 --warmup 200 $X $D
+    leg $v headline_driver --steps 20 --warmup 5 $X $D
     leg $v episodes_4096 --workload touge --walls --cars 4096 --episodes --steps 600 --warmup 100 --settle 200 $X
     leg $v episodes_4096_reset_free --workload touge --walls --cars 4096 --policy feedback --steps 600 --warmup 100 --settle 200 $X
     leg $v configs2_16384_touge --workload touge --cars 16384 --steps 300 --warmup 50 --settle 200 $X
